@@ -1,0 +1,266 @@
+"""ctypes loaders for the CPU oracles -- TEST INFRASTRUCTURE ONLY.
+
+Two interchangeable back ends with one Python surface:
+
+* ``PortOracle``  -- oracle/libworld_oracle.so, this repo's plain-C restatement.
+* ``RefOracle``   -- oracle/_ref/libworld_ref*.so, the UNMODIFIED reference
+  compiled in place from /root/reference by oracle/Makefile (present whenever
+  it was built in the container; the .so travels to the GPU box).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  Nothing under world_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def build(quiet=True):
+    """Compile the restatement (and the in-place reference when available)."""
+    subprocess.run(["make", "-s", "-f", os.path.join(HERE, "Makefile")],
+                   check=True, stdout=subprocess.DEVNULL if quiet else None)
+
+
+class _Base:
+    kind = "?"
+
+    def frame_count(self, fs, n, frame_period):
+        return int(1000.0 * n / fs / frame_period) + 1
+
+    def cheaptrick_fft_size(self, fs, f0_floor=71.0):
+        import math
+        return int(2.0 ** (1.0 + int(math.log(3.0 * fs / f0_floor + 1) / 0.69314718055994529)))
+
+
+class PortOracle(_Base):
+    kind = "port"
+
+    def __init__(self, path=None):
+        path = path or os.path.join(HERE, "libworld_oracle.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        L.wo_randn.restype = C.c_double
+        L.wo_frame_count.restype = C.c_int
+        L.wo_frame_count.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.wo_harvest.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.wo_dio.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                             C.c_int, C.c_double, _dp, _dp]
+        L.wo_stonemask.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        L.wo_cheaptrick.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]
+        L.wo_d4c.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp]
+        L.wo_rfft.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.wo_irfft_unscaled.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.wo_interp1.argtypes = [_dp, _dp, C.c_int, _dp, C.c_int, _dp]
+        L.wo_decimate.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        L.wo_linear_smoothing.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
+        L.wo_dc_correction.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
+        L.wo_round.argtypes = [C.c_double]
+        L.wo_nuttall.argtypes = [C.c_int, _dp]
+
+    # -- primitives --
+    def randn(self, count):
+        st = (C.c_uint32 * 4)()
+        self.lib.wo_randn_seed(st)
+        return np.array([self.lib.wo_randn(st) for _ in range(count)])
+
+    def rfft(self, x):
+        x = _f64(x); n = len(x)
+        re = np.zeros(n // 2 + 1); im = np.zeros(n // 2 + 1)
+        self.lib.wo_rfft(n, _p(x), _p(re), _p(im))
+        return re + 1j * im
+
+    def irfft_unscaled(self, X):
+        n = 2 * (len(X) - 1)
+        re = _f64(X.real); im = _f64(X.imag); out = np.zeros(n)
+        self.lib.wo_irfft_unscaled(n, _p(re), _p(im), _p(out))
+        return out
+
+    def interp1(self, x, y, xi):
+        x, y, xi = _f64(x), _f64(y), _f64(xi)
+        yi = np.zeros(len(xi))
+        self.lib.wo_interp1(_p(x), _p(y), len(x), _p(xi), len(xi), _p(yi))
+        return yi
+
+    def decimate(self, x, r):
+        x = _f64(x)
+        y = np.zeros(len(x))
+        self.lib.wo_decimate(_p(x), len(x), r, _p(y))
+        return y[: (len(x) - 1) // r + 1]
+
+    def linear_smoothing(self, spec, width, fs, fft_size):
+        spec = _f64(spec); out = np.zeros(fft_size // 2 + 1)
+        self.lib.wo_linear_smoothing(_p(spec), width, fs, fft_size, _p(out))
+        return out
+
+    # -- analysis path --
+    def harvest(self, x, fs, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0):
+        x = _f64(x); nf = self.frame_count(fs, len(x), frame_period)
+        tp = np.zeros(nf); f0 = np.zeros(nf)
+        self.lib.wo_harvest(_p(x), len(x), fs, f0_floor, f0_ceil, frame_period, _p(tp), _p(f0))
+        return tp, f0
+
+    def dio(self, x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_period=5.0,
+            speed=1, allowed_range=0.1):
+        x = _f64(x); nf = self.frame_count(fs, len(x), frame_period)
+        tp = np.zeros(nf); f0 = np.zeros(nf)
+        self.lib.wo_dio(_p(x), len(x), fs, f0_floor, f0_ceil, channels_in_octave, frame_period,
+                        speed, allowed_range, _p(tp), _p(f0))
+        return tp, f0
+
+    def stonemask(self, x, fs, tp, f0):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        out = np.zeros(len(f0))
+        self.lib.wo_stonemask(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), _p(out))
+        return out
+
+    def cheaptrick(self, x, fs, tp, f0, q1=-0.15, f0_floor=71.0, fft_size=None):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        fft_size = fft_size or self.cheaptrick_fft_size(fs, f0_floor)
+        sp = np.zeros((len(f0), fft_size // 2 + 1))
+        self.lib.wo_cheaptrick(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), q1, fft_size, _p(sp))
+        return sp
+
+    def d4c(self, x, fs, tp, f0, fft_size, threshold=0.85):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        ap = np.zeros((len(f0), fft_size // 2 + 1))
+        self.lib.wo_d4c(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, threshold, _p(ap))
+        return ap
+
+
+class _DioOption(C.Structure):       # dio.h:16-23
+    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double), ("channels_in_octave", C.c_double),
+                ("frame_period", C.c_double), ("speed", C.c_int), ("allowed_range", C.c_double)]
+
+
+class _HarvestOption(C.Structure):   # harvest.h:16-20
+    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double), ("frame_period", C.c_double)]
+
+
+class _CheapTrickOption(C.Structure):  # cheaptrick.h:16-20
+    _fields_ = [("q1", C.c_double), ("f0_floor", C.c_double), ("fft_size", C.c_int)]
+
+
+class _D4COption(C.Structure):       # d4c.h:16-18
+    _fields_ = [("threshold", C.c_double)]
+
+
+def _rows(a):
+    """double** view over a dense 2-D array (the reference's row-pointer ABI)."""
+    ptrs = (_dp * a.shape[0])()
+    base = a.ctypes.data
+    stride = a.strides[0]
+    for i in range(a.shape[0]):
+        ptrs[i] = C.cast(base + i * stride, _dp)
+    return ptrs
+
+
+class WorldCABI(_Base):
+    """Binding of the reference's 13-symbol C ABI; works for
+    oracle/_ref/libworld_ref.so and, unchanged, for the shipped libworld_hip.so."""
+    kind = "cabi"
+
+    def __init__(self, path):
+        self.path = path
+        self.lib = L = C.CDLL(path)
+        L.Dio.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(_DioOption), _dp, _dp]
+        L.Harvest.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(_HarvestOption), _dp, _dp]
+        L.StoneMask.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        L.CheapTrick.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int,
+                                 C.POINTER(_CheapTrickOption), C.POINTER(_dp)]
+        L.D4C.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int,
+                          C.POINTER(_D4COption), C.POINTER(_dp)]
+        L.GetSamplesForDIO.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.GetSamplesForHarvest.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.GetFFTSizeForCheapTrick.argtypes = [C.c_int, C.POINTER(_CheapTrickOption)]
+        L.GetF0FloorForCheapTrick.argtypes = [C.c_int, C.c_int]
+        L.GetF0FloorForCheapTrick.restype = C.c_double
+        L.InitializeCheapTrickOption.argtypes = [C.c_int, C.POINTER(_CheapTrickOption)]
+
+    def harvest(self, x, fs, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0):
+        x = _f64(x)
+        opt = _HarvestOption(); self.lib.InitializeHarvestOption(C.byref(opt))
+        opt.f0_floor, opt.f0_ceil, opt.frame_period = f0_floor, f0_ceil, frame_period
+        nf = self.lib.GetSamplesForHarvest(fs, len(x), frame_period)
+        tp = np.zeros(nf); f0 = np.zeros(nf)
+        self.lib.Harvest(_p(x), len(x), fs, C.byref(opt), _p(tp), _p(f0))
+        return tp, f0
+
+    def dio(self, x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_period=5.0,
+            speed=1, allowed_range=0.1):
+        x = _f64(x)
+        opt = _DioOption(); self.lib.InitializeDioOption(C.byref(opt))
+        opt.f0_floor, opt.f0_ceil, opt.channels_in_octave = f0_floor, f0_ceil, channels_in_octave
+        opt.frame_period, opt.speed, opt.allowed_range = frame_period, speed, allowed_range
+        nf = self.lib.GetSamplesForDIO(fs, len(x), frame_period)
+        tp = np.zeros(nf); f0 = np.zeros(nf)
+        self.lib.Dio(_p(x), len(x), fs, C.byref(opt), _p(tp), _p(f0))
+        return tp, f0
+
+    def stonemask(self, x, fs, tp, f0):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        out = np.zeros(len(f0))
+        self.lib.StoneMask(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), _p(out))
+        return out
+
+    def cheaptrick(self, x, fs, tp, f0, q1=-0.15, f0_floor=71.0, fft_size=None):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        opt = _CheapTrickOption(); self.lib.InitializeCheapTrickOption(fs, C.byref(opt))
+        opt.q1, opt.f0_floor = q1, f0_floor
+        opt.fft_size = fft_size or self.lib.GetFFTSizeForCheapTrick(fs, C.byref(opt))
+        sp = np.zeros((len(f0), opt.fft_size // 2 + 1))
+        self.lib.CheapTrick(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), C.byref(opt), _rows(sp))
+        return sp
+
+    def d4c(self, x, fs, tp, f0, fft_size, threshold=0.85):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        opt = _D4COption(); self.lib.InitializeD4COption(C.byref(opt))
+        opt.threshold = threshold
+        ap = np.zeros((len(f0), fft_size // 2 + 1))
+        self.lib.D4C(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, C.byref(opt), _rows(ap))
+        return ap
+
+
+def _cpu_has(flag):
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return flag in line.split()
+    except OSError:
+        pass
+    return False
+
+
+class RefOracle(WorldCABI):
+    kind = "reference"
+
+    def __init__(self, optimized=False):
+        name = "libworld_ref_o3.so" if optimized and _cpu_has("avx2") and _cpu_has("fma") else "libworld_ref.so"
+        path = os.path.join(HERE, "_ref", name)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.flags = "-O3 -march=x86-64-v3" if name.endswith("_o3.so") else "-O1 (reference makefile:6)"
+        super().__init__(path)
+
+
+def ref_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libworld_ref.so"))
+
+
+def best_oracle():
+    """The real reference when its prebuilt .so is present, else the port."""
+    return RefOracle() if ref_available() else PortOracle()

@@ -1,0 +1,84 @@
+"""Generate tests/golden/*.npz from the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference, compiled in place into
+oracle/_ref/libworld_ref.so by oracle/Makefile):
+
+    python tests/golden/make_golden.py
+
+Every fixture stores its input samples as int16 (x = q / 32768, the value the
+reference's wavread returns, tools/audioio.cpp:236-249), the exact option
+values used, and the reference outputs.  Dense spectrogram/aperiodicity are
+kept for a subset of frame rows (`rows`) to keep the files small, plus
+whole-array checksums.
+"""
+import os
+import sys
+import wave
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.loader import RefOracle, build  # noqa: E402
+from world_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def wav_int16(path):
+    w = wave.open(path)
+    assert w.getsampwidth() == 2 and w.getnchannels() == 1
+    return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy(), w.getframerate()
+
+
+def analyse(R, q, fs, f0_method, f0_floor_est, row_step, frame_period=5.0, q1=-0.15, threshold=0.85):
+    x = q.astype(np.float64) / 32768.0
+    out = {"q": q, "fs": fs, "f0_method": f0_method, "f0_floor_est": f0_floor_est,
+           "frame_period": frame_period, "q1": q1, "threshold": threshold}
+    if f0_method == "harvest":
+        tp, f0 = R.harvest(x, fs, f0_floor=f0_floor_est, frame_period=frame_period)
+    else:
+        tp, f0raw = R.dio(x, fs, f0_floor=f0_floor_est, frame_period=frame_period)
+        out["f0_dio"] = f0raw
+        f0 = R.stonemask(x, fs, tp, f0raw)
+    fft_size = R.cheaptrick_fft_size(fs, 71.0)
+    sp = R.cheaptrick(x, fs, tp, f0, q1=q1, f0_floor=71.0, fft_size=fft_size)
+    ap = R.d4c(x, fs, tp, f0, fft_size, threshold=threshold)
+    rows = np.arange(0, len(f0), row_step)
+    out.update(tp=tp, f0=f0, fft_size=fft_size, rows=rows, sp_rows=sp[rows], ap_rows=ap[rows],
+               sum_log_sp=np.log(sp).sum(), sum_ap=ap.sum(),
+               sp_row_sums=np.log(sp).sum(axis=1), ap_row_sums=ap.sum(axis=1))
+    return out
+
+
+def main():
+    build()
+    R = RefOracle()
+    q, fs = wav_int16("/root/reference/test/vaiueo2d.wav")
+    # config 0 plumbing of test/test.cpp:89-219 (DIO floor 40 + StoneMask) and its Harvest variant
+    np.savez_compressed(os.path.join(OUT, "vaiueo2d_dio.npz"), **analyse(R, q, fs, "dio", 40.0, 4))
+    np.savez_compressed(os.path.join(OUT, "vaiueo2d_harvest.npz"), **analyse(R, q, fs, "harvest", 40.0, 2))
+    # 48 kHz synthetic vowel, 1.2 s (north-star shapes: fft 2048, D4C 4096, ratio 6)
+    x = synth.vowel(48000, 1.2, seed=12345).numpy()
+    q48 = np.round(x * 32768.0).astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "vowel48k_harvest.npz"), **analyse(R, q48, 48000, "harvest", 71.0, 8))
+    # 16 kHz alt config (config 4 of BASELINE.json): DIO defaults + StoneMask, fft 1024
+    x = synth.vowel(16000, 1.5, seed=7, base_f0=180.0).numpy()
+    q16 = np.round(x * 32768.0).astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "vowel16k_dio.npz"), **analyse(R, q16, 16000, "dio", 71.0, 6))
+    # primitive known answers
+    import ctypes as C
+    L = R.lib
+    np.savez_compressed(
+        os.path.join(OUT, "primitives.npz"),
+        randn5=np.array([-1.3276404961943626, -0.62285530939698219, -1.6091805659234524,
+                         1.1797650642693043, -0.25188251212239265]),
+        interp_x=np.array([1., 2., 4., 7.]), interp_xi=np.array([-1, .5, 1, 1.5, 2, 3.9, 4, 7, 9.]),
+        interp_yi=np.array([-10, 5, 10, 15, 20, 39, 40, 70, 90.]))
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

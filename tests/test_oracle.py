@@ -1,0 +1,79 @@
+"""Pin the CPU oracle: known answers, golden fixtures generated
+from the unmodified reference (tests/golden/make_golden.py), and -- when the
+in-place build of the reference is present -- the reference itself."""
+import numpy as np
+import pytest
+
+from util import RTOL, check_against_golden, load_golden, max_rel
+
+FIXTURES = ["vaiueo2d_dio", "vaiueo2d_harvest", "vowel48k_harvest", "vowel16k_dio"]
+
+
+def test_randn_known_answers(port_oracle):
+    p = np.load(__import__("os").path.join(__import__("util").GOLDEN, "primitives.npz"))
+    assert np.array_equal(port_oracle.randn(5), p["randn5"])
+
+
+def test_interp1_known_answers(port_oracle):
+    import os, util
+    p = np.load(os.path.join(util.GOLDEN, "primitives.npz"))
+    yi = port_oracle.interp1(p["interp_x"], 10 * p["interp_x"], p["interp_xi"])
+    assert np.allclose(yi, p["interp_yi"], rtol=0, atol=1e-12)
+
+
+def test_round_quirk(port_oracle):
+    port_oracle.lib.wo_round.restype = __import__("ctypes").c_int
+    assert port_oracle.lib.wo_round(0.49999999999999994) == 1      # trunc(x + 0.5)
+    assert port_oracle.lib.wo_round(-2.5) == -3
+    assert port_oracle.lib.wo_round(2.4999) == 2
+
+
+@pytest.mark.parametrize("n", [8, 128, 1024, 4096, 65536])
+def test_fft_matches_numpy(port_oracle, n):
+    x = np.random.RandomState(n).randn(n)
+    X = port_oracle.rfft(x)
+    ref = np.fft.rfft(x)
+    assert np.max(np.abs(X - ref)) <= 1e-12 * np.sqrt(n) * np.max(np.abs(ref))
+    back = port_oracle.irfft_unscaled(ref)          # c2r == N * irfft (fft.cpp:26-35)
+    assert np.max(np.abs(back - n * x)) <= 1e-11 * n
+
+
+def test_linear_smoothing_constant(port_oracle):
+    out = port_oracle.linear_smoothing(np.full(1025, 3.0), 200.0, 48000, 2048)
+    assert np.allclose(out, 3.0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_port_matches_golden(port_oracle, name):
+    check_against_golden(port_oracle, load_golden(name), rtol=1e-7)
+
+
+def test_known_checksums_vaiueo2d():
+    g = load_golden("vaiueo2d_harvest")
+    assert int(np.sum(g["f0"] > 0)) == 145
+    assert abs(g["f0"].sum() - 17582.389350921) < 1e-6
+    assert abs(float(g["sum_log_sp"]) - (-1115356.175151584)) < 1e-4
+    assert abs(float(g["sum_ap"]) - 44220.433731155) < 1e-6
+    g = load_golden("vaiueo2d_dio")
+    assert int(np.sum(g["f0"] > 0)) == 122
+    assert abs(g["f0"].sum() - 14045.369481675) < 1e-6
+    assert g["tp"][158] == 0.79 and len(g["tp"]) == 159
+
+
+@pytest.mark.parametrize("name", FIXTURES[:2])
+def test_reference_reproduces_golden(ref_oracle, name):
+    check_against_golden(ref_oracle, load_golden(name), rtol=1e-12)
+
+
+def test_port_matches_reference_fresh_signal(port_oracle, ref_oracle):
+    """A signal that is in no fixture: chirp at 24 kHz (decimation ratio 3)."""
+    from world_amd import synth
+    x = synth.chirp(24000, 0.8, seed=99).numpy()
+    tp_r, f0_r = ref_oracle.harvest(x, 24000)
+    tp_p, f0_p = port_oracle.harvest(x, 24000)
+    assert np.array_equal(tp_r, tp_p)
+    assert np.sum((f0_r > 0) != (f0_p > 0)) == 0 and max_rel(f0_p[f0_r > 0], f0_r[f0_r > 0]) < 1e-9
+    fft = ref_oracle.cheaptrick_fft_size(24000)
+    assert max_rel(port_oracle.cheaptrick(x, 24000, tp_r, f0_r, fft_size=fft),
+                   ref_oracle.cheaptrick(x, 24000, tp_r, f0_r, fft_size=fft)) < 1e-7
+    assert max_rel(port_oracle.d4c(x, 24000, tp_r, f0_r, fft), ref_oracle.d4c(x, 24000, tp_r, f0_r, fft)) < 1e-7

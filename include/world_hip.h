@@ -1,0 +1,145 @@
+/*
+ * world_hip.h -- C ABI of libworld_hip.so, the MI355X (gfx950) implementation of
+ * the WORLD analysis path.
+ *
+ * Part 1 is the drop-in boundary: the 13 `extern "C"` analysis entry points and 4
+ * option structs of mmorise/World with identical names, layouts and argument
+ * meaning (host pointers, caller-owned buffers, `double **` row pointers for the
+ * spectrogram / aperiodicity).  Each declaration cites the reference header it
+ * replaces.  A program written against libworld.a links against libworld_hip.so
+ * unchanged for these symbols.
+ *
+ * Part 2 is the batched, device-resident API the drop-in calls are built on:
+ * many utterances per call, inputs and outputs in HBM (plain device pointers, no
+ * framework types), one HIP stream, no host synchronisation inside a call.
+ */
+#ifndef WORLD_HIP_H_
+#define WORLD_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define WORLD_HIP_API __attribute__((visibility("default")))
+#else
+#define WORLD_HIP_API
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Part 1: drop-in replacements for the reference's analysis API              */
+/* ------------------------------------------------------------------------- */
+
+/* reference src/world/dio.h:16-23 */
+typedef struct {
+  double f0_floor;
+  double f0_ceil;
+  double channels_in_octave;
+  double frame_period; /* msec */
+  int speed;           /* 1, 2, ..., 12 */
+  double allowed_range;
+} DioOption;
+
+/* reference src/world/harvest.h:16-20 */
+typedef struct {
+  double f0_floor;
+  double f0_ceil;
+  double frame_period;
+} HarvestOption;
+
+/* reference src/world/cheaptrick.h:16-20 */
+typedef struct {
+  double q1;
+  double f0_floor;
+  int fft_size;
+} CheapTrickOption;
+
+/* reference src/world/d4c.h:16-18 */
+typedef struct {
+  double threshold;
+} D4COption;
+
+/* reference src/world/dio.h:38,48,61 (src/dio.cpp:639-666) */
+WORLD_HIP_API void Dio(const double *x, int x_length, int fs, const DioOption *option,
+                       double *temporal_positions, double *f0);
+WORLD_HIP_API void InitializeDioOption(DioOption *option);
+WORLD_HIP_API int GetSamplesForDIO(int fs, int x_length, double frame_period);
+
+/* reference src/world/harvest.h:35,45,59 (src/harvest.cpp:1219-1262) */
+WORLD_HIP_API void Harvest(const double *x, int x_length, int fs, const HarvestOption *option,
+                           double *temporal_positions, double *f0);
+WORLD_HIP_API void InitializeHarvestOption(HarvestOption *option);
+WORLD_HIP_API int GetSamplesForHarvest(int fs, int x_length, double frame_period);
+
+/* reference src/world/stonemask.h:27 (src/stonemask.cpp:212-218) */
+WORLD_HIP_API void StoneMask(const double *x, int x_length, int fs, const double *temporal_positions,
+                             const double *f0, int f0_length, double *refined_f0);
+
+/* reference src/world/cheaptrick.h:38,52,65,80 (src/cheaptrick.cpp:191-240) */
+WORLD_HIP_API void CheapTrick(const double *x, int x_length, int fs, const double *temporal_positions,
+                              const double *f0, int f0_length, const CheapTrickOption *option,
+                              double **spectrogram);
+WORLD_HIP_API void InitializeCheapTrickOption(int fs, CheapTrickOption *option);
+WORLD_HIP_API int GetFFTSizeForCheapTrick(int fs, const CheapTrickOption *option);
+WORLD_HIP_API double GetF0FloorForCheapTrick(int fs, int fft_size);
+
+/* reference src/world/d4c.h:35,46 (src/d4c.cpp:342-407) */
+WORLD_HIP_API void D4C(const double *x, int x_length, int fs, const double *temporal_positions,
+                       const double *f0, int f0_length, int fft_size, const D4COption *option,
+                       double **aperiodicity);
+WORLD_HIP_API void InitializeD4COption(D4COption *option);
+
+/* ------------------------------------------------------------------------- */
+/* Part 2: batched device-resident API                                        */
+/* ------------------------------------------------------------------------- */
+/*
+ * Layout.  A batch is n_utt utterances with one sampling rate.  Every array is
+ * dense and padded to a per-batch stride:
+ *   x            [n_utt][x_stride]            samples            (device)
+ *   x_length     [n_utt]                      valid samples      (HOST)
+ *   tpos, f0     [n_utt][f_stride]            per-frame scalars  (device)
+ *   n_frames     [n_utt]                      valid frames       (HOST)
+ *   sp, ap       [n_utt][f_stride][fft/2+1]   dense rows         (device)
+ * Frame counts follow GetSamplesForHarvest/GetSamplesForDIO.  Rows/frames beyond
+ * an utterance's own count are left untouched.  All functions enqueue work on the
+ * context's stream and return without synchronising; 0 = success, non-zero =
+ * failure with the reason available from world_hip_last_error().
+ */
+typedef struct WorldHipContext WorldHipContext;
+
+/* stream = a hipStream_t to enqueue on (NULL = the device's default stream) */
+WORLD_HIP_API WorldHipContext *world_hip_create(int device, void *stream);
+WORLD_HIP_API void world_hip_destroy(WorldHipContext *ctx);
+WORLD_HIP_API const char *world_hip_last_error(void);
+WORLD_HIP_API int world_hip_sync(WorldHipContext *ctx);
+/* bytes of device workspace currently held by the context */
+WORLD_HIP_API unsigned long long world_hip_workspace_bytes(WorldHipContext *ctx);
+
+/* Per-kernel timing with HIP events on the launch stream (process-wide switch).
+ * collect() waits for the recorded kernels and returns "kernel_name ms\n" lines. */
+WORLD_HIP_API void world_hip_profile_enable(int on);
+WORLD_HIP_API int world_hip_profile_collect(char *buf, int cap);
+
+WORLD_HIP_API int world_hip_harvest_batch(WorldHipContext *ctx, int n_utt, int fs, const double *d_x,
+                                          int x_stride, const int *x_length, const HarvestOption *option,
+                                          int f_stride, double *d_tpos, double *d_f0);
+WORLD_HIP_API int world_hip_dio_batch(WorldHipContext *ctx, int n_utt, int fs, const double *d_x,
+                                      int x_stride, const int *x_length, const DioOption *option,
+                                      int f_stride, double *d_tpos, double *d_f0);
+WORLD_HIP_API int world_hip_stonemask_batch(WorldHipContext *ctx, int n_utt, int fs, const double *d_x,
+                                            int x_stride, const int *x_length, const int *n_frames,
+                                            int f_stride, const double *d_tpos, const double *d_f0,
+                                            double *d_refined_f0);
+WORLD_HIP_API int world_hip_cheaptrick_batch(WorldHipContext *ctx, int n_utt, int fs, const double *d_x,
+                                             int x_stride, const int *x_length, const int *n_frames,
+                                             int f_stride, const double *d_tpos, const double *d_f0,
+                                             const CheapTrickOption *option, double *d_spectrogram);
+WORLD_HIP_API int world_hip_d4c_batch(WorldHipContext *ctx, int n_utt, int fs, const double *d_x,
+                                      int x_stride, const int *x_length, const int *n_frames,
+                                      int f_stride, const double *d_tpos, const double *d_f0,
+                                      int fft_size, const D4COption *option, double *d_aperiodicity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WORLD_HIP_H_ */

@@ -13,8 +13,11 @@ this module.  Nothing under world_amd/ does.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _dp = C.POINTER(C.c_double)
@@ -141,97 +144,10 @@ class PortOracle(_Base):
         return ap
 
 
-class _DioOption(C.Structure):       # dio.h:16-23
-    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double), ("channels_in_octave", C.c_double),
-                ("frame_period", C.c_double), ("speed", C.c_int), ("allowed_range", C.c_double)]
-
-
-class _HarvestOption(C.Structure):   # harvest.h:16-20
-    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double), ("frame_period", C.c_double)]
-
-
-class _CheapTrickOption(C.Structure):  # cheaptrick.h:16-20
-    _fields_ = [("q1", C.c_double), ("f0_floor", C.c_double), ("fft_size", C.c_int)]
-
-
-class _D4COption(C.Structure):       # d4c.h:16-18
-    _fields_ = [("threshold", C.c_double)]
-
-
-def _rows(a):
-    """double** view over a dense 2-D array (the reference's row-pointer ABI)."""
-    ptrs = (_dp * a.shape[0])()
-    base = a.ctypes.data
-    stride = a.strides[0]
-    for i in range(a.shape[0]):
-        ptrs[i] = C.cast(base + i * stride, _dp)
-    return ptrs
-
-
-class WorldCABI(_Base):
-    """Binding of the reference's 13-symbol C ABI; works for
-    oracle/_ref/libworld_ref.so and, unchanged, for the shipped libworld_hip.so."""
-    kind = "cabi"
-
-    def __init__(self, path):
-        self.path = path
-        self.lib = L = C.CDLL(path)
-        L.Dio.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(_DioOption), _dp, _dp]
-        L.Harvest.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(_HarvestOption), _dp, _dp]
-        L.StoneMask.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
-        L.CheapTrick.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int,
-                                 C.POINTER(_CheapTrickOption), C.POINTER(_dp)]
-        L.D4C.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int,
-                          C.POINTER(_D4COption), C.POINTER(_dp)]
-        L.GetSamplesForDIO.argtypes = [C.c_int, C.c_int, C.c_double]
-        L.GetSamplesForHarvest.argtypes = [C.c_int, C.c_int, C.c_double]
-        L.GetFFTSizeForCheapTrick.argtypes = [C.c_int, C.POINTER(_CheapTrickOption)]
-        L.GetF0FloorForCheapTrick.argtypes = [C.c_int, C.c_int]
-        L.GetF0FloorForCheapTrick.restype = C.c_double
-        L.InitializeCheapTrickOption.argtypes = [C.c_int, C.POINTER(_CheapTrickOption)]
-
-    def harvest(self, x, fs, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0):
-        x = _f64(x)
-        opt = _HarvestOption(); self.lib.InitializeHarvestOption(C.byref(opt))
-        opt.f0_floor, opt.f0_ceil, opt.frame_period = f0_floor, f0_ceil, frame_period
-        nf = self.lib.GetSamplesForHarvest(fs, len(x), frame_period)
-        tp = np.zeros(nf); f0 = np.zeros(nf)
-        self.lib.Harvest(_p(x), len(x), fs, C.byref(opt), _p(tp), _p(f0))
-        return tp, f0
-
-    def dio(self, x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_period=5.0,
-            speed=1, allowed_range=0.1):
-        x = _f64(x)
-        opt = _DioOption(); self.lib.InitializeDioOption(C.byref(opt))
-        opt.f0_floor, opt.f0_ceil, opt.channels_in_octave = f0_floor, f0_ceil, channels_in_octave
-        opt.frame_period, opt.speed, opt.allowed_range = frame_period, speed, allowed_range
-        nf = self.lib.GetSamplesForDIO(fs, len(x), frame_period)
-        tp = np.zeros(nf); f0 = np.zeros(nf)
-        self.lib.Dio(_p(x), len(x), fs, C.byref(opt), _p(tp), _p(f0))
-        return tp, f0
-
-    def stonemask(self, x, fs, tp, f0):
-        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
-        out = np.zeros(len(f0))
-        self.lib.StoneMask(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), _p(out))
-        return out
-
-    def cheaptrick(self, x, fs, tp, f0, q1=-0.15, f0_floor=71.0, fft_size=None):
-        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
-        opt = _CheapTrickOption(); self.lib.InitializeCheapTrickOption(fs, C.byref(opt))
-        opt.q1, opt.f0_floor = q1, f0_floor
-        opt.fft_size = fft_size or self.lib.GetFFTSizeForCheapTrick(fs, C.byref(opt))
-        sp = np.zeros((len(f0), opt.fft_size // 2 + 1))
-        self.lib.CheapTrick(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), C.byref(opt), _rows(sp))
-        return sp
-
-    def d4c(self, x, fs, tp, f0, fft_size, threshold=0.85):
-        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
-        opt = _D4COption(); self.lib.InitializeD4COption(C.byref(opt))
-        opt.threshold = threshold
-        ap = np.zeros((len(f0), fft_size // 2 + 1))
-        self.lib.D4C(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, C.byref(opt), _rows(ap))
-        return ap
+# The generic binding of the reference's 13-symbol C ABI lives in the product's
+# Python mirror (world_amd/api.py: HostAPI); the oracle side only points it at
+# the in-place build of the reference.
+from world_amd.api import HostAPI as WorldCABI  # noqa: E402
 
 
 def _cpu_has(flag):

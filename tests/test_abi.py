@@ -1,0 +1,65 @@
+"""The C-ABI library: builds for gfx950 (hipcc cross-compiles without a GPU), loads,
+and exports every symbol include/world_hip.h declares.  No compute calls here."""
+import ctypes
+import os
+import re
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    from world_amd import build
+    return build.build()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "world_hip.h")).read()
+    return sorted(set(re.findall(r"WORLD_HIP_API\s+[\w\s\*]+?\b(\w+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_api():
+    names = declared_symbols()
+    for must in ["Dio", "InitializeDioOption", "GetSamplesForDIO", "Harvest", "InitializeHarvestOption",
+                 "GetSamplesForHarvest", "StoneMask", "CheapTrick", "InitializeCheapTrickOption",
+                 "GetFFTSizeForCheapTrick", "GetF0FloorForCheapTrick", "D4C", "InitializeD4COption"]:
+        assert must in names          # the 13 symbols of SURVEY.md 8b
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_option_helpers_are_host_arithmetic(lib_path):
+    """these never touch the GPU, so they can be checked here"""
+    from world_amd.api import CheapTrickOption, DioOption, HarvestOption, load_library
+    lib = load_library(lib_path)
+    h = HarvestOption(); lib.InitializeHarvestOption(ctypes.byref(h))
+    assert (h.f0_floor, h.f0_ceil, h.frame_period) == (71.0, 800.0, 5.0)
+    d = DioOption(); lib.InitializeDioOption(ctypes.byref(d))
+    assert (d.f0_floor, d.f0_ceil, d.channels_in_octave, d.frame_period, d.speed, d.allowed_range) == \
+        (71.0, 800.0, 2.0, 5.0, 1, 0.1)
+    c = CheapTrickOption(); lib.InitializeCheapTrickOption.argtypes = [ctypes.c_int, ctypes.POINTER(CheapTrickOption)]
+    lib.InitializeCheapTrickOption(48000, ctypes.byref(c))
+    assert (c.q1, c.f0_floor, c.fft_size) == (-0.15, 71.0, 2048)
+    lib.InitializeCheapTrickOption(16000, ctypes.byref(c)); assert c.fft_size == 1024
+    lib.GetSamplesForHarvest.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    assert lib.GetSamplesForHarvest(22050, 17500, 5.0) == 159
+    lib.GetF0FloorForCheapTrick.restype = ctypes.c_double
+    lib.GetF0FloorForCheapTrick.argtypes = [ctypes.c_int, ctypes.c_int]
+    assert lib.GetF0FloorForCheapTrick(48000, 2048) == 3.0 * 48000 / (2048 - 3.0)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from world_amd.api import HostAPI, load_library
+    with pytest.raises(ImportError):
+        load_library(str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        HostAPI(str(tmp_path / "nope.so"))

@@ -1,0 +1,132 @@
+"""Parity tests proper: the HIP path (through the C ABI of libworld_hip.so) against
+the golden fixtures generated from the unmodified reference, against the CPU oracle
+on seeded inputs, and -- at BASELINE.json's full sizes -- through size-independent
+properties.  Tolerance (north_star): frame counts / temporal positions bit-exact;
+F0, spectral envelope, aperiodicity within 1e-4 relative."""
+import numpy as np
+import pytest
+
+from util import RTOL, assert_f0_close, check_against_golden, load_golden, max_rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from world_amd.api import HostAPI
+    return HostAPI()          # raises if libworld_hip.so is missing: no fallback
+
+
+@pytest.fixture(scope="module")
+def wh():
+    from world_amd.api import WorldHip
+    return WorldHip()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle.loader import best_oracle
+    return best_oracle()
+
+
+@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest"])
+def test_pipeline_matches_golden(hip, name):
+    check_against_golden(hip, load_golden(name), rtol=RTOL)
+
+
+@pytest.mark.parametrize("name", ["vaiueo2d_dio", "vowel16k_dio"])
+def test_spectral_stages_match_golden_given_f0(hip, name):
+    check_against_golden(hip, load_golden(name), rtol=RTOL, given_f0=True)
+
+
+@pytest.mark.parametrize("fs,seconds,kind", [(48000, 1.0, "vowel"), (24000, 0.8, "chirp"), (16000, 1.2, "vowel"),
+                                             (44100, 0.7, "chirp")])
+def test_matches_oracle_on_fresh_signals(hip, oracle, fs, seconds, kind):
+    from world_amd import synth
+    x = (synth.vowel(fs, seconds, seed=fs + 1) if kind == "vowel" else synth.chirp(fs, seconds, seed=fs + 2)).numpy()
+    tp_o, f0_o = oracle.harvest(x, fs)
+    tp, f0 = hip.harvest(x, fs)
+    assert np.array_equal(tp, tp_o)
+    assert_f0_close(f0, f0_o)
+    fft = hip.cheaptrick_fft_size(fs)
+    assert max_rel(hip.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft), oracle.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft)) <= RTOL
+    assert max_rel(hip.d4c(x, fs, tp_o, f0_o, fft), oracle.d4c(x, fs, tp_o, f0_o, fft)) <= RTOL
+
+
+def test_edge_cases(hip, oracle):
+    """tiny / ragged / silent / clipped inputs and unusual options"""
+    from world_amd import synth
+    fs = 16000
+    # silence: exact zeros -> spectrum is pure RNG stream
+    x = np.zeros(4000)
+    tp, f0 = hip.harvest(x, fs)
+    assert np.all(f0 == 0) and len(f0) == oracle.frame_count(fs, 4000, 5.0)
+    fft = hip.cheaptrick_fft_size(fs)
+    assert max_rel(hip.cheaptrick(x, fs, tp, f0, fft_size=fft), oracle.cheaptrick(x, fs, tp, f0, fft_size=fft)) <= RTOL
+    assert np.all(hip.d4c(x, fs, tp, f0, fft) == 1.0 - 1e-12)
+    # odd length, non-default frame period / floor / ceil / q1 / threshold
+    x = synth.vowel(22050, 0.9, seed=5).numpy()[:19001]
+    tp_o, f0_o = oracle.harvest(x, 22050, f0_floor=50.0, f0_ceil=600.0, frame_period=2.5)
+    tp, f0 = hip.harvest(x, 22050, f0_floor=50.0, f0_ceil=600.0, frame_period=2.5)
+    assert np.array_equal(tp, tp_o)
+    assert_f0_close(f0, f0_o)
+    assert max_rel(hip.cheaptrick(x, 22050, tp_o, f0_o, q1=-0.1, fft_size=1024),
+                   oracle.cheaptrick(x, 22050, tp_o, f0_o, q1=-0.1, fft_size=1024)) <= RTOL
+    assert max_rel(hip.d4c(x, 22050, tp_o, f0_o, 1024, threshold=0.5), oracle.d4c(x, 22050, tp_o, f0_o, 1024, threshold=0.5)) <= RTOL
+    # frame_period 1 ms (the reference's direct path, harvest.cpp:1230-1235)
+    tp_o, f0_o = oracle.harvest(x[:8000], 22050, frame_period=1.0)
+    tp, f0 = hip.harvest(x[:8000], 22050, frame_period=1.0)
+    assert np.array_equal(tp, tp_o)
+    assert_f0_close(f0, f0_o)
+
+
+def test_batched_equals_single_calls(hip, wh):
+    """ragged batch through the device API == one drop-in call per utterance"""
+    import torch
+    from world_amd import synth
+    fs = 48000
+    xs = [synth.utterance(i, fs, s).numpy() for i, s in [(0, 0.9), (1, 0.6), (2, 0.75)]]
+    L = max(len(x) for x in xs)
+    xb = torch.zeros((3, L), dtype=torch.float64)
+    for i, x in enumerate(xs):
+        xb[i, :len(x)] = torch.from_numpy(x)
+    xb = xb.cuda()
+    tpos, f0, sp, ap, nf = wh.analyze(xb, fs, x_len=[len(x) for x in xs])
+    torch.cuda.synchronize()
+    for i, x in enumerate(xs):
+        tp_s, f0_s = hip.harvest(x, fs)
+        n = len(f0_s)
+        assert nf[i] == n
+        assert np.array_equal(tpos[i, :n].cpu().numpy(), tp_s)
+        assert np.array_equal(f0[i, :n].cpu().numpy(), f0_s)
+        sp_s = hip.cheaptrick(x, fs, tp_s, f0_s, fft_size=2048)
+        ap_s = hip.d4c(x, fs, tp_s, f0_s, 2048)
+        assert max_rel(sp[i, :n].cpu().numpy(), sp_s) <= 1e-12
+        assert max_rel(ap[i, :n].cpu().numpy(), ap_s) <= 1e-9
+
+
+def test_full_size_properties(wh):
+    """BASELINE.json config 1 shape (48 kHz, 10 s): properties that need no oracle"""
+    import torch
+    from world_amd import synth
+    fs = 48000
+    x = synth.vowel(fs, 10.0, seed=12345, device="cuda")
+    xb = torch.stack([x, x])                       # duplicated utterance -> identical rows
+    tpos, f0, sp, ap, nf = wh.analyze(xb, fs)
+    torch.cuda.synchronize()
+    assert list(nf) == [2001, 2001] and sp.shape == (2, 2001, 1025)
+    assert torch.equal(tpos[0], torch.arange(2001, dtype=torch.float64, device="cuda") * 5.0 / 1000.0)
+    assert torch.equal(f0[0], f0[1]) and torch.equal(sp[0], sp[1]) and torch.equal(ap[0], ap[1])
+    voiced = f0[0] > 0
+    assert 0.6 < voiced.double().mean().item() < 0.95            # gated 1.6 s on / 0.4 s off
+    assert f0[0][voiced].min() >= 71.0 and f0[0][voiced].max() <= 800.0
+    assert torch.isfinite(sp).all() and (sp > 0).all()
+    assert (ap > 0).all() and (ap <= 1.0).all()
+    assert (ap[0][~voiced] == 1.0 - 1e-12).all()                 # unvoiced rows: d4c.cpp:323-328
+    # F0 tracks the generator's instantaneous frequency where voiced
+    t = tpos[0]
+    f_true = 140.0 + 40.0 * torch.sin(2 * np.pi * 0.7 * t) + 3.0 * torch.sin(2 * np.pi * 5.5 * t)
+    err = ((f0[0] - f_true).abs() / f_true)[voiced]
+    assert err.median().item() < 0.01

@@ -1,0 +1,324 @@
+"""Python face of libworld_hip.so (ctypes; the library is the product, this file is
+plumbing).
+
+Two levels, mirroring include/world_hip.h:
+
+* ``WorldHip``  -- the batched, device-resident API.  Inputs/outputs are torch
+  CUDA(=HIP) tensors of dtype float64; work is enqueued on torch's current
+  stream; nothing synchronises.
+* module-level ``harvest / dio / stonemask / cheaptrick / d4c`` -- numpy in, numpy
+  out, same argument meaning as the reference's C functions of the same names
+  (they call the library's drop-in host-pointer entry points).
+
+The extension must exist: importing this module on a machine where
+``libworld_hip.so`` has not been built raises immediately (no fallback path).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libworld_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class DioOption(C.Structure):        # include/world_hip.h (reference dio.h:16-23)
+    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double), ("channels_in_octave", C.c_double),
+                ("frame_period", C.c_double), ("speed", C.c_int), ("allowed_range", C.c_double)]
+
+
+class HarvestOption(C.Structure):    # reference harvest.h:16-20
+    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double), ("frame_period", C.c_double)]
+
+
+class CheapTrickOption(C.Structure):  # reference cheaptrick.h:16-20
+    _fields_ = [("q1", C.c_double), ("f0_floor", C.c_double), ("fft_size", C.c_int)]
+
+
+class D4COption(C.Structure):        # reference d4c.h:16-18
+    _fields_ = [("threshold", C.c_double)]
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -m world_amd.build` "
+                          "(hipcc, gfx950). There is no non-GPU fallback.")
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.world_hip_create.restype = vp
+    lib.world_hip_create.argtypes = [C.c_int, vp]
+    lib.world_hip_destroy.argtypes = [vp]
+    lib.world_hip_last_error.restype = C.c_char_p
+    lib.world_hip_sync.argtypes = [vp]
+    lib.world_hip_workspace_bytes.restype = C.c_ulonglong
+    lib.world_hip_workspace_bytes.argtypes = [vp]
+    lib.world_hip_harvest_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(HarvestOption),
+                                            C.c_int, vp, vp]
+    lib.world_hip_dio_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(DioOption),
+                                        C.c_int, vp, vp]
+    lib.world_hip_stonemask_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp, vp]
+    lib.world_hip_cheaptrick_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp,
+                                               C.POINTER(CheapTrickOption), vp]
+    lib.world_hip_d4c_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp, C.c_int,
+                                        C.POINTER(D4COption), vp]
+    lib.GetFFTSizeForCheapTrick.argtypes = [C.c_int, C.POINTER(CheapTrickOption)]
+    lib.world_hip_profile_enable.argtypes = [C.c_int]
+    lib.world_hip_profile_collect.argtypes = [C.c_char_p, C.c_int]
+    return lib
+
+
+def frame_count(fs, x_length, frame_period):
+    """GetSamplesForHarvest / GetSamplesForDIO."""
+    return int(1000.0 * x_length / fs / frame_period) + 1
+
+
+def cheaptrick_fft_size(fs, f0_floor=71.0):
+    import math
+    return int(2.0 ** (1.0 + int(math.log(3.0 * fs / f0_floor + 1) / 0.69314718055994529)))
+
+
+def _ints(v):
+    a = np.ascontiguousarray(v, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _rows(a):
+    """double** view over a dense 2-D array (the reference's row-pointer ABI)."""
+    ptrs = (_dp * a.shape[0])()
+    base, stride = a.ctypes.data, a.strides[0]
+    for i in range(a.shape[0]):
+        ptrs[i] = C.cast(base + i * stride, _dp)
+    return ptrs
+
+
+class HostAPI:
+    """numpy binding of the reference's 13-symbol C ABI.  It is the
+    ctypes stub a user of the reference library would write; it works unchanged on
+    libworld_hip.so (default) and on any build of the reference itself."""
+    kind = "cabi"
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing (python -m world_amd.build); there is no fallback.")
+        self.path = path
+        self.lib = L = C.CDLL(path)
+        L.Dio.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(DioOption), _dp, _dp]
+        L.Harvest.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(HarvestOption), _dp, _dp]
+        L.StoneMask.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        L.CheapTrick.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.POINTER(CheapTrickOption),
+                                 C.POINTER(_dp)]
+        L.D4C.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.POINTER(D4COption), C.POINTER(_dp)]
+        L.GetSamplesForDIO.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.GetSamplesForHarvest.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.GetFFTSizeForCheapTrick.argtypes = [C.c_int, C.POINTER(CheapTrickOption)]
+        L.GetF0FloorForCheapTrick.argtypes = [C.c_int, C.c_int]
+        L.GetF0FloorForCheapTrick.restype = C.c_double
+        L.InitializeCheapTrickOption.argtypes = [C.c_int, C.POINTER(CheapTrickOption)]
+
+    def frame_count(self, fs, n, frame_period):
+        return frame_count(fs, n, frame_period)
+
+    def cheaptrick_fft_size(self, fs, f0_floor=71.0):
+        return cheaptrick_fft_size(fs, f0_floor)
+
+    def harvest(self, x, fs, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0):
+        x = _f64(x)
+        opt = HarvestOption(); self.lib.InitializeHarvestOption(C.byref(opt))
+        opt.f0_floor, opt.f0_ceil, opt.frame_period = f0_floor, f0_ceil, frame_period
+        nf = self.lib.GetSamplesForHarvest(fs, len(x), frame_period)
+        tp = np.zeros(nf); f0 = np.zeros(nf)
+        self.lib.Harvest(_p(x), len(x), fs, C.byref(opt), _p(tp), _p(f0))
+        return tp, f0
+
+    def dio(self, x, fs, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_period=5.0,
+            speed=1, allowed_range=0.1):
+        x = _f64(x)
+        opt = DioOption(); self.lib.InitializeDioOption(C.byref(opt))
+        opt.f0_floor, opt.f0_ceil, opt.channels_in_octave = f0_floor, f0_ceil, channels_in_octave
+        opt.frame_period, opt.speed, opt.allowed_range = frame_period, speed, allowed_range
+        nf = self.lib.GetSamplesForDIO(fs, len(x), frame_period)
+        tp = np.zeros(nf); f0 = np.zeros(nf)
+        self.lib.Dio(_p(x), len(x), fs, C.byref(opt), _p(tp), _p(f0))
+        return tp, f0
+
+    def stonemask(self, x, fs, tp, f0):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        out = np.zeros(len(f0))
+        self.lib.StoneMask(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), _p(out))
+        return out
+
+    def cheaptrick(self, x, fs, tp, f0, q1=-0.15, f0_floor=71.0, fft_size=None):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        opt = CheapTrickOption(); self.lib.InitializeCheapTrickOption(fs, C.byref(opt))
+        opt.q1, opt.f0_floor = q1, f0_floor
+        opt.fft_size = fft_size or self.lib.GetFFTSizeForCheapTrick(fs, C.byref(opt))
+        sp = np.zeros((len(f0), opt.fft_size // 2 + 1))
+        self.lib.CheapTrick(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), C.byref(opt), _rows(sp))
+        return sp
+
+    def d4c(self, x, fs, tp, f0, fft_size, threshold=0.85):
+        x, tp, f0 = _f64(x), _f64(tp), _f64(f0)
+        opt = D4COption(); self.lib.InitializeD4COption(C.byref(opt))
+        opt.threshold = threshold
+        ap = np.zeros((len(f0), fft_size // 2 + 1))
+        self.lib.D4C(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, C.byref(opt), _rows(ap))
+        return ap
+
+
+class WorldHip:
+    """Batched analysis on one GPU.  Tensors: x [B, L] float64 on the GPU."""
+
+    def __init__(self, device=None, lib_path=LIB_PATH):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("WorldHip needs a GPU (torch.cuda.is_available() is False)")
+        self.lib = load_library(lib_path)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.ctx = None
+        self._stream = None
+
+    def _context(self):
+        """One library context per torch stream in use (created lazily)."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        if self.ctx is None or s != self._stream:
+            if self.ctx is not None:
+                self.lib.world_hip_destroy(self.ctx)
+            self.ctx = self.lib.world_hip_create(self.device.index, C.c_void_p(s))
+            if not self.ctx:
+                raise RuntimeError("world_hip_create: " + self.lib.world_hip_last_error().decode())
+            self._stream = s
+        return self.ctx
+
+    def close(self):
+        if self.ctx is not None:
+            self.lib.world_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.world_hip_last_error().decode()}")
+
+    def _prep(self, x, x_len):
+        t = self.torch
+        assert x.dtype == t.float64 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+        B, L = x.shape
+        if x_len is None:
+            x_len = [L] * B
+        return B, L, np.ascontiguousarray(x_len, dtype=np.int32)
+
+    def profile(self, fn):
+        """Run fn() with per-kernel HIP-event timing; returns {kernel: [ms per launch, ...]}."""
+        self._context()
+        self.lib.world_hip_profile_enable(1)
+        try:
+            fn()
+        finally:
+            self.lib.world_hip_profile_enable(0)
+        buf = C.create_string_buffer(1 << 22)
+        if self.lib.world_hip_profile_collect(buf, len(buf)) < 0:
+            raise RuntimeError("profile: " + self.lib.world_hip_last_error().decode())
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms = line.split()
+            out.setdefault(name, []).append(float(ms))
+        return out
+
+    def workspace_bytes(self):
+        return int(self.lib.world_hip_workspace_bytes(self._context()))
+
+    # ---- F0 ----
+    def harvest(self, x, fs, x_len=None, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0):
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        nf = np.array([frame_count(fs, int(n), frame_period) for n in xl], dtype=np.int32)
+        F = int(nf.max())
+        tpos = t.zeros((B, F), dtype=t.float64, device=x.device)
+        f0 = t.zeros((B, F), dtype=t.float64, device=x.device)
+        opt = HarvestOption(f0_floor, f0_ceil, frame_period)
+        self._check(self.lib.world_hip_harvest_batch(self._context(), B, fs, x.data_ptr(), L,
+                                                     xl.ctypes.data_as(_ip), C.byref(opt), F,
+                                                     tpos.data_ptr(), f0.data_ptr()), "harvest")
+        return tpos, f0, nf
+
+    def dio(self, x, fs, x_len=None, f0_floor=71.0, f0_ceil=800.0, channels_in_octave=2.0, frame_period=5.0,
+            speed=1, allowed_range=0.1):
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        nf = np.array([frame_count(fs, int(n), frame_period) for n in xl], dtype=np.int32)
+        F = int(nf.max())
+        tpos = t.zeros((B, F), dtype=t.float64, device=x.device)
+        f0 = t.zeros((B, F), dtype=t.float64, device=x.device)
+        opt = DioOption(f0_floor, f0_ceil, channels_in_octave, frame_period, speed, allowed_range)
+        self._check(self.lib.world_hip_dio_batch(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
+                                                 C.byref(opt), F, tpos.data_ptr(), f0.data_ptr()), "dio")
+        return tpos, f0, nf
+
+    def stonemask(self, x, fs, tpos, f0, n_frames, x_len=None):
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        nf = np.ascontiguousarray(n_frames, dtype=np.int32)
+        out = t.zeros_like(f0)
+        self._check(self.lib.world_hip_stonemask_batch(self._context(), B, fs, x.data_ptr(), L,
+                                                       xl.ctypes.data_as(_ip), nf.ctypes.data_as(_ip), f0.shape[1],
+                                                       tpos.data_ptr(), f0.data_ptr(), out.data_ptr()), "stonemask")
+        return out
+
+    # ---- spectral stages ----
+    def cheaptrick(self, x, fs, tpos, f0, n_frames, x_len=None, q1=-0.15, f0_floor=71.0, fft_size=None, out=None):
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        nf = np.ascontiguousarray(n_frames, dtype=np.int32)
+        fft_size = fft_size or cheaptrick_fft_size(fs, f0_floor)
+        F = f0.shape[1]
+        sp = out if out is not None else t.zeros((B, F, fft_size // 2 + 1), dtype=t.float64, device=x.device)
+        opt = CheapTrickOption(q1, f0_floor, fft_size)
+        self._check(self.lib.world_hip_cheaptrick_batch(self._context(), B, fs, x.data_ptr(), L,
+                                                        xl.ctypes.data_as(_ip), nf.ctypes.data_as(_ip), F,
+                                                        tpos.data_ptr(), f0.data_ptr(), C.byref(opt),
+                                                        sp.data_ptr()), "cheaptrick")
+        return sp
+
+    def d4c(self, x, fs, tpos, f0, n_frames, fft_size, x_len=None, threshold=0.85, out=None):
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        nf = np.ascontiguousarray(n_frames, dtype=np.int32)
+        F = f0.shape[1]
+        ap = out if out is not None else t.zeros((B, F, fft_size // 2 + 1), dtype=t.float64, device=x.device)
+        opt = D4COption(threshold)
+        self._check(self.lib.world_hip_d4c_batch(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
+                                                 nf.ctypes.data_as(_ip), F, tpos.data_ptr(), f0.data_ptr(),
+                                                 fft_size, C.byref(opt), ap.data_ptr()), "d4c")
+        return ap
+
+    def analyze(self, x, fs, x_len=None, f0_method="harvest", frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
+                q1=-0.15, threshold=0.85, sp_out=None, ap_out=None):
+        """The north-star pipeline: F0 (Harvest, or DIO+StoneMask) -> CheapTrick -> D4C."""
+        if f0_method == "harvest":
+            tpos, f0, nf = self.harvest(x, fs, x_len, f0_floor, f0_ceil, frame_period)
+        elif f0_method == "dio":
+            tpos, f0_raw, nf = self.dio(x, fs, x_len, f0_floor, f0_ceil, frame_period=frame_period)
+            f0 = self.stonemask(x, fs, tpos, f0_raw, nf, x_len)
+        else:
+            raise ValueError(f0_method)
+        fft_size = cheaptrick_fft_size(fs, 71.0)
+        sp = self.cheaptrick(x, fs, tpos, f0, nf, x_len, q1=q1, fft_size=fft_size, out=sp_out)
+        ap = self.d4c(x, fs, tpos, f0, nf, fft_size, x_len, threshold=threshold, out=ap_out)
+        return tpos, f0, sp, ap, nf

@@ -1,0 +1,187 @@
+// cheaptrick.hip -- CheapTrick spectral envelope on gfx950.
+//
+// Replaces CheapTrick() / CheapTrickGeneralBody() (reference src/cheaptrick.cpp:22-229)
+// and the helpers it pulls from src/common.cpp (DCCorrection :56-75,
+// LinearSmoothing :27-111).  The reference walks frames serially with one RNG
+// stream; here every frame is an independent workgroup:
+//
+//   ct_prepare : per utterance, prefix-sum of randn() calls consumed per frame
+//                -> each frame's xorshift128 state by GF(2) jump-ahead.
+//   ct_frame   : one 256-thread workgroup per (frame, utterance), everything in
+//                LDS: F0-adaptive window + noise -> r2c FFT -> |X|^2 -> DC
+//                correction -> mirrored prefix sum (kept SERIAL and in FP64
+//                order: its rounding is visible in low-energy bins, SURVEY.md
+//                H2) -> rectangular smoothing -> +|randn|*eps -> log -> r2c FFT
+//                (cepstrum) -> lifter -> c2r FFT -> exp -> HBM.
+//
+// HBM traffic per frame: the window's samples of x (L2-resident: adjacent
+// frames overlap ~97%) and one row of the spectrogram written once.
+#include "stage_params.h"
+
+namespace world_hip {
+
+__device__ __forceinline__ double ct_effective_f0(double f0, double floor_f0) {
+  return f0 <= floor_f0 ? kDefaultF0 : f0;              // cheaptrick.cpp:218
+}
+
+// ---------------------------------------------------------------------------
+__global__ void ct_prepare(CtParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  int u = blockIdx.x;
+  int nf = p.b.n_frames[u];
+  int nb = (1 << p.lg_fft) / 2 + 1;
+  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
+  Xs128 *st = p.states + (size_t)u * p.b.f_stride;
+  unsigned running = 0;
+  for (int base = 0; base < nf; base += blockDim.x) {
+    int f = base + threadIdx.x;
+    int cnt = 0;
+    if (f < nf) {
+      double cf0 = ct_effective_f0(f0[f], p.f0_floor);
+      cnt = 2 * mround(1.5 * p.b.fs / cf0) + 1 + nb;     // window draws, then one per bin
+    }
+    int total, off = block_excl_scan_int(cnt, &total, scratch);
+    if (f < nf) st[f] = xs_jump(p.tab.jump, xs_seed(), running + (unsigned)off);
+    running += (unsigned)total;
+  }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ct_frame(CtParams p) {
+  DYN_LDS(lds);
+  const int lgn = p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
+  const int fs = p.b.fs;
+  const int u = blockIdx.y, f = blockIdx.x;
+  if (f >= p.b.n_frames[u]) return;
+
+  // LDS carve-up (bytes): Z: 8N | P: 8(nb+1) | seg: 8*seg_len | scratch: 512
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  double *Zr = reinterpret_cast<double *>(lds);
+  double *P = Zr + N;
+  const int seg_cap = nb + 2 * (N / 3 + 2) + 1;
+  double *seg = P + (nb + 1);
+  double *scratch = seg + seg_cap + (seg_cap & 1);
+
+  const double *x = p.b.x + (size_t)u * p.b.x_stride;
+  const int x_len = p.b.x_len[u];
+  const double pos = p.tpos[(size_t)u * p.b.f_stride + f];
+  const double cf0 = ct_effective_f0(p.f0[(size_t)u * p.b.f_stride + f], p.f0_floor);
+  Xs128 st = p.states[(size_t)u * p.b.f_stride + f];
+  const int tid = threadIdx.x, nt = blockDim.x;
+
+  // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) -------------------------
+  const int hw = mround(1.5 * fs / cf0);
+  const int wlen = 2 * hw + 1;
+  const int origin = mround(pos * fs + 0.001);
+  // noise first (draw order = sample order), window shape into seg
+  block_randn_fill(p.tab.jump, st, wlen, kTiny, false, Zr);
+  double e = 0.0;
+  for (int i = tid; i < wlen; i += nt) {
+    double position = (i - hw) / 1.5 / fs;
+    double w = 0.5 * cos(kPi * position * cf0) + 0.5;
+    seg[i] = w;
+    e += w * w;
+  }
+  e = sqrt(block_sum(e, scratch));
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < wlen; i += nt) {
+    double w = seg[i] / e;
+    seg[i] = w;
+    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + Zr[i];
+    Zr[i] = v;
+    s1 += v; s2 += w;
+  }
+  block_sum2(s1, s2, scratch);
+  const double coef = s1 / s2;
+  for (int i = tid; i < N; i += nt) Zr[i] = i < wlen ? Zr[i] - seg[i] * coef : 0.0;
+
+  // ---- GetPowerSpectrum (cheaptrick.cpp:64-82): r2c, |X|^2 -----------------
+  block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
+
+  // DCCorrection (common.cpp:56-75); replica staged in seg, then added
+  {
+    const int upper = 2 + static_cast<int>(cf0 * N / fs);
+    const int nrep = upper - 1;
+    const double dx = -static_cast<double>(fs) / N;
+    for (int i = tid; i < nrep; i += nt) {
+      double axis = static_cast<double>(i) * fs / N;
+      seg[i] = interp_uniform(cf0, dx, P, upper + 1, axis);
+    }
+    __syncthreads();
+    for (int i = tid; i < nrep; i += nt) P[i] = P[i] + seg[i];
+    __syncthreads();
+  }
+
+  // ---- LinearSmoothing (common.cpp:27-111), width = 2/3 f0 -----------------
+  const double width = cf0 * 2.0 / 3.0;
+  const int bnd = static_cast<int>(width * N / fs) + 1;
+  const int seg_len = half + 2 * bnd + 1;
+  for (int i = tid; i < seg_len; i += nt) {
+    double m;
+    if (i < bnd) m = P[bnd - i];
+    else if (i < half + bnd) m = P[i - bnd];
+    else m = P[half - (i - (half + bnd))];
+    seg[i] = m * fs / N;
+  }
+  // Per-bin noise draws continue the frame's stream after the window draws
+  // (cheaptrick.cpp:147-151).  They land in Zr[0..nb) while one lane runs the
+  // order-sensitive serial prefix sum.
+  Xs128 st_bins = xs_jump(p.tab.jump, st, (unsigned)wlen);
+  __syncthreads();
+  if (tid == 0) {
+    double acc = seg[0];
+    for (int i = 1; i < seg_len; ++i) { acc = seg[i] + acc; seg[i] = acc; }
+  }
+  block_randn_fill(p.tab.jump, st_bins, nb, kEps, true, Zr);
+  __syncthreads();
+  {
+    const double origin_axis = -(bnd - 0.5) * fs / N;
+    const double step = static_cast<double>(fs) / N;
+    for (int i = tid; i <= half; i += nt) {
+      double fa = static_cast<double>(i) / N * fs - width / 2.0;
+      double lo = interp_uniform(origin_axis, step, seg, seg_len, fa);
+      fa += width;
+      double hi = interp_uniform(origin_axis, step, seg, seg_len, fa);
+      double smoothed = (hi - lo) / width;
+      // AddInfinitesimalNoise, then the log of SmoothingWithRecovery (:39-42)
+      double lg = log(smoothed + Zr[i]);
+      P[i] = lg;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) Zr[i] = i <= half ? P[i] : P[N - i];
+  }
+
+  // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
+  const double q1 = p.q1;
+  block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) {
+    (void)im;
+    double sl, cl;
+    if (k == 0) {
+      sl = 1.0;
+      cl = (1.0 - 2.0 * q1) + 2.0 * q1;
+    } else {
+      double quef = static_cast<double>(k) / fs;
+      sl = sin(kPi * cf0 * quef) / (kPi * cf0 * quef);
+      cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * quef * cf0);
+    }
+    P[k] = re * sl * cl / N;
+  });
+  block_irfft(Z, lgn, p.tab.tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
+  double *out = p.spectrogram + ((size_t)u * p.b.f_stride + f) * nb;
+  for (int i = tid; i <= half; i += nt) out[i] = exp(Zr[i]);
+}
+
+// ---------------------------------------------------------------------------
+size_t ct_frame_lds_bytes(int lg_fft) {
+  int N = 1 << lg_fft, nb = N / 2 + 1;
+  int seg_cap = nb + 2 * (N / 3 + 2) + 1;
+  return sizeof(double) * (size_t)(N + nb + 1 + seg_cap + (seg_cap & 1) + 64);
+}
+
+void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
+  WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(ct_frame, dim3(max_frames, p.b.n_utt), 256, ct_frame_lds_bytes(p.lg_fft), stream, p);
+}
+
+}  // namespace world_hip

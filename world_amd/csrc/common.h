@@ -1,0 +1,56 @@
+// common.h -- constants and small device helpers shared by the stage kernels.
+#pragma once
+#include "devrt.h"
+#include "fft.h"
+#include "rng.h"
+#include "tables.h"
+
+namespace world_hip {
+
+// reference src/world/constantnumbers.h:8-37 (values are part of the contract)
+constexpr double kPi = 3.1415926535897932384;
+constexpr double kTiny = 0.000000000001;           // kMySafeGuardMinimum
+constexpr double kEps = 0.00000000000000022204460492503131;
+constexpr double kLog2 = 0.69314718055994529;
+constexpr double kDefaultF0 = 500.0;
+constexpr double kFloorF0D4C = 47.0;
+constexpr double kSafeGuardD4C = 0.000001;
+constexpr double kMaximumValue = 100000.0;
+
+// matlab_round(), src/matlabfunctions.cpp:206-208: truncation of x +- 0.5
+__host__ __device__ __forceinline__ int mround(double x) {
+  return x > 0 ? static_cast<int>(x + 0.5) : static_cast<int>(x - 0.5);
+}
+__host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// interp1Q (src/matlabfunctions.cpp:214-235) for one query point on a uniform
+// grid x0 + k*dx; `n` = number of samples in y (the slope beyond y[n-1] is 0).
+__device__ __forceinline__ double interp_uniform(double x0, double dx, const double *y, int n, double xi) {
+  double p = (xi - x0) / dx;
+  int b = static_cast<int>(p);
+  double frac = p - b;
+  double dy = b < n - 1 ? y[b + 1] - y[b] : 0.0;
+  return y[b] + dy * frac;
+}
+
+// NuttallWindow(), src/common.cpp:113-121
+__device__ __forceinline__ double nuttall_at(int i, int len) {
+  double t = i / (len - 1.0);
+  return 0.355768 - 0.487396 * cos(2.0 * kPi * t) + 0.144232 * cos(4.0 * kPi * t) -
+         0.012604 * cos(6.0 * kPi * t);
+}
+
+// One batch of utterances resident in HBM.  Every per-utterance array is dense
+// and padded to the batch maximum so a (frame, utterance) grid indexes it directly.
+struct BatchView {
+  int n_utt;
+  int fs;
+  int x_stride;          // samples per utterance slot (>= max x_length)
+  int f_stride;          // frames per utterance slot (>= max frame count)
+  const double *x;       // [n_utt][x_stride]
+  const int *x_len;      // [n_utt]
+  const int *n_frames;   // [n_utt]
+};
+
+}  // namespace world_hip

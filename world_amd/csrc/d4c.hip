@@ -1,0 +1,368 @@
+// d4c.hip -- D4C band aperiodicity on gfx950.
+//
+// Replaces D4C() (reference src/d4c.cpp:342-403) and everything it calls:
+// D4CLoveTrain (:227-285), GetStaticCentroid/GetCentroid (:90-143),
+// GetSmoothedPowerSpectrum (:149-166), GetStaticGroupDelay (:172-188),
+// GetCoarseAperiodicity (:194-225), GetAperiodicity (:330-338).
+//
+// The reference draws noise from ONE stream: first the LoveTrain window of every
+// voiced frame in order, then three windows per frame that passed the LoveTrain
+// threshold.  Frame independence is recovered by two prefix sums over the
+// per-frame draw counts (d4c_prepare1 / d4c_prepare2) and GF(2) jump-ahead.
+//
+//   d4c_lovetrain : 256-thread workgroup per frame, one r2c FFT, two band sums.
+//   d4c_body      : 512-thread workgroup per selected frame, all in LDS:
+//                   2 centroid transforms (each = the reference's two r2c FFTs
+//                   packed into ONE complex FFT: z = w x + i (n+1) w x), 1 power
+//                   spectrum, 2 DC corrections, 3 rectangular smoothings
+//                   (block-parallel prefix sums), nap band FFTs each followed by
+//                   an LDS radix-select replacing the reference's std::sort
+//                   (only the sum of the N/2-boundary smallest powers is used),
+//                   then the 3 kHz-grid interpolation written once to HBM.
+#include "stage_params.h"
+
+namespace world_hip {
+
+constexpr int kHanning = 1, kBlackman = 2;
+
+__device__ __forceinline__ double d4c_window_at(int i, int hw, int kind, double ratio, int fs, double f0) {
+  double position = (2.0 * (i - hw) / ratio) / fs;                  // d4c.cpp:36,41
+  if (kind == kHanning) return 0.5 * cos(kPi * position * f0) + 0.5;
+  return 0.42 + 0.5 * cos(kPi * position * f0) + 0.08 * cos(kPi * position * f0 * 2);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void d4c_prepare1(D4cParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  int u = blockIdx.x, nf = p.b.n_frames[u];
+  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
+  Xs128 *st = p.states1 + (size_t)u * p.b.f_stride;
+  unsigned running = 0;
+  for (int base = 0; base < nf; base += blockDim.x) {
+    int f = base + threadIdx.x, cnt = 0;
+    if (f < nf && f0[f] != 0.0) {
+      double cf0 = f0[f] > 40.0 ? f0[f] : 40.0;                      // d4c.cpp:263,279
+      cnt = 2 * mround(3.0 * p.b.fs / cf0 / 2.0) + 1;
+    }
+    int total, off = block_excl_scan_int(cnt, &total, scratch);
+    if (cnt) st[f] = xs_jump(p.tab.jump, xs_seed(), running + (unsigned)off);
+    running += (unsigned)total;
+  }
+  if (threadIdx.x == 0) p.draws1[u] = running;
+}
+
+__global__ void d4c_prepare2(D4cParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  int u = blockIdx.x, nf = p.b.n_frames[u];
+  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
+  const double *ap0 = p.ap0 + (size_t)u * p.b.f_stride;
+  Xs128 *st = p.states2 + (size_t)u * p.b.f_stride;
+  unsigned running = p.draws1[u];
+  for (int base = 0; base < nf; base += blockDim.x) {
+    int f = base + threadIdx.x, cnt = 0;
+    if (f < nf && !(f0[f] == 0 || ap0[f] <= p.threshold)) {          // d4c.cpp:386
+      double cf0 = kFloorF0D4C > f0[f] ? kFloorF0D4C : f0[f];
+      cnt = 3 * (2 * mround(4.0 * p.b.fs / cf0 / 2.0) + 1);
+    }
+    int total, off = block_excl_scan_int(cnt, &total, scratch);
+    if (cnt) st[f] = xs_jump(p.tab.jump, xs_seed(), running + (unsigned)off);
+    running += (unsigned)total;
+  }
+}
+
+// Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84).
+// Samples go to dst[i*dstride], the window shape to win[i*wstride]; returns 2*hw+1.
+__device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, double f0, double pos,
+                                            int kind, double ratio, const uint4 *jump, Xs128 st,
+                                            double *dst, int dstride, double *win, int wstride,
+                                            double *scratch) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int hw = mround(ratio * fs / f0 / 2.0);
+  const int wlen = 2 * hw + 1;
+  const int origin = mround(pos * fs + 0.001);
+  // noise in draw order = sample order
+  {
+    int per_pass = nt * kRun;
+    for (int start = 0; start < wlen; start += per_pass) {
+      int first = start + tid * kRun;
+      if (first < wlen) {
+        Xs128 s = xs_jump(jump, st, (unsigned)first);
+        int end = first + kRun < wlen ? first + kRun : wlen;
+        for (int i = first; i < end; ++i) dst[(size_t)i * dstride] = xs_randn(s) * kSafeGuardD4C;
+      }
+    }
+  }
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < wlen; i += nt) {
+    double w = d4c_window_at(i, hw, kind, ratio, fs, f0);
+    win[(size_t)i * wstride] = w;
+    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + dst[(size_t)i * dstride];
+    dst[(size_t)i * dstride] = v;
+    s1 += v; s2 += w;
+  }
+  block_sum2(s1, s2, scratch);
+  const double coef = s1 / s2;
+  for (int i = tid; i < wlen; i += nt) dst[(size_t)i * dstride] -= win[(size_t)i * wstride] * coef;
+  __syncthreads();
+  return wlen;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y, f = blockIdx.x;
+  if (f >= p.b.n_frames[u]) return;
+  const size_t fi = (size_t)u * p.b.f_stride + f;
+  const double f0 = p.f0[fi];
+  if (f0 == 0.0) { if (threadIdx.x == 0) p.ap0[fi] = 0.0; return; }   // d4c.cpp:274-277
+  const int lgn = p.lg_love, M = 1 << lgn, fs = p.b.fs;
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  double *Zr = reinterpret_cast<double *>(lds);
+  double *win = Zr + M;
+  double *scratch = win + M;
+  const double cf0 = f0 > 40.0 ? f0 : 40.0;
+  const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
+                                kBlackman, 3.0, p.tab.jump, p.states1[fi], Zr, 1, win, 1, scratch);
+  for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) Zr[i] = 0.0;
+  const int b0 = static_cast<int>(ceil(100.0 * M / fs));
+  const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
+  const int b2 = static_cast<int>(ceil(7900.0 * M / fs));
+  double lo = 0.0, hi = 0.0;     // cumulative power (b0, b1] and (b0, b2]   (d4c.cpp:241-249)
+  block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) {
+    if (k > b0 && k <= b2) {
+      double pw = re * re + im * im;
+      hi += pw;
+      if (k <= b1) lo += pw;
+    }
+  });
+  block_sum2(lo, hi, scratch);
+  if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
+}
+
+// ---------------------------------------------------------------------------
+// LinearSmoothing (common.cpp:27-111) on an LDS spectrum of half+1 bins.
+// seg: LDS work area of >= half + 2*bnd + 1 doubles.  in == out allowed.
+__device__ __forceinline__ void d4c_smooth(const double *in, double width, int fs, int N, double *seg,
+                                           double *out, double *scratch) {
+  const int tid = threadIdx.x, nt = blockDim.x, half = N / 2;
+  const int bnd = static_cast<int>(width * N / fs) + 1;
+  const int seg_len = half + 2 * bnd + 1;
+  __syncthreads();
+  for (int i = tid; i < seg_len; i += nt) {
+    double m;
+    if (i < bnd) m = in[bnd - i];
+    else if (i < half + bnd) m = in[i - bnd];
+    else m = in[half - (i - (half + bnd))];
+    seg[i] = m * fs / N;
+  }
+  block_scan_incl_double(seg, seg_len, scratch);
+  const double origin_axis = -(bnd - 0.5) * fs / N;
+  const double step = static_cast<double>(fs) / N;
+  for (int i = tid; i <= half; i += nt) {
+    double fa = static_cast<double>(i) / N * fs - width / 2.0;
+    double lo = interp_uniform(origin_axis, step, seg, seg_len, fa);
+    fa += width;
+    double hi = interp_uniform(origin_axis, step, seg, seg_len, fa);
+    out[i] = (hi - lo) / width;
+  }
+  __syncthreads();
+}
+
+// DCCorrection (common.cpp:56-75) in place on an LDS spectrum; tmp >= 2 + f0*N/fs doubles.
+__device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, int N, double *tmp) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int upper = 2 + static_cast<int>(f0 * N / fs);
+  const int nrep = upper - 1;
+  const double dx = -static_cast<double>(fs) / N;
+  __syncthreads();
+  for (int i = tid; i < nrep; i += nt)
+    tmp[i] = interp_uniform(f0, dx, spec, upper + 1, static_cast<double>(i) * fs / N);
+  __syncthreads();
+  for (int i = tid; i < nrep; i += nt) spec[i] = spec[i] + tmp[i];
+  __syncthreads();
+}
+
+// Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them, by an
+// 8-bit-digit radix select on the IEEE bit patterns.  hist: 256 ints of LDS.
+__device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m, int *hist,
+                                                   double *scratch, double *partial, double *total) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  unsigned long long prefix = 0;
+  int remaining = m - 1;                           // rank (0-based) of the threshold element
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    __syncthreads();
+    for (int i = tid; i < 256; i += nt) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+      unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+      bool match = pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8));
+      if (match) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    // every wave locates the digit redundantly (no further barrier needed)
+    const int per_lane = 256 / WAVE;
+    int lane = lane_id(), local = 0;
+    for (int j = 0; j < per_lane; ++j) local += hist[lane * per_lane + j];
+    int tot, before = wave_excl_scan_int(local, &tot);
+    int digit = -1, below = -1;
+    if (before <= remaining && remaining < before + local) {
+      int acc = before;
+      for (int j = 0; j < per_lane; ++j) {
+        int h = hist[lane * per_lane + j];
+        if (remaining < acc + h) { digit = lane * per_lane + j; below = acc; break; }
+        acc += h;
+      }
+    }
+    digit = wave_max_int(digit);
+    below = wave_max_int(below);
+    remaining -= below;
+    prefix |= (unsigned long long)digit << shift;
+  }
+  const double thr = __longlong_as_double((long long)prefix);
+  double s_lt = 0.0, s_all = 0.0;
+  int c_lt = 0;
+  for (int i = tid; i < n; i += nt) {
+    double x = v[i];
+    s_all += x;
+    if (x < thr) { s_lt += x; c_lt++; }
+  }
+  block_sum2(s_lt, s_all, scratch);
+  int tot_lt;
+  block_excl_scan_int(c_lt, &tot_lt, scratch);
+  *partial = s_lt + (m - tot_lt) * thr;
+  *total = s_all;
+}
+
+__global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y, f = blockIdx.x;
+  if (f >= p.b.n_frames[u]) return;
+  const size_t fi = (size_t)u * p.b.f_stride + f;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int nb_out = p.fft_out / 2 + 1;
+  double *row = p.aperiodicity + fi * nb_out;
+  const double f0 = p.f0[fi];
+  if (f0 == 0 || p.ap0[fi] <= p.threshold) {                          // d4c.cpp:323-328,386
+    for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny;
+    return;
+  }
+  const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
+  // LDS: Z (N complex) | A (H+2) | B (H+2) | hist (256 int) | scratch (64) | coarse (16)
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  double *Zr = reinterpret_cast<double *>(lds);
+  double *A = Zr + 2 * N;
+  double *B = A + (H + 2);
+  int *hist = reinterpret_cast<int *>(B + (H + 2));
+  double *scratch = reinterpret_cast<double *>(hist + 256);
+  double *coarse = scratch + 64;
+
+  const double *x = p.b.x + (size_t)u * p.b.x_stride;
+  const int x_len = p.b.x_len[u];
+  const double pos = p.tpos[fi];
+  const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
+  Xs128 st = p.states2[fi];
+  const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
+
+  // ---- GetStaticCentroid (d4c.cpp:126-143) ----------------------------------
+  for (int c = 0; c < 2; ++c) {
+    const double cpos = c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
+    __syncthreads();
+    // real part <- windowed segment, imaginary part holds the window meanwhile
+    const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, p.tab.jump,
+                                  xs_jump(p.tab.jump, st, (unsigned)(c * wdraws)),
+                                  Zr, 2, Zr + 1, 2, scratch);
+    double pw = 0.0;
+    for (int i = tid; i < wlen; i += nt) pw += Zr[2 * i] * Zr[2 * i];
+    pw = block_sum(pw, scratch);
+    const double nrm = sqrt(pw);
+    for (int i = tid; i < N; i += nt) {
+      double v = i < wlen ? Zr[2 * i] / nrm : 0.0;
+      Zr[2 * i] = v;
+      Zr[2 * i + 1] = v * (i + 1.0);                 // second transform's input (d4c.cpp:111-112)
+    }
+    block_cfft_dif(Z, lgn, p.tab.tw);
+    for (int k = tid; k <= H; k += nt) {
+      cplx za = Z[brev_bits(k, lgn)], zb = Z[brev_bits((N - k) & (N - 1), lgn)];
+      double x1r = 0.5 * (za.re + zb.re), x1i = 0.5 * (za.im - zb.im);
+      double x2r = 0.5 * (za.im + zb.im), x2i = -0.5 * (za.re - zb.re);
+      if (k == 0 || k == H) { x1i = 0.0; x2i = 0.0; }
+      double cen = x2r * x1r + x1i * x2i;            // d4c.cpp:115-116
+      A[k] = c == 0 ? cen : A[k] + cen;
+    }
+  }
+  d4c_dc_correct(A, cf0, fs, N, Zr);
+
+  // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
+  {
+    const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, p.tab.jump,
+                                  xs_jump(p.tab.jump, st, (unsigned)(2 * wdraws)),
+                                  Zr, 1, Zr + N, 1, scratch);
+    for (int i = wlen + tid; i < N; i += nt) Zr[i] = 0.0;
+    block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+  }
+  d4c_dc_correct(B, cf0, fs, N, Zr);
+  d4c_smooth(B, cf0, fs, N, Zr, B, scratch);
+
+  // ---- GetStaticGroupDelay (d4c.cpp:172-188) ----------------------------------
+  for (int i = tid; i <= H; i += nt) A[i] = A[i] / B[i];
+  d4c_smooth(A, cf0 / 2.0, fs, N, Zr, A, scratch);
+  d4c_smooth(A, cf0, fs, N, Zr, B, scratch);
+  for (int i = tid; i <= H; i += nt) A[i] -= B[i];
+
+  // ---- GetCoarseAperiodicity (d4c.cpp:194-225) --------------------------------
+  const int bnd = mround(N * 8.0 / p.wl);
+  const int hwl = p.wl / 2;
+  for (int band = 0; band < p.nap; ++band) {
+    const int center = static_cast<int>(3000.0 * (band + 1) * N / fs);
+    __syncthreads();
+    for (int i = tid; i < N; i += nt)
+      Zr[i] = i <= 2 * hwl ? A[center - hwl + i] * p.nuttall[i] : 0.0;
+    block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+    double part, tot;
+    block_smallest_sum(B, H + 1, H - bnd, hist, scratch, &part, &tot);
+    if (tid == 0) {
+      double c = 10 * log10(part / tot);
+      c = c + (cf0 - 100) / 50.0;                     // d4c.cpp:314-316
+      coarse[1 + band] = c < 0.0 ? c : 0.0;
+    }
+  }
+  if (tid == 0) { coarse[0] = -60.0; coarse[p.nap + 1] = -kTiny; }    // d4c.cpp:373-375
+  __syncthreads();
+
+  // ---- GetAperiodicity (d4c.cpp:330-338): interp1 onto the output bins ---------
+  const int nk = p.nap + 2;
+  for (int i = tid; i < nb_out; i += nt) {
+    double xi = static_cast<double>(i) * fs / p.fft_out;
+    int cnt = 0;                                       // knots <= xi  (histc semantics)
+    for (int k = 0; k < nk; ++k) {
+      double knot = k <= p.nap ? k * 3000.0 : fs / 2.0;
+      if (knot <= xi) cnt++;
+    }
+    int k = cnt < 1 ? 1 : (cnt > nk - 1 ? nk - 1 : cnt);
+    double x0 = (k - 1) <= p.nap ? (k - 1) * 3000.0 : fs / 2.0;
+    double x1 = k <= p.nap ? k * 3000.0 : fs / 2.0;
+    double s = (xi - x0) / (x1 - x0);
+    double y = coarse[k - 1] + s * (coarse[k] - coarse[k - 1]);
+    row[i] = pow(10.0, y / 20.0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)(2 * (1 << lg) + 64); }
+size_t d4c_body_lds_bytes(int lg) {
+  int N = 1 << lg, H = N / 2;
+  return sizeof(double) * (size_t)(2 * N + 2 * (H + 2) + 128 + 64 + 16);
+}
+
+void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
+  WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), 256, d4c_love_lds_bytes(p.lg_love), stream, p);
+  WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(d4c_body, dim3(max_frames, p.b.n_utt), 512, d4c_body_lds_bytes(p.lg_d4c), stream, p);
+}
+
+}  // namespace world_hip

@@ -1,0 +1,94 @@
+// decimate.h -- MATLAB-style decimate() (reference src/matlabfunctions.cpp:27-204)
+// as two chunk-parallel IIR sweeps.
+//
+// The reference runs a 3rd-order IIR forwards over the (reflect-padded) signal,
+// reverses, runs it again and reverses back: two strictly serial recurrences.
+// The filter's poles are well inside the unit circle (|p| <= 0.889 for r = 12),
+// so a sweep restarted from zero state kWarm samples before a chunk has forgotten
+// its start to < 1e-26 by the time it reaches the chunk.  Every
+// thread owns one chunk; the first chunk starts at sample 0 exactly like the
+// reference.
+#pragma once
+#include "common.h"
+
+namespace world_hip {
+
+struct IirCoef { double a0, a1, a2, b0, b1; };
+
+constexpr int kDecChunk = 256;
+constexpr int kDecWarm = 512;
+constexpr int kDecPad = 9;      // kNFact
+
+// filter coefficients, src/matlabfunctions.cpp:29-113
+inline IirCoef decimate_coef(int r) {
+  static const double t[11][5] = {
+      {0.041156734567757189, -0.42599112459189636, 0.041037215479961225, 0.16797464681802227, 0.50392394045406674},
+      {0.95039378983237421, -0.67429146741526791, 0.15412211621346475, 0.071221945171178636, 0.21366583551353591},
+      {1.4499664446880227, -0.98943497080950582, 0.24578252340690215, 0.036710750339322612, 0.11013225101796784},
+      {1.7610939654280557, -1.2554914843859768, 0.3237186507788215, 0.021334858522387423, 0.06400457556716227},
+      {1.9715352749512141, -1.4686795689225347, 0.3893908434965701, 0.013469181309343825, 0.040407543928031475},
+      {2.1225239019534703, -1.6395144861046302, 0.44469707800587366, 0.0090366882681608418, 0.027110064804482525},
+      {2.2357462340187593, -1.7780899984041358, 0.49152555365968692, 0.0063522763407111993, 0.019056829022133598},
+      {2.3236003491759578, -1.8921545617463598, 0.53148928133729068, 0.0046331164041389372, 0.013899349212416812},
+      {2.3936475118069387, -1.9873904075111861, 0.5658879979027055, 0.0034818622251927556, 0.010445586675578267},
+      {2.450743295230728, -2.06794904601978, 0.59574774438332101, 0.0026822508007163792, 0.0080467524021491377},
+      {2.4981398605924205, -2.1368928194784025, 0.62187513816221485, 0.0021097275904709001, 0.0063291827714127002}};
+  IirCoef c = {0, 0, 0, 0, 0};
+  if (r >= 2 && r <= 12) { c.a0 = t[r - 2][0]; c.a1 = t[r - 2][1]; c.a2 = t[r - 2][2]; c.b0 = t[r - 2][3]; c.b1 = t[r - 2][4]; }
+  return c;
+}
+
+// sample j of the signal the reference feeds to FilterForDecimate: x edge-padded by
+// `lag` on both sides (Harvest, harvest.cpp:50-59; lag = 0 for DIO) and then
+// reflect-padded by kNFact (matlabfunctions.cpp:183-186).
+__device__ __forceinline__ double dec_padded(const double *x, int n, int lag, int j) {
+  const int m = n + 2 * lag;                    // length handed to decimate()
+  auto px = [&](int i) { return x[imin(n - 1, imax(0, i - lag))]; };
+  if (j < kDecPad) return 2 * px(0) - px(kDecPad - j);
+  if (j >= kDecPad + m) return 2 * px(m - 1) - px(m - 2 - (j - (kDecPad + m)));
+  return px(j - kDecPad);
+}
+
+__device__ __forceinline__ double iir_step(const IirCoef &c, double in, double &w0, double &w1, double &w2) {
+  double wt = in + c.a0 * w0 + c.a1 * w1 + c.a2 * w2;
+  double out = c.b0 * wt + c.b1 * w0 + c.b1 * w1 + c.b0 * w2;
+  w2 = w1; w1 = w0; w0 = wt;
+  return out;
+}
+
+// forward sweep: fwd[j] for one chunk of the padded signal of length n + 2*lag + 18
+__device__ __forceinline__ void dec_forward_chunk(const double *x, int n, int lag, IirCoef c, int chunk, double *fwd) {
+  const int total = n + 2 * lag + 2 * kDecPad;
+  const int c0 = chunk * kDecChunk;
+  if (c0 >= total) return;
+  const int c1 = imin(total, c0 + kDecChunk);
+  double w0 = 0, w1 = 0, w2 = 0;
+  for (int j = imax(0, c0 - kDecWarm); j < c0; ++j) iir_step(c, dec_padded(x, n, lag, j), w0, w1, w2);
+  for (int j = c0; j < c1; ++j) fwd[j] = iir_step(c, dec_padded(x, n, lag, j), w0, w1, w2);
+}
+
+// backward sweep over fwd; every r-th output starting at `first` is a decimated sample.
+// out[k] = decimated[skip + k] for k < out_len   (matlabfunctions.cpp:195-200, harvest.cpp:62)
+__device__ __forceinline__ void dec_backward_chunk(const double *fwd, int n, int lag, int r, IirCoef c, int chunk,
+                                                   int skip, int out_len, double *out) {
+  const int total = n + 2 * lag + 2 * kDecPad;
+  const int m = n + 2 * lag;
+  const int nout = (m - 1) / r + 1;
+  const int nbeg = r - r * nout + m;
+  const int first = nbeg + kDecPad - 1;         // index (in padded coordinates) of decimated[0]
+  const int c0 = chunk * kDecChunk;
+  if (c0 >= total) return;
+  const int c1 = imin(total, c0 + kDecChunk);
+  double w0 = 0, w1 = 0, w2 = 0;
+  for (int j = imin(total - 1, c1 - 1 + kDecWarm); j >= c1; --j) iir_step(c, fwd[j], w0, w1, w2);
+  for (int j = c1 - 1; j >= c0; --j) {
+    double g = iir_step(c, fwd[j], w0, w1, w2);
+    int d = j - first;
+    if (d >= 0 && d % r == 0 && nbeg + d < m + kDecPad) {   // loop bound of matlabfunctions.cpp:199
+      int k = d / r - skip;
+      if (k >= 0 && k < out_len) out[k] = g;
+    }
+  }
+}
+
+}  // namespace world_hip

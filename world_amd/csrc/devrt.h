@@ -1,0 +1,306 @@
+// devrt.h -- the one place that knows how kernels are launched.
+//
+// Product build (hipcc, gfx950): real HIP launches, 64-lane wavefront
+// collectives (__shfl_xor / ballot), LDS carved from one dynamic region.
+//
+// Test-only build (g++ -DWORLD_EMU, see tests/emu/): the SAME kernel sources are
+// compiled for the host with every block shrunk to ONE thread and every wave to
+// ONE lane, blocks executed serially.  Kernels are written in a block-cooperative
+// style (block-stride loops + the collectives below + __syncthreads), so the
+// emulation runs the identical index arithmetic, RNG bookkeeping and control
+// flow -- it lets `pytest -m "not gpu"` check kernel logic against the oracle in
+// a container without a GPU.  It is never built into libworld_hip.so.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifdef WORLD_EMU
+// ------------------------------------------------------------------ emulation
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct double2 { double x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+static inline double2 make_double2(double a, double b) { double2 r; r.x = a; r.y = b; return r; }
+static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { uint4 r = {a, b, c, d}; return r; }
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern thread_local char *emu_lds_base;
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+#define __launch_bounds__(...)
+static inline void __syncthreads() {}
+typedef int hipError_t;
+typedef void *hipStream_t;
+#define hipSuccess 0
+#define WAVE 1
+#define DYN_LDS(name) char *name = emu_lds_base
+static inline unsigned __brev(unsigned v) {
+  unsigned r = 0;
+  for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+static inline long long __double_as_longlong(double v) { long long r; memcpy(&r, &v, 8); return r; }
+static inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }
+static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
+static inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p += v; return o; }
+namespace devrt {
+void *dmalloc(size_t bytes);
+void dfree(void *p);
+static inline void h2d(void *dst, const void *src, size_t n, hipStream_t) { memcpy(dst, src, n); }
+static inline void d2h(void *dst, const void *src, size_t n, hipStream_t) { memcpy(dst, src, n); }
+static inline void d2d(void *dst, const void *src, size_t n, hipStream_t) { memcpy(dst, src, n); }
+static inline void dzero(void *dst, size_t n, hipStream_t) { memset(dst, 0, n); }
+static inline void sync(hipStream_t) {}
+static inline void set_device(int) {}
+static inline void *hmalloc_pinned(size_t n) { return malloc(n); }
+static inline void hfree_pinned(void *p) { free(p); }
+static inline void *event_create() { return nullptr; }
+static inline void event_destroy(void *) {}
+static inline void event_record(void *, hipStream_t) {}
+static inline void event_sync(void *) {}
+void emu_run_begin(size_t lds_bytes);
+void emu_run_end();
+template <class K, class... A>
+void launch_blocks(const char * /*name*/, K kernel, dim3 grid, int /*threads*/, size_t lds, hipStream_t, A... args) {
+  emu_run_begin(lds);
+  blockDim = dim3(1, 1, 1);
+  gridDim = grid;
+  threadIdx = dim3(0, 0, 0);
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) {
+        blockIdx = dim3(x, y, z);
+        kernel(args...);
+      }
+  emu_run_end();
+}
+}  // namespace devrt
+#else
+// ------------------------------------------------------------------ gfx950
+#include <hip/hip_runtime.h>
+#define WAVE 64
+#define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+namespace devrt {
+void check(hipError_t e, const char *what);
+void *dmalloc(size_t bytes);
+void dfree(void *p);
+void h2d(void *dst, const void *src, size_t n, hipStream_t s);
+void d2h(void *dst, const void *src, size_t n, hipStream_t s);
+void d2d(void *dst, const void *src, size_t n, hipStream_t s);
+void dzero(void *dst, size_t n, hipStream_t s);
+void sync(hipStream_t s);
+void set_device(int device);
+void *hmalloc_pinned(size_t n);
+void hfree_pinned(void *p);
+void *event_create();
+void event_destroy(void *ev);
+void event_record(void *ev, hipStream_t s);
+void event_sync(void *ev);
+// optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+void prof_begin(const char *name, hipStream_t s);
+void prof_end(hipStream_t s);
+extern bool g_profiling;
+void prof_enable(bool on);
+}  // namespace devrt
+#include <string>
+namespace devrt {
+std::string prof_collect();
+template <class K, class... A>
+void launch_blocks(const char *name, K kernel, dim3 grid, int threads, size_t lds, hipStream_t s, A... args) {
+  if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;
+  if (lds > 48 * 1024)   // opt in to the full 160 KiB LDS of a gfx950 CU
+    check(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (g_profiling) prof_begin(name, s);
+  hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, args...);
+  check(hipGetLastError(), name);
+  if (g_profiling) prof_end(s);
+}
+}  // namespace devrt
+#endif
+
+namespace devrt {
+// ---- launch shapes ---------------------------------------------------------
+// "flat" kernels: one thread per item along x (items = blockIdx.x*blockDim.x+threadIdx.x)
+template <class K, class... A>
+void launch_threads(const char *name, K kernel, long items, unsigned ny, unsigned nz, hipStream_t s, A... args) {
+#ifdef WORLD_EMU
+  launch_blocks(name, kernel, dim3((unsigned)items, ny, nz), 1, 0, s, args...);
+#else
+  launch_blocks(name, kernel, dim3((unsigned)((items + 255) / 256), ny, nz), 256, 0, s, args...);
+#endif
+}
+// "wave" kernels: one wavefront per item along x, 4 waves per block
+template <class K, class... A>
+void launch_waves(const char *name, K kernel, long items, unsigned ny, unsigned nz, size_t lds_per_wave, hipStream_t s, A... args) {
+#ifdef WORLD_EMU
+  launch_blocks(name, kernel, dim3((unsigned)items, ny, nz), 1, lds_per_wave, s, args...);
+#else
+  launch_blocks(name, kernel, dim3((unsigned)((items + 3) / 4), ny, nz), 256, 4 * lds_per_wave, s, args...);
+#endif
+}
+}  // namespace devrt
+// launch macros: the kernel's own name labels errors and profile records
+#define WH_BLOCKS(kernel, ...) devrt::launch_blocks(#kernel, kernel, __VA_ARGS__)
+#define WH_THREADS(kernel, ...) devrt::launch_threads(#kernel, kernel, __VA_ARGS__)
+#define WH_WAVES(kernel, ...) devrt::launch_waves(#kernel, kernel, __VA_ARGS__)
+
+// ---- in-kernel helpers -------------------------------------------------------
+__device__ __forceinline__ int flat_thread_x() { return (int)(blockIdx.x * blockDim.x + threadIdx.x); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x % WAVE); }
+__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x / WAVE); }
+__device__ __forceinline__ int waves_per_block() { return (int)((blockDim.x + WAVE - 1) / WAVE); }
+__device__ __forceinline__ int wave_item_x() { return (int)(blockIdx.x * waves_per_block() + wave_in_block()); }
+
+// make one wave's LDS writes visible to its other lanes (no-op for a 1-lane wave)
+__device__ __forceinline__ void wave_sync() {
+#ifndef WORLD_EMU
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// wave collectives (every lane gets the result)
+__device__ __forceinline__ double wave_sum(double v) {
+#ifndef WORLD_EMU
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+#endif
+  return v;
+}
+__device__ __forceinline__ int wave_sum_int(int v) {
+#ifndef WORLD_EMU
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+#endif
+  return v;
+}
+__device__ __forceinline__ int wave_max_int(int v) {
+#ifndef WORLD_EMU
+  for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+#endif
+  return v;
+}
+__device__ __forceinline__ int wave_excl_scan_int(int v, int *total) {
+#ifndef WORLD_EMU
+  int lane = lane_id(), inc = v;
+  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  *total = __shfl(inc, 63, 64);
+  return inc - v;
+#else
+  *total = v;
+  return 0;
+#endif
+}
+__device__ __forceinline__ double wave_bcast(double v, int src_lane) {
+#ifndef WORLD_EMU
+  return __shfl(v, src_lane, 64);
+#else
+  (void)src_lane;
+  return v;
+#endif
+}
+__device__ __forceinline__ int wave_bcast_int(int v, int src_lane) {
+#ifndef WORLD_EMU
+  return __shfl(v, src_lane, 64);
+#else
+  (void)src_lane;
+  return v;
+#endif
+}
+
+// block collectives; `scratch` = LDS area of >= 64 doubles owned by the caller.
+// All threads must call; result returned to all; safe to call back to back.
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+#ifndef WORLD_EMU
+  v = wave_sum(v);
+  int nw = waves_per_block();
+  if (nw == 1) return v;
+  __syncthreads();  // previous users of scratch are done
+  if (lane_id() == 0) scratch[wave_in_block()] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < nw; ++w) t += scratch[w];
+  return t;
+#else
+  (void)scratch;
+  return v;
+#endif
+}
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch) {
+#ifndef WORLD_EMU
+  a = wave_sum(a); b = wave_sum(b);
+  int nw = waves_per_block();
+  if (nw == 1) return;
+  __syncthreads();
+  if (lane_id() == 0) { scratch[wave_in_block()] = a; scratch[32 + wave_in_block()] = b; }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0;
+  for (int w = 0; w < nw; ++w) { ta += scratch[w]; tb += scratch[32 + w]; }
+  a = ta; b = tb;
+#else
+  (void)scratch;
+#endif
+}
+// exclusive scan of one int per thread over the block (thread order); *total = block sum
+__device__ __forceinline__ int block_excl_scan_int(int v, int *total, double *scratch) {
+#ifndef WORLD_EMU
+  int wt, off = wave_excl_scan_int(v, &wt);
+  int nw = waves_per_block();
+  if (nw == 1) { *total = wt; return off; }
+  int *is = reinterpret_cast<int *>(scratch);
+  __syncthreads();
+  if (lane_id() == 0) is[wave_in_block()] = wt;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) { int c = is[w]; if (w < wave_in_block()) base += c; tot += c; }
+  *total = tot;
+  return base + off;
+#else
+  (void)scratch;
+  *total = v;
+  return 0;
+#endif
+}
+
+// In-place inclusive prefix sum of a[0..n) in LDS by the whole block.
+// Each thread sums a contiguous chunk serially, chunk totals are scanned across
+// the block, then offsets are added back.  (With one thread -- the emulation --
+// this is the plain serial left-to-right sum.)  NOT used where the reference's
+// serial rounding is part of the result (CheapTrick's smoothing keeps a serial
+// scan); used for D4C where the order is benign.
+__device__ __forceinline__ void block_scan_incl_double(double *a, int n, double *scratch) {
+  int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+  int chunk = (n + nt - 1) / nt;
+  int lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = lo; i < hi; ++i) { s += a[i]; a[i] = s; }
+#ifndef WORLD_EMU
+  // exclusive scan of chunk totals in thread order
+  double inc = s;
+  int lane = lane_id();
+  for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  int nw = waves_per_block(), w = wave_in_block();
+  __syncthreads();
+  if (lane == 63) scratch[w] = inc;
+  __syncthreads();
+  double base = 0.0;
+  for (int k = 0; k < w; ++k) base += scratch[k];
+  double off = base + (inc - s);
+  (void)nw;
+  for (int i = lo; i < hi; ++i) a[i] += off;
+#else
+  (void)scratch;
+#endif
+  __syncthreads();
+}

@@ -1,0 +1,57 @@
+// harvest.h -- parameter block shared by the Harvest kernels (harvest.hip,
+// harvest_contour.hip) and the host planner (pipeline.cpp).
+#pragma once
+#include "common.h"
+
+namespace world_hip {
+
+struct HarvestParams {
+  BatchView b;
+  // ---- options (HarvestOption, reference src/world/harvest.h:16-20) ----
+  double f0_floor, f0_ceil, frame_period;
+  // ---- derived on the host exactly as HarvestGeneralBody does (harvest.cpp:1145-1165) ----
+  int ratio;               // decimation ratio = matlab_round(fs / 8000)
+  double afs;              // fs / ratio
+  int nch;                 // number of band-pass channels
+  int maxc;                // max_candidates = matlab_round(nch / 10) * 7
+  int lag;                 // edge padding before decimation (harvest.cpp:50-51)
+  int y_stride;            // decimated samples per utterance slot
+  int fb_stride;           // 1 ms ("basic") frames per utterance slot
+  int ev_cap;              // capacity of one event list
+  int refine_cap;          // LDS doubles per refinement window
+  int sec_cap;             // voiced sections per utterance slot
+  int ext_cap;             // doubles of extended-section storage per utterance
+  const int *y_len;        // [n_utt] decimated length = ceil(x_len / ratio)
+  const int *nfb;          // [n_utt] basic frame count
+  const double *band_f0;   // [nch]  boundary_f0_list
+  const int *band_half;    // [nch]  filter half length L
+  const int *band_off;     // [nch]  offset of the band's taps in band_taps
+  const double *band_taps; // Nuttall * cos band-pass FIRs (harvest.cpp:101-108), built on the host
+  int max_half;            // max L
+  Tables tab;
+  // ---- workspace (device) ----
+  double *fwd;             // [n_utt][m_stride] forward-filtered padded signal
+  int m_stride;
+  double *y;               // [n_utt][y_stride]
+  double *events;          // [n_utt][nch][4][ev_cap] fine zero-crossing positions
+  int *ev_count;           // [n_utt][nch][4]
+  double *raw;             // [n_utt][nch][fb_stride]
+  double *cand_a, *score_a;  // [n_utt][fb_stride][maxc]
+  double *cand_b, *score_b;  // [n_utt][fb_stride][maxc]
+  int *nc;                 // [n_utt] candidates per frame (max over frames)
+  double *c0, *c1, *c2, *c3; // [n_utt][fb_stride(+600)] contour scratch
+  int *sec;                // [n_utt][6][sec_cap]: start, end, ext start, ext end, slice offset, slice origin
+  int *sec_n;              // [n_utt][2]: number of sections, number kept by ExtendSub
+  double *sec_sum;         // [n_utt][sec_cap] sum of a section's extended f0
+  double *ext;             // [n_utt][ext_cap] extended f0 of every section (step 3)
+  double *basic_f0;        // [n_utt][fb_stride] result at 1 ms hop
+  // ---- outputs ----
+  double *tpos;            // [n_utt][f_stride]
+  double *f0;              // [n_utt][f_stride]
+};
+
+void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
+                    hipStream_t stream);
+void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream);
+
+}  // namespace world_hip

@@ -1,0 +1,352 @@
+// harvest.hip -- Harvest F0 estimation on gfx950, front half: from the waveform
+// to refined, pruned F0 candidates at a 1 ms hop.  (The contour logic that turns
+// candidates into the final F0 track is in harvest_contour.hip.)
+//
+// Reference: HarvestGeneralBody (src/harvest.cpp:1145-1215) and everything below
+// it.  What changes on MI355X:
+//
+//  * The 152-band filter bank is NOT 152 x (r2c + c2r) FFTs of 65k..131k points
+//    streamed through HBM (harvest.cpp:99-148).  The filters are short symmetric
+//    FIRs (<= 2*246+1 taps at 8 kHz), so each (band, utterance) workgroup
+//    convolves directly out of LDS -- FP64 FMA bound, the decimated signal is
+//    read from L2 once per band -- and the filtered signal never exists in HBM:
+//    the four zero-crossing detectors (harvest.cpp:162-238) run on the LDS tile
+//    and only the compacted sub-sample crossing times are written out.
+//    Power-of-two scaling (the reference's unnormalised inverse FFT) cancels
+//    exactly in the crossing-time ratio.
+//  * Candidate refinement (46 % of the reference's CPU time: two zero-padded r2c
+//    FFTs of 128..2048 points per candidate, harvest.cpp:541-584) only ever reads
+//    <= 6 harmonic bins of each spectrum, so it is done as 6-bin DFTs over the
+//    un-padded window: one wavefront per frame, lanes = (harmonic, sample phase).
+#include "decimate.h"
+#include "harvest.h"
+
+namespace world_hip {
+
+// ---------------------------------------------------------------------------
+// decimation to ~8 kHz (GetWaveformAndSpectrumSub, harvest.cpp:43-66)
+__global__ void hv_decimate_fwd(HarvestParams p, IirCoef c) {
+  int u = blockIdx.y, chunk = flat_thread_x();
+  dec_forward_chunk(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], p.lag, c, chunk,
+                    p.fwd + (size_t)u * p.m_stride);
+}
+__global__ void hv_decimate_bwd(HarvestParams p, IirCoef c) {
+  int u = blockIdx.y, chunk = flat_thread_x();
+  dec_backward_chunk(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], p.lag, p.ratio, c, chunk,
+                     p.lag / p.ratio, p.y_len[u], p.y + (size_t)u * p.y_stride);
+}
+__global__ void hv_copy_signal(HarvestParams p) {          // ratio == 1 (harvest.cpp:45-48)
+  int u = blockIdx.y, i = flat_thread_x();
+  if (i < p.y_len[u]) p.y[(size_t)u * p.y_stride + i] = p.b.x[(size_t)u * p.b.x_stride + i];
+}
+// y <- y - mean(y)  (harvest.cpp:81-85); one workgroup per utterance
+__global__ void hv_remove_mean(HarvestParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  int u = blockIdx.x, n = p.y_len[u];
+  double *y = p.y + (size_t)u * p.y_stride;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += y[i];
+  double mean = block_sum(s, scratch) / n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] -= mean;
+}
+
+// ---------------------------------------------------------------------------
+// Band-pass FIR + the four zero-crossing families, one workgroup per (band, utt).
+constexpr int kTile = 1024;             // filtered samples produced per step (+2 look-ahead)
+constexpr int kBpThreads = 256;
+
+// sub-sample crossing time between samples e-1 and e (harvest.cpp:183-186)
+__device__ __forceinline__ double fine_edge(int e, double prev, double cur) { return e - prev / (cur - prev); }
+
+__global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
+  DYN_LDS(lds);
+  const int band = blockIdx.x, u = blockIdx.y;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int L = p.band_half[band], ntap = 2 * L + 1;
+  const int n = p.y_len[u];
+  const double *y = p.y + (size_t)u * p.y_stride;
+  // LDS: ytile[kTile + 2 + 2*maxL] | s[kTile + 2] | scratch[64].  The taps are read
+  // with a wave-uniform index, i.e. through the scalar cache, not from LDS.
+  double *yt = reinterpret_cast<double *>(lds);
+  double *s = yt + (kTile + 2 + 2 * p.max_half + 2);
+  double *scratch = s + (kTile + 4);
+  const double *__restrict__ taps = p.band_taps + p.band_off[band];
+
+  double *ev = p.events + ((size_t)(u * p.nch + band) * 4) * p.ev_cap;
+  int count[4] = {0, 0, 0, 0};
+
+  for (int t0 = 0; t0 < n; t0 += kTile) {
+    // filtered[i] = sum_{j=-L..L} h[L+j] * y[i+1-j]  for i in [t0, t0+kTile+2)
+    // (the reference's delay compensation is L+1, harvest.cpp:140-142) -> needs
+    // y[t0+1-L .. t0+kTile+2+L]
+    const int ylo = t0 + 1 - L;
+    const int ycount = kTile + 2 + 2 * L;
+    __syncthreads();
+    for (int k = tid; k < ycount; k += nt) {
+      int idx = ylo + k;
+      yt[k] = (idx >= 0 && idx < n) ? y[idx] : 0.0;
+    }
+    __syncthreads();
+    for (int k = tid; k < kTile + 2; k += nt) {
+      // y index for tap j (0..2L): i + 1 - (j - L) = i + 1 + L - j  -> yt[k + 2L - j]
+      double acc = 0.0;
+      const double *yy = yt + k + 2 * L;
+      for (int j = 0; j < ntap; ++j) acc = fma(taps[j], yy[-j], acc);
+      s[k] = acc;
+    }
+    __syncthreads();
+    // events: each thread inspects kTile/nt consecutive samples, in order
+    constexpr int kPer = 4;
+    for (int fam = 0; fam < 4; ++fam) {
+      double *dst = ev + (size_t)fam * p.ev_cap;
+      for (int sub = 0; sub < kTile; sub += nt * kPer) {
+        double found[kPer];
+        int nfound = 0;
+        for (int q = 0; q < kPer; ++q) {
+          int k = sub + tid * kPer + q;
+          int i = t0 + k;
+          if (k >= kTile) break;
+          double a, b;                   // the family's signal at i and i+1
+          bool in_range;
+          if (fam < 2) { a = s[k]; b = s[k + 1]; in_range = i <= n - 2; }
+          else { a = s[k + 1] - s[k]; b = s[k + 2] - s[k + 1]; in_range = i <= n - 3; }
+          bool hit = fam % 2 == 0 ? (0.0 < a && b <= 0.0) : (a < 0.0 && 0.0 <= b);
+          if (in_range && hit) found[nfound++] = fine_edge(i + 1, a, b);
+        }
+        int total, off = block_excl_scan_int(nfound, &total, scratch);
+        for (int q = 0; q < nfound; ++q)
+          if (count[fam] + off + q < p.ev_cap) dst[count[fam] + off + q] = found[q];
+        count[fam] += total;
+      }
+    }
+  }
+  if (tid == 0)
+    for (int fam = 0; fam < 4; ++fam) p.ev_count[(u * p.nch + band) * 4 + fam] = imin(count[fam], p.ev_cap);
+}
+
+// ---------------------------------------------------------------------------
+// interp1 of the interval F0s onto the 1 ms grid + gating (harvest.cpp:240-293);
+// one thread per (frame, band, utt).
+__device__ __forceinline__ double interval_loc(const double *e, int k, double fs) { return (e[k] + e[k + 1]) / 2.0 / fs; }
+__device__ __forceinline__ double interval_f0(const double *e, int k, double fs) { return fs / (e[k + 1] - e[k]); }
+
+// interp1 (matlabfunctions.cpp:136-176) of the n_int intervals of one family at time t
+__device__ __forceinline__ double interp_intervals(const double *e, int n_int, double fs, double t) {
+  int lo = 0, hi = n_int;                       // count of locations <= t
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (interval_loc(e, mid, fs) <= t) lo = mid + 1; else hi = mid;
+  }
+  int k = lo < 1 ? 1 : (lo > n_int - 1 ? n_int - 1 : lo);
+  double x0 = interval_loc(e, k - 1, fs), x1 = interval_loc(e, k, fs);
+  double y0 = interval_f0(e, k - 1, fs), y1 = interval_f0(e, k, fs);
+  double sl = (t - x0) / (x1 - x0);
+  return y0 + sl * (y1 - y0);
+}
+
+__global__ void hv_raw_candidates(HarvestParams p) {
+  const int frame = flat_thread_x(), band = blockIdx.y, u = blockIdx.z;
+  if (frame >= p.nfb[u]) return;
+  const int *cnt = p.ev_count + (u * p.nch + band) * 4;
+  const double *ev = p.events + ((size_t)(u * p.nch + band) * 4) * p.ev_cap;
+  double out = 0.0;
+  int n_int[4];
+  bool ok = true;
+  for (int fam = 0; fam < 4; ++fam) {
+    n_int[fam] = cnt[fam] >= 2 ? cnt[fam] - 1 : 0;
+    if (n_int[fam] - 2 <= 0) ok = false;                 // CheckEvent(n - 2), harvest.cpp:263-269
+  }
+  if (ok) {
+    const double t = frame * 1 / 1000.0;                  // harvest.cpp:1175 (frame_period = 1)
+    double v0 = interp_intervals(ev, n_int[0], p.afs, t);
+    double v1 = interp_intervals(ev + p.ev_cap, n_int[1], p.afs, t);
+    double v2 = interp_intervals(ev + 2 * (size_t)p.ev_cap, n_int[2], p.afs, t);
+    double v3 = interp_intervals(ev + 3 * (size_t)p.ev_cap, n_int[3], p.afs, t);
+    double c = (v0 + v1 + v2 + v3) / 4.0;
+    const double fb = p.band_f0[band];
+    if (c > fb * 1.1 || c < fb * 0.9 || c > p.f0_ceil || c < p.f0_floor) c = 0.0;
+    out = c;
+  }
+  p.raw[((size_t)u * p.nch + band) * p.fb_stride + frame] = out;
+}
+
+// ---------------------------------------------------------------------------
+// DetectOfficialF0Candidates (harvest.cpp:348-412): runs of >= 10 voiced bands.
+__global__ void hv_detect(HarvestParams p) {
+  const int frame = flat_thread_x(), u = blockIdx.y;
+  if (frame >= p.nfb[u]) return;
+  const double *raw = p.raw + (size_t)u * p.nch * p.fb_stride + frame;
+  double *out = p.cand_a + ((size_t)u * p.fb_stride + frame) * p.maxc;
+  int cnt = 0, st = 0, prev = 0;
+  for (int j = 1; j < p.nch; ++j) {
+    int cur = (j == p.nch - 1) ? 0 : (raw[(size_t)j * p.fb_stride] > 0 ? 1 : 0);
+    if (cur - prev == 1) st = j;
+    if (cur - prev == -1 && j - st >= 10) {
+      double s = 0.0;
+      for (int k = st; k < j; ++k) s += raw[(size_t)k * p.fb_stride];
+      if (cnt < p.maxc) out[cnt++] = s / (j - st);
+    }
+    prev = cur;
+  }
+  for (int j = cnt; j < p.maxc; ++j) out[j] = 0.0;
+  if (cnt > 0) atomicMax(p.nc + u, cnt);
+}
+
+// ---------------------------------------------------------------------------
+// OverlapF0Candidates + RefineF0Candidates (harvest.cpp:417-631), one wavefront
+// per (frame, utt).  Slot s = j + nc*m takes candidate j of frame-m (m = 1..3) or
+// frame+(m-3) (m = 4..6); each non-zero slot is refined by instantaneous frequency.
+__device__ __forceinline__ int floor_log2_int(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
+
+__global__ void hv_refine(HarvestParams p) {
+  DYN_LDS(lds);
+  const int frame = wave_item_x(), u = blockIdx.y;
+  if (frame >= p.nfb[u]) return;
+  const int lane = lane_id();
+  double *mw = reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * 3 * p.refine_cap;
+  double *ym = mw + p.refine_cap, *yd = ym + p.refine_cap;      // y*main window, y*diff window
+  const int nfb = p.nfb[u], nc = p.nc[u], nslot = nc * 7;
+  const double *src = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
+  double *dst_f0 = p.cand_b + ((size_t)u * p.fb_stride + frame) * p.maxc;
+  double *dst_sc = p.score_b + ((size_t)u * p.fb_stride + frame) * p.maxc;
+  const double *y = p.y + (size_t)u * p.y_stride;
+  const int y_len = p.y_len[u];
+  const double fs = p.afs;
+  const double pos = frame * 1 / 1000.0;
+
+  for (int slot = 0; slot < nslot; ++slot) {
+    const int m = slot / nc, j = slot - m * nc;
+    const int sf = m == 0 ? frame : (m <= 3 ? frame - m : frame + (m - 3));
+    double f0c = (sf >= 0 && sf < nfb) ? src[(size_t)sf * p.maxc + j] : 0.0;
+    double rf0 = 0.0, rsc = 0.0;
+    if (f0c > 0.0) {                                             // GetRefinedF0, harvest.cpp:589-617
+      const int hw = static_cast<int>(1.5 * fs / f0c + 1.0);
+      const int blen = 2 * hw + 1;
+      const double wlen_t = (2.0 * hw + 1.0) / fs;
+      const int lgN = 2 + floor_log2_int(blen);                  // fft_size = 2^(2+floor(log2(2hw+1)))
+      const int N = 1 << lgN;
+      const double base0 = static_cast<double>(-hw) / fs;
+      const int first = mround((pos + base0) * fs + 0.001);      // GetBaseIndex, harvest.cpp:434-441
+      // main window (harvest.cpp:446-456)
+      for (int i = lane; i < blen; i += WAVE) {
+        double t = ((first + i) - 1.0) / fs - pos;
+        mw[i] = 0.42 + 0.5 * cos(2.0 * kPi * t / wlen_t) + 0.08 * cos(4.0 * kPi * t / wlen_t);
+      }
+      wave_sync();
+      for (int i = lane; i < blen; i += WAVE) {
+        double dwv;                                              // GetDiffWindow, harvest.cpp:462-468
+        if (i == 0) dwv = -mw[1] / 2.0;
+        else if (i == blen - 1) dwv = mw[blen - 2] / 2.0;
+        else dwv = -(mw[i + 1] - mw[i - 1]) / 2.0;
+        double xv = y[imax(0, imin(y_len - 1, first + i - 1))];
+        ym[i] = xv * mw[i];
+        yd[i] = xv * dwv;
+      }
+      wave_sync();
+      // 6-bin DFTs: lane = (harmonic h = lane%8, sample phase g = lane/8)
+      const int nh = imin(static_cast<int>(fs / 2.0 / f0c), 6);
+      const int LH = WAVE >= 8 ? 8 : 1;                           // harmonics handled side by side
+      const int G = WAVE / LH;                                    // sample phases
+      double pw[6], ni[6];
+      for (int h0 = 0; h0 < 6; h0 += LH) {
+        const int h = h0 + lane % LH, g = lane / LH;
+        double are = 0, aim = 0, dre = 0, dim = 0;
+        if (h < nh) {
+          const int idx = mround(f0c * N / fs * (h + 1));        // FixF0, harvest.cpp:515
+          for (int i = g; i < blen; i += G) {
+            double2 w = p.tab.tw[(size_t)((idx * i) & (N - 1)) << (kTwLog2 - lgN)];
+            double a = ym[i], d = yd[i];
+            are = fma(a, w.x, are); aim = fma(-a, w.y, aim);
+            dre = fma(d, w.x, dre); dim = fma(-d, w.y, dim);
+          }
+        }
+#ifndef WORLD_EMU
+        for (int s = 8; s < 64; s <<= 1) {
+          are += __shfl_xor(are, s, 64); aim += __shfl_xor(aim, s, 64);
+          dre += __shfl_xor(dre, s, 64); dim += __shfl_xor(dim, s, 64);
+        }
+#endif
+        double pwv = are * are + aim * aim;                      // harvest.cpp:564-569
+        double niv = are * dim - aim * dre;
+        for (int k = 0; k < LH && h0 + k < 6; ++k) {
+          pw[h0 + k] = wave_bcast(pwv, k);
+          ni[h0 + k] = wave_bcast(niv, k);
+        }
+      }
+      double num = 0.0, den = 0.0, sc = 0.0;                     // FixF0, harvest.cpp:507-536
+      for (int h = 0; h < nh; ++h) {
+        const int idx = mround(f0c * N / fs * (h + 1));
+        double inst = pw[h] == 0.0 ? 0.0 : static_cast<double>(idx) * fs / N + ni[h] / pw[h] * fs / 2.0 / kPi;
+        double amp = sqrt(pw[h]);
+        num += amp * inst;
+        den += amp * (h + 1.0);
+        sc += fabs((inst / (h + 1.0) - f0c) / f0c);
+      }
+      rf0 = num / (den + kTiny);
+      rsc = 1.0 / (sc / nh + kTiny);
+      if (rf0 < p.f0_floor || rf0 > p.f0_ceil || rsc < 2.5) { rf0 = 0.0; rsc = 0.0; }
+      wave_sync();
+    }
+    if (lane == 0) { dst_f0[slot] = rf0; dst_sc[slot] = rsc; }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RemoveUnreliableCandidates (harvest.cpp:636-688): keep a candidate only if a
+// neighbouring frame holds one within 5 %.  Reads the refined set (b), writes (a).
+__device__ __forceinline__ double nearest_error(double ref, const double *c, int nc) {
+  double err = 1.0;                                   // SelectBestF0 with allowed_range = 1
+  for (int i = 0; i < nc; ++i) {
+    double e = fabs(ref - c[i]) / ref;
+    if (e > err) continue;
+    err = e;
+  }
+  return err;
+}
+__global__ void hv_prune(HarvestParams p) {
+  const int frame = flat_thread_x(), u = blockIdx.y;
+  const int nfb = p.nfb[u];
+  if (frame >= nfb) return;
+  const int nslot = p.nc[u] * 7;
+  const size_t row = ((size_t)u * p.fb_stride + frame) * p.maxc;
+  for (int j = 0; j < nslot; ++j) {
+    double ref = p.cand_b[row + j], sc = p.score_b[row + j];
+    if (frame >= 1 && frame < nfb - 1 && ref != 0) {
+      double e1 = nearest_error(ref, p.cand_b + row + p.maxc, nslot);
+      double e2 = nearest_error(ref, p.cand_b + row - p.maxc, nslot);
+      if ((e1 < e2 ? e1 : e2) > 0.05) { ref = 0; sc = 0; }
+    }
+    p.cand_a[row + j] = ref;
+    p.score_a[row + j] = sc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+size_t hv_band_lds_bytes(int max_half) {
+  return sizeof(double) * (size_t)((kTile + 2 + 2 * max_half + 2) + (kTile + 4) + 64);
+}
+
+void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
+                    hipStream_t stream) {
+  const int B = p.b.n_utt;
+  devrt::dzero(p.y, sizeof(double) * (size_t)B * p.y_stride, stream);
+  devrt::dzero(p.nc, sizeof(int) * B, stream);
+  if (p.ratio == 1) {
+    WH_THREADS(hv_copy_signal, max_y_len, B, 1, stream, p);
+  } else {
+    IirCoef c = decimate_coef(p.ratio);
+    long chunks = (max_x_len + 2 * p.lag + 2 * kDecPad + kDecChunk - 1) / kDecChunk;
+    WH_THREADS(hv_decimate_fwd, chunks, B, 1, stream, p, c);
+    WH_THREADS(hv_decimate_bwd, chunks, B, 1, stream, p, c);
+  }
+  WH_BLOCKS(hv_remove_mean, dim3(B), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(hv_band_events, dim3(p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
+  WH_THREADS(hv_raw_candidates, max_fb, p.nch, B, stream, p);
+  WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
+  WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
+  WH_THREADS(hv_prune, max_fb, B, 1, stream, p);
+  launch_harvest_contour(p, max_fb, max_frames, stream);
+}
+
+}  // namespace world_hip

@@ -1,0 +1,350 @@
+// harvest_contour.hip -- Harvest, back half: candidates -> F0 contour.
+//
+// Reference: FixF0Contour (src/harvest.cpp:1027-1044) = SearchF0Base (:693-705),
+// FixStep1 (:710-722), FixStep2 (:748-762), FixStep3 (:968-995: GetMultiChannelF0,
+// Extend/ExtendF0/ExtendSub, MergeF0/MergeF0Sub), FixStep4 (:1000-1022), then
+// SmoothF0Contour (:1079-1113) and the hop subsampling of Harvest() (:1246-1251).
+//
+// The reference is one serial pass per utterance.  Here everything that is local
+// to a frame or to a voiced section runs in parallel -- one thread per frame for
+// the base pick / steps 1-2, one wavefront per voiced section for the candidate
+// tracking of step 3 (lanes = candidate slots, "nearest candidate, last wins" as
+// a (error, index) reduction), one thread per section for step 4 and for the
+// zero-phase smoother -- and only the short inherently ordered parts (section
+// selection with its running mean, the merge of overlapping sections) are walked
+// in order by a single wavefront per utterance.
+#include "harvest.h"
+
+namespace world_hip {
+
+__device__ __forceinline__ double *hc_row(double *base, const HarvestParams &p, int u) {
+  return base + (size_t)u * p.fb_stride;
+}
+
+// ---- SearchF0Base + FixStep1 -------------------------------------------------
+__device__ __forceinline__ double hc_base_at(const HarvestParams &p, int u, int f, int nslot) {
+  const double *c = p.cand_a + ((size_t)u * p.fb_stride + f) * p.maxc;
+  const double *s = p.score_a + ((size_t)u * p.fb_stride + f) * p.maxc;
+  double best = 0.0, top = 0.0;
+  for (int j = 0; j < nslot; ++j)
+    if (s[j] > top) { best = c[j]; top = s[j]; }        // first maximum wins
+  return best;
+}
+__global__ void hc_step1(HarvestParams p) {
+  const int f = flat_thread_x(), u = blockIdx.y;
+  if (f >= p.nfb[u]) return;
+  const int nslot = p.nc[u] * 7;
+  double v = 0.0;
+  if (f >= 2) {
+    double b0 = hc_base_at(p, u, f, nslot);
+    if (b0 != 0.0) {
+      double b1 = hc_base_at(p, u, f - 1, nslot), b2 = hc_base_at(p, u, f - 2, nslot);
+      double ref = b1 * 2 - b2;
+      v = fabs((b0 - ref) / ref) > 0.008 && fabs((b0 - b1)) / b1 > 0.008 ? 0.0 : b0;
+    }
+  }
+  hc_row(p.c1, p, u)[f] = v;
+}
+
+// ---- FixStep2: voiced runs with end - start < 6 are removed -------------------
+__global__ void hc_step2(HarvestParams p) {
+  const int f = flat_thread_x(), u = blockIdx.y;
+  const int nf = p.nfb[u];
+  if (f >= nf) return;
+  const double *in = hc_row(p.c1, p, u);
+  auto voiced = [&](int i) { return i > 0 && i < nf - 1 && in[i] > 0; };   // ends forced unvoiced (:733)
+  double v = in[f];
+  if (voiced(f)) {
+    int back = 0, fwd = 0;
+    while (back < 6 && voiced(f - back - 1)) ++back;
+    while (fwd < 6 && voiced(f + fwd + 1)) ++fwd;
+    if (back + fwd < 6) v = 0.0;
+  }
+  hc_row(p.c2, p, u)[f] = v;
+}
+
+// ---- GetBoundaryList (:727-743) as a block scan --------------------------------
+// sec[u][0][k] = start, sec[u][1][k] = end of the k-th voiced run of `src`;
+// sec[u][4][k] = offset of the run's private slice (length end-start+1+extra),
+// sec_n[u][0] = number of runs.  One workgroup per utterance.
+struct SecArgs { const double *src; int force_ends; int extra; };
+
+__global__ void hc_sections(HarvestParams p, SecArgs a) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  const int u = blockIdx.x, nf = p.nfb[u];
+  const double *in = a.src + (size_t)u * p.fb_stride;
+  int *st = p.sec + (size_t)u * 6 * p.sec_cap, *ed = st + p.sec_cap, *off = st + 4 * p.sec_cap;
+  auto voiced = [&](int i) {
+    if (i < 0 || i >= nf) return false;
+    if (a.force_ends && (i == 0 || i == nf - 1)) return false;
+    return in[i] > 0;
+  };
+  int n_start = 0, n_end = 0;
+  for (int base = 0; base < nf; base += blockDim.x) {
+    int f = base + threadIdx.x;
+    bool v = f < nf && voiced(f);
+    int is_start = v && !voiced(f - 1), is_end = v && !voiced(f + 1);
+    int tot_s, off_s = block_excl_scan_int(is_start, &tot_s, scratch);
+    int tot_e, off_e = block_excl_scan_int(is_end, &tot_e, scratch);
+    if (is_start && n_start + off_s < p.sec_cap) st[n_start + off_s] = f;
+    if (is_end && n_end + off_e < p.sec_cap) ed[n_end + off_e] = f;
+    n_start += tot_s; n_end += tot_e;
+  }
+  __syncthreads();
+  const int ns = imin(n_start, p.sec_cap);
+  if (threadIdx.x == 0) {
+    p.sec_n[u * 2] = ns;
+    p.sec_n[u * 2 + 1] = 0;
+    int acc = 0;
+    for (int k = 0; k < ns; ++k) { off[k] = acc; acc += ed[k] - st[k] + 1 + a.extra; }
+  }
+}
+
+// ---- FixStep3, part 1: Extend() per section (:791-878) --------------------------
+// nearest candidate of `ref` within `allowed`, ties -> the LAST one (SelectBestF0, :636-650)
+__device__ __forceinline__ double wave_nearest(double ref, const double *c, int nslot, double allowed) {
+  double best_e = allowed;
+  int best_i = -1;
+  for (int i = lane_id(); i < nslot; i += WAVE) {
+    double e = fabs(ref - c[i]) / ref;
+    if (e > best_e) continue;
+    best_e = e; best_i = i;
+  }
+#ifndef WORLD_EMU
+  for (int m = 32; m >= 1; m >>= 1) {
+    double oe = __shfl_xor(best_e, m, 64);
+    int oi = __shfl_xor(best_i, m, 64);
+    if (oe < best_e || (oe == best_e && oi > best_i)) { best_e = oe; best_i = oi; }
+  }
+#endif
+  return best_i < 0 ? 0.0 : c[best_i];
+}
+
+constexpr int kExtReach = 100;       // frames a section may grow in each direction (:865)
+constexpr int kExtMargin = kExtReach + 1;
+
+__global__ void hc_extend(HarvestParams p) {
+  const int k = wave_item_x(), u = blockIdx.y;
+  if (k >= p.sec_n[u * 2]) return;
+  const int nf = p.nfb[u], nslot = p.nc[u] * 7, lane = lane_id();
+  int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
+  const int st = sec[k], ed = sec[p.sec_cap + k];
+  const int lo = st - kExtMargin;                       // frame index of slice element 0
+  double *e = p.ext + (size_t)u * p.ext_cap + sec[4 * p.sec_cap + k];
+  const double *in = hc_row(p.c2, p, u);
+  const int len = ed - st + 1 + 2 * kExtMargin;
+  for (int i = lane; i < len; i += WAVE) {              // GetMultiChannelF0 (:767-778)
+    int f = lo + i;
+    e[i] = (f >= st && f <= ed) ? in[f] : 0.0;
+  }
+  wave_sync();
+  const double *cands = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
+  int new_ed = ed, new_st = st;
+  for (int dir = 0; dir < 2; ++dir) {                   // forwards first, then backwards
+    const int shift = dir == 0 ? 1 : -1;
+    const int origin = dir == 0 ? ed : st;
+    const int last = dir == 0 ? imin(nf - 2, ed + kExtReach) : imax(1, st - kExtReach);
+    const int dist = last > origin ? last - origin : origin - last;
+    double cur = e[origin - lo];
+    int moved = origin, miss = 0;
+    for (int i = 0; i <= dist; ++i) {
+      const int t = origin + shift * i + shift;
+      double v = wave_nearest(cur, cands + (size_t)t * p.maxc, nslot, 0.18);
+      if (lane == 0) e[t - lo] = v;
+      if (v == 0.0) { miss++; } else { cur = v; miss = 0; moved = t; }
+      if (miss == 4) break;
+    }
+    if (dir == 0) new_ed = moved; else new_st = moved;
+  }
+  wave_sync();
+  // sum over [new_st, new_ed) for ExtendSub's running mean (:850)
+  double s = 0.0;
+  for (int f = new_st + lane; f < new_ed; f += WAVE) s += e[f - lo];
+  s = wave_sum(s);
+  if (lane == 0) {
+    sec[2 * p.sec_cap + k] = new_st;
+    sec[3 * p.sec_cap + k] = new_ed;
+    sec[5 * p.sec_cap + k] = lo;
+    p.sec_sum[(size_t)u * p.sec_cap + k] = s;
+  }
+}
+
+// ---- FixStep3, part 2: ExtendSub + MergeF0, one wavefront per utterance ----------
+__device__ __forceinline__ double wave_best_score(double f0, const double *c, const double *s, int nslot) {
+  double r = 0.0;                                        // SearchScore (:901-907)
+  for (int i = lane_id(); i < nslot; i += WAVE)
+    if (f0 == c[i] && r < s[i]) r = s[i];
+#ifndef WORLD_EMU
+  for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(r, m, 64); r = o > r ? o : r; }
+#endif
+  return r;
+}
+
+__global__ void hc_merge(HarvestParams p) {
+  const int u = wave_item_x();
+  if (u >= p.b.n_utt) return;
+  const int lane = lane_id(), nf = p.nfb[u], nslot = p.nc[u] * 7;
+  const int ns = p.sec_n[u * 2];
+  int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
+  int *order = sec;                                       // original starts are no longer needed
+  int *b_st = sec + 2 * p.sec_cap, *b_ed = sec + 3 * p.sec_cap;
+  int *s_off = sec + 4 * p.sec_cap, *s_lo = sec + 5 * p.sec_cap;
+  const double *sums = p.sec_sum + (size_t)u * p.sec_cap;
+  const double *ext = p.ext + (size_t)u * p.ext_cap;
+  const double *step2 = hc_row(p.c2, p, u);
+  double *out = hc_row(p.c3, p, u);
+  const double *cands = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
+  const double *scores = p.score_a + (size_t)u * p.fb_stride * p.maxc;
+
+  // ExtendSub (:840-856): stable compaction of the sections longer than 2200/mean_f0;
+  // mean_f0 is deliberately NOT reset between sections.
+  int kept = 0;
+  if (lane == 0) {
+    double mean = 0.0;
+    for (int s = 0; s < ns; ++s) {
+      int st = b_st[s], ed = b_ed[s];
+      mean += sums[s];
+      mean /= ed - st;
+      if (2200.0 / mean < ed - st) {
+        int t;
+        t = b_st[kept]; b_st[kept] = b_st[s]; b_st[s] = t;
+        t = b_ed[kept]; b_ed[kept] = b_ed[s]; b_ed[s] = t;
+        t = s_off[kept]; s_off[kept] = s_off[s]; s_off[s] = t;
+        t = s_lo[kept]; s_lo[kept] = s_lo[s]; s_lo[s] = t;
+        kept++;
+      }
+    }
+    p.sec_n[u * 2 + 1] = kept;
+    // MakeSortedOrder (:883-896), quirks included
+    for (int i = 0; i < kept; ++i) order[i] = i;
+    for (int i = 1; i < kept; ++i)
+      for (int j = i - 1; j >= 0; --j) {
+        if (b_st[order[j]] > b_st[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+        else break;
+      }
+  }
+  wave_sync();
+  kept = wave_bcast_int(kept, 0);
+  if (kept == 0) {
+    for (int f = lane; f < nf; f += WAVE) out[f] = step2[f];
+    return;
+  }
+  // value of channel `ch` at frame f: its slice inside its extended run, zero elsewhere
+  auto chan = [&](int ch, int f) {
+    return (f >= b_st[ch] && f <= b_ed[ch]) ? ext[s_off[ch] + (f - s_lo[ch])] : 0.0;
+  };
+  // MergeF0 (:937-963)
+  for (int f = lane; f < nf; f += WAVE) out[f] = chan(0, f);
+  wave_sync();
+  int cur_st = b_st[0], cur_ed = b_ed[0];                 // the reference's boundary_list[0], [1]
+  for (int i = 1; i < kept; ++i) {
+    const int o = order[i];
+    // the reference reads boundary_list[o*2(+1)] AFTER possibly having overwritten entry 0
+    const int st2 = o == 0 ? cur_st : b_st[o];
+    const int ed2 = o == 0 ? cur_ed : b_ed[o];
+    if (st2 - cur_ed > 0) {
+      for (int f = st2 + lane; f <= ed2; f += WAVE) out[f] = chan(o, f);
+      cur_st = st2; cur_ed = ed2;
+    } else {
+      // MergeF0Sub (:912-932)
+      const int st1 = cur_st, ed1 = cur_ed;
+      if (st1 <= st2 && ed1 >= ed2) { cur_ed = ed1; wave_sync(); continue; }
+      double s1 = 0.0, s2 = 0.0;
+      for (int f = st2; f <= ed1; ++f) {
+        s1 += wave_best_score(out[f], cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
+        s2 += wave_best_score(chan(o, f), cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
+      }
+      if (s1 > s2) { for (int f = ed1 + lane; f <= ed2; f += WAVE) out[f] = chan(o, f); }
+      else { for (int f = st2 + lane; f <= ed2; f += WAVE) out[f] = chan(o, f); }
+      cur_ed = ed2;
+    }
+    wave_sync();
+  }
+}
+
+// ---- FixStep4 (:1000-1022): short unvoiced gaps are bridged linearly ---------------
+__global__ void hc_step4(HarvestParams p) {
+  const int k = flat_thread_x(), u = blockIdx.y;
+  const int ns = p.sec_n[u * 2];
+  if (k >= ns - 1) return;
+  const int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
+  const int ed = sec[p.sec_cap + k], nst = sec[k + 1];
+  const int dist = nst - ed - 1;
+  if (dist >= 9) return;
+  const double *in = hc_row(p.c3, p, u);
+  double *out = hc_row(p.c0, p, u);
+  double t0 = in[ed] + 1, t1 = in[nst] - 1;
+  double coef = (t1 - t0) / (dist + 1.0);
+  int c = 1;
+  for (int j = ed + 1; j <= nst - 1; ++j) out[j] = t0 + coef * c++;
+}
+
+// ---- SmoothF0Contour (:1049-1113): zero-phase 2nd-order Butterworth per section ------
+// The reference pads 300 zeros, holds the section's end values over the whole padded
+// signal and runs the IIR forwards and backwards from rest.  300 samples is ~40 time
+// constants of this filter (pole radius 0.875), so each sweep has converged to the
+// DC steady state of the held value when it reaches the section: starting AT the
+// section edge from that steady state differs by < 1e-17.
+constexpr int kSmoothTail = 300;
+__global__ void hc_smooth(HarvestParams p) {
+  const int k = flat_thread_x(), u = blockIdx.y;
+  if (k >= p.sec_n[u * 2]) return;
+  const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
+  const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
+  const int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
+  const int st = sec[k], ed = sec[p.sec_cap + k];
+  const double *in = hc_row(p.c0, p, u);
+  double *tmp = p.ext + (size_t)u * p.ext_cap + sec[4 * p.sec_cap + k];   // ed-st+1+kSmoothTail
+  double *out = hc_row(p.basic_f0, p, u);
+  const int len = ed - st + 1;
+  // forward sweep from the steady state of the held first value
+  double w0 = in[st] / (1.0 - a0 - a1), w1 = w0;
+  for (int i = 0; i < len + kSmoothTail; ++i) {
+    double x = i < len ? in[st + i] : in[ed];
+    double wt = x + a0 * w0 + a1 * w1;
+    tmp[i] = b0 * wt + b1 * w0 + b0 * w1;
+    w1 = w0; w0 = wt;
+  }
+  // backward sweep; beyond the tail the forward output equals the held last value
+  w0 = in[ed] / (1.0 - a0 - a1); w1 = w0;
+  for (int i = len + kSmoothTail - 1; i >= 0; --i) {
+    double wt = tmp[i] + a0 * w0 + a1 * w1;
+    double y = b0 * wt + b1 * w0 + b0 * w1;
+    w1 = w0; w0 = wt;
+    if (i < len) out[st + i] = y;
+  }
+}
+
+// ---- Harvest() hop subsampling (:1246-1251) -------------------------------------------
+__global__ void hc_output(HarvestParams p) {
+  const int i = flat_thread_x(), u = blockIdx.y;
+  if (i >= p.b.n_frames[u]) return;
+  const double t = i * p.frame_period / 1000.0;
+  const int nfb = p.nfb[u];
+  p.tpos[(size_t)u * p.b.f_stride + i] = t;
+  const int src = p.frame_period == 1.0 ? i : imin(nfb - 1, mround(t * 1000.0));
+  p.f0[(size_t)u * p.b.f_stride + i] = hc_row(p.basic_f0, p, u)[src];
+}
+
+void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
+  const int B = p.b.n_utt;
+  const size_t row_bytes = sizeof(double) * (size_t)B * p.fb_stride;
+  WH_THREADS(hc_step1, max_fb, B, 1, stream, p);
+  WH_THREADS(hc_step2, max_fb, B, 1, stream, p);
+  SecArgs a2 = {p.c2, 1, 2 * kExtMargin};
+  WH_BLOCKS(hc_sections, dim3(B), 256, 64 * sizeof(double), stream, p, a2);
+  WH_WAVES(hc_extend, p.sec_cap, B, 1, 0, stream, p);
+  WH_WAVES(hc_merge, B, 1, 1, 0, stream, p);
+  devrt::d2d(p.c0, p.c3, row_bytes, stream);
+  SecArgs a3 = {p.c3, 1, 0};
+  WH_BLOCKS(hc_sections, dim3(B), 256, 64 * sizeof(double), stream, p, a3);
+  WH_THREADS(hc_step4, p.sec_cap, B, 1, stream, p);
+  SecArgs a4 = {p.c0, 0, kSmoothTail};
+  WH_BLOCKS(hc_sections, dim3(B), 256, 64 * sizeof(double), stream, p, a4);
+  devrt::dzero(p.basic_f0, row_bytes, stream);
+  WH_THREADS(hc_smooth, p.sec_cap, B, 1, stream, p);
+  WH_THREADS(hc_output, max_frames, B, 1, stream, p);
+}
+
+}  // namespace world_hip

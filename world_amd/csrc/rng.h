@@ -1,0 +1,83 @@
+// rng.h -- the reference's randn() stream, reproduced exactly and in parallel.
+//
+// randn() (reference src/matlabfunctions.cpp:237-264) is xorshift128 advanced 12
+// times per call, the 12 outputs' top 28 bits summed and recentred.  CheapTrick
+// and D4C add this noise to every windowed sample, so the stream position of
+// every frame is part of the numerical contract.  The generator
+// is linear over GF(2): jumping ahead by k calls is a 128x128 bit-matrix applied
+// to the state; tables.cpp precomputes the matrices for k = 2^j as nibble tables.
+#pragma once
+#include "devrt.h"
+#include "tables.h"
+
+namespace world_hip {
+
+struct Xs128 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Xs128 xs_seed() {           // randn_reseed(), :237-242
+  Xs128 s;
+  s.x = 123456789u; s.y = 362436069u; s.z = 521288629u; s.w = 88675123u;
+  return s;
+}
+
+__device__ __forceinline__ uint32_t xs_step(Xs128 &s) {
+  uint32_t t = s.x ^ (s.x << 11);
+  s.x = s.y; s.y = s.z; s.z = s.w;
+  s.w = (s.w ^ (s.w >> 19)) ^ (t ^ (t >> 8));
+  return s.w;
+}
+
+__device__ __forceinline__ double xs_randn(Xs128 &s) {   // randn(), :244-264
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc += xs_step(s) >> 4;
+  return acc / 268435456.0 - 6.0;
+}
+
+// state <- M_level * state  (advance by 2^level randn() calls)
+__device__ __forceinline__ Xs128 xs_jump_level(const uint4 *jump, Xs128 s, int level) {
+  const uint4 *tab = jump + (size_t)level * kJumpStride;
+  uint32_t in[4] = {s.x, s.y, s.z, s.w};
+  uint32_t a = 0, b = 0, c = 0, d = 0;
+#pragma unroll
+  for (int wd = 0; wd < 4; ++wd) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      uint4 e = tab[(wd * 8 + n) * 16 + ((in[wd] >> (4 * n)) & 15u)];
+      a ^= e.x; b ^= e.y; c ^= e.z; d ^= e.w;
+    }
+  }
+  Xs128 r; r.x = a; r.y = b; r.z = c; r.w = d;
+  return r;
+}
+
+// advance by an arbitrary number of randn() calls
+__device__ __forceinline__ Xs128 xs_jump(const uint4 *jump, Xs128 s, uint32_t calls) {
+  for (int level = 0; calls != 0; ++level, calls >>= 1)
+    if (calls & 1u) s = xs_jump_level(jump, s, level);
+  return s;
+}
+
+// Block-cooperative generation: out[i] = scale * f(randn #(i)) for i < count,
+// starting from `base` (the state before the first of the `count` calls).
+// Each thread owns contiguous runs of kRun draws; threads jump to their run.
+// `absval` selects |randn| (CheapTrick's AddInfinitesimalNoise, cheaptrick.cpp:147-151).
+constexpr int kRunLog2 = 3;
+constexpr int kRun = 1 << kRunLog2;
+__device__ __forceinline__ void block_randn_fill(const uint4 *jump, Xs128 base, int count,
+                                                 double scale, bool absval, double *out) {
+  int per_pass = (int)blockDim.x * kRun;
+  for (int start = 0; start < count; start += per_pass) {
+    int first = start + (int)threadIdx.x * kRun;
+    if (first < count) {
+      Xs128 s = xs_jump(jump, base, (uint32_t)first);
+      int end = first + kRun < count ? first + kRun : count;
+      for (int i = first; i < end; ++i) {
+        double r = xs_randn(s);
+        out[i] = (absval ? fabs(r) : r) * scale;
+      }
+    }
+  }
+}
+
+}  // namespace world_hip

@@ -1,0 +1,42 @@
+// stage_params.h -- parameter blocks of the per-frame spectral stages
+// (cheaptrick.hip, d4c.hip) and their host launchers.
+#pragma once
+#include "common.h"
+
+namespace world_hip {
+
+struct CtParams {
+  BatchView b;
+  const double *tpos;    // [n_utt][f_stride]
+  const double *f0;      // [n_utt][f_stride]
+  double *spectrogram;   // [n_utt][f_stride][fft/2+1]
+  Xs128 *states;         // [n_utt][f_stride] RNG state at the start of each frame
+  Tables tab;
+  double q1;
+  double f0_floor;       // GetF0FloorForCheapTrick()
+  int lg_fft;            // log2(fft_size)
+};
+
+struct D4cParams {
+  BatchView b;
+  const double *tpos;     // [n_utt][f_stride]
+  const double *f0;       // [n_utt][f_stride]
+  double *aperiodicity;   // [n_utt][f_stride][fft_out/2+1]
+  double *ap0;            // [n_utt][f_stride]  LoveTrain result
+  Xs128 *states1;         // [n_utt][f_stride]  stream position of the LoveTrain window
+  Xs128 *states2;         // [n_utt][f_stride]  stream position of the frame's 3 body windows
+  unsigned *draws1;       // [n_utt] total draws of pass 1
+  const double *nuttall;  // [wl] NuttallWindow(wl), built on the host
+  Tables tab;
+  double threshold;
+  int fft_out;            // caller's fft_size (rows have fft_out/2+1 bins)
+  int lg_love;            // log2 of the LoveTrain FFT
+  int lg_d4c;             // log2 of fft_size_d4c
+  int nap;                // number_of_aperiodicities
+  int wl;                 // Nuttall window length
+};
+
+void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream);
+void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
+
+}  // namespace world_hip

@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- analysis frames/sec of the MI355X WORLD analysis path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--seconds S]
+
+One "step" = one pass of Harvest + CheapTrick + D4C (48 kHz, 5 ms hop, CheapTrick
+fft 2048, D4C internal fft 4096) over one batch of synthetic utterances already
+resident in HBM, results left in HBM.  The default workload is BASELINE.json
+configs[1]: ONE 48 kHz x 10 s utterance per GPU (2001 frames); `--batch B` runs B
+utterances per step (the per-GPU share of configs[3] is --batch 128 --seconds 5).
+With N > 1 ranks every rank analyses its own utterances (utterances are the
+independent unit; weak scaling, no data-path collective).
+
+Rank 0 prints ONE JSON line: metric/value (whole-job frames/s), `roofline` for the
+kernel that dominates the step (HIP-event timing on the launch stream, taken in a
+separate profiled pass) and `cpu_baseline` (the CPU oracle on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FS = 48000
+FRAME_PERIOD = 5.0
+FFT_SIZE = 2048
+# compulsory HBM bytes per output frame of the full pipeline at 48 kHz:
+# one hop of x read once (240 samples * 8 B) + tpos + f0 + two rows of 1025 doubles written once
+BYTES_PER_FRAME = 240 * 8 + 8 + 8 + 2 * 1025 * 8
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+
+
+def cpu_baseline(x_np, reps=1):
+    """Time the CPU oracle (the unmodified reference when its in-place build travelled
+    here, else this repo's C restatement) on the same utterance, one host core."""
+    from oracle.loader import best_oracle
+    o = best_oracle()
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(reps):
+        tp, f0 = o.harvest(x_np, FS, frame_period=FRAME_PERIOD)
+        o.cheaptrick(x_np, FS, tp, f0, fft_size=FFT_SIZE)
+        o.d4c(x_np, FS, tp, f0, FFT_SIZE)
+        frames += len(f0)
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1,
+            "kind": "reference" if o.kind == "reference" else "port",
+            "sample": f"{reps} x ({len(x_np) / FS:.1f} s of 48 kHz audio, Harvest+CheapTrick+D4C, {frames // reps} frames), "
+                      f"{getattr(o, 'flags', 'gcc -O2 restatement')}, {dt:.1f} s of CPU time",
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from world_amd import synth
+    from world_amd.api import WorldHip, frame_count
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    dev = torch.device("cuda", local)
+    # synthetic utterances of this rank (distinct per rank and per slot), resident in HBM
+    B = args.batch
+    xs = [synth.vowel(FS, args.seconds, seed=12345, device=dev) if (rank == 0 and i == 0)
+          else synth.utterance(rank * B + i, FS, args.seconds, device=dev) for i in range(B)]
+    x = torch.stack(xs).contiguous()
+    n = x.shape[1]
+    nf = frame_count(FS, n, FRAME_PERIOD)
+    wh = WorldHip(device=local)
+    sp = torch.empty((B, nf, FFT_SIZE // 2 + 1), dtype=torch.float64, device=dev)
+    ap_ = torch.empty_like(sp)
+
+    def step():
+        return wh.analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp, ap_out=ap_)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames_per_step = nf * B * world
+    value = frames_per_step * args.steps / dt
+
+    # ---- roofline leg: per-kernel HIP-event timing of a few extra steps (rank 0) ----
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        prof = wh.profile(lambda: [step() for _ in range(3)])
+        torch.cuda.synchronize()
+        kernels = {k: {"launches_per_step": len(v) // 3, "ms_per_step": sum(v) / 3.0, "avg_ms": sum(v) / len(v)}
+                   for k, v in prof.items()}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        units = nf * B                              # frames one launch of the dominant kernel covers
+        alg_bytes = BYTES_PER_FRAME * units
+        achieved = alg_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
+                    "note": "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~6 MFLOP/frame vs 18.3 kB/frame"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(xs[0].cpu().numpy())
+
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        out = {
+            "metric": "analysis frames/sec (Harvest+CheapTrick+D4C, 48 kHz, 5 ms hop)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {B} x (48 kHz, {args.seconds:g} s) utterance(s) per GPU, "
+                                   f"Harvest+CheapTrick+D4C, fft_size=2048, frame_period=5 ms, inputs/outputs in HBM",
+                       "frames_per_step": frames_per_step, "utterances_per_gpu": B,
+                       "parallelism": f"utterance-sharded x{world}, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
+                kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            "workspace_bytes": wh.workspace_bytes(),
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -42,10 +42,20 @@ class D4COption(C.Structure):        # reference d4c.h:16-18
     _fields_ = [("threshold", C.c_double)]
 
 
+def _hip_runtime_first():
+    """torch ships its own libamdhip64; load it BEFORE libworld_hip.so so the process
+    ends up with exactly one HIP runtime (the one torch allocates device memory with)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def load_library(path=LIB_PATH):
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it with `python -m world_amd.build` "
                           "(hipcc, gfx950). There is no non-GPU fallback.")
+    _hip_runtime_first()
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.world_hip_create.restype = vp
@@ -112,6 +122,7 @@ class HostAPI:
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing (python -m world_amd.build); there is no fallback.")
         self.path = path
+        _hip_runtime_first()
         self.lib = L = C.CDLL(path)
         L.Dio.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(DioOption), _dp, _dp]
         L.Harvest.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(HarvestOption), _dp, _dp]

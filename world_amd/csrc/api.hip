@@ -155,7 +155,9 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
     if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
     max_frames = std::max(max_frames, n_frames[u]);
   }
-  size_t need = pad256(sizeof(Xs128) * (size_t)n_utt * f_stride) + 2 * pad256(sizeof(int) * n_utt);
+  const size_t noise_stride = (size_t)max_frames * ct_max_draws_per_frame(opt->fft_size) + 64;
+  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 3 * pad256(sizeof(int) * n_utt) +
+                pad256(sizeof(double) * n_utt * noise_stride);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   CtParams p;
@@ -163,7 +165,10 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
   p.b.x_len = upload(c, std::vector<int>(x_length, x_length + n_utt));
   p.b.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
   p.tpos = d_tpos; p.f0 = d_f0; p.spectrogram = d_sp;
-  p.states = c->arena.take<Xs128>((size_t)n_utt * f_stride);
+  p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
+  p.totals = c->arena.take<unsigned>(n_utt);
+  p.noise = c->arena.take<double>((size_t)n_utt * noise_stride);
+  p.noise_stride = noise_stride;
   p.tab = c->tab;
   p.q1 = opt->q1;
   p.f0_floor = 3.0 * fs / (opt->fft_size - 3.0);                       // cheaptrick.cpp:196-198
@@ -206,7 +211,9 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     c->nuttall_len = wl;
   }
   size_t fr = (size_t)n_utt * f_stride;
-  size_t need = 2 * pad256(sizeof(Xs128) * fr) + pad256(sizeof(double) * fr) + 3 * pad256(sizeof(int) * n_utt);
+  const size_t noise_stride = (size_t)max_frames * d4c_max_draws_per_frame(fs) + 64;
+  size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 4 * pad256(sizeof(int) * n_utt) +
+                pad256(sizeof(double) * n_utt * noise_stride);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   D4cParams p;
@@ -215,9 +222,12 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.b.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
   p.tpos = d_tpos; p.f0 = d_f0; p.aperiodicity = d_ap;
   p.ap0 = c->arena.take<double>(fr);
-  p.states1 = c->arena.take<Xs128>(fr);
-  p.states2 = c->arena.take<Xs128>(fr);
+  p.offsets1 = c->arena.take<unsigned>(fr);
+  p.offsets2 = c->arena.take<unsigned>(fr);
   p.draws1 = c->arena.take<unsigned>(n_utt);
+  p.draws2 = c->arena.take<unsigned>(n_utt);
+  p.noise = c->arena.take<double>((size_t)n_utt * noise_stride);
+  p.noise_stride = noise_stride;
   p.nuttall = c->d_nuttall;
   p.tab = c->tab;
   p.threshold = opt->threshold;
@@ -305,6 +315,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.ext_cap = max_fb + 304 * p.sec_cap + 8;
   p.max_half = hb.max_half;
   p.tab = c->tab;
+  p.nseg = hv_segments(max_y);
 
   const size_t B = n_utt;
   const size_t cand_elems = B * p.fb_stride * p.maxc;
@@ -314,6 +325,8 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   need += pad256(sizeof(double) * B * p.y_stride);
   need += pad256(sizeof(double) * B * p.nch * 4 * p.ev_cap);
   need += pad256(sizeof(int) * B * p.nch * 4);
+  need += pad256(sizeof(double) * B * p.nch * 4 * hv_segment_list_doubles(p.nseg));
+  need += pad256(sizeof(int) * B * p.nch * 4 * p.nseg);
   need += pad256(sizeof(double) * B * p.nch * p.fb_stride);
   need += 4 * pad256(sizeof(double) * cand_elems);
   need += pad256(sizeof(int) * B);
@@ -334,6 +347,8 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.y = c->arena.take<double>(B * p.y_stride);
   p.events = c->arena.take<double>(B * p.nch * 4 * p.ev_cap);
   p.ev_count = c->arena.take<int>(B * p.nch * 4);
+  p.seg_events = c->arena.take<double>(B * p.nch * 4 * hv_segment_list_doubles(p.nseg));
+  p.seg_count = c->arena.take<int>(B * p.nch * 4 * p.nseg);
   p.raw = c->arena.take<double>(B * p.nch * p.fb_stride);
   p.cand_a = c->arena.take<double>(cand_elems); p.score_a = c->arena.take<double>(cand_elems);
   p.cand_b = c->arena.take<double>(cand_elems); p.score_b = c->arena.take<double>(cand_elems);

@@ -32,7 +32,7 @@ __global__ void ct_prepare(CtParams p) {
   int nf = p.b.n_frames[u];
   int nb = (1 << p.lg_fft) / 2 + 1;
   const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
-  Xs128 *st = p.states + (size_t)u * p.b.f_stride;
+  unsigned *off_out = p.offsets + (size_t)u * p.b.f_stride;
   unsigned running = 0;
   for (int base = 0; base < nf; base += blockDim.x) {
     int f = base + threadIdx.x;
@@ -42,9 +42,10 @@ __global__ void ct_prepare(CtParams p) {
       cnt = 2 * mround(1.5 * p.b.fs / cf0) + 1 + nb;     // window draws, then one per bin
     }
     int total, off = block_excl_scan_int(cnt, &total, scratch);
-    if (f < nf) st[f] = xs_jump(p.tab.jump, xs_seed(), running + (unsigned)off);
+    if (f < nf) off_out[f] = running + (unsigned)off;
     running += (unsigned)total;
   }
+  if (threadIdx.x == 0) p.totals[u] = running;
 }
 
 // ---------------------------------------------------------------------------
@@ -67,15 +68,14 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[(size_t)u * p.b.f_stride + f];
   const double cf0 = ct_effective_f0(p.f0[(size_t)u * p.b.f_stride + f], p.f0_floor);
-  Xs128 st = p.states[(size_t)u * p.b.f_stride + f];
+  const double *noise = p.noise + (size_t)u * p.noise_stride + p.offsets[(size_t)u * p.b.f_stride + f];
   const int tid = threadIdx.x, nt = blockDim.x;
 
   // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) -------------------------
   const int hw = mround(1.5 * fs / cf0);
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
-  // noise first (draw order = sample order), window shape into seg
-  block_randn_fill(p.tab.jump, st, wlen, kTiny, false, Zr);
+  // window shape into seg; the frame's draws (sample order) come from the noise stream
   double e = 0.0;
   for (int i = tid; i < wlen; i += nt) {
     double position = (i - hw) / 1.5 / fs;
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   for (int i = tid; i < wlen; i += nt) {
     double w = seg[i] / e;
     seg[i] = w;
-    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + Zr[i];
+    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kTiny;
     Zr[i] = v;
     s1 += v; s2 += w;
   }
@@ -124,16 +124,11 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
     else m = P[half - (i - (half + bnd))];
     seg[i] = m * fs / N;
   }
-  // Per-bin noise draws continue the frame's stream after the window draws
-  // (cheaptrick.cpp:147-151).  They land in Zr[0..nb) while one lane runs the
-  // order-sensitive serial prefix sum.
-  Xs128 st_bins = xs_jump(p.tab.jump, st, (unsigned)wlen);
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0) {                       // the order-sensitive serial prefix sum
     double acc = seg[0];
     for (int i = 1; i < seg_len; ++i) { acc = seg[i] + acc; seg[i] = acc; }
   }
-  block_randn_fill(p.tab.jump, st_bins, nb, kEps, true, Zr);
   __syncthreads();
   {
     const double origin_axis = -(bnd - 0.5) * fs / N;
@@ -144,8 +139,9 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
       fa += width;
       double hi = interp_uniform(origin_axis, step, seg, seg_len, fa);
       double smoothed = (hi - lo) / width;
-      // AddInfinitesimalNoise, then the log of SmoothingWithRecovery (:39-42)
-      double lg = log(smoothed + Zr[i]);
+      // AddInfinitesimalNoise: the per-bin draws continue the frame's stream after the
+      // window draws (cheaptrick.cpp:147-151); then the log of SmoothingWithRecovery (:39-42)
+      double lg = log(smoothed + fabs(noise[wlen + i]) * kEps);
       P[i] = lg;
     }
     __syncthreads();
@@ -179,8 +175,12 @@ size_t ct_frame_lds_bytes(int lg_fft) {
   return sizeof(double) * (size_t)(N + nb + 1 + seg_cap + (seg_cap & 1) + 64);
 }
 
+size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size / 2 + 1; }   // window < fft_size, + bins
+
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  RngFillArgs fill = {p.noise, p.noise_stride, nullptr, p.totals, p.tab.jump};
+  launch_rng_fill(fill, p.b.n_utt, (size_t)max_frames * ct_max_draws_per_frame(1 << p.lg_fft), stream);
   WH_BLOCKS(ct_frame, dim3(max_frames, p.b.n_utt), 256, ct_frame_lds_bytes(p.lg_fft), stream, p);
 }
 

@@ -37,7 +37,7 @@ __global__ void d4c_prepare1(D4cParams p) {
   double *scratch = reinterpret_cast<double *>(lds);
   int u = blockIdx.x, nf = p.b.n_frames[u];
   const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
-  Xs128 *st = p.states1 + (size_t)u * p.b.f_stride;
+  unsigned *off_out = p.offsets1 + (size_t)u * p.b.f_stride;
   unsigned running = 0;
   for (int base = 0; base < nf; base += blockDim.x) {
     int f = base + threadIdx.x, cnt = 0;
@@ -46,7 +46,7 @@ __global__ void d4c_prepare1(D4cParams p) {
       cnt = 2 * mround(3.0 * p.b.fs / cf0 / 2.0) + 1;
     }
     int total, off = block_excl_scan_int(cnt, &total, scratch);
-    if (cnt) st[f] = xs_jump(p.tab.jump, xs_seed(), running + (unsigned)off);
+    if (f < nf) off_out[f] = running + (unsigned)off;
     running += (unsigned)total;
   }
   if (threadIdx.x == 0) p.draws1[u] = running;
@@ -58,8 +58,8 @@ __global__ void d4c_prepare2(D4cParams p) {
   int u = blockIdx.x, nf = p.b.n_frames[u];
   const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
   const double *ap0 = p.ap0 + (size_t)u * p.b.f_stride;
-  Xs128 *st = p.states2 + (size_t)u * p.b.f_stride;
-  unsigned running = p.draws1[u];
+  unsigned *off_out = p.offsets2 + (size_t)u * p.b.f_stride;
+  unsigned running = 0;                  // positions are relative to the start of pass 2
   for (int base = 0; base < nf; base += blockDim.x) {
     int f = base + threadIdx.x, cnt = 0;
     if (f < nf && !(f0[f] == 0 || ap0[f] <= p.threshold)) {          // d4c.cpp:386
@@ -67,45 +67,34 @@ __global__ void d4c_prepare2(D4cParams p) {
       cnt = 3 * (2 * mround(4.0 * p.b.fs / cf0 / 2.0) + 1);
     }
     int total, off = block_excl_scan_int(cnt, &total, scratch);
-    if (cnt) st[f] = xs_jump(p.tab.jump, xs_seed(), running + (unsigned)off);
+    if (f < nf) off_out[f] = running + (unsigned)off;
     running += (unsigned)total;
   }
+  if (threadIdx.x == 0) p.draws2[u] = running;
 }
 
 // Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84).
-// Samples go to dst[i*dstride], the window shape to win[i*wstride]; returns 2*hw+1.
+// Samples go to dst[i*dstride]; the window shape is recomputed in the second pass
+// instead of being stored (saves 32 KB of LDS per workgroup).  Returns 2*hw+1.
 __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, double f0, double pos,
-                                            int kind, double ratio, const uint4 *jump, Xs128 st,
-                                            double *dst, int dstride, double *win, int wstride,
-                                            double *scratch) {
+                                            int kind, double ratio, const double *noise,
+                                            double *dst, int dstride, double *scratch) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int hw = mround(ratio * fs / f0 / 2.0);
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
-  // noise in draw order = sample order
-  {
-    int per_pass = nt * kRun;
-    for (int start = 0; start < wlen; start += per_pass) {
-      int first = start + tid * kRun;
-      if (first < wlen) {
-        Xs128 s = xs_jump(jump, st, (unsigned)first);
-        int end = first + kRun < wlen ? first + kRun : wlen;
-        for (int i = first; i < end; ++i) dst[(size_t)i * dstride] = xs_randn(s) * kSafeGuardD4C;
-      }
-    }
-  }
-  __syncthreads();
   double s1 = 0.0, s2 = 0.0;
   for (int i = tid; i < wlen; i += nt) {
     double w = d4c_window_at(i, hw, kind, ratio, fs, f0);
-    win[(size_t)i * wstride] = w;
-    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + dst[(size_t)i * dstride];
+    // noise[i]: the window's draws in sample order (d4c.cpp:67-69)
+    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kSafeGuardD4C;
     dst[(size_t)i * dstride] = v;
     s1 += v; s2 += w;
   }
   block_sum2(s1, s2, scratch);
   const double coef = s1 / s2;
-  for (int i = tid; i < wlen; i += nt) dst[(size_t)i * dstride] -= win[(size_t)i * wstride] * coef;
+  for (int i = tid; i < wlen; i += nt)
+    dst[(size_t)i * dstride] -= d4c_window_at(i, hw, kind, ratio, fs, f0) * coef;
   __syncthreads();
   return wlen;
 }
@@ -121,11 +110,11 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   const int lgn = p.lg_love, M = 1 << lgn, fs = p.b.fs;
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
-  double *win = Zr + M;
-  double *scratch = win + M;
+  double *scratch = Zr + M;
   const double cf0 = f0 > 40.0 ? f0 : 40.0;
   const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
-                                kBlackman, 3.0, p.tab.jump, p.states1[fi], Zr, 1, win, 1, scratch);
+                                kBlackman, 3.0, p.noise + (size_t)u * p.noise_stride + p.offsets1[fi],
+                                Zr, 1, scratch);
   for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) Zr[i] = 0.0;
   const int b0 = static_cast<int>(ceil(100.0 * M / fs));
   const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
@@ -251,30 +240,37 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
     return;
   }
   const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
-  // LDS: Z (N complex) | A (H+2) | B (H+2) | hist (256 int) | scratch (64) | coarse (16)
+  // LDS: Z (N complex + 8) | hist (256 int) | scratch (64) | coarse (16).  The packed
+  // centroid transform needs all of Z; afterwards Z is re-carved into the real-FFT /
+  // prefix-sum work area [0, N), B = [N, N+H+1) and A = [N+H+1, N+2H+2).  During the
+  // centroid phase A lives in registers (each thread always owns the same bins).
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
-  double *A = Zr + 2 * N;
-  double *B = A + (H + 2);
-  int *hist = reinterpret_cast<int *>(B + (H + 2));
+  double *B = Zr + N;
+  double *A = B + (H + 1);
+  int *hist = reinterpret_cast<int *>(Zr + 2 * N + 8);
   double *scratch = reinterpret_cast<double *>(hist + 256);
   double *coarse = scratch + 64;
+#ifdef WORLD_EMU
+  constexpr int kBinsPerThread = 4096 / 2 + 1;          // one emulated thread owns every bin
+#else
+  constexpr int kBinsPerThread = (4096 / 2 + 1 + 511) / 512;
+#endif
+  double a_reg[kBinsPerThread];
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[fi];
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
-  Xs128 st = p.states2[fi];
+  const double *noise = p.noise + (size_t)u * p.noise_stride + p.offsets2[fi];
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
 
   // ---- GetStaticCentroid (d4c.cpp:126-143) ----------------------------------
   for (int c = 0; c < 2; ++c) {
     const double cpos = c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
     __syncthreads();
-    // real part <- windowed segment, imaginary part holds the window meanwhile
-    const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, p.tab.jump,
-                                  xs_jump(p.tab.jump, st, (unsigned)(c * wdraws)),
-                                  Zr, 2, Zr + 1, 2, scratch);
+    const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
+                                  Zr, 2, scratch);
     double pw = 0.0;
     for (int i = tid; i < wlen; i += nt) pw += Zr[2 * i] * Zr[2 * i];
     pw = block_sum(pw, scratch);
@@ -285,22 +281,30 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
       Zr[2 * i + 1] = v * (i + 1.0);                 // second transform's input (d4c.cpp:111-112)
     }
     block_cfft_dif(Z, lgn, p.tab.tw);
-    for (int k = tid; k <= H; k += nt) {
+#pragma unroll
+    for (int slot = 0; slot < kBinsPerThread; ++slot) {
+      const int k = tid + slot * nt;
+      if (k > H) break;
       cplx za = Z[brev_bits(k, lgn)], zb = Z[brev_bits((N - k) & (N - 1), lgn)];
       double x1r = 0.5 * (za.re + zb.re), x1i = 0.5 * (za.im - zb.im);
       double x2r = 0.5 * (za.im + zb.im), x2i = -0.5 * (za.re - zb.re);
       if (k == 0 || k == H) { x1i = 0.0; x2i = 0.0; }
       double cen = x2r * x1r + x1i * x2i;            // d4c.cpp:115-116
-      A[k] = c == 0 ? cen : A[k] + cen;
+      a_reg[slot] = c == 0 ? cen : a_reg[slot] + cen;
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int slot = 0; slot < kBinsPerThread; ++slot) {
+    const int k = tid + slot * nt;
+    if (k <= H) A[k] = a_reg[slot];
   }
   d4c_dc_correct(A, cf0, fs, N, Zr);
 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
   {
-    const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, p.tab.jump,
-                                  xs_jump(p.tab.jump, st, (unsigned)(2 * wdraws)),
-                                  Zr, 1, Zr + N, 1, scratch);
+    const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
+                                  Zr, 1, scratch);
     for (int i = wlen + tid; i < N; i += nt) Zr[i] = 0.0;
     block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
   }
@@ -352,16 +356,24 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
 }
 
 // ---------------------------------------------------------------------------
-size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)(2 * (1 << lg) + 64); }
+size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64); }
 size_t d4c_body_lds_bytes(int lg) {
-  int N = 1 << lg, H = N / 2;
-  return sizeof(double) * (size_t)(2 * N + 2 * (H + 2) + 128 + 64 + 16);
+  int N = 1 << lg;
+  return sizeof(double) * (size_t)(2 * N + 8 + 128 + 64 + 16);
 }
 
+// worst case per frame: 3 body windows of 2*round(2 fs/47)+1 draws (pass 2 > pass 1)
+size_t d4c_max_draws_per_frame(int fs) { return 3 * (size_t)(2 * mround(4.0 * fs / kFloorF0D4C / 2.0) + 1); }
+
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
+  const size_t max_draws = (size_t)max_frames * d4c_max_draws_per_frame(p.b.fs);
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  RngFillArgs fill1 = {p.noise, p.noise_stride, nullptr, p.draws1, p.tab.jump};
+  launch_rng_fill(fill1, p.b.n_utt, max_draws, stream);
   WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), 256, d4c_love_lds_bytes(p.lg_love), stream, p);
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  RngFillArgs fill2 = {p.noise, p.noise_stride, p.draws1, p.draws2, p.tab.jump};   // pass 2 continues the stream
+  launch_rng_fill(fill2, p.b.n_utt, max_draws, stream);
   WH_BLOCKS(d4c_body, dim3(max_frames, p.b.n_utt), 512, d4c_body_lds_bytes(p.lg_d4c), stream, p);
 }
 

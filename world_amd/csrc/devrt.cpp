@@ -78,8 +78,8 @@ std::string prof_collect() {
     char line[160];
     snprintf(line, sizeof line, "%s %.6f\n", r.name, ms);
     out += line;
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
   }
   g_recs.clear();
   return out;

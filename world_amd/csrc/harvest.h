@@ -33,6 +33,9 @@ struct HarvestParams {
   double *fwd;             // [n_utt][m_stride] forward-filtered padded signal
   int m_stride;
   double *y;               // [n_utt][y_stride]
+  double *seg_events;      // [n_utt][nch][4][nseg][segment capacity] per-segment crossing times
+  int *seg_count;          // [n_utt][nch][4][nseg]
+  int nseg;                // time segments per utterance slot
   double *events;          // [n_utt][nch][4][ev_cap] fine zero-crossing positions
   int *ev_count;           // [n_utt][nch][4]
   double *raw;             // [n_utt][nch][fb_stride]
@@ -50,6 +53,8 @@ struct HarvestParams {
   double *f0;              // [n_utt][f_stride]
 };
 
+int hv_segments(int max_y_len);
+size_t hv_segment_list_doubles(int nseg);
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
                     hipStream_t stream);
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream);

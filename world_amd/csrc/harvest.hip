@@ -52,31 +52,46 @@ __global__ void hv_remove_mean(HarvestParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// Band-pass FIR + the four zero-crossing families, one workgroup per (band, utt).
+// Band-pass FIR + the four zero-crossing families.  One workgroup per
+// (time segment, band, utterance); a segment is kSegTiles tiles of kTile samples.
+// Each workgroup appends the sub-sample crossing times of its segment to its own
+// list; hv_compact_events then concatenates the segments in time order.
 constexpr int kTile = 1024;             // filtered samples produced per step (+2 look-ahead)
+constexpr int kSegTiles = 4;
+constexpr int kSeg = kTile * kSegTiles;
+constexpr int kSegCap = kSeg / 2 + 2;   // a crossing needs two samples
 constexpr int kBpThreads = 256;
+constexpr int kOutPer = kTile / kBpThreads;   // outputs accumulated side by side per thread
 
 // sub-sample crossing time between samples e-1 and e (harvest.cpp:183-186)
 __device__ __forceinline__ double fine_edge(int e, double prev, double cur) { return e - prev / (cur - prev); }
 
 __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
   DYN_LDS(lds);
-  const int band = blockIdx.x, u = blockIdx.y;
+  const int seg = blockIdx.x, band = blockIdx.y, u = blockIdx.z;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int L = p.band_half[band], ntap = 2 * L + 1;
   const int n = p.y_len[u];
+  const int seg_begin = seg * kSeg;
+  int *cnt_out = p.seg_count + ((size_t)(u * p.nch + band) * 4) * p.nseg + seg;
+  if (seg_begin >= n) {
+    if (tid == 0) for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = 0;
+    return;
+  }
+  const int seg_end = imin(n, seg_begin + kSeg);
+  const int L = p.band_half[band], ntap = 2 * L + 1;
   const double *y = p.y + (size_t)u * p.y_stride;
-  // LDS: ytile[kTile + 2 + 2*maxL] | s[kTile + 2] | scratch[64].  The taps are read
-  // with a wave-uniform index, i.e. through the scalar cache, not from LDS.
-  double *yt = reinterpret_cast<double *>(lds);
+  // LDS: taps[2*maxL+2] | ytile[kTile + 2 + 2*maxL + 2] | s[kTile + 4] | scratch[64]
+  double *taps = reinterpret_cast<double *>(lds);
+  double *yt = taps + (2 * p.max_half + 2);
   double *s = yt + (kTile + 2 + 2 * p.max_half + 2);
   double *scratch = s + (kTile + 4);
-  const double *__restrict__ taps = p.band_taps + p.band_off[band];
+  for (int j = tid; j < ntap; j += nt) taps[j] = p.band_taps[p.band_off[band] + j];
 
-  double *ev = p.events + ((size_t)(u * p.nch + band) * 4) * p.ev_cap;
+  double *ev = p.seg_events + (((size_t)(u * p.nch + band) * 4) * p.nseg + seg) * kSegCap;
+  const size_t fam_stride = (size_t)p.nseg * kSegCap;
   int count[4] = {0, 0, 0, 0};
 
-  for (int t0 = 0; t0 < n; t0 += kTile) {
+  for (int t0 = seg_begin; t0 < seg_end; t0 += kTile) {
     // filtered[i] = sum_{j=-L..L} h[L+j] * y[i+1-j]  for i in [t0, t0+kTile+2)
     // (the reference's delay compensation is L+1, harvest.cpp:140-142) -> needs
     // y[t0+1-L .. t0+kTile+2+L]
@@ -88,18 +103,32 @@ __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
       yt[k] = (idx >= 0 && idx < n) ? y[idx] : 0.0;
     }
     __syncthreads();
-    for (int k = tid; k < kTile + 2; k += nt) {
-      // y index for tap j (0..2L): i + 1 - (j - L) = i + 1 + L - j  -> yt[k + 2L - j]
+    // y index for output k, tap j (0..2L): i + 1 - (j - L)  ->  yt[k + 2L - j]
+    for (int k0 = tid; k0 < kTile; k0 += nt * kOutPer) {
+      double acc[kOutPer];
+#pragma unroll
+      for (int q = 0; q < kOutPer; ++q) acc[q] = 0.0;
+      const double *yy = yt + k0 + 2 * L;
+      for (int j = 0; j < ntap; ++j) {
+        const double h = taps[j];
+#pragma unroll
+        for (int q = 0; q < kOutPer; ++q) acc[q] = fma(h, yy[q * nt - j], acc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < kOutPer; ++q)
+        if (k0 + q * nt < kTile) s[k0 + q * nt] = acc[q];
+    }
+    for (int e = tid; e < 2; e += nt) {              // the two look-ahead samples
       double acc = 0.0;
-      const double *yy = yt + k + 2 * L;
+      const double *yy = yt + kTile + e + 2 * L;
       for (int j = 0; j < ntap; ++j) acc = fma(taps[j], yy[-j], acc);
-      s[k] = acc;
+      s[kTile + e] = acc;
     }
     __syncthreads();
-    // events: each thread inspects kTile/nt consecutive samples, in order
+    // events: each thread inspects kPer consecutive samples, in time order
     constexpr int kPer = 4;
     for (int fam = 0; fam < 4; ++fam) {
-      double *dst = ev + (size_t)fam * p.ev_cap;
+      double *dst = ev + fam * fam_stride;
       for (int sub = 0; sub < kTile; sub += nt * kPer) {
         double found[kPer];
         int nfound = 0;
@@ -116,13 +145,29 @@ __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
         }
         int total, off = block_excl_scan_int(nfound, &total, scratch);
         for (int q = 0; q < nfound; ++q)
-          if (count[fam] + off + q < p.ev_cap) dst[count[fam] + off + q] = found[q];
+          if (count[fam] + off + q < kSegCap) dst[count[fam] + off + q] = found[q];
         count[fam] += total;
       }
     }
   }
   if (tid == 0)
-    for (int fam = 0; fam < 4; ++fam) p.ev_count[(u * p.nch + band) * 4 + fam] = imin(count[fam], p.ev_cap);
+    for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = imin(count[fam], kSegCap);
+}
+
+// concatenate the per-segment lists of one (family, band, utterance) in time order
+__global__ void hv_compact_events(HarvestParams p) {
+  const int bf = blockIdx.x, u = blockIdx.y;        // bf = band * 4 + family
+  const int *cnt = p.seg_count + ((size_t)u * p.nch * 4 + bf) * p.nseg;
+  const double *src = p.seg_events + ((size_t)u * p.nch * 4 + bf) * p.nseg * kSegCap;
+  double *dst = p.events + ((size_t)u * p.nch * 4 + bf) * p.ev_cap;
+  int base = 0;
+  for (int sgm = 0; sgm < p.nseg; ++sgm) {
+    const int c = cnt[sgm];
+    for (int i = threadIdx.x; i < c; i += blockDim.x)
+      if (base + i < p.ev_cap) dst[base + i] = src[(size_t)sgm * kSegCap + i];
+    base += c;
+  }
+  if (threadIdx.x == 0) p.ev_count[(u * p.nch * 4) + bf] = imin(base, p.ev_cap);
 }
 
 // ---------------------------------------------------------------------------
@@ -304,28 +349,30 @@ __device__ __forceinline__ double nearest_error(double ref, const double *c, int
   }
   return err;
 }
-__global__ void hv_prune(HarvestParams p) {
-  const int frame = flat_thread_x(), u = blockIdx.y;
+__global__ void hv_prune(HarvestParams p) {             // one thread per (frame, slot)
+  const int item = flat_thread_x(), u = blockIdx.y;
+  const int frame = item / p.maxc, j = item - frame * p.maxc;
   const int nfb = p.nfb[u];
   if (frame >= nfb) return;
   const int nslot = p.nc[u] * 7;
+  if (j >= nslot) return;
   const size_t row = ((size_t)u * p.fb_stride + frame) * p.maxc;
-  for (int j = 0; j < nslot; ++j) {
-    double ref = p.cand_b[row + j], sc = p.score_b[row + j];
-    if (frame >= 1 && frame < nfb - 1 && ref != 0) {
-      double e1 = nearest_error(ref, p.cand_b + row + p.maxc, nslot);
-      double e2 = nearest_error(ref, p.cand_b + row - p.maxc, nslot);
-      if ((e1 < e2 ? e1 : e2) > 0.05) { ref = 0; sc = 0; }
-    }
-    p.cand_a[row + j] = ref;
-    p.score_a[row + j] = sc;
+  double ref = p.cand_b[row + j], sc = p.score_b[row + j];
+  if (frame >= 1 && frame < nfb - 1 && ref != 0) {
+    double e1 = nearest_error(ref, p.cand_b + row + p.maxc, nslot);
+    double e2 = nearest_error(ref, p.cand_b + row - p.maxc, nslot);
+    if ((e1 < e2 ? e1 : e2) > 0.05) { ref = 0; sc = 0; }
   }
+  p.cand_a[row + j] = ref;
+  p.score_a[row + j] = sc;
 }
 
 // ---------------------------------------------------------------------------
 size_t hv_band_lds_bytes(int max_half) {
-  return sizeof(double) * (size_t)((kTile + 2 + 2 * max_half + 2) + (kTile + 4) + 64);
+  return sizeof(double) * (size_t)((2 * max_half + 2) + (kTile + 2 + 2 * max_half + 2) + (kTile + 4) + 64);
 }
+int hv_segments(int max_y_len) { return (max_y_len + kSeg - 1) / kSeg; }
+size_t hv_segment_list_doubles(int nseg) { return (size_t)nseg * kSegCap; }
 
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
                     hipStream_t stream) {
@@ -341,11 +388,12 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
     WH_THREADS(hv_decimate_bwd, chunks, B, 1, stream, p, c);
   }
   WH_BLOCKS(hv_remove_mean, dim3(B), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(hv_band_events, dim3(p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
+  WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
+  WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);
   WH_THREADS(hv_raw_candidates, max_fb, p.nch, B, stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
   WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
-  WH_THREADS(hv_prune, max_fb, B, 1, stream, p);
+  WH_THREADS(hv_prune, (long)max_fb * p.maxc, B, 1, stream, p);
   launch_harvest_contour(p, max_fb, max_frames, stream);
 }
 

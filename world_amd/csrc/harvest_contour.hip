@@ -287,32 +287,47 @@ __global__ void hc_step4(HarvestParams p) {
 // DC steady state of the held value when it reaches the section: starting AT the
 // section edge from that steady state differs by < 1e-17.
 constexpr int kSmoothTail = 300;
+// One wavefront per voiced section; every lane filters one chunk of the section,
+// warmed up over the kSmoothTail samples before it (same convergence argument).
 __global__ void hc_smooth(HarvestParams p) {
-  const int k = flat_thread_x(), u = blockIdx.y;
+  const int k = wave_item_x(), u = blockIdx.y;
   if (k >= p.sec_n[u * 2]) return;
   const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
   const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
+  const double dc = 1.0 / (1.0 - a0 - a1);             // state of the recursion at rest on a constant 1
   const int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
   const int st = sec[k], ed = sec[p.sec_cap + k];
   const double *in = hc_row(p.c0, p, u);
   double *tmp = p.ext + (size_t)u * p.ext_cap + sec[4 * p.sec_cap + k];   // ed-st+1+kSmoothTail
   double *out = hc_row(p.basic_f0, p, u);
-  const int len = ed - st + 1;
-  // forward sweep from the steady state of the held first value
-  double w0 = in[st] / (1.0 - a0 - a1), w1 = w0;
-  for (int i = 0; i < len + kSmoothTail; ++i) {
-    double x = i < len ? in[st + i] : in[ed];
-    double wt = x + a0 * w0 + a1 * w1;
-    tmp[i] = b0 * wt + b1 * w0 + b0 * w1;
-    w1 = w0; w0 = wt;
+  const int len = ed - st + 1, total = len + kSmoothTail;
+  const int chunk = (total + WAVE - 1) / WAVE;
+  const int j0 = lane_id() * chunk, j1 = imin(total, j0 + chunk);
+  const double first = in[st], last = in[ed];
+  // forward sweep: the section with its end values held on both sides
+  {
+    auto xin = [&](int j) { return j < 0 ? first : (j < len ? in[st + j] : last); };
+    int j = j0 - kSmoothTail;
+    double w0 = xin(j) * dc, w1 = w0;
+    for (; j < j1; ++j) {
+      double wt = xin(j) + a0 * w0 + a1 * w1;
+      double y = b0 * wt + b1 * w0 + b0 * w1;
+      w1 = w0; w0 = wt;
+      if (j >= j0) tmp[j] = y;
+    }
   }
-  // backward sweep; beyond the tail the forward output equals the held last value
-  w0 = in[ed] / (1.0 - a0 - a1); w1 = w0;
-  for (int i = len + kSmoothTail - 1; i >= 0; --i) {
-    double wt = tmp[i] + a0 * w0 + a1 * w1;
-    double y = b0 * wt + b1 * w0 + b0 * w1;
-    w1 = w0; w0 = wt;
-    if (i < len) out[st + i] = y;
+  wave_sync();
+  // backward sweep over the forward output (which has settled on `last` beyond the tail)
+  {
+    auto tin = [&](int j) { return j >= total ? last : tmp[j]; };
+    int j = j1 - 1 + kSmoothTail;
+    double w0 = tin(j) * dc, w1 = w0;
+    for (; j >= j0; --j) {
+      double wt = tin(j) + a0 * w0 + a1 * w1;
+      double y = b0 * wt + b1 * w0 + b0 * w1;
+      w1 = w0; w0 = wt;
+      if (j < j1 && j < len) out[st + j] = y;
+    }
   }
 }
 
@@ -343,7 +358,7 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   SecArgs a4 = {p.c0, 0, kSmoothTail};
   WH_BLOCKS(hc_sections, dim3(B), 256, 64 * sizeof(double), stream, p, a4);
   devrt::dzero(p.basic_f0, row_bytes, stream);
-  WH_THREADS(hc_smooth, p.sec_cap, B, 1, stream, p);
+  WH_WAVES(hc_smooth, p.sec_cap, B, 1, 0, stream, p);
   WH_THREADS(hc_output, max_frames, B, 1, stream, p);
 }
 

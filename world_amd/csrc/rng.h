@@ -58,26 +58,19 @@ __device__ __forceinline__ Xs128 xs_jump(const uint4 *jump, Xs128 s, uint32_t ca
   return s;
 }
 
-// Block-cooperative generation: out[i] = scale * f(randn #(i)) for i < count,
-// starting from `base` (the state before the first of the `count` calls).
-// Each thread owns contiguous runs of kRun draws; threads jump to their run.
-// `absval` selects |randn| (CheapTrick's AddInfinitesimalNoise, cheaptrick.cpp:147-151).
-constexpr int kRunLog2 = 3;
-constexpr int kRun = 1 << kRunLog2;
-__device__ __forceinline__ void block_randn_fill(const uint4 *jump, Xs128 base, int count,
-                                                 double scale, bool absval, double *out) {
-  int per_pass = (int)blockDim.x * kRun;
-  for (int start = 0; start < count; start += per_pass) {
-    int first = start + (int)threadIdx.x * kRun;
-    if (first < count) {
-      Xs128 s = xs_jump(jump, base, (uint32_t)first);
-      int end = first + kRun < count ? first + kRun : count;
-      for (int i = first; i < end; ++i) {
-        double r = xs_randn(s);
-        out[i] = (absval ? fabs(r) : r) * scale;
-      }
-    }
-  }
-}
+// Whole-stream generation (rng_fill.hip): thread t produces draws
+// [begin + t*kFillRun, begin + (t+1)*kFillRun) of an utterance's stream with ONE
+// jump-ahead, so the jump cost is amortised over kFillRun draws and every draw of
+// the utterance is produced exactly once, in parallel.  Raw N(0,1) values are
+// stored; consumers apply their own scale (1e-12, 1e-6, |.|*eps).
+constexpr int kFillRun = 32;
+struct RngFillArgs {
+  double *noise;            // [n_utt][stride]; draw (begin[u] + k) lands at noise[u][k]
+  size_t stride;
+  const unsigned *begin;    // [n_utt] stream position of the first draw (nullptr = 0)
+  const unsigned *count;    // [n_utt] number of draws to produce
+  const uint4 *jump;
+};
+void launch_rng_fill(const RngFillArgs &a, int n_utt, size_t max_count, hipStream_t stream);
 
 }  // namespace world_hip

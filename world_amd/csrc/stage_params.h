@@ -10,7 +10,10 @@ struct CtParams {
   const double *tpos;    // [n_utt][f_stride]
   const double *f0;      // [n_utt][f_stride]
   double *spectrogram;   // [n_utt][f_stride][fft/2+1]
-  Xs128 *states;         // [n_utt][f_stride] RNG state at the start of each frame
+  unsigned *offsets;     // [n_utt][f_stride] stream position of each frame's first draw
+  unsigned *totals;      // [n_utt] draws consumed by the utterance
+  double *noise;         // [n_utt][noise_stride] the utterance's randn() stream
+  size_t noise_stride;
   Tables tab;
   double q1;
   double f0_floor;       // GetF0FloorForCheapTrick()
@@ -23,9 +26,12 @@ struct D4cParams {
   const double *f0;       // [n_utt][f_stride]
   double *aperiodicity;   // [n_utt][f_stride][fft_out/2+1]
   double *ap0;            // [n_utt][f_stride]  LoveTrain result
-  Xs128 *states1;         // [n_utt][f_stride]  stream position of the LoveTrain window
-  Xs128 *states2;         // [n_utt][f_stride]  stream position of the frame's 3 body windows
+  unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
+  unsigned *offsets2;     // [n_utt][f_stride]  position of the frame's 3 body windows within pass 2
   unsigned *draws1;       // [n_utt] total draws of pass 1
+  unsigned *draws2;       // [n_utt] total draws of pass 2
+  double *noise;          // [n_utt][noise_stride] randn() values of the current pass
+  size_t noise_stride;
   const double *nuttall;  // [wl] NuttallWindow(wl), built on the host
   Tables tab;
   double threshold;
@@ -38,5 +44,7 @@ struct D4cParams {
 
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream);
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
+size_t ct_max_draws_per_frame(int fft_size);
+size_t d4c_max_draws_per_frame(int fs);
 
 }  // namespace world_hip

@@ -21,14 +21,20 @@ def emu():
     return HostAPI(os.path.join(EMU_DIR, "libworld_emu.so"))
 
 
-@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest"])
+@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest", "vaiueo2d_dio", "vowel16k_dio"])
 def test_emulated_pipeline_matches_golden(emu, name):
     check_against_golden(emu, load_golden(name), rtol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["vaiueo2d_dio", "vowel16k_dio"])
-def test_emulated_spectral_stages_given_f0(emu, name):
-    check_against_golden(emu, load_golden(name), rtol=1e-7, given_f0=True)
+def test_emulated_dio_with_decimation(emu, port_oracle):
+    """DioOption.speed > 1 exercises decimate() on the raw signal (dio.cpp:69-70)"""
+    from world_amd import synth
+    x = synth.vowel(44100, 0.6, seed=11).numpy()
+    for speed in (4, 11):
+        tp_o, f0_o = port_oracle.dio(x, 44100, speed=speed, f0_floor=60.0, channels_in_octave=3.0, allowed_range=0.15)
+        tp, f0 = emu.dio(x, 44100, speed=speed, f0_floor=60.0, channels_in_octave=3.0, allowed_range=0.15)
+        assert np.array_equal(tp, tp_o)
+        assert np.array_equal(f0 > 0, f0_o > 0) and np.allclose(f0, f0_o, rtol=1e-9, atol=0)
 
 
 def test_emulated_ragged_and_tiny_inputs(emu, port_oracle):

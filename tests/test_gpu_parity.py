@@ -31,14 +31,45 @@ def oracle():
     return best_oracle()
 
 
-@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest"])
+@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest", "vaiueo2d_dio", "vowel16k_dio"])
 def test_pipeline_matches_golden(hip, name):
+    """BASELINE.json configs[0] (test.cpp plumbing on vaiueo2d.wav, DIO and Harvest variants),
+    the 48 kHz north-star shapes and the 16 kHz alt config, against the reference's own outputs"""
     check_against_golden(hip, load_golden(name), rtol=RTOL)
 
 
 @pytest.mark.parametrize("name", ["vaiueo2d_dio", "vowel16k_dio"])
 def test_spectral_stages_match_golden_given_f0(hip, name):
     check_against_golden(hip, load_golden(name), rtol=RTOL, given_f0=True)
+
+
+@pytest.mark.parametrize("fs,speed", [(48000, 1), (44100, 11), (16000, 2)])
+def test_dio_stonemask_match_oracle(hip, oracle, fs, speed):
+    from world_amd import synth
+    x = synth.vowel(fs, 0.9, seed=fs + speed).numpy()
+    tp_o, f0_o = oracle.dio(x, fs, speed=speed)
+    tp, f0 = hip.dio(x, fs, speed=speed)
+    assert np.array_equal(tp, tp_o)
+    assert_f0_close(f0, f0_o, what="dio")
+    assert_f0_close(hip.stonemask(x, fs, tp_o, f0_o), oracle.stonemask(x, fs, tp_o, f0_o), what="stonemask")
+
+
+def test_batched_dio_path(hip, wh):
+    """config 4 shape in small: 16 kHz batch through DIO + StoneMask + CheapTrick(1024) + D4C"""
+    import torch
+    from world_amd import synth
+    fs = 16000
+    xs = [synth.utterance(i, fs, 0.8).numpy() for i in range(3)]
+    xb = torch.stack([torch.from_numpy(x) for x in xs]).cuda()
+    tpos, f0, sp, ap, nf = wh.analyze(xb, fs, f0_method="dio")
+    torch.cuda.synchronize()
+    for i, x in enumerate(xs):
+        tp_s, f0_s = hip.dio(x, fs)
+        r_s = hip.stonemask(x, fs, tp_s, f0_s)
+        n = len(r_s)
+        assert np.array_equal(f0[i, :n].cpu().numpy(), r_s)
+        assert max_rel(sp[i, :n].cpu().numpy(), hip.cheaptrick(x, fs, tp_s, r_s, fft_size=1024)) <= 1e-12
+        assert max_rel(ap[i, :n].cpu().numpy(), hip.d4c(x, fs, tp_s, r_s, 1024)) <= 1e-9
 
 
 @pytest.mark.parametrize("fs,seconds,kind", [(48000, 1.0, "vowel"), (24000, 0.8, "chirp"), (16000, 1.2, "vowel"),

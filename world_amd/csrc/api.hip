@@ -16,7 +16,9 @@
 #include <vector>
 
 #include "common.h"
+#include "bandfilter.h"
 #include "decimate.h"
+#include "dio.h"
 #include "harvest.h"
 #include "stage_params.h"
 
@@ -66,6 +68,7 @@ struct WorldHipContext {
   world_hip::HarvestBands bands;
   double *d_nuttall = nullptr;   // D4C band window
   int nuttall_len = 0;
+  void *dio_bands = nullptr;     // world_hip::DioBands (cached DIO filter tables)
   // pinned, double-buffered staging for the small per-call host arrays
   char *stage[2] = {nullptr, nullptr};
   void *stage_ev[2] = {nullptr, nullptr};
@@ -367,13 +370,146 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
 // ---------------------------------------------------------------------------
 // DIO / StoneMask
 // ---------------------------------------------------------------------------
-static void run_dio(WorldHipContext *, int, int, const double *, int, const int *, const DioOption *, int, double *,
-                    double *) {
-  fail("Dio: not implemented in this build");
+struct DioBands {                // cached per (fs, f0_floor, f0_ceil, channels, ratio)
+  int fs = 0, ratio = 0;
+  double f0_floor = 0, f0_ceil = 0, cpo = 0;
+  int nb = 0, cut = 0, max_ntap = 0;
+  double *d_band_f0 = nullptr, *d_taps = nullptr, *d_lowcut = nullptr;
+  int *d_hal = nullptr, *d_off = nullptr;
+};
+
+static void prepare_dio_bands(WorldHipContext *c, DioBands &db, int fs, const DioOption *opt, int ratio) {
+  if (db.fs == fs && db.ratio == ratio && db.f0_floor == opt->f0_floor && db.f0_ceil == opt->f0_ceil &&
+      db.cpo == opt->channels_in_octave && db.nb > 0)
+    return;
+  const double afs = static_cast<double>(fs) / ratio;
+  // dio.cpp:582-586
+  const int nb = 1 + static_cast<int>(log(opt->f0_ceil / opt->f0_floor) / kLog2 * opt->channels_in_octave);
+  std::vector<double> fb(nb), taps, lowcut;
+  std::vector<int> hal(nb), off(nb);
+  int max_ntap = 0;
+  for (int i = 0; i < nb; ++i) {
+    fb[i] = opt->f0_floor * pow(2.0, (i + 1) / opt->channels_in_octave);
+    hal[i] = mround(afs / fb[i] / 2.0);                               // dio.cpp:532
+    off[i] = (int)taps.size();
+    const int len = 4 * hal[i];                                      // NuttallWindow(hal*4), dio.cpp:301
+    max_ntap = std::max(max_ntap, len);
+    for (int k = 0; k < len; ++k) {
+      double t = k / (len - 1.0);
+      taps.push_back(0.355768 - 0.487396 * cos(2.0 * kPi * t) + 0.144232 * cos(4.0 * kPi * t) -
+                     0.012604 * cos(6.0 * kPi * t));
+    }
+  }
+  // DesignLowCutFilter (dio.cpp:40-53): delta minus a normalised Hanning window, centred
+  const int cut = mround(afs / 50.0);
+  const int n = 2 * cut + 1;
+  lowcut.resize(n);
+  for (int i = 1; i <= n; ++i) lowcut[i - 1] = 0.5 - 0.5 * cos(i * 2.0 * kPi / (n + 1));
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) sum += lowcut[i];
+  for (int i = 0; i < n; ++i) lowcut[i] = -lowcut[i] / sum;
+  lowcut[cut] += 1.0;
+  devrt::sync(c->stream);
+  if (db.d_band_f0) {
+    devrt::dfree(db.d_band_f0); devrt::dfree(db.d_taps); devrt::dfree(db.d_lowcut); devrt::dfree(db.d_hal);
+    devrt::dfree(db.d_off);
+  }
+  db.d_band_f0 = static_cast<double *>(devrt::dmalloc(sizeof(double) * nb));
+  db.d_taps = static_cast<double *>(devrt::dmalloc(sizeof(double) * taps.size()));
+  db.d_lowcut = static_cast<double *>(devrt::dmalloc(sizeof(double) * n));
+  db.d_hal = static_cast<int *>(devrt::dmalloc(sizeof(int) * nb));
+  db.d_off = static_cast<int *>(devrt::dmalloc(sizeof(int) * nb));
+  devrt::h2d(db.d_band_f0, fb.data(), sizeof(double) * nb, c->stream);
+  devrt::h2d(db.d_taps, taps.data(), sizeof(double) * taps.size(), c->stream);
+  devrt::h2d(db.d_lowcut, lowcut.data(), sizeof(double) * n, c->stream);
+  devrt::h2d(db.d_hal, hal.data(), sizeof(int) * nb, c->stream);
+  devrt::h2d(db.d_off, off.data(), sizeof(int) * nb, c->stream);
+  devrt::sync(c->stream);
+  db.fs = fs; db.ratio = ratio; db.f0_floor = opt->f0_floor; db.f0_ceil = opt->f0_ceil;
+  db.cpo = opt->channels_in_octave; db.nb = nb; db.cut = cut; db.max_ntap = max_ntap;
 }
-static void run_stonemask(WorldHipContext *, int, int, const double *, int, const int *, const int *, int,
-                          const double *, const double *, double *) {
-  fail("StoneMask: not implemented in this build");
+
+static void run_dio(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                    const DioOption *opt, int f_stride, double *d_tpos, double *d_f0) {
+  check_batch(n_utt, fs, d_x, x_stride, x_length);
+  if (!(opt->f0_floor > 0) || !(opt->f0_ceil > opt->f0_floor) || !(opt->frame_period > 0) ||
+      !(opt->channels_in_octave > 0))
+    fail("bad DioOption");
+  DioParams p;
+  p.ratio = std::max(std::min(opt->speed, 12), 1);                    // dio.cpp:589
+  p.afs = static_cast<double>(fs) / p.ratio;
+  DioBands &db = *reinterpret_cast<DioBands *>(c->dio_bands);
+  prepare_dio_bands(c, db, fs, opt, p.ratio);
+  p.f0_floor = opt->f0_floor; p.f0_ceil = opt->f0_ceil; p.frame_period = opt->frame_period;
+  p.allowed_range = opt->allowed_range;
+  p.nb = db.nb; p.cut = db.cut; p.max_ntap = db.max_ntap;
+  p.vrm = static_cast<int>(0.5 + 1000.0 / opt->frame_period / opt->f0_floor) * 2 + 1;   // dio.cpp:263-264
+  std::vector<int> xl(x_length, x_length + n_utt), yl(n_utt), nfr(n_utt);
+  int max_x = 0, max_y = 0, max_fr = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    yl[u] = 1 + xl[u] / p.ratio;                                      // dio.cpp:590
+    nfr[u] = frame_count(fs, xl[u], opt->frame_period);
+    if (nfr[u] > f_stride) fail("f_stride %d too small for %d frames", f_stride, nfr[u]);
+    max_x = std::max(max_x, xl[u]); max_y = std::max(max_y, yl[u]); max_fr = std::max(max_fr, nfr[u]);
+  }
+  p.y_stride = (max_y + 8) & ~7;
+  p.z_stride = (max_y + 2 * p.cut + 8) & ~7;
+  p.m_stride = (max_x + 2 * kDecPad + 8) & ~7;
+  p.nseg = band_segments(max_y);
+  p.ev_cap = max_y / 2 + 2;
+  const size_t B = n_utt;
+  const size_t seg_list = (size_t)p.nseg * kSegCap;
+  size_t need = 4 * pad256(sizeof(int) * B);
+  need += pad256(sizeof(double) * B * p.m_stride) + pad256(sizeof(double) * B * p.y_stride) +
+          pad256(sizeof(double) * B * p.z_stride);
+  need += pad256(sizeof(double) * B * p.nb * 4 * seg_list) + pad256(sizeof(int) * B * p.nb * 4 * p.nseg);
+  need += pad256(sizeof(double) * B * p.nb * 4 * p.ev_cap) + pad256(sizeof(int) * B * p.nb * 4);
+  need += 2 * pad256(sizeof(double) * B * p.nb * f_stride) + 2 * pad256(sizeof(double) * B * f_stride);
+  ensure_arena(c, need);
+  c->arena.reset();
+  CallScope scope(c, 3 * sizeof(int) * n_utt + 512);
+  p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
+  p.b.x_len = upload(c, xl);
+  p.b.n_frames = upload(c, nfr);
+  p.y_len = upload(c, yl);
+  p.band_f0 = db.d_band_f0; p.band_hal = db.d_hal; p.band_off = db.d_off; p.band_taps = db.d_taps;
+  p.lowcut_taps = db.d_lowcut;
+  p.fwd = c->arena.take<double>(B * p.m_stride);
+  p.y = c->arena.take<double>(B * p.y_stride);
+  p.z = c->arena.take<double>(B * p.z_stride);
+  p.seg_events = c->arena.take<double>(B * p.nb * 4 * seg_list);
+  p.seg_count = c->arena.take<int>(B * p.nb * 4 * p.nseg);
+  p.events = c->arena.take<double>(B * p.nb * 4 * p.ev_cap);
+  p.ev_count = c->arena.take<int>(B * p.nb * 4);
+  p.cand = c->arena.take<double>(B * p.nb * f_stride);
+  p.score = c->arena.take<double>(B * p.nb * f_stride);
+  p.t1 = c->arena.take<double>(B * f_stride);
+  p.t2 = c->arena.take<double>(B * f_stride);
+  p.tpos = d_tpos; p.f0 = d_f0;
+  launch_dio(p, max_x, max_y, max_fr, c->stream);
+}
+
+static void run_stonemask(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride,
+                          const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
+                          const double *d_f0, double *d_refined) {
+  check_batch(n_utt, fs, d_x, x_stride, x_length);
+  int max_frames = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
+    max_frames = std::max(max_frames, n_frames[u]);
+  }
+  StoneMaskParams p;
+  p.win_cap = 2 * static_cast<int>(1.5 * fs / 40.0 + 1.0) + 4;       // longest window: f0 just above 40 Hz
+  if (2 * p.win_cap > kTwN * 2) fail("StoneMask: fs=%d needs an FFT beyond %d points", fs, kTwN);
+  ensure_arena(c, 2 * pad256(sizeof(int) * n_utt));
+  c->arena.reset();
+  CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
+  p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
+  p.b.x_len = upload(c, std::vector<int>(x_length, x_length + n_utt));
+  p.b.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
+  p.tpos = d_tpos; p.f0 = d_f0; p.refined = d_refined;
+  p.tab = c->tab;
+  launch_stonemask(p, max_frames, c->stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -417,6 +553,7 @@ WorldHipContext *world_hip_create(int device, void *stream) {
     devrt::sync(c->stream);
     c->tab.tw = d_tw;
     c->tab.jump = d_jump;
+    c->dio_bands = new DioBands;
     return c;
   } catch (const std::exception &e) {
     g_last_error = e.what();
@@ -432,6 +569,14 @@ void world_hip_destroy(WorldHipContext *c) {
     devrt::dfree(const_cast<uint4 *>(c->tab.jump));
     if (c->arena.base) devrt::dfree(c->arena.base);
     if (c->d_nuttall) devrt::dfree(c->d_nuttall);
+    if (c->dio_bands) {
+      DioBands *db = static_cast<DioBands *>(c->dio_bands);
+      if (db->d_band_f0) {
+        devrt::dfree(db->d_band_f0); devrt::dfree(db->d_taps); devrt::dfree(db->d_lowcut); devrt::dfree(db->d_hal);
+        devrt::dfree(db->d_off);
+      }
+      delete db;
+    }
     for (int k = 0; k < 2; ++k) {
       if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
       if (c->stage_ev[k]) devrt::event_destroy(c->stage_ev[k]);

@@ -1,0 +1,265 @@
+// dio.hip -- DIO F0 estimation on gfx950 (reference src/dio.cpp:578-648 and below).
+//
+// Same MI355X design as Harvest's front half (bandfilter.h): the reference's
+// whole-utterance FFT filtering -- spectrum * low-cut filter spectrum
+// (GetSpectrumForEstimation :60-106), then per channel spectrum * Nuttall low-pass
+// and an inverse FFT (GetFilteredSignal :296-343) -- is the linear convolution
+// with two short FIRs, evaluated directly out of LDS; the four zero-crossing
+// detectors run on the LDS tile.  Candidates/scores (:441-572) are one thread per
+// (frame, channel); the contour fix (:112-289) is frame-parallel for steps 1-2 and
+// one wavefront per utterance (lanes = channels) for the two tracking sweeps.
+#include "bandfilter.h"
+#include "decimate.h"
+#include "dio.h"
+
+namespace world_hip {
+
+// ---- front end: decimate / copy, remove DC, low-cut FIR --------------------------
+__global__ void dio_decimate_fwd(DioParams p, IirCoef c) {
+  int u = blockIdx.y, chunk = flat_thread_x();
+  dec_forward_chunk(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], 0, c, chunk, p.fwd + (size_t)u * p.m_stride);
+}
+__global__ void dio_decimate_bwd(DioParams p, IirCoef c) {
+  int u = blockIdx.y, chunk = flat_thread_x();
+  dec_backward_chunk(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], 0, p.ratio, c, chunk, 0, p.y_len[u],
+                     p.y + (size_t)u * p.y_stride);
+}
+__global__ void dio_copy_signal(DioParams p) {              // dio.cpp:71-72
+  int u = blockIdx.y, i = flat_thread_x();
+  if (i < p.b.x_len[u]) p.y[(size_t)u * p.y_stride + i] = p.b.x[(size_t)u * p.b.x_stride + i];
+}
+__global__ void dio_remove_mean(DioParams p) {               // dio.cpp:74-79
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  int u = blockIdx.x, n = p.y_len[u];
+  double *y = p.y + (size_t)u * p.y_stride;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += y[i];
+  double mean = block_sum(s, scratch) / n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] -= mean;
+}
+
+// z[m] = (y * lowcut)[m] for m in [-C, y_len + C), stored at z[m + C]  (dio.cpp:40-53,85-101)
+__global__ void __launch_bounds__(kBpThreads) dio_lowcut(DioParams p) {
+  DYN_LDS(lds);
+  const int tile = blockIdx.x, u = blockIdx.y;
+  const int out_len = p.y_len[u] + 2 * p.cut;
+  const int t0 = tile * kTile;
+  if (t0 >= out_len) return;
+  BandJob job;
+  job.in = p.y + (size_t)u * p.y_stride;
+  job.in_len = p.y_len[u];
+  job.n = out_len;
+  job.taps = p.lowcut_taps;
+  job.ntap = 2 * p.cut + 1;
+  job.shift = 0;
+  job.max_ntap = job.ntap;
+  double *taps = reinterpret_cast<double *>(lds);
+  double *yt = taps + (job.max_ntap + 1);
+  double *s = yt + (kTile + 2 + job.max_ntap + 3);
+  for (int j = threadIdx.x; j < job.ntap; j += blockDim.x) taps[j] = job.taps[j];
+  fir_tile(job, taps, t0, yt, s);
+  double *z = p.z + (size_t)u * p.z_stride;
+  for (int k = threadIdx.x; k < kTile; k += blockDim.x)
+    if (t0 + k < out_len) z[t0 + k] = s[k];
+}
+
+// ---- channels: Nuttall low-pass + zero-crossing events ----------------------------
+__global__ void __launch_bounds__(kBpThreads) dio_band_events(DioParams p) {
+  const int seg = blockIdx.x, band = blockIdx.y, u = blockIdx.z;
+  const int hal = p.band_hal[band];
+  BandJob job;
+  job.in = p.z + (size_t)u * p.z_stride;
+  job.in_len = p.y_len[u] + 2 * p.cut;
+  job.n = p.y_len[u];
+  job.taps = p.band_taps + p.band_off[band];
+  job.ntap = 4 * hal;
+  job.shift = 2 * hal + p.cut;                    // index_bias 2*hal (dio.cpp:335), + the storage offset of z
+  job.max_ntap = p.max_ntap;
+  job.nseg = p.nseg;
+  job.seg_events = p.seg_events + ((size_t)(u * p.nb + band) * 4) * p.nseg * kSegCap;
+  job.seg_count = p.seg_count + ((size_t)(u * p.nb + band) * 4) * p.nseg;
+  band_events_segment(job, seg);
+}
+__global__ void dio_compact_events(DioParams p) {
+  const int bf = blockIdx.x, u = blockIdx.y;
+  const size_t list = (size_t)u * p.nb * 4 + bf;
+  compact_event_segments(p.seg_events + list * p.nseg * kSegCap, p.seg_count + list * p.nseg, p.nseg,
+                         p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list);
+}
+
+// ---- candidates and scores (dio.cpp:441-572), one thread per (frame, channel, utt) ----
+__global__ void dio_candidates(DioParams p) {
+  const int frame = flat_thread_x(), band = blockIdx.y, u = blockIdx.z;
+  if (frame >= p.b.n_frames[u]) return;
+  const int *cnt = p.ev_count + (u * p.nb + band) * 4;
+  const double *ev = p.events + ((size_t)(u * p.nb + band) * 4) * p.ev_cap;
+  double cand = 0.0, score = kMaximumValue;
+  int n_int[4];
+  bool ok = true;
+  for (int fam = 0; fam < 4; ++fam) {
+    n_int[fam] = cnt[fam] >= 2 ? cnt[fam] - 1 : 0;
+    if (n_int[fam] - 2 <= 0) ok = false;                     // dio.cpp:475-484
+  }
+  if (ok) {
+    const double t = frame * p.frame_period / 1000.0;         // dio.cpp:609-610
+    double v[4];
+    for (int fam = 0; fam < 4; ++fam) v[fam] = interp_intervals(ev + (size_t)fam * p.ev_cap, n_int[fam], p.afs, t);
+    double c = (v[0] + v[1] + v[2] + v[3]) / 4.0;
+    double s = sqrt(((v[0] - c) * (v[0] - c) + (v[1] - c) * (v[1] - c) + (v[2] - c) * (v[2] - c) +
+                     (v[3] - c) * (v[3] - c)) / 3.0);
+    const double fb = p.band_f0[band];
+    if (c > fb || c < fb / 2.0 || c > p.f0_ceil || c < p.f0_floor) { c = 0.0; s = kMaximumValue; }
+    cand = c; score = s;
+  }
+  const size_t at = ((size_t)u * p.nb + band) * p.b.f_stride + frame;
+  p.cand[at] = cand;
+  p.score[at] = score / (cand + kTiny);                       // dio.cpp:564-565
+}
+
+// ---- GetBestF0Contour + FixStep1 + FixStep2 (dio.cpp:112-169), one thread per frame ----
+__device__ __forceinline__ double dio_best_at(const DioParams &p, int u, int f) {
+  const size_t row = (size_t)u * p.nb * p.b.f_stride + f;
+  double best = p.cand[row], sc = p.score[row];
+  for (int b = 1; b < p.nb; ++b) {
+    double s = p.score[row + (size_t)b * p.b.f_stride];
+    if (sc > s) { sc = s; best = p.cand[row + (size_t)b * p.b.f_stride]; }
+  }
+  return best;
+}
+__device__ __forceinline__ double dio_step1_at(const DioParams &p, int u, int f, int nf) {
+  const int vrm = p.vrm;
+  if (f < vrm) return 0.0;
+  auto base = [&](int i) { return (i >= vrm && i < nf - vrm) ? dio_best_at(p, u, i) : 0.0; };
+  double b0 = base(f), b1 = base(f - 1);
+  return fabs((b0 - b1) / (kTiny + b0)) < p.allowed_range ? b0 : 0.0;
+}
+__global__ void dio_step1(DioParams p) {
+  const int f = flat_thread_x(), u = blockIdx.y;
+  const int nf = p.b.n_frames[u];
+  if (f >= nf || nf <= p.vrm) return;                         // dio.cpp:266: nothing is written
+  p.t1[(size_t)u * p.b.f_stride + f] = dio_step1_at(p, u, f, nf);
+}
+__global__ void dio_step2(DioParams p) {
+  const int f = flat_thread_x(), u = blockIdx.y;
+  const int nf = p.b.n_frames[u];
+  if (f >= nf || nf <= p.vrm) return;
+  const double *t1 = p.t1 + (size_t)u * p.b.f_stride;
+  const int center = (p.vrm - 1) / 2;
+  double v = t1[f];
+  if (f >= center && f < nf - center)
+    for (int j = -center; j <= center; ++j)
+      if (t1[f + j] == 0) { v = 0.0; break; }
+  p.t2[(size_t)u * p.b.f_stride + f] = v;
+}
+
+// ---- FixStep3 / FixStep4 (dio.cpp:190-253): the two tracking sweeps ------------------
+// One wavefront per utterance; lanes hold the channels' candidates of the target frame.
+__device__ __forceinline__ double dio_track(const DioParams &p, int u, double cur, double past, int target) {
+  const double ref = (cur * 3.0 - past) / 2.0;
+  // nearest candidate, FIRST minimum wins (strict <, dio.cpp:199-205)
+  double best = 0.0, emin = 0.0;
+  int best_i = 1 << 30;
+  for (int b = lane_id(); b < p.nb; b += WAVE) {
+    double c = p.cand[((size_t)u * p.nb + b) * p.b.f_stride + target];
+    double e = fabs(ref - c);
+    if (best_i == (1 << 30) || e < emin) { emin = e; best = c; best_i = b; }
+  }
+#ifndef WORLD_EMU
+  for (int m = 32; m >= 1; m >>= 1) {
+    double oe = __shfl_xor(emin, m, 64), ob = __shfl_xor(best, m, 64);
+    int oi = __shfl_xor(best_i, m, 64);
+    if (oi != (1 << 30) && (best_i == (1 << 30) || oe < emin || (oe == emin && oi < best_i))) {
+      emin = oe; best = ob; best_i = oi;
+    }
+  }
+#endif
+  if (fabs(1.0 - best / ref) > p.allowed_range) return 0.0;
+  return best;
+}
+
+__global__ void dio_track_sweeps(DioParams p) {
+  const int u = wave_item_x();
+  if (u >= p.b.n_utt) return;
+  const int nf = p.b.n_frames[u];
+  if (nf <= p.vrm) return;
+  const int lane = lane_id();
+  const double *t2 = p.t2 + (size_t)u * p.b.f_stride;
+  double *s3 = p.t1 + (size_t)u * p.b.f_stride;               // step-3 result (t1 is free again)
+  double *out = p.f0 + (size_t)u * p.b.f_stride;
+  for (int f = lane; f < nf; f += WAVE) s3[f] = t2[f];
+  wave_sync();
+  // step 3: from every falling edge forwards (GetNumberOfVoicedSections, :174-184)
+  {
+    int i = 1;
+    while (i < nf) {
+      // next falling edge at or after i: t2[i] == 0 && t2[i-1] != 0
+      while (i < nf && !(t2[i] == 0 && t2[i - 1] != 0)) ++i;
+      if (i >= nf) break;
+      const int edge = i - 1;
+      // limit = the next falling edge's index, or nf - 1
+      int nxt = i + 1;
+      while (nxt < nf && !(t2[nxt] == 0 && t2[nxt - 1] != 0)) ++nxt;
+      const int limit = nxt < nf ? nxt - 1 : nf - 1;
+      for (int j = edge; j < limit; ++j) {
+        double v = dio_track(p, u, s3[j], s3[j - 1], j + 1);
+        if (lane == 0) s3[j + 1] = v;
+        wave_sync();
+        if (v == 0) break;
+      }
+      i = nxt;
+    }
+  }
+  wave_sync();
+  for (int f = lane; f < nf; f += WAVE) out[f] = s3[f];
+  wave_sync();
+  // step 4: from every rising edge backwards, edges taken from the STEP-2 contour
+  {
+    int i = nf - 1;
+    while (i >= 1) {
+      while (i >= 1 && !(t2[i - 1] == 0 && t2[i] != 0)) --i;
+      if (i < 1) break;
+      const int edge = i;
+      int prv = i - 1;
+      while (prv >= 1 && !(t2[prv - 1] == 0 && t2[prv] != 0)) --prv;
+      const int limit = prv >= 1 ? prv : 1;
+      for (int j = edge; j > limit; --j) {
+        double v = dio_track(p, u, out[j], out[j + 1], j - 1);
+        if (lane == 0) out[j - 1] = v;
+        wave_sync();
+        if (v == 0) break;
+      }
+      i = prv;
+    }
+  }
+}
+
+__global__ void dio_time_axis(DioParams p) {
+  const int i = flat_thread_x(), u = blockIdx.y;
+  if (i < p.b.n_frames[u]) p.tpos[(size_t)u * p.b.f_stride + i] = i * p.frame_period / 1000.0;
+}
+
+void launch_dio(const DioParams &p, int max_x_len, int max_y_len, int max_frames, hipStream_t stream) {
+  const int B = p.b.n_utt;
+  devrt::dzero(p.y, sizeof(double) * (size_t)B * p.y_stride, stream);
+  if (p.ratio == 1) {
+    WH_THREADS(dio_copy_signal, max_x_len, B, 1, stream, p);
+  } else {
+    IirCoef c = decimate_coef(p.ratio);
+    long chunks = (max_x_len + 2 * kDecPad + kDecChunk - 1) / kDecChunk;
+    WH_THREADS(dio_decimate_fwd, chunks, B, 1, stream, p, c);
+    WH_THREADS(dio_decimate_bwd, chunks, B, 1, stream, p, c);
+  }
+  WH_BLOCKS(dio_remove_mean, dim3(B), 256, 64 * sizeof(double), stream, p);
+  const int lc_tiles = (max_y_len + 2 * p.cut + kTile - 1) / kTile;
+  WH_BLOCKS(dio_lowcut, dim3(lc_tiles, B), kBpThreads, band_lds_bytes(2 * p.cut + 1), stream, p);
+  WH_BLOCKS(dio_band_events, dim3(p.nseg, p.nb, B), kBpThreads, band_lds_bytes(p.max_ntap), stream, p);
+  WH_BLOCKS(dio_compact_events, dim3(p.nb * 4, B), 256, 0, stream, p);
+  WH_THREADS(dio_candidates, max_frames, p.nb, B, stream, p);
+  WH_THREADS(dio_time_axis, max_frames, B, 1, stream, p);
+  WH_THREADS(dio_step1, max_frames, B, 1, stream, p);
+  WH_THREADS(dio_step2, max_frames, B, 1, stream, p);
+  WH_WAVES(dio_track_sweeps, B, 1, 1, 0, stream, p);
+}
+
+}  // namespace world_hip

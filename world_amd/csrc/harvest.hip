@@ -18,6 +18,7 @@
 //    FFTs of 128..2048 points per candidate, harvest.cpp:541-584) only ever reads
 //    <= 6 harmonic bins of each spectrum, so it is done as 6-bin DFTs over the
 //    un-padded window: one wavefront per frame, lanes = (harmonic, sample phase).
+#include "bandfilter.h"
 #include "decimate.h"
 #include "harvest.h"
 
@@ -52,144 +53,35 @@ __global__ void hv_remove_mean(HarvestParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// Band-pass FIR + the four zero-crossing families.  One workgroup per
-// (time segment, band, utterance); a segment is kSegTiles tiles of kTile samples.
-// Each workgroup appends the sub-sample crossing times of its segment to its own
-// list; hv_compact_events then concatenates the segments in time order.
-constexpr int kTile = 1024;             // filtered samples produced per step (+2 look-ahead)
-constexpr int kSegTiles = 4;
-constexpr int kSeg = kTile * kSegTiles;
-constexpr int kSegCap = kSeg / 2 + 2;   // a crossing needs two samples
-constexpr int kBpThreads = 256;
-constexpr int kOutPer = kTile / kBpThreads;   // outputs accumulated side by side per thread
-
-// sub-sample crossing time between samples e-1 and e (harvest.cpp:183-186)
-__device__ __forceinline__ double fine_edge(int e, double prev, double cur) { return e - prev / (cur - prev); }
-
+// Band-pass FIR + the four zero-crossing families (bandfilter.h).  One workgroup
+// per (time segment, band, utterance).
 __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
-  DYN_LDS(lds);
   const int seg = blockIdx.x, band = blockIdx.y, u = blockIdx.z;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int n = p.y_len[u];
-  const int seg_begin = seg * kSeg;
-  int *cnt_out = p.seg_count + ((size_t)(u * p.nch + band) * 4) * p.nseg + seg;
-  if (seg_begin >= n) {
-    if (tid == 0) for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = 0;
-    return;
-  }
-  const int seg_end = imin(n, seg_begin + kSeg);
-  const int L = p.band_half[band], ntap = 2 * L + 1;
-  const double *y = p.y + (size_t)u * p.y_stride;
-  // LDS: taps[2*maxL+2] | ytile[kTile + 2 + 2*maxL + 2] | s[kTile + 4] | scratch[64]
-  double *taps = reinterpret_cast<double *>(lds);
-  double *yt = taps + (2 * p.max_half + 2);
-  double *s = yt + (kTile + 2 + 2 * p.max_half + 2);
-  double *scratch = s + (kTile + 4);
-  for (int j = tid; j < ntap; j += nt) taps[j] = p.band_taps[p.band_off[band] + j];
-
-  double *ev = p.seg_events + (((size_t)(u * p.nch + band) * 4) * p.nseg + seg) * kSegCap;
-  const size_t fam_stride = (size_t)p.nseg * kSegCap;
-  int count[4] = {0, 0, 0, 0};
-
-  for (int t0 = seg_begin; t0 < seg_end; t0 += kTile) {
-    // filtered[i] = sum_{j=-L..L} h[L+j] * y[i+1-j]  for i in [t0, t0+kTile+2)
-    // (the reference's delay compensation is L+1, harvest.cpp:140-142) -> needs
-    // y[t0+1-L .. t0+kTile+2+L]
-    const int ylo = t0 + 1 - L;
-    const int ycount = kTile + 2 + 2 * L;
-    __syncthreads();
-    for (int k = tid; k < ycount; k += nt) {
-      int idx = ylo + k;
-      yt[k] = (idx >= 0 && idx < n) ? y[idx] : 0.0;
-    }
-    __syncthreads();
-    // y index for output k, tap j (0..2L): i + 1 - (j - L)  ->  yt[k + 2L - j]
-    for (int k0 = tid; k0 < kTile; k0 += nt * kOutPer) {
-      double acc[kOutPer];
-#pragma unroll
-      for (int q = 0; q < kOutPer; ++q) acc[q] = 0.0;
-      const double *yy = yt + k0 + 2 * L;
-      for (int j = 0; j < ntap; ++j) {
-        const double h = taps[j];
-#pragma unroll
-        for (int q = 0; q < kOutPer; ++q) acc[q] = fma(h, yy[q * nt - j], acc[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < kOutPer; ++q)
-        if (k0 + q * nt < kTile) s[k0 + q * nt] = acc[q];
-    }
-    for (int e = tid; e < 2; e += nt) {              // the two look-ahead samples
-      double acc = 0.0;
-      const double *yy = yt + kTile + e + 2 * L;
-      for (int j = 0; j < ntap; ++j) acc = fma(taps[j], yy[-j], acc);
-      s[kTile + e] = acc;
-    }
-    __syncthreads();
-    // events: each thread inspects kPer consecutive samples, in time order
-    constexpr int kPer = 4;
-    for (int fam = 0; fam < 4; ++fam) {
-      double *dst = ev + fam * fam_stride;
-      for (int sub = 0; sub < kTile; sub += nt * kPer) {
-        double found[kPer];
-        int nfound = 0;
-        for (int q = 0; q < kPer; ++q) {
-          int k = sub + tid * kPer + q;
-          int i = t0 + k;
-          if (k >= kTile) break;
-          double a, b;                   // the family's signal at i and i+1
-          bool in_range;
-          if (fam < 2) { a = s[k]; b = s[k + 1]; in_range = i <= n - 2; }
-          else { a = s[k + 1] - s[k]; b = s[k + 2] - s[k + 1]; in_range = i <= n - 3; }
-          bool hit = fam % 2 == 0 ? (0.0 < a && b <= 0.0) : (a < 0.0 && 0.0 <= b);
-          if (in_range && hit) found[nfound++] = fine_edge(i + 1, a, b);
-        }
-        int total, off = block_excl_scan_int(nfound, &total, scratch);
-        for (int q = 0; q < nfound; ++q)
-          if (count[fam] + off + q < kSegCap) dst[count[fam] + off + q] = found[q];
-        count[fam] += total;
-      }
-    }
-  }
-  if (tid == 0)
-    for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = imin(count[fam], kSegCap);
+  BandJob job;
+  job.in = p.y + (size_t)u * p.y_stride;
+  job.in_len = p.y_len[u];
+  job.n = p.y_len[u];
+  job.taps = p.band_taps + p.band_off[band];
+  job.ntap = 2 * p.band_half[band] + 1;
+  job.shift = p.band_half[band] + 1;             // delay compensation L+1 (harvest.cpp:140-142)
+  job.max_ntap = 2 * p.max_half + 1;
+  job.nseg = p.nseg;
+  job.seg_events = p.seg_events + ((size_t)(u * p.nch + band) * 4) * p.nseg * kSegCap;
+  job.seg_count = p.seg_count + ((size_t)(u * p.nch + band) * 4) * p.nseg;
+  band_events_segment(job, seg);
 }
 
 // concatenate the per-segment lists of one (family, band, utterance) in time order
 __global__ void hv_compact_events(HarvestParams p) {
   const int bf = blockIdx.x, u = blockIdx.y;        // bf = band * 4 + family
-  const int *cnt = p.seg_count + ((size_t)u * p.nch * 4 + bf) * p.nseg;
-  const double *src = p.seg_events + ((size_t)u * p.nch * 4 + bf) * p.nseg * kSegCap;
-  double *dst = p.events + ((size_t)u * p.nch * 4 + bf) * p.ev_cap;
-  int base = 0;
-  for (int sgm = 0; sgm < p.nseg; ++sgm) {
-    const int c = cnt[sgm];
-    for (int i = threadIdx.x; i < c; i += blockDim.x)
-      if (base + i < p.ev_cap) dst[base + i] = src[(size_t)sgm * kSegCap + i];
-    base += c;
-  }
-  if (threadIdx.x == 0) p.ev_count[(u * p.nch * 4) + bf] = imin(base, p.ev_cap);
+  const size_t list = (size_t)u * p.nch * 4 + bf;
+  compact_event_segments(p.seg_events + list * p.nseg * kSegCap, p.seg_count + list * p.nseg, p.nseg,
+                         p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list);
 }
 
 // ---------------------------------------------------------------------------
 // interp1 of the interval F0s onto the 1 ms grid + gating (harvest.cpp:240-293);
 // one thread per (frame, band, utt).
-__device__ __forceinline__ double interval_loc(const double *e, int k, double fs) { return (e[k] + e[k + 1]) / 2.0 / fs; }
-__device__ __forceinline__ double interval_f0(const double *e, int k, double fs) { return fs / (e[k + 1] - e[k]); }
-
-// interp1 (matlabfunctions.cpp:136-176) of the n_int intervals of one family at time t
-__device__ __forceinline__ double interp_intervals(const double *e, int n_int, double fs, double t) {
-  int lo = 0, hi = n_int;                       // count of locations <= t
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (interval_loc(e, mid, fs) <= t) lo = mid + 1; else hi = mid;
-  }
-  int k = lo < 1 ? 1 : (lo > n_int - 1 ? n_int - 1 : lo);
-  double x0 = interval_loc(e, k - 1, fs), x1 = interval_loc(e, k, fs);
-  double y0 = interval_f0(e, k - 1, fs), y1 = interval_f0(e, k, fs);
-  double sl = (t - x0) / (x1 - x0);
-  return y0 + sl * (y1 - y0);
-}
-
 __global__ void hv_raw_candidates(HarvestParams p) {
   const int frame = flat_thread_x(), band = blockIdx.y, u = blockIdx.z;
   if (frame >= p.nfb[u]) return;
@@ -368,10 +260,8 @@ __global__ void hv_prune(HarvestParams p) {             // one thread per (frame
 }
 
 // ---------------------------------------------------------------------------
-size_t hv_band_lds_bytes(int max_half) {
-  return sizeof(double) * (size_t)((2 * max_half + 2) + (kTile + 2 + 2 * max_half + 2) + (kTile + 4) + 64);
-}
-int hv_segments(int max_y_len) { return (max_y_len + kSeg - 1) / kSeg; }
+size_t hv_band_lds_bytes(int max_half) { return band_lds_bytes(2 * max_half + 1); }
+int hv_segments(int max_y_len) { return band_segments(max_y_len); }
 size_t hv_segment_list_doubles(int nseg) { return (size_t)nseg * kSegCap; }
 
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,

@@ -1,0 +1,40 @@
+"""Condense rocprofv3 output (kernel stats + PMC counter CSVs) into one text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("world_hip::", "").replace("void ", "")[:48]
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
+    print(f"{'kernel':50s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for r in rows[:40]:
+        print(f"{short(r['Name']):50s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} "
+              f"{float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}")
+
+print()
+print("== PMC counters, per-dispatch average by kernel ==")
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            a = acc[k][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    print(f"-- {os.path.basename(d)}")
+    for k in sorted(acc, key=lambda k: -sum(v[0] for v in acc[k].values()))[:12]:
+        vals = "  ".join(f"{c}={v[0]/max(v[1],1):.4g}" for c, v in sorted(acc[k].items()))
+        n = max(v[1] for v in acc[k].values())
+        print(f"   {k:48s} n={n:<5d} {vals}")

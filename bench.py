@@ -9,7 +9,9 @@ resident in HBM, results left in HBM.  The default workload is BASELINE.json
 configs[1]: ONE 48 kHz x 10 s utterance per GPU (2001 frames); `--batch B` runs B
 utterances per step (the per-GPU share of configs[3] is --batch 128 --seconds 5).
 With N > 1 ranks every rank analyses its own utterances (utterances are the
-independent unit; weak scaling, no data-path collective).
+independent unit; weak scaling) and the per-rank f0 / spectrogram /
+aperiodicity shards are reassembled on every rank with one RCCL all-gather per
+array (north_star), double-buffered so step k's gather overlaps step k+1's compute.
 
 Rank 0 prints ONE JSON line: metric/value (whole-job frames/s), `roofline` for the
 kernel that dominates the step (HIP-event timing on the launch stream, taken in a
@@ -62,10 +64,13 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
     args = ap.parse_args()
+    args.no_gather_cfg = args.no_gather
 
     import torch
     import torch.distributed as dist
+    from world_amd import distributed as wd
     from world_amd import synth
     from world_amd.api import WorldHip, frame_count
 
@@ -93,19 +98,39 @@ def main():
     n = x.shape[1]
     nf = frame_count(FS, n, FRAME_PERIOD)
     wh = WorldHip(device=local)
-    sp = torch.empty((B, nf, FFT_SIZE // 2 + 1), dtype=torch.float64, device=dev)
-    ap_ = torch.empty_like(sp)
+    nbuf = 2 if world > 1 else 1
+    sp_bufs = [torch.empty((B, nf, FFT_SIZE // 2 + 1), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    ap_bufs = [torch.empty_like(sp_bufs[0]) for _ in range(nbuf)]
+    pending = [None] * nbuf
+    counter = [0]
 
     def step():
-        return wh.analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp, ap_out=ap_)
+        """analysis of this rank's utterances; at N > 1 followed by the asynchronous
+        all-gather of (f0, sp, ap) whose completion is awaited two steps later"""
+        k = counter[0] % nbuf
+        counter[0] += 1
+        if pending[k] is not None:
+            wd.wait_all(pending[k][1])
+        tpos, f0, sp, ap, _ = wh.analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k], ap_out=ap_bufs[k])
+        if world > 1 and not args.no_gather:
+            pending[k] = wd.all_gather_results([f0, sp, ap], async_op=True)
+        return tpos, f0, sp, ap
+
+    def drain():
+        for k in range(nbuf):
+            if pending[k] is not None:
+                wd.wait_all(pending[k][1])
+                pending[k] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -120,6 +145,7 @@ def main():
     roofline = None
     kernels = {}
     if rank == 0:
+        args.no_gather = True          # kernel timing only; other ranks are past the timed region
         prof = wh.profile(lambda: [step() for _ in range(3)])
         torch.cuda.synchronize()
         kernels = {k: {"launches_per_step": len(v) // 3, "ms_per_step": sum(v) / 3.0, "avg_ms": sum(v) / len(v)}
@@ -148,7 +174,9 @@ def main():
             "config": {"workload": f"configs[1]: {B} x (48 kHz, {args.seconds:g} s) utterance(s) per GPU, "
                                    f"Harvest+CheapTrick+D4C, fft_size=2048, frame_period=5 ms, inputs/outputs in HBM",
                        "frames_per_step": frames_per_step, "utterances_per_gpu": B,
-                       "parallelism": f"utterance-sharded x{world}, no collective"},
+                       "parallelism": f"utterance-sharded x{world}" + (
+                           ", async RCCL all-gather of f0/sp/ap per step" if world > 1 and not args.no_gather_cfg
+                           else ", no collective")},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
                 kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -69,6 +69,8 @@ struct WorldHipContext {
   double *d_nuttall = nullptr;   // D4C band window
   int nuttall_len = 0;
   void *dio_bands = nullptr;     // world_hip::DioBands (cached DIO filter tables)
+  double *d_noise = nullptr;     // noise[k] = k-th randn() after reseed (grow-only constant table)
+  size_t noise_len = 0;
   // pinned, double-buffered staging for the small per-call host arrays
   char *stage[2] = {nullptr, nullptr};
   void *stage_ev[2] = {nullptr, nullptr};
@@ -89,6 +91,28 @@ static void ensure_arena(WorldHipContext *c, size_t bytes) {
 }
 
 static size_t pad256(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+// The randn() stream is a constant of the algorithm: make sure its first `draws`
+// values are resident (generated once per context by jump-ahead, extended on demand).
+static const double *ensure_noise(WorldHipContext *c, size_t draws) {
+  if (draws > 0xFFFFFFF0ull) fail("utterance consumes more than 2^32 randn() draws");
+  if (draws > c->noise_len) {
+    size_t cap = draws + draws / 4;
+    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    devrt::sync(c->stream);
+    double *fresh = static_cast<double *>(devrt::dmalloc(sizeof(double) * cap));
+    if (c->d_noise) {
+      devrt::d2d(fresh, c->d_noise, sizeof(double) * c->noise_len, c->stream);
+      devrt::sync(c->stream);
+      devrt::dfree(c->d_noise);
+    }
+    RngFillArgs fill = {fresh, c->noise_len, cap, c->tab.jump};
+    launch_rng_fill(fill, c->stream);
+    c->d_noise = fresh;
+    c->noise_len = cap;
+  }
+  return c->d_noise;
+}
 
 // Small host arrays travel through pinned staging so the async copy never reads
 // memory the caller (or a destroyed std::vector) owns.  Two buffers alternate per
@@ -158,9 +182,7 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
     if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
     max_frames = std::max(max_frames, n_frames[u]);
   }
-  const size_t noise_stride = (size_t)max_frames * ct_max_draws_per_frame(opt->fft_size) + 64;
-  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 3 * pad256(sizeof(int) * n_utt) +
-                pad256(sizeof(double) * n_utt * noise_stride);
+  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 3 * pad256(sizeof(int) * n_utt);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   CtParams p;
@@ -169,9 +191,7 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
   p.b.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
   p.tpos = d_tpos; p.f0 = d_f0; p.spectrogram = d_sp;
   p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
-  p.totals = c->arena.take<unsigned>(n_utt);
-  p.noise = c->arena.take<double>((size_t)n_utt * noise_stride);
-  p.noise_stride = noise_stride;
+  p.noise = ensure_noise(c, (size_t)max_frames * ct_max_draws_per_frame(opt->fft_size));
   p.tab = c->tab;
   p.q1 = opt->q1;
   p.f0_floor = 3.0 * fs / (opt->fft_size - 3.0);                       // cheaptrick.cpp:196-198
@@ -214,9 +234,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     c->nuttall_len = wl;
   }
   size_t fr = (size_t)n_utt * f_stride;
-  const size_t noise_stride = (size_t)max_frames * d4c_max_draws_per_frame(fs) + 64;
-  size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 4 * pad256(sizeof(int) * n_utt) +
-                pad256(sizeof(double) * n_utt * noise_stride);
+  size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 4 * pad256(sizeof(int) * n_utt);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   D4cParams p;
@@ -228,9 +246,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.offsets1 = c->arena.take<unsigned>(fr);
   p.offsets2 = c->arena.take<unsigned>(fr);
   p.draws1 = c->arena.take<unsigned>(n_utt);
-  p.draws2 = c->arena.take<unsigned>(n_utt);
-  p.noise = c->arena.take<double>((size_t)n_utt * noise_stride);
-  p.noise_stride = noise_stride;
+  p.noise = ensure_noise(c, (size_t)max_frames * d4c_max_draws_per_frame(fs));
   p.nuttall = c->d_nuttall;
   p.tab = c->tab;
   p.threshold = opt->threshold;
@@ -569,6 +585,7 @@ void world_hip_destroy(WorldHipContext *c) {
     devrt::dfree(const_cast<uint4 *>(c->tab.jump));
     if (c->arena.base) devrt::dfree(c->arena.base);
     if (c->d_nuttall) devrt::dfree(c->d_nuttall);
+    if (c->d_noise) devrt::dfree(c->d_noise);
     if (c->dio_bands) {
       DioBands *db = static_cast<DioBands *>(c->dio_bands);
       if (db->d_band_f0) {
@@ -594,7 +611,9 @@ int world_hip_sync(WorldHipContext *c) {
   return guarded(c, [&] { devrt::sync(c->stream); });
 }
 
-unsigned long long world_hip_workspace_bytes(WorldHipContext *c) { return c ? c->arena.cap : 0; }
+unsigned long long world_hip_workspace_bytes(WorldHipContext *c) {
+  return c ? c->arena.cap + sizeof(double) * c->noise_len : 0;
+}
 
 // per-kernel HIP-event timing (used by bench.py for the roofline figure)
 void world_hip_profile_enable(int on) {

@@ -45,7 +45,6 @@ __global__ void ct_prepare(CtParams p) {
     if (f < nf) off_out[f] = running + (unsigned)off;
     running += (unsigned)total;
   }
-  if (threadIdx.x == 0) p.totals[u] = running;
 }
 
 // ---------------------------------------------------------------------------
@@ -63,12 +62,13 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   const int seg_cap = nb + 2 * (N / 3 + 2) + 1;
   double *seg = P + (nb + 1);
   double *scratch = seg + seg_cap + (seg_cap & 1);
+  const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[(size_t)u * p.b.f_stride + f];
   const double cf0 = ct_effective_f0(p.f0[(size_t)u * p.b.f_stride + f], p.f0_floor);
-  const double *noise = p.noise + (size_t)u * p.noise_stride + p.offsets[(size_t)u * p.b.f_stride + f];
+  const double *noise = p.noise + p.offsets[(size_t)u * p.b.f_stride + f];
   const int tid = threadIdx.x, nt = blockDim.x;
 
   // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) -------------------------
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   for (int i = tid; i < N; i += nt) Zr[i] = i < wlen ? Zr[i] - seg[i] * coef : 0.0;
 
   // ---- GetPowerSpectrum (cheaptrick.cpp:64-82): r2c, |X|^2 -----------------
-  block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
+  block_rfft(Z, lgn, tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
 
   // DCCorrection (common.cpp:56-75); replica staged in seg, then added
   {
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
 
   // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
   const double q1 = p.q1;
-  block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) {
+  block_rfft(Z, lgn, tw, [&](int k, double re, double im) {
     (void)im;
     double sl, cl;
     if (k == 0) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
     }
     P[k] = re * sl * cl / N;
   });
-  block_irfft(Z, lgn, p.tab.tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
+  block_irfft(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   double *out = p.spectrogram + ((size_t)u * p.b.f_stride + f) * nb;
   for (int i = tid; i <= half; i += nt) out[i] = exp(Zr[i]);
 }
@@ -172,15 +172,13 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
 size_t ct_frame_lds_bytes(int lg_fft) {
   int N = 1 << lg_fft, nb = N / 2 + 1;
   int seg_cap = nb + 2 * (N / 3 + 2) + 1;
-  return sizeof(double) * (size_t)(N + nb + 1 + seg_cap + (seg_cap & 1) + 64);
+  return sizeof(double) * (size_t)(N + nb + 1 + seg_cap + (seg_cap & 1) + 64 + N / 4 + 2);
 }
 
 size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size / 2 + 1; }   // window < fft_size, + bins
 
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  RngFillArgs fill = {p.noise, p.noise_stride, nullptr, p.totals, p.tab.jump};
-  launch_rng_fill(fill, p.b.n_utt, (size_t)max_frames * ct_max_draws_per_frame(1 << p.lg_fft), stream);
   WH_BLOCKS(ct_frame, dim3(max_frames, p.b.n_utt), 256, ct_frame_lds_bytes(p.lg_fft), stream, p);
 }
 

@@ -59,7 +59,7 @@ __global__ void d4c_prepare2(D4cParams p) {
   const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
   const double *ap0 = p.ap0 + (size_t)u * p.b.f_stride;
   unsigned *off_out = p.offsets2 + (size_t)u * p.b.f_stride;
-  unsigned running = 0;                  // positions are relative to the start of pass 2
+  unsigned running = p.draws1[u];        // pass 2 continues the stream where pass 1 ended
   for (int base = 0; base < nf; base += blockDim.x) {
     int f = base + threadIdx.x, cnt = 0;
     if (f < nf && !(f0[f] == 0 || ap0[f] <= p.threshold)) {          // d4c.cpp:386
@@ -70,7 +70,6 @@ __global__ void d4c_prepare2(D4cParams p) {
     if (f < nf) off_out[f] = running + (unsigned)off;
     running += (unsigned)total;
   }
-  if (threadIdx.x == 0) p.draws2[u] = running;
 }
 
 // Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84).
@@ -111,16 +110,17 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   double *scratch = Zr + M;
+  const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
   const double cf0 = f0 > 40.0 ? f0 : 40.0;
   const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
-                                kBlackman, 3.0, p.noise + (size_t)u * p.noise_stride + p.offsets1[fi],
+                                kBlackman, 3.0, p.noise + p.offsets1[fi],
                                 Zr, 1, scratch);
   for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) Zr[i] = 0.0;
   const int b0 = static_cast<int>(ceil(100.0 * M / fs));
   const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
   const int b2 = static_cast<int>(ceil(7900.0 * M / fs));
   double lo = 0.0, hi = 0.0;     // cumulative power (b0, b1] and (b0, b2]   (d4c.cpp:241-249)
-  block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) {
+  block_rfft(Z, lgn, tw, [&](int k, double re, double im) {
     if (k > b0 && k <= b2) {
       double pw = re * re + im * im;
       hi += pw;
@@ -251,6 +251,8 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
   int *hist = reinterpret_cast<int *>(Zr + 2 * N + 8);
   double *scratch = reinterpret_cast<double *>(hist + 256);
   double *coarse = scratch + 64;
+  // twiddles for the packed centroid transform (2^lgn complex points) and the real ones
+  const TwLds tw = stage_twiddles(coarse + 16, lgn, p.tab.tw);
 #ifdef WORLD_EMU
   constexpr int kBinsPerThread = 4096 / 2 + 1;          // one emulated thread owns every bin
 #else
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[fi];
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
-  const double *noise = p.noise + (size_t)u * p.noise_stride + p.offsets2[fi];
+  const double *noise = p.noise + p.offsets2[fi];
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
 
   // ---- GetStaticCentroid (d4c.cpp:126-143) ----------------------------------
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
       Zr[2 * i] = v;
       Zr[2 * i + 1] = v * (i + 1.0);                 // second transform's input (d4c.cpp:111-112)
     }
-    block_cfft_dif(Z, lgn, p.tab.tw);
+    block_cfft_dif(Z, lgn, tw);
 #pragma unroll
     for (int slot = 0; slot < kBinsPerThread; ++slot) {
       const int k = tid + slot * nt;
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
     const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
                                   Zr, 1, scratch);
     for (int i = wlen + tid; i < N; i += nt) Zr[i] = 0.0;
-    block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+    block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
   }
   d4c_dc_correct(B, cf0, fs, N, Zr);
   d4c_smooth(B, cf0, fs, N, Zr, B, scratch);
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
     __syncthreads();
     for (int i = tid; i < N; i += nt)
       Zr[i] = i <= 2 * hwl ? A[center - hwl + i] * p.nuttall[i] : 0.0;
-    block_rfft(Z, lgn, p.tab.tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+    block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
     double part, tot;
     block_smallest_sum(B, H + 1, H - bnd, hist, scratch, &part, &tot);
     if (tid == 0) {
@@ -356,24 +358,21 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
 }
 
 // ---------------------------------------------------------------------------
-size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64); }
+size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 4 + 2); }
 size_t d4c_body_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(2 * N + 8 + 128 + 64 + 16);
+  return sizeof(double) * (size_t)(2 * N + 8 + 128 + 64 + 16 + N / 4 + 2);
 }
 
-// worst case per frame: 3 body windows of 2*round(2 fs/47)+1 draws (pass 2 > pass 1)
-size_t d4c_max_draws_per_frame(int fs) { return 3 * (size_t)(2 * mround(4.0 * fs / kFloorF0D4C / 2.0) + 1); }
+// worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz
+size_t d4c_max_draws_per_frame(int fs) {
+  return (size_t)(2 * mround(3.0 * fs / 40.0 / 2.0) + 1) + 3 * (size_t)(2 * mround(4.0 * fs / kFloorF0D4C / 2.0) + 1);
+}
 
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
-  const size_t max_draws = (size_t)max_frames * d4c_max_draws_per_frame(p.b.fs);
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  RngFillArgs fill1 = {p.noise, p.noise_stride, nullptr, p.draws1, p.tab.jump};
-  launch_rng_fill(fill1, p.b.n_utt, max_draws, stream);
   WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), 256, d4c_love_lds_bytes(p.lg_love), stream, p);
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  RngFillArgs fill2 = {p.noise, p.noise_stride, p.draws1, p.draws2, p.tab.jump};   // pass 2 continues the stream
-  launch_rng_fill(fill2, p.b.n_utt, max_draws, stream);
   WH_BLOCKS(d4c_body, dim3(max_frames, p.b.n_utt), 512, d4c_body_lds_bytes(p.lg_d4c), stream, p);
 }
 

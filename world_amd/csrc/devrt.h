@@ -48,6 +48,10 @@ static inline unsigned __brev(unsigned v) {
   for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
   return r;
 }
+static inline void sincospi(double x, double *s, double *c) {
+  *s = sin(3.14159265358979323846 * x);
+  *c = cos(3.14159265358979323846 * x);
+}
 static inline long long __double_as_longlong(double v) { long long r; memcpy(&r, &v, 8); return r; }
 static inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }

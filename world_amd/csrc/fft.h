@@ -27,15 +27,37 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { cplx r; r.re = a.re + b.re; r.im = a.im + b.im; return r; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { cplx r; r.re = a.re - b.re; r.im = a.im - b.im; return r; }
 __device__ __forceinline__ cplx cconj(cplx a) { a.im = -a.im; return a; }
-// e^{-2 pi i k / 2^lg} (forward) from the shared table; sign=+1 gives the conjugate
-__device__ __forceinline__ cplx twiddle(const double2 *tw, int k, int lg, int sign) {
-  double2 t = tw[(size_t)k << (kTwLog2 - lg)];
-  cplx r; r.re = t.x; r.im = sign > 0 ? t.y : -t.y; return r;
+// Twiddles come from a quarter-wave cosine table staged in LDS by the owning kernel:
+// q[r] = cos(2 pi r / 2^lg), r = 0 .. 2^lg/4.  (A butterfly needs three twiddles; from
+// the HBM table each was an L2-latency gather on the critical path between barriers.)
+struct TwLds { const double *q; int lg; };
+
+// stage the table for transforms up to 2^lg points; call before the first transform
+__device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2 *global_tw) {
+  const int quarter = 1 << (lg - 2);
+  for (int i = threadIdx.x; i <= quarter; i += blockDim.x) q[i] = global_tw[(size_t)i << (kTwLog2 - lg)].x;
+  __syncthreads();
+  TwLds t; t.q = q; t.lg = lg; return t;
+}
+__device__ __forceinline__ size_t twiddle_lds_doubles(int lg) { return (size_t)(1 << (lg - 2)) + 2; }
+
+// e^{-2 pi i k / 2^lg} (forward, sign=-1) or its conjugate (sign=+1), 0 <= k < 2^lg
+__device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign) {
+  const int K = k << (tw.lg - lg);
+  const int quarter = 1 << (tw.lg - 2);
+  const int quad = K >> (tw.lg - 2), r = K & (quarter - 1);
+  const double a = tw.q[r], b = tw.q[quarter - r];
+  double c, s;
+  if (quad == 0) { c = a; s = b; }
+  else if (quad == 1) { c = -b; s = a; }
+  else if (quad == 2) { c = -a; s = -b; }
+  else { c = b; s = -a; }
+  cplx w; w.re = c; w.im = sign > 0 ? s : -s; return w;
 }
 __device__ __forceinline__ int brev_bits(int k, int bits) { return (int)(__brev((unsigned)k) >> (32 - bits)); }
 
 // ---- forward: natural in -> bit-reversed out --------------------------------
-__device__ __forceinline__ void block_cfft_dif(cplx *z, int lg, const double2 *tw) {
+__device__ __forceinline__ void block_cfft_dif(cplx *z, int lg, const TwLds &tw) {
   int n = 1 << lg;
   int lev = lg;                       // current sub-transform length = 2^lev
   while (lev >= 2) {
@@ -67,7 +89,7 @@ __device__ __forceinline__ void block_cfft_dif(cplx *z, int lg, const double2 *t
 }
 
 // ---- inverse (unscaled): bit-reversed in -> natural out ----------------------
-__device__ __forceinline__ void block_cfft_dit(cplx *z, int lg, const double2 *tw) {
+__device__ __forceinline__ void block_cfft_dit(cplx *z, int lg, const TwLds &tw) {
   int n = 1 << lg;
   int lev = 0;                        // sub-transforms of length 2^lev are done
   if (lg & 1) {
@@ -108,7 +130,7 @@ __device__ __forceinline__ void block_cfft_dit(cplx *z, int lg, const double2 *t
 // called once for every k in [0, N/2] (same semantics as the reference's r2c:
 // X[k] = sum x[n] e^{-2 pi i k n / N}, imaginary part of DC/Nyquist = 0).
 template <class Emit>
-__device__ __forceinline__ void block_rfft(cplx *z, int lgn, const double2 *tw, Emit emit) {
+__device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Emit emit) {
   int lgh = lgn - 1, h = 1 << lgh;
   block_cfft_dif(z, lgh, tw);
   for (int k = threadIdx.x; k <= h; k += blockDim.x) {
@@ -132,7 +154,7 @@ __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const double2 *tw, 
 // is ignored, src/fft.cpp:28-29).  On return the N real outputs are in `z`
 // viewed as doubles (out[n] = reinterpret_cast<double*>(z)[n]).
 template <class Spec>
-__device__ __forceinline__ void block_irfft(cplx *z, int lgn, const double2 *tw, Spec spec) {
+__device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, Spec spec) {
   int lgh = lgn - 1, h = 1 << lgh;
   __syncthreads();
   for (int k = threadIdx.x; k < h; k += blockDim.x) {

@@ -40,16 +40,35 @@ __global__ void hv_copy_signal(HarvestParams p) {          // ratio == 1 (harves
   int u = blockIdx.y, i = flat_thread_x();
   if (i < p.y_len[u]) p.y[(size_t)u * p.y_stride + i] = p.b.x[(size_t)u * p.b.x_stride + i];
 }
-// y <- y - mean(y)  (harvest.cpp:81-85); one workgroup per utterance
+// y <- y - mean(y)  (harvest.cpp:81-85): per-slice partial sums, then every workgroup
+// adds the partials in the same fixed order (deterministic) and subtracts the mean.
+constexpr int kMeanSlice = 4096;
+__global__ void hv_partial_sums(HarvestParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  const int slice = blockIdx.x, u = blockIdx.y, n = p.y_len[u];
+  const double *y = p.y + (size_t)u * p.y_stride;
+  const int lo = slice * kMeanSlice, hi = imin(n, lo + kMeanSlice);
+  double s = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) s += y[i];
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) p.fwd[(size_t)u * p.m_stride + slice] = s;     // fwd is free after decimation
+}
 __global__ void hv_remove_mean(HarvestParams p) {
   DYN_LDS(lds);
   double *scratch = reinterpret_cast<double *>(lds);
-  int u = blockIdx.x, n = p.y_len[u];
+  const int slice = blockIdx.x, u = blockIdx.y, n = p.y_len[u];
   double *y = p.y + (size_t)u * p.y_stride;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += y[i];
-  double mean = block_sum(s, scratch) / n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] -= mean;
+  const int nslice = (n + kMeanSlice - 1) / kMeanSlice;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < nslice; ++k) s += p.fwd[(size_t)u * p.m_stride + k];
+    scratch[0] = s / n;
+  }
+  __syncthreads();
+  const double mean = scratch[0];
+  const int lo = slice * kMeanSlice, hi = imin(n, lo + kMeanSlice);
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) y[i] -= mean;
 }
 
 // ---------------------------------------------------------------------------
@@ -116,15 +135,22 @@ __global__ void hv_detect(HarvestParams p) {
   const double *raw = p.raw + (size_t)u * p.nch * p.fb_stride + frame;
   double *out = p.cand_a + ((size_t)u * p.fb_stride + frame) * p.maxc;
   int cnt = 0, st = 0, prev = 0;
-  for (int j = 1; j < p.nch; ++j) {
-    int cur = (j == p.nch - 1) ? 0 : (raw[(size_t)j * p.fb_stride] > 0 ? 1 : 0);
-    if (cur - prev == 1) st = j;
-    if (cur - prev == -1 && j - st >= 10) {
-      double s = 0.0;
-      for (int k = st; k < j; ++k) s += raw[(size_t)k * p.fb_stride];
-      if (cnt < p.maxc) out[cnt++] = s / (j - st);
+  double run_sum = 0.0;                 // sum of the current voiced run, in band order (:374-375)
+  constexpr int kBatch = 8;             // bands fetched together: 8 loads in flight per thread
+  for (int j0 = 0; j0 < p.nch; j0 += kBatch) {
+    double v[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) v[q] = j0 + q < p.nch ? raw[(size_t)(j0 + q) * p.fb_stride] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const int j = j0 + q;
+      if (j >= p.nch || j == 0) continue;                     // vuv[0] is forced to 0 (:400)
+      const int cur = (j == p.nch - 1) ? 0 : (v[q] > 0 ? 1 : 0);
+      if (cur - prev == 1) { st = j; run_sum = 0.0; }
+      if (cur - prev == -1 && j - st >= 10 && cnt < p.maxc) out[cnt++] = run_sum / (j - st);
+      if (cur) run_sum += v[q];
+      prev = cur;
     }
-    prev = cur;
   }
   for (int j = cnt; j < p.maxc; ++j) out[j] = 0.0;
   if (cnt > 0) atomicMax(p.nc + u, cnt);
@@ -168,7 +194,8 @@ __global__ void hv_refine(HarvestParams p) {
       // main window (harvest.cpp:446-456)
       for (int i = lane; i < blen; i += WAVE) {
         double t = ((first + i) - 1.0) / fs - pos;
-        mw[i] = 0.42 + 0.5 * cos(2.0 * kPi * t / wlen_t) + 0.08 * cos(4.0 * kPi * t / wlen_t);
+        const double c1 = cos(2.0 * kPi * t / wlen_t);
+        mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);    // cos(2a) = 2 cos^2(a) - 1
       }
       wave_sync();
       for (int i = lane; i < blen; i += WAVE) {
@@ -191,11 +218,17 @@ __global__ void hv_refine(HarvestParams p) {
         double are = 0, aim = 0, dre = 0, dim = 0;
         if (h < nh) {
           const int idx = mround(f0c * N / fs * (h + 1));        // FixF0, harvest.cpp:515
+          // e^{-2 pi i idx n / N} by rotation: exact start / step from the integer phase
+          double wc, ws, rc, rs;
+          sincospi(2.0 * ((idx * g) & (N - 1)) / N, &ws, &wc);
+          sincospi(2.0 * ((idx * G) & (N - 1)) / N, &rs, &rc);
           for (int i = g; i < blen; i += G) {
-            double2 w = p.tab.tw[(size_t)((idx * i) & (N - 1)) << (kTwLog2 - lgN)];
             double a = ym[i], d = yd[i];
-            are = fma(a, w.x, are); aim = fma(-a, w.y, aim);
-            dre = fma(d, w.x, dre); dim = fma(-d, w.y, dim);
+            are = fma(a, wc, are); aim = fma(-a, ws, aim);
+            dre = fma(d, wc, dre); dim = fma(-d, ws, dim);
+            const double nc = wc * rc - ws * rs;
+            ws = ws * rc + wc * rs;
+            wc = nc;
           }
         }
 #ifndef WORLD_EMU
@@ -277,7 +310,9 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
     WH_THREADS(hv_decimate_fwd, chunks, B, 1, stream, p, c);
     WH_THREADS(hv_decimate_bwd, chunks, B, 1, stream, p, c);
   }
-  WH_BLOCKS(hv_remove_mean, dim3(B), 256, 64 * sizeof(double), stream, p);
+  const int slices = (max_y_len + kMeanSlice - 1) / kMeanSlice;
+  WH_BLOCKS(hv_partial_sums, dim3(slices, B), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(hv_remove_mean, dim3(slices, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
   WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);
   WH_THREADS(hv_raw_candidates, max_fb, p.nch, B, stream, p);

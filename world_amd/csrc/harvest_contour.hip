@@ -85,11 +85,12 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
     int f = base + threadIdx.x;
     bool v = f < nf && voiced(f);
     int is_start = v && !voiced(f - 1), is_end = v && !voiced(f + 1);
-    int tot_s, off_s = block_excl_scan_int(is_start, &tot_s, scratch);
-    int tot_e, off_e = block_excl_scan_int(is_end, &tot_e, scratch);
+    // starts in the low half-word, ends in the high one: one scan for both
+    int tot, off = block_excl_scan_int(is_start | (is_end << 16), &tot, scratch);
+    const int off_s = off & 0xFFFF, off_e = off >> 16;
     if (is_start && n_start + off_s < p.sec_cap) st[n_start + off_s] = f;
     if (is_end && n_end + off_e < p.sec_cap) ed[n_end + off_e] = f;
-    n_start += tot_s; n_end += tot_e;
+    n_start += tot & 0xFFFF; n_end += tot >> 16;
   }
   __syncthreads();
   const int ns = imin(n_start, p.sec_cap);
@@ -348,15 +349,15 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   WH_THREADS(hc_step1, max_fb, B, 1, stream, p);
   WH_THREADS(hc_step2, max_fb, B, 1, stream, p);
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin};
-  WH_BLOCKS(hc_sections, dim3(B), 256, 64 * sizeof(double), stream, p, a2);
+  WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
   WH_WAVES(hc_extend, p.sec_cap, B, 1, 0, stream, p);
   WH_WAVES(hc_merge, B, 1, 1, 0, stream, p);
   devrt::d2d(p.c0, p.c3, row_bytes, stream);
   SecArgs a3 = {p.c3, 1, 0};
-  WH_BLOCKS(hc_sections, dim3(B), 256, 64 * sizeof(double), stream, p, a3);
+  WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a3);
   WH_THREADS(hc_step4, p.sec_cap, B, 1, stream, p);
   SecArgs a4 = {p.c0, 0, kSmoothTail};
-  WH_BLOCKS(hc_sections, dim3(B), 256, 64 * sizeof(double), stream, p, a4);
+  WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a4);
   devrt::dzero(p.basic_f0, row_bytes, stream);
   WH_WAVES(hc_smooth, p.sec_cap, B, 1, 0, stream, p);
   WH_THREADS(hc_output, max_frames, B, 1, stream, p);

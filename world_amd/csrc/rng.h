@@ -61,16 +61,18 @@ __device__ __forceinline__ Xs128 xs_jump(const uint4 *jump, Xs128 s, uint32_t ca
 // Whole-stream generation (rng_fill.hip): thread t produces draws
 // [begin + t*kFillRun, begin + (t+1)*kFillRun) of an utterance's stream with ONE
 // jump-ahead, so the jump cost is amortised over kFillRun draws and every draw of
-// the utterance is produced exactly once, in parallel.  Raw N(0,1) values are
+// the stream is produced exactly once, in parallel.  Raw N(0,1) values are
 // stored; consumers apply their own scale (1e-12, 1e-6, |.|*eps).
 constexpr int kFillRun = 32;
+//
+// The stream is the same for every utterance and every call (the reference reseeds
+// at the top of CheapTrick() and D4C()), so the context keeps ONE table
+// noise[k] = k-th randn() in HBM and only ever extends it: [begin, end) below.
 struct RngFillArgs {
-  double *noise;            // [n_utt][stride]; draw (begin[u] + k) lands at noise[u][k]
-  size_t stride;
-  const unsigned *begin;    // [n_utt] stream position of the first draw (nullptr = 0)
-  const unsigned *count;    // [n_utt] number of draws to produce
+  double *noise;            // noise[k] = draw number k of the stream
+  size_t begin, end;        // positions to (re)generate
   const uint4 *jump;
 };
-void launch_rng_fill(const RngFillArgs &a, int n_utt, size_t max_count, hipStream_t stream);
+void launch_rng_fill(const RngFillArgs &a, hipStream_t stream);
 
 }  // namespace world_hip

@@ -1,23 +1,25 @@
 // rng_fill.hip -- the reference's randn() stream (src/matlabfunctions.cpp:237-264)
-// materialised in HBM, one utterance stream per row, by jump-ahead (see rng.h).
+// materialised in HBM by jump-ahead (see rng.h): noise[k] = k-th draw after reseed.
 #include "rng.h"
 
 namespace world_hip {
 
 __global__ void rng_stream_fill(RngFillArgs a) {
-  const int u = blockIdx.y;
-  const size_t start = (size_t)flat_thread_x() * kFillRun;
-  const unsigned cnt = a.count[u];
-  if (start >= cnt) return;
-  const unsigned first = (a.begin ? a.begin[u] : 0u) + (unsigned)start;
-  Xs128 s = xs_jump(a.jump, xs_seed(), first);
-  double *out = a.noise + (size_t)u * a.stride + start;
-  const int n = cnt - start < (size_t)kFillRun ? (int)(cnt - start) : kFillRun;
-  for (int i = 0; i < n; ++i) out[i] = xs_randn(s);
+  const size_t start = a.begin + (size_t)blockIdx.y * ((size_t)gridDim.x * blockDim.x) * kFillRun +
+                       (size_t)flat_thread_x() * kFillRun;
+  if (start >= a.end) return;
+  Xs128 s = xs_jump(a.jump, xs_seed(), (uint32_t)start);
+  const int n = a.end - start < (size_t)kFillRun ? (int)(a.end - start) : kFillRun;
+  for (int i = 0; i < n; ++i) a.noise[start + i] = xs_randn(s);
 }
 
-void launch_rng_fill(const RngFillArgs &a, int n_utt, size_t max_count, hipStream_t stream) {
-  WH_THREADS(rng_stream_fill, (long)((max_count + kFillRun - 1) / kFillRun), n_utt, 1, stream, a);
+void launch_rng_fill(const RngFillArgs &a, hipStream_t stream) {
+  if (a.end <= a.begin) return;
+  const size_t runs = (a.end - a.begin + kFillRun - 1) / kFillRun;
+  // x carries up to 2^20 runs, y the rest (a launch dimension is limited to 2^31-1 threads)
+  const size_t per_y = (size_t)1 << 20;
+  const unsigned ny = (unsigned)((runs + per_y - 1) / per_y);
+  WH_THREADS(rng_stream_fill, (long)(runs < per_y ? runs : per_y), ny, 1, stream, a);
 }
 
 }  // namespace world_hip

@@ -11,9 +11,7 @@ struct CtParams {
   const double *f0;      // [n_utt][f_stride]
   double *spectrogram;   // [n_utt][f_stride][fft/2+1]
   unsigned *offsets;     // [n_utt][f_stride] stream position of each frame's first draw
-  unsigned *totals;      // [n_utt] draws consumed by the utterance
-  double *noise;         // [n_utt][noise_stride] the utterance's randn() stream
-  size_t noise_stride;
+  const double *noise;   // noise[k] = k-th randn() of the stream (context-wide table)
   Tables tab;
   double q1;
   double f0_floor;       // GetF0FloorForCheapTrick()
@@ -28,10 +26,8 @@ struct D4cParams {
   double *ap0;            // [n_utt][f_stride]  LoveTrain result
   unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
   unsigned *offsets2;     // [n_utt][f_stride]  position of the frame's 3 body windows within pass 2
-  unsigned *draws1;       // [n_utt] total draws of pass 1
-  unsigned *draws2;       // [n_utt] total draws of pass 2
-  double *noise;          // [n_utt][noise_stride] randn() values of the current pass
-  size_t noise_stride;
+  unsigned *draws1;       // [n_utt] total draws of pass 1 (pass 2 continues the stream there)
+  const double *noise;    // noise[k] = k-th randn() of the stream (context-wide table)
   const double *nuttall;  // [wl] NuttallWindow(wl), built on the host
   Tables tab;
   double threshold;

@@ -36,6 +36,9 @@ def _newest_header():
 
 
 def build(force=False, verbose=False):
+    extra = os.environ.get("WORLD_HIP_EXTRA_FLAGS", "").split()
+    if extra:
+        force = True
     os.makedirs(OBJ, exist_ok=True)
     units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
     hdr = max(_newest_header(), os.path.getmtime(os.path.join(HERE, "..", "include", "world_hip.h")))
@@ -44,7 +47,7 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, u)
         obj = os.path.join(OBJ, u + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr):
-            jobs.append([hipcc(), *FLAGS, "-x", "hip", "-c", src, "-o", obj])
+            jobs.append([hipcc(), *FLAGS, *extra, "-x", "hip", "-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -15,12 +15,16 @@
 
 namespace world_hip {
 
-constexpr int kTile = 1024;             // filtered samples produced per step (+2 look-ahead)
-constexpr int kSegTiles = 4;
-constexpr int kSeg = kTile * kSegTiles; // one workgroup = one segment of one channel
-constexpr int kSegCap = kSeg / 2 + 2;   // a crossing needs two samples
 constexpr int kBpThreads = 256;
-constexpr int kOutPer = kTile / kBpThreads;   // outputs accumulated side by side per thread
+constexpr int kOutPer = 8;                     // consecutive outputs per thread (register sliding window)
+constexpr int kTile = kBpThreads * kOutPer;    // filtered samples produced per step (+2 look-ahead)
+constexpr int kSegTiles = 2;
+constexpr int kSeg = kTile * kSegTiles;        // one workgroup = one segment of one channel
+constexpr int kSegCap = kSeg / 2 + 2;          // a crossing needs two samples
+
+// LDS arrays indexed with a stride of kOutPer per lane are stored with one pad slot
+// every kOutPer doubles: lane stride 9 doubles -> ds_read_b64 / ds_write_b64 conflict-free.
+__host__ __device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
 
 struct BandJob {
   const double *in;       // input signal, zero outside [0, in_len)
@@ -36,14 +40,17 @@ struct BandJob {
 };
 
 inline size_t band_lds_bytes(int max_ntap) {
-  return sizeof(double) * (size_t)((max_ntap + 1) + (kTile + 2 + max_ntap + 3) + (kTile + 4) + 64);
+  return sizeof(double) * (size_t)((max_ntap + 1) + pad8(kTile + 2 + max_ntap + 3) + 1 + pad8(kTile + 4) + 1 + 64);
 }
 inline int band_segments(int n) { return (n + kSeg - 1) / kSeg; }
 
 // sub-sample crossing time between samples e-1 and e (harvest.cpp:183-186, dio.cpp:380-382)
 __device__ __forceinline__ double fine_edge(int e, double prev, double cur) { return e - prev / (cur - prev); }
 
-// One tile: s[k] = filtered[t0 + k] for k in [0, kTile + 2).  taps are in LDS.
+// One tile: s[pad8(k)] = filtered[t0 + k] for k in [0, kTile + 2).  taps are in LDS.
+// Each thread produces kOutPer consecutive outputs from a register window that
+// slides one input sample per tap: per tap one LDS read of the input, one broadcast
+// read of the tap and kOutPer FMAs -> FP64-FMA bound instead of LDS bound.
 __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps, int t0, double *yt, double *s) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ntap = job.ntap;
@@ -53,28 +60,35 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
   __syncthreads();
   for (int k = tid; k < count; k += nt) {
     int idx = lo + k;
-    yt[k] = (idx >= 0 && idx < job.in_len) ? job.in[idx] : 0.0;
+    yt[pad8(k)] = (idx >= 0 && idx < job.in_len) ? job.in[idx] : 0.0;
   }
   __syncthreads();
-  for (int k0 = tid; k0 < kTile; k0 += nt * kOutPer) {
-    double acc[kOutPer];
+  for (int k0 = tid * kOutPer; k0 < kTile; k0 += nt * kOutPer) {
+    double acc[kOutPer], w[kOutPer];
+    const int base = k0 + ntap - 1;
 #pragma unroll
-    for (int q = 0; q < kOutPer; ++q) acc[q] = 0.0;
-    const double *yy = yt + k0 + (ntap - 1);
-    for (int j = 0; j < ntap; ++j) {
-      const double h = taps[j];
+    for (int q = 0; q < kOutPer; ++q) { acc[q] = 0.0; w[q] = yt[pad8(base + q)]; }
+    // logical window at tap j: L_j[q] = in-tile[base + q - j] = w[(q - j) mod kOutPer]
+    for (int j0 = 0; j0 < ntap; j0 += kOutPer) {
 #pragma unroll
-      for (int q = 0; q < kOutPer; ++q) acc[q] = fma(h, yy[q * nt - j], acc[q]);
+      for (int u = 0; u < kOutPer; ++u) {
+        const int j = j0 + u;
+        if (j < ntap) {
+          if (j > 0) w[(kOutPer - u) % kOutPer] = yt[pad8(base - j)];
+          const double h = taps[j];
+#pragma unroll
+          for (int q = 0; q < kOutPer; ++q) acc[q] = fma(h, w[(q + kOutPer - u) % kOutPer], acc[q]);
+        }
+      }
     }
 #pragma unroll
-    for (int q = 0; q < kOutPer; ++q)
-      if (k0 + q * nt < kTile) s[k0 + q * nt] = acc[q];
+    for (int q = 0; q < kOutPer; ++q) s[pad8(k0 + q)] = acc[q];
   }
   for (int e = tid; e < 2; e += nt) {              // the two look-ahead samples
     double acc = 0.0;
-    const double *yy = yt + kTile + e + (ntap - 1);
-    for (int j = 0; j < ntap; ++j) acc = fma(taps[j], yy[-j], acc);
-    s[kTile + e] = acc;
+    const int base = kTile + e + (ntap - 1);
+    for (int j = 0; j < ntap; ++j) acc = fma(taps[j], yt[pad8(base - j)], acc);
+    s[pad8(kTile + e)] = acc;
   }
   __syncthreads();
 }
@@ -94,8 +108,8 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
   const int seg_end = imin(n, seg_begin + kSeg);
   double *taps = reinterpret_cast<double *>(lds);
   double *yt = taps + (job.max_ntap + 1);
-  double *s = yt + (kTile + 2 + job.max_ntap + 3);
-  double *scratch = s + (kTile + 4);
+  double *s = yt + pad8(kTile + 2 + job.max_ntap + 3) + 1;
+  double *scratch = s + pad8(kTile + 4) + 1;
   for (int j = tid; j < job.ntap; j += nt) taps[j] = job.taps[j];
 
   double *ev = job.seg_events + (size_t)seg * kSegCap;
@@ -116,8 +130,9 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
           if (k >= kTile) break;
           double a, b;                   // the family's signal at i and i+1
           bool in_range;
-          if (fam < 2) { a = s[k]; b = s[k + 1]; in_range = i <= n - 2; }
-          else { a = s[k + 1] - s[k]; b = s[k + 2] - s[k + 1]; in_range = i <= n - 3; }
+          const double s0 = s[pad8(k)], s1 = s[pad8(k + 1)];
+          if (fam < 2) { a = s0; b = s1; in_range = i <= n - 2; }
+          else { const double s2 = s[pad8(k + 2)]; a = s1 - s0; b = s2 - s1; in_range = i <= n - 3; }
           bool hit = fam % 2 == 0 ? (0.0 < a && b <= 0.0) : (a < 0.0 && 0.0 <= b);
           if (in_range && hit) found[nfound++] = fine_edge(i + 1, a, b);
         }

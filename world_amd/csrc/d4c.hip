@@ -27,8 +27,9 @@ constexpr int kHanning = 1, kBlackman = 2;
 
 __device__ __forceinline__ double d4c_window_at(int i, int hw, int kind, double ratio, int fs, double f0) {
   double position = (2.0 * (i - hw) / ratio) / fs;                  // d4c.cpp:36,41
-  if (kind == kHanning) return 0.5 * cos(kPi * position * f0) + 0.5;
-  return 0.42 + 0.5 * cos(kPi * position * f0) + 0.08 * cos(kPi * position * f0 * 2);
+  const double c1 = cos(kPi * position * f0);
+  if (kind == kHanning) return 0.5 * c1 + 0.5;
+  return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);             // cos(2a) = 2 cos^2(a) - 1
 }
 
 // ---------------------------------------------------------------------------
@@ -73,8 +74,15 @@ __global__ void d4c_prepare2(D4cParams p) {
 }
 
 // Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84).
-// Samples go to dst[i*dstride]; the window shape is recomputed in the second pass
-// instead of being stored (saves 32 KB of LDS per workgroup).  Returns 2*hw+1.
+// Samples go to dst[i*dstride]; each thread keeps the window values of its own
+// samples in registers between the two passes.  Returns 2*hw+1.
+#ifdef WORLD_EMU
+constexpr int kWinLove = 4096, kWinBody = 4096;
+#else
+constexpr int kWinLove = 4096 / 256;               // samples per thread of a 256-thread LoveTrain block
+constexpr int kWinBody = 4096 / 512;               // ... of a 512-thread body block
+#endif
+template <int kWinPerThread>
 __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, double f0, double pos,
                                             int kind, double ratio, const double *noise,
                                             double *dst, int dstride, double *scratch) {
@@ -83,8 +91,13 @@ __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, 
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < wlen; i += nt) {
-    double w = d4c_window_at(i, hw, kind, ratio, fs, f0);
+  double wreg[kWinPerThread];
+#pragma unroll
+  for (int q = 0; q < kWinPerThread; ++q) {
+    const int i = tid + q * nt;
+    if (i >= wlen) break;
+    const double w = d4c_window_at(i, hw, kind, ratio, fs, f0);
+    wreg[q] = w;
     // noise[i]: the window's draws in sample order (d4c.cpp:67-69)
     double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kSafeGuardD4C;
     dst[(size_t)i * dstride] = v;
@@ -92,8 +105,12 @@ __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, 
   }
   block_sum2(s1, s2, scratch);
   const double coef = s1 / s2;
-  for (int i = tid; i < wlen; i += nt)
-    dst[(size_t)i * dstride] -= d4c_window_at(i, hw, kind, ratio, fs, f0) * coef;
+#pragma unroll
+  for (int q = 0; q < kWinPerThread; ++q) {
+    const int i = tid + q * nt;
+    if (i >= wlen) break;
+    dst[(size_t)i * dstride] -= wreg[q] * coef;
+  }
   __syncthreads();
   return wlen;
 }
@@ -112,7 +129,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   double *scratch = Zr + M;
   const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
   const double cf0 = f0 > 40.0 ? f0 : 40.0;
-  const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
+  const int wlen = d4c_windowed<kWinLove>(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
                                 kBlackman, 3.0, p.noise + p.offsets1[fi],
                                 Zr, 1, scratch);
   for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) Zr[i] = 0.0;
@@ -174,50 +191,99 @@ __device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, 
   __syncthreads();
 }
 
-// Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them, by an
-// 8-bit-digit radix select on the IEEE bit patterns.  hist: 256 ints of LDS.
-__device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m, int *hist,
+// Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them: a radix
+// select on the IEEE bit patterns (monotone for non-negative doubles), 4 bits per
+// pass.  Every thread keeps its keys in registers; a digit's population is counted
+// with wave ballots (no LDS atomics, no contention), the 16 per-wave counts meet in
+// LDS (double-buffered: one barrier per pass), and passes whose digit is shared by
+// all keys (common sign/exponent prefix) are skipped.  cnt: 2 * 16 * 16 ints of LDS.
+#ifdef WORLD_EMU
+constexpr int kSelKeys = 4096 / 2 + 1;
+#else
+constexpr int kSelKeys = (4096 / 2 + 1 + 511) / 512;
+#endif
+__device__ __forceinline__ int wave_count(bool pred) {
+#ifndef WORLD_EMU
+  return __popcll(__ballot(pred));
+#else
+  return pred ? 1 : 0;
+#endif
+}
+__device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m, int *cnt,
                                                    double *scratch, double *partial, double *total) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  unsigned long long prefix = 0;
-  int remaining = m - 1;                           // rank (0-based) of the threshold element
-  for (int pass = 0; pass < 8; ++pass) {
-    const int shift = 56 - 8 * pass;
-    __syncthreads();
-    for (int i = tid; i < 256; i += nt) hist[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-      unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
-      bool match = pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8));
-      if (match) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
-    }
-    __syncthreads();
-    // every wave locates the digit redundantly (no further barrier needed)
-    const int per_lane = 256 / WAVE;
-    int lane = lane_id(), local = 0;
-    for (int j = 0; j < per_lane; ++j) local += hist[lane * per_lane + j];
-    int tot, before = wave_excl_scan_int(local, &tot);
-    int digit = -1, below = -1;
-    if (before <= remaining && remaining < before + local) {
-      int acc = before;
-      for (int j = 0; j < per_lane; ++j) {
-        int h = hist[lane * per_lane + j];
-        if (remaining < acc + h) { digit = lane * per_lane + j; below = acc; break; }
-        acc += h;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wv = wave_in_block(), nw = waves_per_block();
+  unsigned long long key[kSelKeys];
+  unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+  for (int q = 0; q < kSelKeys; ++q) {
+    const int i = tid + q * nt;
+    key[q] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;   // padding sorts last
+    if (i < n) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
+  }
+  // block-wide min / max of the keys -> the leading nibbles every key shares
+#ifndef WORLD_EMU
+  for (int s = 32; s >= 1; s >>= 1) {
+    unsigned long long a = __shfl_xor(kmin, s, 64), b = __shfl_xor(kmax, s, 64);
+    kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+  }
+  unsigned long long *ks = reinterpret_cast<unsigned long long *>(scratch);
+  __syncthreads();
+  if (lane == 0) { ks[wv] = kmin; ks[32 + wv] = kmax; }
+  __syncthreads();
+  for (int w = 0; w < nw; ++w) { kmin = ks[w] < kmin ? ks[w] : kmin; kmax = ks[32 + w] > kmax ? ks[32 + w] : kmax; }
+#endif
+  int first_pass = 0;
+  while (first_pass < 16 && ((kmin ^ kmax) >> (60 - 4 * first_pass)) == 0) ++first_pass;
+  unsigned long long prefix = first_pass ? (kmin >> (64 - 4 * first_pass)) << (64 - 4 * first_pass) : 0ull;
+  int remaining = m - 1;                           // rank (0-based, ascending) of the threshold element
+  for (int pass = first_pass; pass < 16; ++pass) {
+    const int shift = 60 - 4 * pass;
+    int *slot = cnt + (pass & 1) * 256;            // [wave][digit]
+    // this wave's population of every digit among keys that match the prefix so far
+    int mine = 0;                                   // lane d < 16 ends up holding digit d's count
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < kSelKeys; ++q) {
+        const bool match = (pass == 0 || (key[q] >> (shift + 4)) == (prefix >> (shift + 4))) &&
+                           key[q] != ~0ull && (int)((key[q] >> shift) & 15ull) == d;
+        c += wave_count(match);
       }
+#ifndef WORLD_EMU
+      if (lane == d) mine = c;
+#else
+      slot[wv * 16 + d] = c;
+      (void)mine;
+#endif
     }
-    digit = wave_max_int(digit);
-    below = wave_max_int(below);
+#ifndef WORLD_EMU
+    if (lane < 16) slot[wv * 16 + lane] = mine;
+#endif
+    __syncthreads();
+    // every wave walks the 16 digit totals redundantly (no second barrier needed)
+    int digit = 15, below = 0, acc = 0;
+    bool found = false;
+    for (int d = 0; d < 16; ++d) {
+      int h = 0;
+      for (int w = 0; w < nw; ++w) h += slot[w * 16 + d];
+      if (!found && remaining < acc + h) { digit = d; below = acc; found = true; }
+      acc += h;
+    }
     remaining -= below;
     prefix |= (unsigned long long)digit << shift;
   }
   const double thr = __longlong_as_double((long long)prefix);
   double s_lt = 0.0, s_all = 0.0;
   int c_lt = 0;
-  for (int i = tid; i < n; i += nt) {
-    double x = v[i];
-    s_all += x;
-    if (x < thr) { s_lt += x; c_lt++; }
+#pragma unroll
+  for (int q = 0; q < kSelKeys; ++q) {
+    const int i = tid + q * nt;
+    if (i < n) {
+      const double x = __longlong_as_double((long long)key[q]);
+      s_all += x;
+      if (x < thr) { s_lt += x; c_lt++; }
+    }
   }
   block_sum2(s_lt, s_all, scratch);
   int tot_lt;
@@ -226,7 +292,7 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
   *total = s_all;
 }
 
-__global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
+__global__ void __launch_bounds__(512, 4) d4c_body(D4cParams p) {   // 2 workgroups per CU
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
@@ -240,7 +306,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
     return;
   }
   const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
-  // LDS: Z (N complex + 8) | hist (256 int) | scratch (64) | coarse (16).  The packed
+  // LDS: Z (N complex + 8) | select counters (512 int) | scratch (64) | coarse (16) | twiddles.  The packed
   // centroid transform needs all of Z; afterwards Z is re-carved into the real-FFT /
   // prefix-sum work area [0, N), B = [N, N+H+1) and A = [N+H+1, N+2H+2).  During the
   // centroid phase A lives in registers (each thread always owns the same bins).
@@ -249,7 +315,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
   double *B = Zr + N;
   double *A = B + (H + 1);
   int *hist = reinterpret_cast<int *>(Zr + 2 * N + 8);
-  double *scratch = reinterpret_cast<double *>(hist + 256);
+  double *scratch = reinterpret_cast<double *>(hist + 512);
   double *coarse = scratch + 64;
   // twiddles for the packed centroid transform (2^lgn complex points) and the real ones
   const TwLds tw = stage_twiddles(coarse + 16, lgn, p.tab.tw);
@@ -271,7 +337,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
   for (int c = 0; c < 2; ++c) {
     const double cpos = c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
     __syncthreads();
-    const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
+    const int wlen = d4c_windowed<kWinBody>(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
                                   Zr, 2, scratch);
     double pw = 0.0;
     for (int i = tid; i < wlen; i += nt) pw += Zr[2 * i] * Zr[2 * i];
@@ -305,7 +371,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
   {
-    const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
+    const int wlen = d4c_windowed<kWinBody>(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
                                   Zr, 1, scratch);
     for (int i = wlen + tid; i < N; i += nt) Zr[i] = 0.0;
     block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
@@ -361,7 +427,7 @@ __global__ void __launch_bounds__(512) d4c_body(D4cParams p) {
 size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 4 + 2); }
 size_t d4c_body_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(2 * N + 8 + 128 + 64 + 16 + N / 4 + 2);
+  return sizeof(double) * (size_t)(2 * N + 8 + 256 + 64 + 16 + N / 4 + 2);
 }
 
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz

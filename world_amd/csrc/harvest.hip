@@ -212,12 +212,15 @@ __global__ void hv_refine(HarvestParams p) {
       const int nh = imin(static_cast<int>(fs / 2.0 / f0c), 6);
       const int LH = WAVE >= 8 ? 8 : 1;                           // harmonics handled side by side
       const int G = WAVE / LH;                                    // sample phases
-      double pw[6], ni[6];
+      // per-harmonic terms of FixF0 (harvest.cpp:507-536); each harmonic's lane group
+      // evaluates its own term once, the six results are then summed in harmonic order
+      double inst_h[6], amp_h[6], dev_h[6];
       for (int h0 = 0; h0 < 6; h0 += LH) {
         const int h = h0 + lane % LH, g = lane / LH;
         double are = 0, aim = 0, dre = 0, dim = 0;
+        int idx = 0;
         if (h < nh) {
-          const int idx = mround(f0c * N / fs * (h + 1));        // FixF0, harvest.cpp:515
+          idx = mround(f0c * N / fs * (h + 1));                  // FixF0, harvest.cpp:515
           // e^{-2 pi i idx n / N} by rotation: exact start / step from the integer phase
           double wc, ws, rc, rs;
           sincospi(2.0 * ((idx * g) & (N - 1)) / N, &ws, &wc);
@@ -237,21 +240,22 @@ __global__ void hv_refine(HarvestParams p) {
           dre += __shfl_xor(dre, s, 64); dim += __shfl_xor(dim, s, 64);
         }
 #endif
-        double pwv = are * are + aim * aim;                      // harvest.cpp:564-569
-        double niv = are * dim - aim * dre;
+        const double pwv = are * are + aim * aim;                // harvest.cpp:564-569
+        const double niv = are * dim - aim * dre;
+        const double inst = pwv == 0.0 ? 0.0 : static_cast<double>(idx) * fs / N + niv / pwv * fs / 2.0 / kPi;
+        const double amp = sqrt(pwv);
+        const double dev = fabs((inst / (h + 1.0) - f0c) / f0c);
         for (int k = 0; k < LH && h0 + k < 6; ++k) {
-          pw[h0 + k] = wave_bcast(pwv, k);
-          ni[h0 + k] = wave_bcast(niv, k);
+          inst_h[h0 + k] = wave_bcast(inst, k);
+          amp_h[h0 + k] = wave_bcast(amp, k);
+          dev_h[h0 + k] = wave_bcast(dev, k);
         }
       }
-      double num = 0.0, den = 0.0, sc = 0.0;                     // FixF0, harvest.cpp:507-536
+      double num = 0.0, den = 0.0, sc = 0.0;
       for (int h = 0; h < nh; ++h) {
-        const int idx = mround(f0c * N / fs * (h + 1));
-        double inst = pw[h] == 0.0 ? 0.0 : static_cast<double>(idx) * fs / N + ni[h] / pw[h] * fs / 2.0 / kPi;
-        double amp = sqrt(pw[h]);
-        num += amp * inst;
-        den += amp * (h + 1.0);
-        sc += fabs((inst / (h + 1.0) - f0c) / f0c);
+        num += amp_h[h] * inst_h[h];
+        den += amp_h[h] * (h + 1.0);
+        sc += dev_h[h];
       }
       rf0 = num / (den + kTiny);
       rsc = 1.0 / (sc / nh + kTiny);

@@ -68,17 +68,32 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
     const int base = k0 + ntap - 1;
 #pragma unroll
     for (int q = 0; q < kOutPer; ++q) { acc[q] = 0.0; w[q] = yt[pad8(base + q)]; }
-    // logical window at tap j: L_j[q] = in-tile[base + q - j] = w[(q - j) mod kOutPer]
-    for (int j0 = 0; j0 < ntap; j0 += kOutPer) {
+    // logical window at tap j: L_j[q] = in-tile[base + q - j] = w[(q - j) mod kOutPer].
+    // Groups of kOutPer taps: the group's kOutPer new inputs and taps are fetched
+    // first (independent LDS reads in flight), then kOutPer^2 FMAs run from registers.
+    const int ntap_main = ntap - (ntap % kOutPer);
+    for (int j0 = 0; j0 < ntap_main; j0 += kOutPer) {
+      double fresh[kOutPer], h[kOutPer];
 #pragma unroll
       for (int u = 0; u < kOutPer; ++u) {
-        const int j = j0 + u;
-        if (j < ntap) {
-          if (j > 0) w[(kOutPer - u) % kOutPer] = yt[pad8(base - j)];
-          const double h = taps[j];
+        h[u] = taps[j0 + u];
+        fresh[u] = yt[pad8(base - (j0 + u))];          // slot u = 0 is only needed for j0 > 0
+      }
 #pragma unroll
-          for (int q = 0; q < kOutPer; ++q) acc[q] = fma(h, w[(q + kOutPer - u) % kOutPer], acc[q]);
-        }
+      for (int u = 0; u < kOutPer; ++u) {
+        if (j0 + u > 0) w[(kOutPer - u) % kOutPer] = fresh[u];
+#pragma unroll
+        for (int q = 0; q < kOutPer; ++q) acc[q] = fma(h[u], w[(q + kOutPer - u) % kOutPer], acc[q]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kOutPer; ++u) {                 // remaining ntap % kOutPer taps
+      const int j = ntap_main + u;
+      if (j < ntap) {
+        if (j > 0) w[(kOutPer - u) % kOutPer] = yt[pad8(base - j)];
+        const double hh = taps[j];
+#pragma unroll
+        for (int q = 0; q < kOutPer; ++q) acc[q] = fma(hh, w[(q + kOutPer - u) % kOutPer], acc[q]);
       }
     }
 #pragma unroll
@@ -117,29 +132,44 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
   int count[4] = {0, 0, 0, 0};
   for (int t0 = seg_begin; t0 < seg_end; t0 += kTile) {
     fir_tile(job, taps, t0, yt, s);
-    // events: each thread inspects kPer consecutive samples, in time order
-    constexpr int kPer = 4;
-    for (int fam = 0; fam < 4; ++fam) {
-      double *dst = ev + fam * fam_stride;
-      for (int sub = 0; sub < kTile; sub += nt * kPer) {
-        double found[kPer];
-        int nfound = 0;
-        for (int q = 0; q < kPer; ++q) {
-          int k = sub + tid * kPer + q;
-          int i = t0 + k;
-          if (k >= kTile) break;
-          double a, b;                   // the family's signal at i and i+1
-          bool in_range;
-          const double s0 = s[pad8(k)], s1 = s[pad8(k + 1)];
-          if (fam < 2) { a = s0; b = s1; in_range = i <= n - 2; }
-          else { const double s2 = s[pad8(k + 2)]; a = s1 - s0; b = s2 - s1; in_range = i <= n - 3; }
-          bool hit = fam % 2 == 0 ? (0.0 < a && b <= 0.0) : (a < 0.0 && 0.0 <= b);
-          if (in_range && hit) found[nfound++] = fine_edge(i + 1, a, b);
+    // events: every thread inspects kOutPer consecutive samples (time order).  Pass 1
+    // counts the crossings of all four families (16-bit counters packed in one word),
+    // ONE block scan turns the counts into list positions, pass 2 re-detects and writes.
+    for (int sub = 0; sub < kTile; sub += nt * kOutPer) {
+      const int kbase = sub + tid * kOutPer;
+      double sv[kOutPer + 2];
+#pragma unroll
+      for (int q = 0; q < kOutPer + 2; ++q) sv[q] = kbase + q < kTile + 2 ? s[pad8(kbase + q)] : 0.0;
+      auto crossing = [&](int fam, int q, double &a, double &b) {
+        const int i = t0 + kbase + q;
+        bool in_range;
+        if (fam < 2) { a = sv[q]; b = sv[q + 1]; in_range = i <= n - 2; }
+        else { a = sv[q + 1] - sv[q]; b = sv[q + 2] - sv[q + 1]; in_range = i <= n - 3; }
+        const bool hit = fam % 2 == 0 ? (0.0 < a && b <= 0.0) : (a < 0.0 && 0.0 <= b);
+        return in_range && hit && kbase + q < kTile;
+      };
+      unsigned long long packed = 0;
+#pragma unroll
+      for (int fam = 0; fam < 4; ++fam) {
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < kOutPer; ++q) { double a, b; c += crossing(fam, q, a, b) ? 1 : 0; }
+        packed |= (unsigned long long)c << (16 * fam);
+      }
+      unsigned long long total, off = block_excl_scan_u64(packed, &total, scratch);
+#pragma unroll
+      for (int fam = 0; fam < 4; ++fam) {
+        double *dst = ev + fam * fam_stride;
+        int at = count[fam] + (int)((off >> (16 * fam)) & 0xFFFF);
+#pragma unroll
+        for (int q = 0; q < kOutPer; ++q) {
+          double a, b;
+          if (crossing(fam, q, a, b)) {
+            if (at < kSegCap) dst[at] = fine_edge(t0 + kbase + q + 1, a, b);
+            ++at;
+          }
         }
-        int total, off = block_excl_scan_int(nfound, &total, scratch);
-        for (int q = 0; q < nfound; ++q)
-          if (count[fam] + off + q < kSegCap) dst[count[fam] + off + q] = found[q];
-        count[fam] += total;
+        count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
       }
     }
   }

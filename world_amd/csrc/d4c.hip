@@ -217,7 +217,7 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q) {
     const int i = tid + q * nt;
-    key[q] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;   // padding sorts last
+    key[q] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;   // padding never matches
     if (i < n) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
   }
   // block-wide min / max of the keys -> the leading nibbles every key shares
@@ -232,24 +232,26 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
   __syncthreads();
   for (int w = 0; w < nw; ++w) { kmin = ks[w] < kmin ? ks[w] : kmin; kmax = ks[32 + w] > kmax ? ks[32 + w] : kmax; }
 #endif
-  int first_pass = 0;
-  while (first_pass < 16 && ((kmin ^ kmax) >> (60 - 4 * first_pass)) == 0) ++first_pass;
-  unsigned long long prefix = first_pass ? (kmin >> (64 - 4 * first_pass)) << (64 - 4 * first_pass) : 0ull;
+  int pass = 0;
+  while (pass < 16 && ((kmin ^ kmax) >> (60 - 4 * pass)) == 0) ++pass;
+  unsigned long long prefix = pass ? (kmin >> (64 - 4 * pass)) << (64 - 4 * pass) : 0ull;
   int remaining = m - 1;                           // rank (0-based, ascending) of the threshold element
-  for (int pass = first_pass; pass < 16; ++pass) {
+  int bucket = n;                                   // keys that still match the prefix
+  // After a few nibbles the bucket holding the threshold has ONE key left; stop there.
+  for (; pass < 16 && bucket > 1; ++pass) {
     const int shift = 60 - 4 * pass;
     int *slot = cnt + (pass & 1) * 256;            // [wave][digit]
-    // this wave's population of every digit among keys that match the prefix so far
-    int mine = 0;                                   // lane d < 16 ends up holding digit d's count
+    int dq[kSelKeys];                               // this pass's digit of every key (16 = not in the bucket)
 #pragma unroll
+    for (int q = 0; q < kSelKeys; ++q) {
+      const bool in = key[q] != ~0ull && (pass == 0 || (key[q] >> (shift + 4)) == (prefix >> (shift + 4)));
+      dq[q] = in ? (int)((key[q] >> shift) & 15ull) : 16;
+    }
+    int mine = 0;                                   // lane d < 16 ends up holding digit d's count
     for (int d = 0; d < 16; ++d) {
       int c = 0;
 #pragma unroll
-      for (int q = 0; q < kSelKeys; ++q) {
-        const bool match = (pass == 0 || (key[q] >> (shift + 4)) == (prefix >> (shift + 4))) &&
-                           key[q] != ~0ull && (int)((key[q] >> shift) & 15ull) == d;
-        c += wave_count(match);
-      }
+      for (int q = 0; q < kSelKeys; ++q) c += wave_count(dq[q] == d);
 #ifndef WORLD_EMU
       if (lane == d) mine = c;
 #else
@@ -262,16 +264,28 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
 #endif
     __syncthreads();
     // every wave walks the 16 digit totals redundantly (no second barrier needed)
-    int digit = 15, below = 0, acc = 0;
+    int digit = 15, below = 0, acc = 0, hsel = 0;
     bool found = false;
     for (int d = 0; d < 16; ++d) {
       int h = 0;
       for (int w = 0; w < nw; ++w) h += slot[w * 16 + d];
-      if (!found && remaining < acc + h) { digit = d; below = acc; found = true; }
+      if (!found && remaining < acc + h) { digit = d; below = acc; hsel = h; found = true; }
       acc += h;
     }
     remaining -= below;
+    bucket = hsel;
     prefix |= (unsigned long long)digit << shift;
+  }
+  if (pass < 16) {
+    // the bucket holds exactly one key: it is the threshold; its owner publishes it
+    const int shift = 64 - 4 * pass;               // bits fixed so far
+    unsigned long long *ks2 = reinterpret_cast<unsigned long long *>(scratch) + 48;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSelKeys; ++q)
+      if (key[q] != ~0ull && (shift == 64 || (key[q] >> shift) == (prefix >> shift))) ks2[0] = key[q];
+    __syncthreads();
+    prefix = ks2[0];
   }
   const double thr = __longlong_as_double((long long)prefix);
   double s_lt = 0.0, s_all = 0.0;
@@ -292,7 +306,10 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
   *total = s_all;
 }
 
-__global__ void __launch_bounds__(512, 4) d4c_body(D4cParams p) {   // 2 workgroups per CU
+#ifndef D4C_MIN_WAVES
+#define D4C_MIN_WAVES 4      // 4 waves/SIMD = two 512-thread workgroups per CU
+#endif
+__global__ void __launch_bounds__(512, D4C_MIN_WAVES) d4c_body(D4cParams p) {
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;

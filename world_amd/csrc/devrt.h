@@ -276,6 +276,31 @@ __device__ __forceinline__ int block_excl_scan_int(int v, int *total, double *sc
 #endif
 }
 
+// exclusive scan of one 64-bit value per thread (four 16-bit counters packed together)
+__device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *total,
+                                                                  double *scratch) {
+#ifndef WORLD_EMU
+  const int lane = lane_id();
+  unsigned long long inc = v;
+  for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  const unsigned long long wt = __shfl(inc, 63, 64);
+  const int nw = waves_per_block();
+  if (nw == 1) { *total = wt; return inc - v; }
+  unsigned long long *us = reinterpret_cast<unsigned long long *>(scratch);
+  __syncthreads();
+  if (lane == 0) us[wave_in_block()] = wt;
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) { unsigned long long c = us[w]; if (w < wave_in_block()) base += c; tot += c; }
+  *total = tot;
+  return base + (inc - v);
+#else
+  (void)scratch;
+  *total = v;
+  return 0;
+#endif
+}
+
 // In-place inclusive prefix sum of a[0..n) in LDS by the whole block.
 // Each thread sums a contiguous chunk serially, chunk totals are scanned across
 // the block, then offsets are added back.  (With one thread -- the emulation --

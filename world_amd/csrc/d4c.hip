@@ -263,15 +263,34 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
     if (lane < 16) slot[wv * 16 + lane] = mine;
 #endif
     __syncthreads();
-    // every wave walks the 16 digit totals redundantly (no second barrier needed)
-    int digit = 15, below = 0, acc = 0, hsel = 0;
-    bool found = false;
-    for (int d = 0; d < 16; ++d) {
+    // every wave locates the digit redundantly (no second barrier needed): lane d sums
+    // digit d over the waves, a 16-lane scan finds where the rank falls
+    int digit = 15, below = 0, hsel = 0;
+#ifndef WORLD_EMU
+    {
       int h = 0;
-      for (int w = 0; w < nw; ++w) h += slot[w * 16 + d];
-      if (!found && remaining < acc + h) { digit = d; below = acc; hsel = h; found = true; }
-      acc += h;
+      if (lane < 16) for (int w = 0; w < nw; ++w) h += slot[w * 16 + lane];
+      int inc = h;
+      for (int dd = 1; dd < 16; dd <<= 1) { int o = __shfl_up(inc, dd, 64); if (lane >= dd) inc += o; }
+      const int before = inc - h;
+      const bool here = lane < 16 && before <= remaining && remaining < inc;
+      const int src = __ffsll((long long)__ballot(here)) - 1;     // exactly one lane
+      digit = src;
+      below = __shfl(before, src, 64);
+      hsel = __shfl(h, src, 64);
     }
+#else
+    {
+      int acc = 0;
+      bool found = false;
+      for (int d = 0; d < 16; ++d) {
+        int h = 0;
+        for (int w = 0; w < nw; ++w) h += slot[w * 16 + d];
+        if (!found && remaining < acc + h) { digit = d; below = acc; hsel = h; found = true; }
+        acc += h;
+      }
+    }
+#endif
     remaining -= below;
     bucket = hsel;
     prefix |= (unsigned long long)digit << shift;

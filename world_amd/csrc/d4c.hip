@@ -192,24 +192,17 @@ __device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, 
 }
 
 // Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them: a radix
-// select on the IEEE bit patterns (monotone for non-negative doubles), 4 bits per
-// pass.  Every thread keeps its keys in registers; a digit's population is counted
-// with wave ballots (no LDS atomics, no contention), the 16 per-wave counts meet in
-// LDS (double-buffered: one barrier per pass), and passes whose digit is shared by
-// all keys (common sign/exponent prefix) are skipped.  cnt: 2 * 16 * 16 ints of LDS.
+// select on the IEEE bit patterns (monotone for non-negative doubles), one byte per
+// pass, histogram in LDS.  Keys stay in registers; bytes shared by all keys (common
+// sign/exponent prefix, found from the block min/max) are skipped, and the walk stops
+// as soon as the bucket holding the threshold contains a single key -- typically after
+// two or three passes instead of eight.  hist: 2 x 256 ints of LDS (ping-pong).
 #ifdef WORLD_EMU
 constexpr int kSelKeys = 4096 / 2 + 1;
 #else
 constexpr int kSelKeys = (4096 / 2 + 1 + 511) / 512;
 #endif
-__device__ __forceinline__ int wave_count(bool pred) {
-#ifndef WORLD_EMU
-  return __popcll(__ballot(pred));
-#else
-  return pred ? 1 : 0;
-#endif
-}
-__device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m, int *cnt,
+__device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m, int *hist,
                                                    double *scratch, double *partial, double *total) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wv = wave_in_block(), nw = waves_per_block();
   unsigned long long key[kSelKeys];
@@ -220,7 +213,7 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
     key[q] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;   // padding never matches
     if (i < n) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
   }
-  // block-wide min / max of the keys -> the leading nibbles every key shares
+  for (int i = tid; i < 512; i += nt) hist[i] = 0;
 #ifndef WORLD_EMU
   for (int s = 32; s >= 1; s >>= 1) {
     unsigned long long a = __shfl_xor(kmin, s, 64), b = __shfl_xor(kmax, s, 64);
@@ -231,78 +224,54 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
   if (lane == 0) { ks[wv] = kmin; ks[32 + wv] = kmax; }
   __syncthreads();
   for (int w = 0; w < nw; ++w) { kmin = ks[w] < kmin ? ks[w] : kmin; kmax = ks[32 + w] > kmax ? ks[32 + w] : kmax; }
+#else
+  (void)lane; (void)wv; (void)nw;
 #endif
   int pass = 0;
-  while (pass < 16 && ((kmin ^ kmax) >> (60 - 4 * pass)) == 0) ++pass;
-  unsigned long long prefix = pass ? (kmin >> (64 - 4 * pass)) << (64 - 4 * pass) : 0ull;
+  while (pass < 8 && ((kmin ^ kmax) >> (56 - 8 * pass)) == 0) ++pass;
+  unsigned long long prefix = pass ? (kmin >> (64 - 8 * pass)) << (64 - 8 * pass) : 0ull;
   int remaining = m - 1;                           // rank (0-based, ascending) of the threshold element
   int bucket = n;                                   // keys that still match the prefix
-  // After a few nibbles the bucket holding the threshold has ONE key left; stop there.
-  for (; pass < 16 && bucket > 1; ++pass) {
-    const int shift = 60 - 4 * pass;
-    int *slot = cnt + (pass & 1) * 256;            // [wave][digit]
-    int dq[kSelKeys];                               // this pass's digit of every key (16 = not in the bucket)
+  for (int it = 0; pass < 8 && bucket > 1; ++pass, ++it) {
+    const int shift = 56 - 8 * pass;
+    int *h = hist + (it & 1) * 256;                 // this pass's histogram (already zero)
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q) {
-      const bool in = key[q] != ~0ull && (pass == 0 || (key[q] >> (shift + 4)) == (prefix >> (shift + 4)));
-      dq[q] = in ? (int)((key[q] >> shift) & 15ull) : 16;
+      const bool in = key[q] != ~0ull && (pass == 0 || (key[q] >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (in) atomicAdd(&h[(int)((key[q] >> shift) & 255ull)], 1);
     }
-    int mine = 0;                                   // lane d < 16 ends up holding digit d's count
-    for (int d = 0; d < 16; ++d) {
-      int c = 0;
-#pragma unroll
-      for (int q = 0; q < kSelKeys; ++q) c += wave_count(dq[q] == d);
-#ifndef WORLD_EMU
-      if (lane == d) mine = c;
-#else
-      slot[wv * 16 + d] = c;
-      (void)mine;
-#endif
-    }
-#ifndef WORLD_EMU
-    if (lane < 16) slot[wv * 16 + lane] = mine;
-#endif
     __syncthreads();
-    // every wave locates the digit redundantly (no second barrier needed): lane d sums
-    // digit d over the waves, a 16-lane scan finds where the rank falls
-    int digit = 15, below = 0, hsel = 0;
-#ifndef WORLD_EMU
-    {
-      int h = 0;
-      if (lane < 16) for (int w = 0; w < nw; ++w) h += slot[w * 16 + lane];
-      int inc = h;
-      for (int dd = 1; dd < 16; dd <<= 1) { int o = __shfl_up(inc, dd, 64); if (lane >= dd) inc += o; }
-      const int before = inc - h;
-      const bool here = lane < 16 && before <= remaining && remaining < inc;
-      const int src = __ffsll((long long)__ballot(here)) - 1;     // exactly one lane
-      digit = src;
-      below = __shfl(before, src, 64);
-      hsel = __shfl(h, src, 64);
-    }
-#else
-    {
-      int acc = 0;
-      bool found = false;
-      for (int d = 0; d < 16; ++d) {
-        int h = 0;
-        for (int w = 0; w < nw; ++w) h += slot[w * 16 + d];
-        if (!found && remaining < acc + h) { digit = d; below = acc; hsel = h; found = true; }
-        acc += h;
+    for (int i = tid; i < 256; i += nt) hist[((it & 1) ^ 1) * 256 + i] = 0;   // next pass's histogram
+    // every wave locates the byte redundantly: each lane sums its bins, a wave scan finds the rank
+    const int per_lane = 256 / WAVE;
+    int local = 0;
+    for (int j = 0; j < per_lane; ++j) local += h[lane_id() * per_lane + j];
+    int tot, before = wave_excl_scan_int(local, &tot);
+    int digit = -1, below = -1, hsel = -1;
+    if (before <= remaining && remaining < before + local) {
+      int acc = before;
+      for (int j = 0; j < per_lane; ++j) {
+        int c = h[lane_id() * per_lane + j];
+        if (remaining < acc + c) { digit = lane_id() * per_lane + j; below = acc; hsel = c; break; }
+        acc += c;
       }
     }
-#endif
+    digit = wave_max_int(digit);
+    below = wave_max_int(below);
+    hsel = wave_max_int(hsel);
     remaining -= below;
     bucket = hsel;
     prefix |= (unsigned long long)digit << shift;
   }
-  if (pass < 16) {
+  if (pass < 8) {
     // the bucket holds exactly one key: it is the threshold; its owner publishes it
-    const int shift = 64 - 4 * pass;               // bits fixed so far
+    const int fixed = 64 - 8 * pass;               // low bits not yet decided
     unsigned long long *ks2 = reinterpret_cast<unsigned long long *>(scratch) + 48;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q)
-      if (key[q] != ~0ull && (shift == 64 || (key[q] >> shift) == (prefix >> shift))) ks2[0] = key[q];
+      if (key[q] != ~0ull && (fixed == 64 || (key[q] >> fixed) == (prefix >> fixed))) ks2[0] = key[q];
     __syncthreads();
     prefix = ks2[0];
   }

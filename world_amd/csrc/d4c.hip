@@ -11,14 +11,16 @@
 // per-frame draw counts (d4c_prepare1 / d4c_prepare2) and GF(2) jump-ahead.
 //
 //   d4c_lovetrain : 256-thread workgroup per frame, one r2c FFT, two band sums.
-//   d4c_body      : 512-thread workgroup per selected frame, all in LDS:
+//   d4c_groupdelay: 512-thread workgroup per selected frame, all in LDS:
 //                   2 centroid transforms (each = the reference's two r2c FFTs
 //                   packed into ONE complex FFT: z = w x + i (n+1) w x), 1 power
 //                   spectrum, 2 DC corrections, 3 rectangular smoothings
-//                   (block-parallel prefix sums), nap band FFTs each followed by
-//                   an LDS radix-select replacing the reference's std::sort
-//                   (only the sum of the N/2-boundary smallest powers is used),
-//                   then the 3 kHz-grid interpolation written once to HBM.
+//                   (block-parallel prefix sums) -> static group delay to HBM.
+//   d4c_band      : workgroup per (3 kHz band, selected frame): windowed slice ->
+//                   r2c FFT -> power -> radix select in registers replacing the
+//                   reference's std::sort (only the sum of the N/2-boundary
+//                   smallest powers is used) -> one coarse aperiodicity value.
+//   d4c_finish    : the 3 kHz-grid interpolation, every row written once to HBM.
 #include "stage_params.h"
 
 namespace world_hip {
@@ -74,15 +76,8 @@ __global__ void d4c_prepare2(D4cParams p) {
 }
 
 // Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84).
-// Samples go to dst[i*dstride]; each thread keeps the window values of its own
-// samples in registers between the two passes.  Returns 2*hw+1.
-#ifdef WORLD_EMU
-constexpr int kWinLove = 4096, kWinBody = 4096;
-#else
-constexpr int kWinLove = 4096 / 256;               // samples per thread of a 256-thread LoveTrain block
-constexpr int kWinBody = 4096 / 512;               // ... of a 512-thread body block
-#endif
-template <int kWinPerThread>
+// Samples go to dst[i*dstride]; the window shape is recomputed in the second pass
+// (one cosine) rather than stored: no LDS, no long-lived registers.  Returns 2*hw+1.
 __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, double f0, double pos,
                                             int kind, double ratio, const double *noise,
                                             double *dst, int dstride, double *scratch) {
@@ -91,13 +86,8 @@ __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, 
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
   double s1 = 0.0, s2 = 0.0;
-  double wreg[kWinPerThread];
-#pragma unroll
-  for (int q = 0; q < kWinPerThread; ++q) {
-    const int i = tid + q * nt;
-    if (i >= wlen) break;
+  for (int i = tid; i < wlen; i += nt) {
     const double w = d4c_window_at(i, hw, kind, ratio, fs, f0);
-    wreg[q] = w;
     // noise[i]: the window's draws in sample order (d4c.cpp:67-69)
     double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kSafeGuardD4C;
     dst[(size_t)i * dstride] = v;
@@ -105,12 +95,8 @@ __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, 
   }
   block_sum2(s1, s2, scratch);
   const double coef = s1 / s2;
-#pragma unroll
-  for (int q = 0; q < kWinPerThread; ++q) {
-    const int i = tid + q * nt;
-    if (i >= wlen) break;
-    dst[(size_t)i * dstride] -= wreg[q] * coef;
-  }
+  for (int i = tid; i < wlen; i += nt)
+    dst[(size_t)i * dstride] -= d4c_window_at(i, hw, kind, ratio, fs, f0) * coef;
   __syncthreads();
   return wlen;
 }
@@ -129,7 +115,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   double *scratch = Zr + M;
   const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
   const double cf0 = f0 > 40.0 ? f0 : 40.0;
-  const int wlen = d4c_windowed<kWinLove>(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
+  const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
                                 kBlackman, 3.0, p.noise + p.offsets1[fi],
                                 Zr, 1, scratch);
   for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) Zr[i] = 0.0;
@@ -202,15 +188,14 @@ constexpr int kSelKeys = 4096 / 2 + 1;
 #else
 constexpr int kSelKeys = (4096 / 2 + 1 + 511) / 512;
 #endif
-__device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m, int *hist,
+// key[q] = bit pattern of element tid + q*T (~0 = no element).
+__device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int n, int m, int *hist,
                                                    double *scratch, double *partial, double *total) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wv = wave_in_block(), nw = waves_per_block();
-  unsigned long long key[kSelKeys];
   unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q) {
     const int i = tid + q * nt;
-    key[q] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;   // padding never matches
     if (i < n) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
   }
   for (int i = tid; i < 512; i += nt) hist[i] = 0;
@@ -294,36 +279,28 @@ __device__ __forceinline__ void block_smallest_sum(const double *v, int n, int m
   *total = s_all;
 }
 
-#ifndef D4C_MIN_WAVES
-#define D4C_MIN_WAVES 4      // 4 waves/SIMD = two 512-thread workgroups per CU
-#endif
-__global__ void __launch_bounds__(512, D4C_MIN_WAVES) d4c_body(D4cParams p) {
+// ---------------------------------------------------------------------------
+// Stage A of D4CGeneralBody: static group delay of one selected frame -> HBM.
+// (GetStaticCentroid, GetSmoothedPowerSpectrum, GetStaticGroupDelay: d4c.cpp:126-188)
+__global__ void __launch_bounds__(512, 4) d4c_groupdelay(D4cParams p) {      // 4 waves/SIMD = 2 workgroups/CU
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int nb_out = p.fft_out / 2 + 1;
-  double *row = p.aperiodicity + fi * nb_out;
   const double f0 = p.f0[fi];
-  if (f0 == 0 || p.ap0[fi] <= p.threshold) {                          // d4c.cpp:323-328,386
-    for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny;
-    return;
-  }
+  if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
   const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
-  // LDS: Z (N complex + 8) | select counters (512 int) | scratch (64) | coarse (16) | twiddles.  The packed
-  // centroid transform needs all of Z; afterwards Z is re-carved into the real-FFT /
-  // prefix-sum work area [0, N), B = [N, N+H+1) and A = [N+H+1, N+2H+2).  During the
-  // centroid phase A lives in registers (each thread always owns the same bins).
+  // LDS: Z (N complex + 8) | scratch (64) | twiddles.  The packed centroid transform
+  // needs all of Z; afterwards Z is re-carved into the real-FFT / prefix-sum work area
+  // [0, N), B = [N, N+H+1) and A = [N+H+1, N+2H+2).  During the centroid phase A lives
+  // in registers (each thread always owns the same bins).
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   double *B = Zr + N;
   double *A = B + (H + 1);
-  int *hist = reinterpret_cast<int *>(Zr + 2 * N + 8);
-  double *scratch = reinterpret_cast<double *>(hist + 512);
-  double *coarse = scratch + 64;
-  // twiddles for the packed centroid transform (2^lgn complex points) and the real ones
-  const TwLds tw = stage_twiddles(coarse + 16, lgn, p.tab.tw);
+  double *scratch = Zr + 2 * N + 8;
+  const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
 #ifdef WORLD_EMU
   constexpr int kBinsPerThread = 4096 / 2 + 1;          // one emulated thread owns every bin
 #else
@@ -342,8 +319,8 @@ __global__ void __launch_bounds__(512, D4C_MIN_WAVES) d4c_body(D4cParams p) {
   for (int c = 0; c < 2; ++c) {
     const double cpos = c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
     __syncthreads();
-    const int wlen = d4c_windowed<kWinBody>(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
-                                  Zr, 2, scratch);
+    const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
+                                            Zr, 2, scratch);
     double pw = 0.0;
     for (int i = tid; i < wlen; i += nt) pw += Zr[2 * i] * Zr[2 * i];
     pw = block_sum(pw, scratch);
@@ -376,8 +353,8 @@ __global__ void __launch_bounds__(512, D4C_MIN_WAVES) d4c_body(D4cParams p) {
 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
   {
-    const int wlen = d4c_windowed<kWinBody>(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
-                                  Zr, 1, scratch);
+    const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
+                                            Zr, 1, scratch);
     for (int i = wlen + tid; i < N; i += nt) Zr[i] = 0.0;
     block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
   }
@@ -388,29 +365,70 @@ __global__ void __launch_bounds__(512, D4C_MIN_WAVES) d4c_body(D4cParams p) {
   for (int i = tid; i <= H; i += nt) A[i] = A[i] / B[i];
   d4c_smooth(A, cf0 / 2.0, fs, N, Zr, A, scratch);
   d4c_smooth(A, cf0, fs, N, Zr, B, scratch);
-  for (int i = tid; i <= H; i += nt) A[i] -= B[i];
+  double *gd = p.gd + fi * p.gd_stride;
+  for (int i = tid; i <= H; i += nt) gd[i] = A[i] - B[i];
+}
 
-  // ---- GetCoarseAperiodicity (d4c.cpp:194-225) --------------------------------
+// ---------------------------------------------------------------------------
+// Stage B: one workgroup per (band, selected frame).  GetCoarseAperiodicity
+// (d4c.cpp:194-225): Nuttall-windowed slice of the group delay -> r2c -> power ->
+// share of the N/2-boundary smallest bins.  The power values never touch LDS: the
+// transform's merge step hands bin tid + q*T to thread tid, which is exactly the key
+// layout of the radix select.
+__global__ void __launch_bounds__(512) d4c_band(D4cParams p) {
+  DYN_LDS(lds);
+  const int band = blockIdx.x, f = blockIdx.y, u = blockIdx.z;
+  if (f >= p.b.n_frames[u]) return;
+  const size_t fi = (size_t)u * p.b.f_stride + f;
+  const double f0 = p.f0[fi];
+  if (f0 == 0 || p.ap0[fi] <= p.threshold) return;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  double *Zr = reinterpret_cast<double *>(lds);
+  int *hist = reinterpret_cast<int *>(Zr + N);
+  double *scratch = reinterpret_cast<double *>(hist + 512);
+  const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
+  const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   const int bnd = mround(N * 8.0 / p.wl);
   const int hwl = p.wl / 2;
-  for (int band = 0; band < p.nap; ++band) {
-    const int center = static_cast<int>(3000.0 * (band + 1) * N / fs);
-    __syncthreads();
-    for (int i = tid; i < N; i += nt)
-      Zr[i] = i <= 2 * hwl ? A[center - hwl + i] * p.nuttall[i] : 0.0;
-    block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
-    double part, tot;
-    block_smallest_sum(B, H + 1, H - bnd, hist, scratch, &part, &tot);
-    if (tid == 0) {
-      double c = 10 * log10(part / tot);
-      c = c + (cf0 - 100) / 50.0;                     // d4c.cpp:314-316
-      coarse[1 + band] = c < 0.0 ? c : 0.0;
-    }
+  const int center = static_cast<int>(3000.0 * (band + 1) * N / fs);
+  const double *gd = p.gd + fi * p.gd_stride;
+  for (int i = tid; i < N; i += nt)
+    Zr[i] = i <= 2 * hwl ? gd[center - hwl + i] * p.nuttall[i] : 0.0;
+  unsigned long long key[kSelKeys];
+#pragma unroll
+  for (int q = 0; q < kSelKeys; ++q) key[q] = ~0ull;
+  int filled = 0;
+  block_rfft(Z, lgn, tw, [&](int k, double re, double im) {
+    (void)k;
+    key[filled < kSelKeys ? filled : kSelKeys - 1] = (unsigned long long)__double_as_longlong(re * re + im * im);
+    ++filled;
+  });
+  double part, tot;
+  block_smallest_sum(key, H + 1, H - bnd, hist, scratch, &part, &tot);
+  if (tid == 0) {
+    double c = 10 * log10(part / tot);
+    c = c + (cf0 - 100) / 50.0;                       // d4c.cpp:314-316
+    p.coarse[fi * 16 + 1 + band] = c < 0.0 ? c : 0.0;
   }
-  if (tid == 0) { coarse[0] = -60.0; coarse[p.nap + 1] = -kTiny; }    // d4c.cpp:373-375
-  __syncthreads();
+}
 
-  // ---- GetAperiodicity (d4c.cpp:330-338): interp1 onto the output bins ---------
+// ---------------------------------------------------------------------------
+// Stage C: GetAperiodicity (d4c.cpp:323-338) -- every frame's output row.
+__global__ void d4c_finish(D4cParams p) {
+  const int u = blockIdx.y, f = blockIdx.x;
+  if (f >= p.b.n_frames[u]) return;
+  const size_t fi = (size_t)u * p.b.f_stride + f;
+  const int tid = threadIdx.x, nt = blockDim.x, fs = p.b.fs;
+  const int nb_out = p.fft_out / 2 + 1;
+  double *row = p.aperiodicity + fi * nb_out;
+  const double f0 = p.f0[fi];
+  if (f0 == 0 || p.ap0[fi] <= p.threshold) {                          // d4c.cpp:323-328,386
+    for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny;
+    return;
+  }
+  const double *coarse_in = p.coarse + fi * 16;
   const int nk = p.nap + 2;
   for (int i = tid; i < nb_out; i += nt) {
     double xi = static_cast<double>(i) * fs / p.fft_out;
@@ -420,19 +438,24 @@ __global__ void __launch_bounds__(512, D4C_MIN_WAVES) d4c_body(D4cParams p) {
       if (knot <= xi) cnt++;
     }
     int k = cnt < 1 ? 1 : (cnt > nk - 1 ? nk - 1 : cnt);
+    auto cval = [&](int j) { return j == 0 ? -60.0 : (j == p.nap + 1 ? -kTiny : coarse_in[j]); };   // d4c.cpp:373-375
     double x0 = (k - 1) <= p.nap ? (k - 1) * 3000.0 : fs / 2.0;
     double x1 = k <= p.nap ? k * 3000.0 : fs / 2.0;
     double s = (xi - x0) / (x1 - x0);
-    double y = coarse[k - 1] + s * (coarse[k] - coarse[k - 1]);
+    double y = cval(k - 1) + s * (cval(k) - cval(k - 1));
     row[i] = pow(10.0, y / 20.0);
   }
 }
 
 // ---------------------------------------------------------------------------
 size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 4 + 2); }
-size_t d4c_body_lds_bytes(int lg) {
+size_t d4c_groupdelay_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(2 * N + 8 + 256 + 64 + 16 + N / 4 + 2);
+  return sizeof(double) * (size_t)(2 * N + 8 + 64 + N / 4 + 2);
+}
+size_t d4c_band_lds_bytes(int lg) {
+  int N = 1 << lg;
+  return sizeof(double) * (size_t)(N + 256 + 64 + N / 4 + 2);
 }
 
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz
@@ -444,7 +467,9 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), 256, d4c_love_lds_bytes(p.lg_love), stream, p);
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(d4c_body, dim3(max_frames, p.b.n_utt), 512, d4c_body_lds_bytes(p.lg_d4c), stream, p);
+  WH_BLOCKS(d4c_groupdelay, dim3(max_frames, p.b.n_utt), 512, d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
+  WH_BLOCKS(d4c_band, dim3(p.nap, max_frames, p.b.n_utt), 512, d4c_band_lds_bytes(p.lg_d4c), stream, p);
+  WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 0, stream, p);
 }
 
 }  // namespace world_hip

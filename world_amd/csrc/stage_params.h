@@ -24,6 +24,9 @@ struct D4cParams {
   const double *f0;       // [n_utt][f_stride]
   double *aperiodicity;   // [n_utt][f_stride][fft_out/2+1]
   double *ap0;            // [n_utt][f_stride]  LoveTrain result
+  double *gd;             // [n_utt][f_stride][gd_stride] static group delay of the selected frames
+  int gd_stride;
+  double *coarse;         // [n_utt][f_stride][16] coarse aperiodicity (dB) per band, slot 1 + band
   unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
   unsigned *offsets2;     // [n_utt][f_stride]  position of the frame's 3 body windows within pass 2
   unsigned *draws1;       // [n_utt] total draws of pass 1 (pass 2 continues the stream there)

@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
+                         "stream with its own workspace; 1 = strictly one after the other)")
     args = ap.parse_args()
     args.no_gather_cfg = args.no_gather
 
@@ -97,29 +100,40 @@ def main():
     x = torch.stack(xs).contiguous()
     n = x.shape[1]
     nf = frame_count(FS, n, FRAME_PERIOD)
-    wh = WorldHip(device=local)
-    nbuf = 2 if world > 1 else 1
+    # Steps are independent analysis jobs.  `--streams S` keeps S of them in flight: job k
+    # runs on HIP stream k % S with its own library context (workspace) and output buffers,
+    # so one job's short serial kernels (contour logic, decimation) overlap another job's
+    # wide ones.  Every job still does the full work; nothing is cached between steps.
+    S = max(1, args.streams)
+    nbuf = max(S, 2 if world > 1 else 1)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nbuf)]
+    whs = [WorldHip(device=local) for _ in range(nbuf)]
+    wh = whs[0]
     sp_bufs = [torch.empty((B, nf, FFT_SIZE // 2 + 1), dtype=torch.float64, device=dev) for _ in range(nbuf)]
     ap_bufs = [torch.empty_like(sp_bufs[0]) for _ in range(nbuf)]
     pending = [None] * nbuf
     counter = [0]
+    torch.cuda.synchronize()
 
     def step():
         """analysis of this rank's utterances; at N > 1 followed by the asynchronous
-        all-gather of (f0, sp, ap) whose completion is awaited two steps later"""
+        all-gather of (f0, sp, ap) whose completion is awaited when the slot is reused"""
         k = counter[0] % nbuf
         counter[0] += 1
-        if pending[k] is not None:
-            wd.wait_all(pending[k][1])
-        tpos, f0, sp, ap, _ = wh.analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k], ap_out=ap_bufs[k])
-        if world > 1 and not args.no_gather:
-            pending[k] = wd.all_gather_results([f0, sp, ap], async_op=True)
+        with torch.cuda.stream(streams[k]):
+            if pending[k] is not None:
+                wd.wait_all(pending[k][1])
+            tpos, f0, sp, ap, _ = whs[k].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k],
+                                                 ap_out=ap_bufs[k])
+            if world > 1 and not args.no_gather:
+                pending[k] = wd.all_gather_results([f0, sp, ap], async_op=True)
         return tpos, f0, sp, ap
 
     def drain():
         for k in range(nbuf):
             if pending[k] is not None:
-                wd.wait_all(pending[k][1])
+                with torch.cuda.stream(streams[k]):
+                    wd.wait_all(pending[k][1])
                 pending[k] = None
 
     for _ in range(args.warmup):
@@ -141,12 +155,25 @@ def main():
     frames_per_step = nf * B * world
     value = frames_per_step * args.steps / dt
 
+    # latency of ONE job with nothing else in flight (not the headline number)
+    lat = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            with torch.cuda.stream(streams[0]):
+                whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
+            torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 3 * 1e3
+
     # ---- roofline leg: per-kernel HIP-event timing of a few extra steps (rank 0) ----
     roofline = None
     kernels = {}
     if rank == 0:
-        args.no_gather = True          # kernel timing only; other ranks are past the timed region
-        prof = wh.profile(lambda: [step() for _ in range(3)])
+        def lone():
+            with torch.cuda.stream(streams[0]):
+                whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
+        prof = wh.profile(lambda: [lone() for _ in range(3)])
         torch.cuda.synchronize()
         kernels = {k: {"launches_per_step": len(v) // 3, "ms_per_step": sum(v) / 3.0, "avg_ms": sum(v) / len(v)}
                    for k, v in prof.items()}
@@ -163,6 +190,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(xs[0].cpu().numpy())
 
+    barrier()
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
@@ -173,14 +201,15 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: {B} x (48 kHz, {args.seconds:g} s) utterance(s) per GPU, "
                                    f"Harvest+CheapTrick+D4C, fft_size=2048, frame_period=5 ms, inputs/outputs in HBM",
-                       "frames_per_step": frames_per_step, "utterances_per_gpu": B,
+                       "frames_per_step": frames_per_step, "utterances_per_gpu": B, "jobs_in_flight": S,
                        "parallelism": f"utterance-sharded x{world}" + (
                            ", async RCCL all-gather of f0/sp/ap per step" if world > 1 and not args.no_gather_cfg
                            else ", no collective")},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
                 kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-            "workspace_bytes": wh.workspace_bytes(),
+            "single_job_latency_ms": lat,
+            "workspace_bytes": sum(w.workspace_bytes() for w in whs),
         }
         print(json.dumps(out))
 

@@ -237,7 +237,6 @@ class WorldHip:
 
     def profile(self, fn):
         """Run fn() with per-kernel HIP-event timing; returns {kernel: [ms per launch, ...]}."""
-        self._context()
         self.lib.world_hip_profile_enable(1)
         try:
             fn()
@@ -253,7 +252,7 @@ class WorldHip:
         return out
 
     def workspace_bytes(self):
-        return int(self.lib.world_hip_workspace_bytes(self._context()))
+        return int(self.lib.world_hip_workspace_bytes(self.ctx)) if self.ctx is not None else 0
 
     # ---- F0 ----
     def harvest(self, x, fs, x_len=None, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0):

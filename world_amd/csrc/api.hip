@@ -319,6 +319,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.f0_floor = opt->f0_floor; p.f0_ceil = opt->f0_ceil; p.frame_period = opt->frame_period;
   p.nch = hb.nch;
   p.maxc = mround(hb.nch / 10.0) * 7;                                  // harvest.cpp:1179-1181
+  if (p.maxc > 256) fail("Harvest: %d candidate slots per frame exceed the 256 the tracking kernel handles", p.maxc);
   p.lag = static_cast<int>(ceil(140.0 / p.ratio) * p.ratio);           // harvest.cpp:50-51
   std::vector<int> xl(x_length, x_length + n_utt), yl(n_utt), nfb(n_utt), nfr(n_utt);
   int max_x = 0, max_y = 0, max_fb = 0, max_fr = 0;

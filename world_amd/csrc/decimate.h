@@ -15,10 +15,13 @@ namespace world_hip {
 
 struct IirCoef { double a0, a1, a2, b0, b1; };
 
-constexpr int kDecChunk = 128;
+constexpr int kDecThreads = 256;
+constexpr int kDecChunk = 32;                         // outputs per thread
+constexpr int kDecSpan = kDecThreads * kDecChunk;     // outputs per workgroup
 constexpr int kDecWarm = 384;     // 0.889^384 = 2e-20 (r = 12); r <= 6: 0.7985^384 = 3e-38
 constexpr int kDecBatch = 8;      // samples fetched together ahead of the serial recurrence
-constexpr int kDecPad = 9;      // kNFact
+constexpr int kDecPad = 9;        // kNFact
+inline size_t dec_lds_bytes() { return sizeof(double) * (size_t)(kDecSpan + kDecWarm + 8); }
 
 // filter coefficients, src/matlabfunctions.cpp:29-113
 inline IirCoef decimate_coef(int r) {
@@ -57,53 +60,71 @@ __device__ __forceinline__ double iir_step(const IirCoef &c, double in, double &
   return out;
 }
 
-// forward sweep: fwd[j] for one chunk of the padded signal of length n + 2*lag + 18
-__device__ __forceinline__ void dec_forward_chunk(const double *x, int n, int lag, IirCoef c, int chunk, double *fwd) {
+// forward sweep over the padded signal of length n + 2*lag + 18: one workgroup
+// stages its span (+ warm-up) in LDS with coalesced loads, then every thread runs
+// the recurrence over its warm-up and its chunk out of LDS.
+__device__ __forceinline__ void dec_forward_block(const double *x, int n, int lag, IirCoef c, int block, double *fwd,
+                                                  double *stage) {
   const int total = n + 2 * lag + 2 * kDecPad;
-  const int c0 = chunk * kDecChunk;
-  if (c0 >= total) return;
-  const int c1 = imin(total, c0 + kDecChunk);
-  double w0 = 0, w1 = 0, w2 = 0;
-  for (int j0 = imax(0, c0 - kDecWarm); j0 < c1; j0 += kDecBatch) {
-    double v[kDecBatch];
+  const int b0 = block * kDecSpan;
+  if (b0 >= total) return;
+  const int lo = b0 - kDecWarm;                          // stage[k] = padded[lo + k]
+  const int cnt = imin(total, b0 + kDecSpan) - lo;
+  for (int k = threadIdx.x; k < cnt; k += blockDim.x) stage[k] = lo + k >= 0 ? dec_padded(x, n, lag, lo + k) : 0.0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < kDecThreads; t += blockDim.x) {
+    const int c0 = b0 + t * kDecChunk;
+    if (c0 >= total) break;
+    const int c1 = imin(total, c0 + kDecChunk);
+    double w0 = 0, w1 = 0, w2 = 0;
+    for (int j0 = imax(0, c0 - kDecWarm); j0 < c1; j0 += kDecBatch) {
+      double v[kDecBatch];
 #pragma unroll
-    for (int q = 0; q < kDecBatch; ++q) v[q] = j0 + q < c1 ? dec_padded(x, n, lag, j0 + q) : 0.0;
+      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 + q < c1 ? stage[j0 + q - lo] : 0.0;
 #pragma unroll
-    for (int q = 0; q < kDecBatch; ++q) {
-      const int j = j0 + q;
-      if (j >= c1) break;
-      double out = iir_step(c, v[q], w0, w1, w2);
-      if (j >= c0) fwd[j] = out;
+      for (int q = 0; q < kDecBatch; ++q) {
+        const int j = j0 + q;
+        if (j >= c1) break;
+        double out = iir_step(c, v[q], w0, w1, w2);
+        if (j >= c0) fwd[j] = out;
+      }
     }
   }
 }
 
 // backward sweep over fwd; every r-th output starting at `first` is a decimated sample.
 // out[k] = decimated[skip + k] for k < out_len   (matlabfunctions.cpp:195-200, harvest.cpp:62)
-__device__ __forceinline__ void dec_backward_chunk(const double *fwd, int n, int lag, int r, IirCoef c, int chunk,
-                                                   int skip, int out_len, double *out) {
+__device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int lag, int r, IirCoef c, int block,
+                                                   int skip, int out_len, double *out, double *stage) {
   const int total = n + 2 * lag + 2 * kDecPad;
   const int m = n + 2 * lag;
   const int nout = (m - 1) / r + 1;
   const int nbeg = r - r * nout + m;
   const int first = nbeg + kDecPad - 1;         // index (in padded coordinates) of decimated[0]
-  const int c0 = chunk * kDecChunk;
-  if (c0 >= total) return;
-  const int c1 = imin(total, c0 + kDecChunk);
-  double w0 = 0, w1 = 0, w2 = 0;
-  for (int j0 = imin(total - 1, c1 - 1 + kDecWarm); j0 >= c0; j0 -= kDecBatch) {
-    double v[kDecBatch];
+  const int b0 = block * kDecSpan;
+  if (b0 >= total) return;
+  const int hi = imin(total, b0 + kDecSpan + kDecWarm);  // stage[k] = fwd[b0 + k], k < hi - b0
+  for (int k = threadIdx.x; k < hi - b0; k += blockDim.x) stage[k] = fwd[b0 + k];
+  __syncthreads();
+  for (int t = threadIdx.x; t < kDecThreads; t += blockDim.x) {
+    const int c0 = b0 + t * kDecChunk;
+    if (c0 >= total) break;
+    const int c1 = imin(total, c0 + kDecChunk);
+    double w0 = 0, w1 = 0, w2 = 0;
+    for (int j0 = imin(total - 1, c1 - 1 + kDecWarm); j0 >= c0; j0 -= kDecBatch) {
+      double v[kDecBatch];
 #pragma unroll
-    for (int q = 0; q < kDecBatch; ++q) v[q] = j0 - q >= c0 ? fwd[j0 - q] : 0.0;
+      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 - q >= c0 ? stage[j0 - q - b0] : 0.0;
 #pragma unroll
-    for (int q = 0; q < kDecBatch; ++q) {
-      const int j = j0 - q;
-      if (j < c0) break;
-      double g = iir_step(c, v[q], w0, w1, w2);
-      int d = j - first;
-      if (j < c1 && d >= 0 && d % r == 0 && nbeg + d < m + kDecPad) {   // loop bound of matlabfunctions.cpp:199
-        int k = d / r - skip;
-        if (k >= 0 && k < out_len) out[k] = g;
+      for (int q = 0; q < kDecBatch; ++q) {
+        const int j = j0 - q;
+        if (j < c0) break;
+        double g = iir_step(c, v[q], w0, w1, w2);
+        int d = j - first;
+        if (j < c1 && d >= 0 && d % r == 0 && nbeg + d < m + kDecPad) {   // loop bound of matlabfunctions.cpp:199
+          int k = d / r - skip;
+          if (k >= 0 && k < out_len) out[k] = g;
+        }
       }
     }
   }

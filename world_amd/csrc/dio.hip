@@ -15,14 +15,17 @@
 namespace world_hip {
 
 // ---- front end: decimate / copy, remove DC, low-cut FIR --------------------------
-__global__ void dio_decimate_fwd(DioParams p, IirCoef c) {
-  int u = blockIdx.y, chunk = flat_thread_x();
-  dec_forward_chunk(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], 0, c, chunk, p.fwd + (size_t)u * p.m_stride);
+__global__ void __launch_bounds__(kDecThreads) dio_decimate_fwd(DioParams p, IirCoef c) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y;
+  dec_forward_block(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], 0, c, blockIdx.x, p.fwd + (size_t)u * p.m_stride,
+                    reinterpret_cast<double *>(lds));
 }
-__global__ void dio_decimate_bwd(DioParams p, IirCoef c) {
-  int u = blockIdx.y, chunk = flat_thread_x();
-  dec_backward_chunk(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], 0, p.ratio, c, chunk, 0, p.y_len[u],
-                     p.y + (size_t)u * p.y_stride);
+__global__ void __launch_bounds__(kDecThreads) dio_decimate_bwd(DioParams p, IirCoef c) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y;
+  dec_backward_block(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], 0, p.ratio, c, blockIdx.x, 0, p.y_len[u],
+                     p.y + (size_t)u * p.y_stride, reinterpret_cast<double *>(lds));
 }
 __global__ void dio_copy_signal(DioParams p) {              // dio.cpp:71-72
   int u = blockIdx.y, i = flat_thread_x();
@@ -246,9 +249,9 @@ void launch_dio(const DioParams &p, int max_x_len, int max_y_len, int max_frames
     WH_THREADS(dio_copy_signal, max_x_len, B, 1, stream, p);
   } else {
     IirCoef c = decimate_coef(p.ratio);
-    long chunks = (max_x_len + 2 * kDecPad + kDecChunk - 1) / kDecChunk;
-    WH_THREADS(dio_decimate_fwd, chunks, B, 1, stream, p, c);
-    WH_THREADS(dio_decimate_bwd, chunks, B, 1, stream, p, c);
+    const int spans = (max_x_len + 2 * kDecPad + kDecSpan - 1) / kDecSpan;
+    WH_BLOCKS(dio_decimate_fwd, dim3(spans, B), kDecThreads, dec_lds_bytes(), stream, p, c);
+    WH_BLOCKS(dio_decimate_bwd, dim3(spans, B), kDecThreads, dec_lds_bytes(), stream, p, c);
   }
   WH_BLOCKS(dio_remove_mean, dim3(B), 256, 64 * sizeof(double), stream, p);
   const int lc_tiles = (max_y_len + 2 * p.cut + kTile - 1) / kTile;

@@ -26,15 +26,17 @@ namespace world_hip {
 
 // ---------------------------------------------------------------------------
 // decimation to ~8 kHz (GetWaveformAndSpectrumSub, harvest.cpp:43-66)
-__global__ void hv_decimate_fwd(HarvestParams p, IirCoef c) {
-  int u = blockIdx.y, chunk = flat_thread_x();
-  dec_forward_chunk(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], p.lag, c, chunk,
-                    p.fwd + (size_t)u * p.m_stride);
+__global__ void __launch_bounds__(kDecThreads) hv_decimate_fwd(HarvestParams p, IirCoef c) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y;
+  dec_forward_block(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], p.lag, c, blockIdx.x,
+                    p.fwd + (size_t)u * p.m_stride, reinterpret_cast<double *>(lds));
 }
-__global__ void hv_decimate_bwd(HarvestParams p, IirCoef c) {
-  int u = blockIdx.y, chunk = flat_thread_x();
-  dec_backward_chunk(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], p.lag, p.ratio, c, chunk,
-                     p.lag / p.ratio, p.y_len[u], p.y + (size_t)u * p.y_stride);
+__global__ void __launch_bounds__(kDecThreads) hv_decimate_bwd(HarvestParams p, IirCoef c) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y;
+  dec_backward_block(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], p.lag, p.ratio, c, blockIdx.x,
+                     p.lag / p.ratio, p.y_len[u], p.y + (size_t)u * p.y_stride, reinterpret_cast<double *>(lds));
 }
 __global__ void hv_copy_signal(HarvestParams p) {          // ratio == 1 (harvest.cpp:45-48)
   int u = blockIdx.y, i = flat_thread_x();
@@ -310,9 +312,9 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
     WH_THREADS(hv_copy_signal, max_y_len, B, 1, stream, p);
   } else {
     IirCoef c = decimate_coef(p.ratio);
-    long chunks = (max_x_len + 2 * p.lag + 2 * kDecPad + kDecChunk - 1) / kDecChunk;
-    WH_THREADS(hv_decimate_fwd, chunks, B, 1, stream, p, c);
-    WH_THREADS(hv_decimate_bwd, chunks, B, 1, stream, p, c);
+    const int spans = (max_x_len + 2 * p.lag + 2 * kDecPad + kDecSpan - 1) / kDecSpan;
+    WH_BLOCKS(hv_decimate_fwd, dim3(spans, B), kDecThreads, dec_lds_bytes(), stream, p, c);
+    WH_BLOCKS(hv_decimate_bwd, dim3(spans, B), kDecThreads, dec_lds_bytes(), stream, p, c);
   }
   const int slices = (max_y_len + kMeanSlice - 1) / kMeanSlice;
   WH_BLOCKS(hv_partial_sums, dim3(slices, B), 256, 64 * sizeof(double), stream, p);

@@ -122,6 +122,7 @@ __device__ __forceinline__ double wave_nearest(double ref, const double *c, int 
   return best_i < 0 ? 0.0 : c[best_i];
 }
 
+constexpr int kMaxSlots = 256;       // candidate slots per frame handled by the tracking lanes (maxc <= 256)
 constexpr int kExtReach = 100;       // frames a section may grow in each direction (:865)
 constexpr int kExtMargin = kExtReach + 1;
 
@@ -149,12 +150,50 @@ __global__ void hc_extend(HarvestParams p) {
     const int dist = last > origin ? last - origin : origin - last;
     double cur = e[origin - lo];
     int moved = origin, miss = 0;
-    for (int i = 0; i <= dist; ++i) {
-      const int t = origin + shift * i + shift;
-      double v = wave_nearest(cur, cands + (size_t)t * p.maxc, nslot, 0.18);
-      if (lane == 0) e[t - lo] = v;
-      if (v == 0.0) { miss++; } else { cur = v; miss = 0; moved = t; }
-      if (miss == 4) break;
+    // The frames to visit do not depend on the tracking result, so their candidate
+    // rows are fetched kAhead frames at a time (independent loads in flight) and the
+    // ordered part -- nearest candidate of the previous pick -- runs from registers.
+    constexpr int kAhead = 8;
+    constexpr int kSlotsPerLane = (kMaxSlots + WAVE - 1) / WAVE;
+    bool stop = false;
+    for (int i0 = 0; i0 <= dist && !stop; i0 += kAhead) {
+      double row[kAhead][kSlotsPerLane];
+#pragma unroll
+      for (int a = 0; a < kAhead; ++a) {
+        const int t = origin + shift * (i0 + a) + shift;
+#pragma unroll
+        for (int r = 0; r < kSlotsPerLane; ++r) {
+          const int sl = lane + r * WAVE;
+          row[a][r] = (i0 + a <= dist && sl < nslot) ? cands[(size_t)t * p.maxc + sl] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < kAhead; ++a) {
+        if (i0 + a > dist || stop) break;
+        const int t = origin + shift * (i0 + a) + shift;
+        // nearest candidate within 18 %, ties -> the LAST slot (SelectBestF0, :636-650)
+        double best_e = 0.18, best_v = 0.0;
+        int best_i = -1;
+#pragma unroll
+        for (int r = 0; r < kSlotsPerLane; ++r) {
+          const int sl = lane + r * WAVE;
+          if (sl < nslot) {
+            double err = fabs(cur - row[a][r]) / cur;
+            if (!(err > best_e)) { best_e = err; best_i = sl; best_v = row[a][r]; }
+          }
+        }
+#ifndef WORLD_EMU
+        for (int m = 32; m >= 1; m >>= 1) {
+          double oe = __shfl_xor(best_e, m, 64), ov = __shfl_xor(best_v, m, 64);
+          int oi = __shfl_xor(best_i, m, 64);
+          if (oe < best_e || (oe == best_e && oi > best_i)) { best_e = oe; best_i = oi; best_v = ov; }
+        }
+#endif
+        const double v = best_i < 0 ? 0.0 : best_v;
+        if (lane == 0) e[t - lo] = v;
+        if (v == 0.0) { miss++; } else { cur = v; miss = 0; moved = t; }
+        if (miss == 4) stop = true;
+      }
     }
     if (dir == 0) new_ed = moved; else new_st = moved;
   }
@@ -305,16 +344,24 @@ __global__ void hc_smooth(HarvestParams p) {
   const int chunk = (total + WAVE - 1) / WAVE;
   const int j0 = lane_id() * chunk, j1 = imin(total, j0 + chunk);
   const double first = in[st], last = in[ed];
+  constexpr int kBatch = 8;              // inputs fetched together ahead of the serial recurrence
   // forward sweep: the section with its end values held on both sides
   {
     auto xin = [&](int j) { return j < 0 ? first : (j < len ? in[st + j] : last); };
     int j = j0 - kSmoothTail;
     double w0 = xin(j) * dc, w1 = w0;
-    for (; j < j1; ++j) {
-      double wt = xin(j) + a0 * w0 + a1 * w1;
-      double y = b0 * wt + b1 * w0 + b0 * w1;
-      w1 = w0; w0 = wt;
-      if (j >= j0) tmp[j] = y;
+    for (; j < j1; j += kBatch) {
+      double v[kBatch];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) v[q] = j + q < j1 ? xin(j + q) : 0.0;
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+        if (j + q >= j1) break;
+        double wt = v[q] + a0 * w0 + a1 * w1;
+        double y = b0 * wt + b1 * w0 + b0 * w1;
+        w1 = w0; w0 = wt;
+        if (j + q >= j0) tmp[j + q] = y;
+      }
     }
   }
   wave_sync();
@@ -323,11 +370,18 @@ __global__ void hc_smooth(HarvestParams p) {
     auto tin = [&](int j) { return j >= total ? last : tmp[j]; };
     int j = j1 - 1 + kSmoothTail;
     double w0 = tin(j) * dc, w1 = w0;
-    for (; j >= j0; --j) {
-      double wt = tin(j) + a0 * w0 + a1 * w1;
-      double y = b0 * wt + b1 * w0 + b0 * w1;
-      w1 = w0; w0 = wt;
-      if (j < j1 && j < len) out[st + j] = y;
+    for (; j >= j0; j -= kBatch) {
+      double v[kBatch];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) v[q] = j - q >= j0 ? tin(j - q) : 0.0;
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+        if (j - q < j0) break;
+        double wt = v[q] + a0 * w0 + a1 * w1;
+        double y = b0 * wt + b1 * w0 + b0 * w1;
+        w1 = w0; w0 = wt;
+        if (j - q < j1 && j - q < len) out[st + j - q] = y;
+      }
     }
   }
 }

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   double e = 0.0;
   for (int i = tid; i < wlen; i += nt) {
     double position = (i - hw) / 1.5 / fs;
-    double w = 0.5 * cos(kPi * position * cf0) + 0.5;
+    double w = 0.5 * cospi(position * cf0) + 0.5;       // cos(pi * position * f0), cheaptrick.cpp:101-102
     seg[i] = w;
     e += w * w;
   }
@@ -89,12 +89,12 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
     double w = seg[i] / e;
     seg[i] = w;
     double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kTiny;
-    Zr[i] = v;
+    rfft_in(Z, i) = v;
     s1 += v; s2 += w;
   }
   block_sum2(s1, s2, scratch);
   const double coef = s1 / s2;
-  for (int i = tid; i < N; i += nt) Zr[i] = i < wlen ? Zr[i] - seg[i] * coef : 0.0;
+  for (int i = tid; i < N; i += nt) rfft_in(Z, i) = i < wlen ? rfft_in(Z, i) - seg[i] * coef : 0.0;
 
   // ---- GetPowerSpectrum (cheaptrick.cpp:64-82): r2c, |X|^2 -----------------
   block_rfft(Z, lgn, tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
       P[i] = lg;
     }
     __syncthreads();
-    for (int i = tid; i < N; i += nt) Zr[i] = i <= half ? P[i] : P[N - i];
+    for (int i = tid; i < N; i += nt) rfft_in(Z, i) = i <= half ? P[i] : P[N - i];
   }
 
   // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   });
   block_irfft(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   double *out = p.spectrogram + ((size_t)u * p.b.f_stride + f) * nb;
-  for (int i = tid; i <= half; i += nt) out[i] = exp(Zr[i]);
+  for (int i = tid; i <= half; i += nt) out[i] = exp(rfft_in(Z, i));
 }
 
 // ---------------------------------------------------------------------------

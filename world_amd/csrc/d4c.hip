@@ -29,7 +29,7 @@ constexpr int kHanning = 1, kBlackman = 2;
 
 __device__ __forceinline__ double d4c_window_at(int i, int hw, int kind, double ratio, int fs, double f0) {
   double position = (2.0 * (i - hw) / ratio) / fs;                  // d4c.cpp:36,41
-  const double c1 = cos(kPi * position * f0);
+  const double c1 = cospi(position * f0);                           // cos(pi * position * f0)
   if (kind == kHanning) return 0.5 * c1 + 0.5;
   return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);             // cos(2a) = 2 cos^2(a) - 1
 }
@@ -75,28 +75,30 @@ __global__ void d4c_prepare2(D4cParams p) {
   }
 }
 
-// Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84).
-// Samples go to dst[i*dstride]; the window shape is recomputed in the second pass
-// (one cosine) rather than stored: no LDS, no long-lived registers.  Returns 2*hw+1.
+// Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84),
+// written straight into a transform's input: sample i goes to the real part of
+// complex element i (`packed`, the centroid transform) or to real element i of an
+// r2c input.  The window shape is recomputed in the second pass (one cosine) rather
+// than stored: no LDS, no long-lived registers.  Returns 2*hw+1.
 __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, double f0, double pos,
                                             int kind, double ratio, const double *noise,
-                                            double *dst, int dstride, double *scratch) {
+                                            cplx *z, bool packed, double *scratch) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int hw = mround(ratio * fs / f0 / 2.0);
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
+  auto at = [&](int i) -> double & { return packed ? z[swz(i)].re : rfft_in(z, i); };
   double s1 = 0.0, s2 = 0.0;
   for (int i = tid; i < wlen; i += nt) {
     const double w = d4c_window_at(i, hw, kind, ratio, fs, f0);
     // noise[i]: the window's draws in sample order (d4c.cpp:67-69)
     double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kSafeGuardD4C;
-    dst[(size_t)i * dstride] = v;
+    at(i) = v;
     s1 += v; s2 += w;
   }
   block_sum2(s1, s2, scratch);
   const double coef = s1 / s2;
-  for (int i = tid; i < wlen; i += nt)
-    dst[(size_t)i * dstride] -= d4c_window_at(i, hw, kind, ratio, fs, f0) * coef;
+  for (int i = tid; i < wlen; i += nt) at(i) -= d4c_window_at(i, hw, kind, ratio, fs, f0) * coef;
   __syncthreads();
   return wlen;
 }
@@ -116,9 +118,8 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
   const double cf0 = f0 > 40.0 ? f0 : 40.0;
   const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
-                                kBlackman, 3.0, p.noise + p.offsets1[fi],
-                                Zr, 1, scratch);
-  for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) Zr[i] = 0.0;
+                                kBlackman, 3.0, p.noise + p.offsets1[fi], Z, false, scratch);
+  for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) rfft_in(Z, i) = 0.0;
   const int b0 = static_cast<int>(ceil(100.0 * M / fs));
   const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
   const int b2 = static_cast<int>(ceil(7900.0 * M / fs));
@@ -186,7 +187,7 @@ __device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, 
 #ifdef WORLD_EMU
 constexpr int kSelKeys = 4096 / 2 + 1;
 #else
-constexpr int kSelKeys = (4096 / 2 + 1 + 511) / 512;
+constexpr int kSelKeys = (4096 / 2 + 1 + 255) / 256;    // 256-thread workgroups
 #endif
 // key[q] = bit pattern of element tid + q*T (~0 = no element).
 __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int n, int m, int *hist,
@@ -282,7 +283,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 // ---------------------------------------------------------------------------
 // Stage A of D4CGeneralBody: static group delay of one selected frame -> HBM.
 // (GetStaticCentroid, GetSmoothedPowerSpectrum, GetStaticGroupDelay: d4c.cpp:126-188)
-__global__ void __launch_bounds__(512, 4) d4c_groupdelay(D4cParams p) {      // 4 waves/SIMD = 2 workgroups/CU
+__global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
@@ -304,9 +305,10 @@ __global__ void __launch_bounds__(512, 4) d4c_groupdelay(D4cParams p) {      // 
 #ifdef WORLD_EMU
   constexpr int kBinsPerThread = 4096 / 2 + 1;          // one emulated thread owns every bin
 #else
-  constexpr int kBinsPerThread = (4096 / 2 + 1 + 511) / 512;
+  constexpr int kBinsPerThread = (4096 / 2 + 1 + 255) / 256;
 #endif
   double a_reg[kBinsPerThread];
+  const FftPlan plan_c = make_plan(lgn);            // the packed centroid transform: 2^lgn complex points
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
   const int x_len = p.b.x_len[u];
@@ -320,22 +322,23 @@ __global__ void __launch_bounds__(512, 4) d4c_groupdelay(D4cParams p) {      // 
     const double cpos = c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
     __syncthreads();
     const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
-                                            Zr, 2, scratch);
+                                  Z, true, scratch);
     double pw = 0.0;
-    for (int i = tid; i < wlen; i += nt) pw += Zr[2 * i] * Zr[2 * i];
+    for (int i = tid; i < wlen; i += nt) { const double v = Z[swz(i)].re; pw += v * v; }
     pw = block_sum(pw, scratch);
     const double nrm = sqrt(pw);
     for (int i = tid; i < N; i += nt) {
-      double v = i < wlen ? Zr[2 * i] / nrm : 0.0;
-      Zr[2 * i] = v;
-      Zr[2 * i + 1] = v * (i + 1.0);                 // second transform's input (d4c.cpp:111-112)
+      cplx &e = Z[swz(i)];
+      double v = i < wlen ? e.re / nrm : 0.0;
+      e.re = v;
+      e.im = v * (i + 1.0);                          // second transform's input (d4c.cpp:111-112)
     }
-    block_cfft_dif(Z, lgn, tw);
+    block_cfft_dif(Z, plan_c, tw);
 #pragma unroll
     for (int slot = 0; slot < kBinsPerThread; ++slot) {
       const int k = tid + slot * nt;
       if (k > H) break;
-      cplx za = Z[brev_bits(k, lgn)], zb = Z[brev_bits((N - k) & (N - 1), lgn)];
+      cplx za = Z[fft_slot(plan_c, k)], zb = Z[fft_slot(plan_c, (N - k) & (N - 1))];
       double x1r = 0.5 * (za.re + zb.re), x1i = 0.5 * (za.im - zb.im);
       double x2r = 0.5 * (za.im + zb.im), x2i = -0.5 * (za.re - zb.re);
       if (k == 0 || k == H) { x1i = 0.0; x2i = 0.0; }
@@ -354,8 +357,8 @@ __global__ void __launch_bounds__(512, 4) d4c_groupdelay(D4cParams p) {      // 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
   {
     const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
-                                            Zr, 1, scratch);
-    for (int i = wlen + tid; i < N; i += nt) Zr[i] = 0.0;
+                                  Z, false, scratch);
+    for (int i = wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
     block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
   }
   d4c_dc_correct(B, cf0, fs, N, Zr);
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(512, 4) d4c_groupdelay(D4cParams p) {      // 
 // share of the N/2-boundary smallest bins.  The power values never touch LDS: the
 // transform's merge step hands bin tid + q*T to thread tid, which is exactly the key
 // layout of the radix select.
-__global__ void __launch_bounds__(512) d4c_band(D4cParams p) {
+__global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
   DYN_LDS(lds);
   const int band = blockIdx.x, f = blockIdx.y, u = blockIdx.z;
   if (f >= p.b.n_frames[u]) return;
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(512) d4c_band(D4cParams p) {
   const int center = static_cast<int>(3000.0 * (band + 1) * N / fs);
   const double *gd = p.gd + fi * p.gd_stride;
   for (int i = tid; i < N; i += nt)
-    Zr[i] = i <= 2 * hwl ? gd[center - hwl + i] * p.nuttall[i] : 0.0;
+    rfft_in(Z, i) = i <= 2 * hwl ? gd[center - hwl + i] * p.nuttall[i] : 0.0;
   unsigned long long key[kSelKeys];
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q) key[q] = ~0ull;
@@ -467,8 +470,8 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), 256, d4c_love_lds_bytes(p.lg_love), stream, p);
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(d4c_groupdelay, dim3(max_frames, p.b.n_utt), 512, d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
-  WH_BLOCKS(d4c_band, dim3(p.nap, max_frames, p.b.n_utt), 512, d4c_band_lds_bytes(p.lg_d4c), stream, p);
+  WH_BLOCKS(d4c_groupdelay, dim3(max_frames, p.b.n_utt), 256, d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
+  WH_BLOCKS(d4c_band, dim3(p.nap, max_frames, p.b.n_utt), 256, d4c_band_lds_bytes(p.lg_d4c), stream, p);
   WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 0, stream, p);
 }
 

@@ -48,6 +48,7 @@ static inline unsigned __brev(unsigned v) {
   for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
   return r;
 }
+static inline double cospi(double x) { return cos(3.14159265358979323846 * x); }
 static inline void sincospi(double x, double *s, double *c) {
   *s = sin(3.14159265358979323846 * x);
   *c = cos(3.14159265358979323846 * x);

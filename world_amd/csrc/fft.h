@@ -4,11 +4,12 @@
 //
 // One workgroup owns one transform held entirely in LDS as interleaved complex
 // doubles.  Forward transforms are decimation-in-frequency (natural order in,
-// bit-reversed order out); inverse transforms are decimation-in-time
-// (bit-reversed in, natural out).  Nobody ever permutes: consumers of a forward
-// transform read bin k at LDS slot brev(k), producers of an inverse transform
-// write bin k to slot brev(k).  Radix-4 butterflies (one barrier per two
-// levels) with a radix-2 clean-up level when log2 is odd.
+// digit-reversed order out); inverse transforms are decimation-in-time
+// (digit-reversed in, natural out).  Nobody ever permutes: consumers of a forward
+// transform read bin k at LDS slot fft_slot(k), producers of an inverse transform
+// write bin k there.  Butterflies are radix-16 in registers (radix-8/4/2 for the
+// remainder), so the data crosses LDS once per 4 levels; slots are XOR-swizzled so
+// that every wide LDS read is bank-conflict free.
 //
 // Real transforms of length N run as N/2-point complex transforms with the
 // usual split/merge step, fused into a caller-supplied functor so |X|^2,
@@ -54,88 +55,201 @@ __device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign
   else { c = b; s = -a; }
   cplx w; w.re = c; w.im = sign > 0 ? s : -s; return w;
 }
-__device__ __forceinline__ int brev_bits(int k, int bits) { return (int)(__brev((unsigned)k) >> (32 - bits)); }
-
-// ---- forward: natural in -> bit-reversed out --------------------------------
-__device__ __forceinline__ void block_cfft_dif(cplx *z, int lg, const TwLds &tw) {
-  int n = 1 << lg;
-  int lev = lg;                       // current sub-transform length = 2^lev
-  while (lev >= 2) {
-    int q = 1 << (lev - 2);
-    __syncthreads();
-    for (int b = threadIdx.x; b < n / 4; b += blockDim.x) {
-      int j = b & (q - 1);
-      int base = ((b >> (lev - 2)) << lev) + j;
-      cplx a0 = z[base], a1 = z[base + q], a2 = z[base + 2 * q], a3 = z[base + 3 * q];
-      cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
-      cplx t3; t3.re = d.im; t3.im = -d.re;                 // (a1-a3) * (-i)
-      cplx w1 = twiddle(tw, j, lev, -1), w2 = twiddle(tw, 2 * j, lev, -1), w3 = twiddle(tw, 3 * j, lev, -1);
-      z[base] = cadd(t0, t2);
-      z[base + q] = cmul(csub(t0, t2), w2);
-      z[base + 2 * q] = cmul(cadd(t1, t3), w1);
-      z[base + 3 * q] = cmul(csub(t1, t3), w3);
-    }
-    lev -= 2;
+// ---------------------------------------------------------------------------
+// Mixed-radix plan: radix-16 stages, then one radix-8/4/2 stage for the remainder.
+// A radix-R butterfly is evaluated entirely in registers, so a 2048-point
+// transform crosses LDS 3 times (16 x 16 x 8) instead of 6 (radix-4) or 11.
+struct FftPlan {
+  int lg, ns;
+  unsigned stages;                                   // log2(radix) of stage s in nibble s (no arrays: stays in registers)
+  __host__ __device__ __forceinline__ int rl(int s) const { return (int)((stages >> (4 * s)) & 15u); }
+};
+__host__ __device__ __forceinline__ FftPlan make_plan(int lg) {
+  FftPlan p; p.lg = lg; p.ns = 0; p.stages = 0;
+  int r = lg;
+  while (r >= 4) { p.stages |= 4u << (4 * p.ns++); r -= 4; }
+  if (r) p.stages |= (unsigned)r << (4 * p.ns++);
+  return p;
+}
+// LDS slot swizzle: XOR the 16-byte slot index with bits 4..7 of itself.  With the
+// butterfly->thread mapping below every ds_read_b128 of every stage of every plan
+// (256..4096 points) is conflict-free in the gfx950 bank model (MI355X_MICROARCH.md
+// section LDS; brute-forced in DESIGN.md), at zero cost in LDS capacity.
+__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 4) & 15); }
+// slot that holds bin k after the forward (DIF) transform = slot the inverse (DIT)
+// transform expects bin k in: the digits of k, least significant first, select
+// nested blocks.
+__device__ __forceinline__ int fft_slot(const FftPlan &p, int k) {
+  int pos = 0, rem = p.lg;
+  for (int s = 0; s < p.ns; ++s) {
+    const int rl = p.rl(s);
+    rem -= rl;
+    pos += (k & ((1 << rl) - 1)) << rem;
+    k >>= rl;
   }
-  if (lev == 1) {
+  return swz(pos);
+}
+
+// ---- in-register DFTs, natural order in and out; FWD: e^{-i..}, else e^{+i..} -----
+template <bool FWD> __device__ __forceinline__ cplx mul_i4(cplx a) {          // a * W4 = a * (-/+ i)
+  cplx r; if (FWD) { r.re = a.im; r.im = -a.re; } else { r.re = -a.im; r.im = a.re; } return r;
+}
+template <bool FWD> __device__ __forceinline__ void dft4(cplx &a0, cplx &a1, cplx &a2, cplx &a3) {
+  cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_i4<FWD>(csub(a1, a3));
+  a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
+}
+// a * W16^m (m = 0..15) with the trivial powers special-cased
+template <bool FWD, int M> __device__ __forceinline__ cplx mul_w16(cplx a) {
+  constexpr double c1 = 0.92387953251128674, s1 = 0.38268343236508977, h = 0.70710678118654752;
+  constexpr int m = M & 15;
+  if (m == 0) return a;
+  if (m == 4) return mul_i4<FWD>(a);
+  if (m == 8) { cplx r; r.re = -a.re; r.im = -a.im; return r; }
+  if (m == 12) { cplx r = mul_i4<FWD>(a); r.re = -r.re; r.im = -r.im; return r; }
+  constexpr double ct[16] = {1, c1, h, s1, 0, -s1, -h, -c1, -1, -c1, -h, -s1, 0, s1, h, c1};
+  constexpr double st[16] = {0, s1, h, c1, 1, c1, h, s1, 0, -s1, -h, -c1, -1, -c1, -h, -s1};
+  cplx w; w.re = ct[m]; w.im = FWD ? -st[m] : st[m];
+  return cmul(a, w);
+}
+template <bool FWD> __device__ __forceinline__ void dft2(cplx *a) {
+  cplx t = a[0]; a[0] = cadd(t, a[1]); a[1] = csub(t, a[1]);
+}
+template <bool FWD> __device__ __forceinline__ void dft4v(cplx *a) { dft4<FWD>(a[0], a[1], a[2], a[3]); }
+template <bool FWD> __device__ __forceinline__ void dft8(cplx *a) {
+  // 8 = 2 x 4: n = 4 n1 + n2, k = k1 + 2 k2
+  cplx u0[4], u1[4];
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) { u0[n2] = cadd(a[n2], a[n2 + 4]); u1[n2] = csub(a[n2], a[n2 + 4]); }
+  u1[1] = mul_w16<FWD, 2>(u1[1]); u1[2] = mul_w16<FWD, 4>(u1[2]); u1[3] = mul_w16<FWD, 6>(u1[3]);   // W8^{n2}
+  dft4<FWD>(u0[0], u0[1], u0[2], u0[3]);
+  dft4<FWD>(u1[0], u1[1], u1[2], u1[3]);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) { a[2 * k2] = u0[k2]; a[2 * k2 + 1] = u1[k2]; }
+}
+template <bool FWD> __device__ __forceinline__ void dft16(cplx *a) {
+  // 16 = 4 x 4: n = 4 n1 + n2, k = k1 + 4 k2
+  cplx u[4][4];                                   // u[n2][k1]
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    u[n2][0] = a[n2]; u[n2][1] = a[n2 + 4]; u[n2][2] = a[n2 + 8]; u[n2][3] = a[n2 + 12];
+    dft4<FWD>(u[n2][0], u[n2][1], u[n2][2], u[n2][3]);
+  }
+  u[1][1] = mul_w16<FWD, 1>(u[1][1]); u[1][2] = mul_w16<FWD, 2>(u[1][2]); u[1][3] = mul_w16<FWD, 3>(u[1][3]);
+  u[2][1] = mul_w16<FWD, 2>(u[2][1]); u[2][2] = mul_w16<FWD, 4>(u[2][2]); u[2][3] = mul_w16<FWD, 6>(u[2][3]);
+  u[3][1] = mul_w16<FWD, 3>(u[3][1]); u[3][2] = mul_w16<FWD, 6>(u[3][2]); u[3][3] = mul_w16<FWD, 9>(u[3][3]);
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    dft4<FWD>(u[0][k1], u[1][k1], u[2][k1], u[3][k1]);
+    a[k1] = u[0][k1]; a[k1 + 4] = u[1][k1]; a[k1 + 8] = u[2][k1]; a[k1 + 12] = u[3][k1];
+  }
+}
+template <bool FWD, int LR> __device__ __forceinline__ void dft_reg(cplx *a) {
+  if (LR == 1) dft2<FWD>(a);
+  else if (LR == 2) dft4v<FWD>(a);
+  else if (LR == 3) dft8<FWD>(a);
+  else dft16<FWD>(a);
+}
+// a[k] *= w^k for k = 1 .. R-1.  Powers are formed with product depth <= 4 and applied
+// as soon as they exist, so at most R/2 twiddles are live next to the R data values.
+template <int LR> __device__ __forceinline__ void mul_powers(cplx *a, cplx w1) {
+  constexpr int R = 1 << LR;
+  if (R == 2) { a[1] = cmul(a[1], w1); return; }
+  cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+  a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3);
+  if (R == 4) return;
+  cplx w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+  a[4 % R] = cmul(a[4 % R], w4); a[5 % R] = cmul(a[5 % R], w5); a[6 % R] = cmul(a[6 % R], w6); a[7 % R] = cmul(a[7 % R], w7);
+  if (R == 8) return;
+  const cplx w8 = cmul(w4, w4);
+  a[8 % R] = cmul(a[8 % R], w8);
+  a[9 % R] = cmul(a[9 % R], cmul(w8, w1)); a[10 % R] = cmul(a[10 % R], cmul(w8, w2)); a[11 % R] = cmul(a[11 % R], cmul(w8, w3));
+  a[12 % R] = cmul(a[12 % R], cmul(w8, w4)); a[13 % R] = cmul(a[13 % R], cmul(w8, w5)); a[14 % R] = cmul(a[14 % R], cmul(w8, w6));
+  a[15 % R] = cmul(a[15 % R], cmul(w8, w7));
+}
+
+// one decimation-in-frequency stage: sub-transforms of length 2^lev split R ways
+template <int LR> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int lev, const TwLds &tw) {
+  constexpr int R = 1 << LR;
+  const int q = 1 << (lev - LR), nbf = 1 << (lg - LR);
+  for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
+    const int j = b & (q - 1);
+    const int base = ((b >> (lev - LR)) << lev) + j;
+    cplx a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = z[swz(base + r * q)];
+    dft_reg<true, LR>(a);
+    if (q > 1) mul_powers<LR>(a, twiddle(tw, j, lev, -1));
+#pragma unroll
+    for (int k = 0; k < R; ++k) z[swz(base + k * q)] = a[k];
+  }
+}
+// one decimation-in-time stage: R finished sub-transforms of length 2^done are merged
+template <int LR> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
+  constexpr int R = 1 << LR;
+  const int q = 1 << done, L = done + LR, nbf = 1 << (lg - LR);
+  for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
+    const int j = b & (q - 1);
+    const int base = ((b >> done) << L) + j;
+    cplx a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = z[swz(base + r * q)];
+    if (q > 1) mul_powers<LR>(a, twiddle(tw, j, L, +1));
+    dft_reg<false, LR>(a);
+#pragma unroll
+    for (int k = 0; k < R; ++k) z[swz(base + k * q)] = a[k];
+  }
+}
+
+// ---- forward: element n at slot swz(n) in -> bin k at slot fft_slot(plan, k) out ----
+__device__ __forceinline__ void block_cfft_dif(cplx *z, const FftPlan &p, const TwLds &tw) {
+  int lev = p.lg;
+  for (int s = 0; s < p.ns; ++s) {
     __syncthreads();
-    for (int b = threadIdx.x; b < n / 2; b += blockDim.x) {
-      cplx a = z[2 * b], c = z[2 * b + 1];
-      z[2 * b] = cadd(a, c);
-      z[2 * b + 1] = csub(a, c);
+    switch (p.rl(s)) {
+      case 4: dif_stage<4>(z, p.lg, lev, tw); break;
+      case 3: dif_stage<3>(z, p.lg, lev, tw); break;
+      case 2: dif_stage<2>(z, p.lg, lev, tw); break;
+      default: dif_stage<1>(z, p.lg, lev, tw); break;
     }
+    lev -= p.rl(s);
   }
   __syncthreads();
 }
 
-// ---- inverse (unscaled): bit-reversed in -> natural out ----------------------
-__device__ __forceinline__ void block_cfft_dit(cplx *z, int lg, const TwLds &tw) {
-  int n = 1 << lg;
-  int lev = 0;                        // sub-transforms of length 2^lev are done
-  if (lg & 1) {
+// ---- inverse (unscaled): bin k at slot fft_slot(plan, k) in -> element n at slot swz(n) out ----
+__device__ __forceinline__ void block_cfft_dit(cplx *z, const FftPlan &p, const TwLds &tw) {
+  int done = 0;
+  for (int s = p.ns - 1; s >= 0; --s) {
     __syncthreads();
-    for (int b = threadIdx.x; b < n / 2; b += blockDim.x) {
-      cplx a = z[2 * b], c = z[2 * b + 1];
-      z[2 * b] = cadd(a, c);
-      z[2 * b + 1] = csub(a, c);
+    switch (p.rl(s)) {
+      case 4: dit_stage<4>(z, p.lg, done, tw); break;
+      case 3: dit_stage<3>(z, p.lg, done, tw); break;
+      case 2: dit_stage<2>(z, p.lg, done, tw); break;
+      default: dit_stage<1>(z, p.lg, done, tw); break;
     }
-    lev = 1;
-  }
-  while (lev < lg) {
-    int q = 1 << lev;
-    int L = lev + 2;                  // resulting length 2^L
-    __syncthreads();
-    for (int b = threadIdx.x; b < n / 4; b += blockDim.x) {
-      int j = b & (q - 1);
-      int base = ((b >> lev) << L) + j;
-      cplx b0 = z[base], b1 = z[base + q], b2 = z[base + 2 * q], b3 = z[base + 3 * q];
-      cplx w1 = twiddle(tw, j, L, +1), w2 = twiddle(tw, 2 * j, L, +1);
-      cplx x1 = cmul(b1, w2), x3 = cmul(b3, w2);
-      cplx p0 = cadd(b0, x1), p1 = csub(b0, x1), p2 = cadd(b2, x3), p3 = csub(b2, x3);
-      cplx y2 = cmul(p2, w1), y3 = cmul(p3, w1);
-      cplx iy3; iy3.re = -y3.im; iy3.im = y3.re;            // (+i) * y3
-      z[base] = cadd(p0, y2);
-      z[base + 2 * q] = csub(p0, y2);
-      z[base + q] = cadd(p1, iy3);
-      z[base + 3 * q] = csub(p1, iy3);
-    }
-    lev += 2;
+    done += p.rl(s);
   }
   __syncthreads();
 }
 
 // ---- real forward transform of length N = 2^lgn -------------------------------
-// `z` holds the N real samples (as N/2 complex slots, z[m] = x[2m] + i x[2m+1]).
-// After the call the buffer holds scrambled data; emit(k, Xre, Xim) has been
-// called once for every k in [0, N/2] (same semantics as the reference's r2c:
-// X[k] = sum x[n] e^{-2 pi i k n / N}, imaginary part of DC/Nyquist = 0).
+// Input: real sample n stored as the re/im halves of complex slot swz(n / 2)
+// (use rfft_in() to address it).  After the call the buffer holds scrambled data;
+// emit(k, Xre, Xim) has been called once for every k in [0, N/2] (same semantics as
+// the reference's r2c: X[k] = sum x[n] e^{-2 pi i k n / N}, imaginary part of
+// DC/Nyquist = 0); thread t receives k = t, t + T, t + 2T, ...
+__device__ __forceinline__ double &rfft_in(cplx *z, int n) {
+  cplx &c = z[swz(n >> 1)];
+  return (n & 1) ? c.im : c.re;
+}
 template <class Emit>
 __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Emit emit) {
-  int lgh = lgn - 1, h = 1 << lgh;
-  block_cfft_dif(z, lgh, tw);
+  const int lgh = lgn - 1, h = 1 << lgh;
+  const FftPlan plan = make_plan(lgh);
+  block_cfft_dif(z, plan, tw);
   for (int k = threadIdx.x; k <= h; k += blockDim.x) {
     int ka = k & (h - 1), kb = (h - k) & (h - 1);
-    cplx za = z[brev_bits(ka, lgh)], zb = z[brev_bits(kb, lgh)];
+    cplx za = z[fft_slot(plan, ka)], zb = z[fft_slot(plan, kb)];
     cplx e, o;                                         // even / odd sub-spectra
     e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
     o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
@@ -151,11 +265,11 @@ __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Em
 
 // ---- real inverse transform (unscaled: N * irfft, like the reference's c2r) ----
 // spec(k) returns X[k] for k in [0, N/2] (the imaginary part of DC and Nyquist
-// is ignored, src/fft.cpp:28-29).  On return the N real outputs are in `z`
-// viewed as doubles (out[n] = reinterpret_cast<double*>(z)[n]).
+// is ignored, src/fft.cpp:28-29).  On return real output n is rfft_in(z, n).
 template <class Spec>
 __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, Spec spec) {
-  int lgh = lgn - 1, h = 1 << lgh;
+  const int lgh = lgn - 1, h = 1 << lgh;
+  const FftPlan plan = make_plan(lgh);
   __syncthreads();
   for (int k = threadIdx.x; k < h; k += blockDim.x) {
     cplx x = spec(k), y = spec(h - k);
@@ -165,9 +279,9 @@ __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, S
     cplx w = twiddle(tw, k, lgn, +1);
     cplx t = cmul(d, w);
     cplx r; r.re = s.re - t.im; r.im = s.im + t.re;     // s + i*w*d
-    z[brev_bits(k, lgh)] = r;
+    z[fft_slot(plan, k)] = r;
   }
-  block_cfft_dit(z, lgh, tw);
+  block_cfft_dit(z, plan, tw);
 }
 
 }  // namespace world_hip

@@ -196,7 +196,7 @@ __global__ void hv_refine(HarvestParams p) {
       // main window (harvest.cpp:446-456)
       for (int i = lane; i < blen; i += WAVE) {
         double t = ((first + i) - 1.0) / fs - pos;
-        const double c1 = cos(2.0 * kPi * t / wlen_t);
+        const double c1 = cospi(2.0 * t / wlen_t);                  // cos(2 pi t / T) without range reduction
         mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);    // cos(2a) = 2 cos^2(a) - 1
       }
       wave_sync();
@@ -224,9 +224,10 @@ __global__ void hv_refine(HarvestParams p) {
         if (h < nh) {
           idx = mround(f0c * N / fs * (h + 1));                  // FixF0, harvest.cpp:515
           // e^{-2 pi i idx n / N} by rotation: exact start / step from the integer phase
-          double wc, ws, rc, rs;
-          sincospi(2.0 * ((idx * g) & (N - 1)) / N, &ws, &wc);
-          sincospi(2.0 * ((idx * G) & (N - 1)) / N, &rs, &rc);
+          const double2 w0 = p.tab.tw[(size_t)((idx * g) & (N - 1)) << (kTwLog2 - lgN)];
+          const double2 st = p.tab.tw[(size_t)((idx * G) & (N - 1)) << (kTwLog2 - lgN)];
+          double wc = w0.x, ws = w0.y;
+          const double rc = st.x, rs = st.y;
           for (int i = g; i < blen; i += G) {
             double a = ym[i], d = yd[i];
             are = fma(a, wc, are); aim = fma(-a, ws, aim);

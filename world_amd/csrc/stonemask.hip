@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(256) sm_frame(StoneMaskParams p) {
     const int r = mround((pos + bt) * fs);
     raw[i] = r;
     const double t = (r - 1.0) / fs - pos;
-    mw[i] = 0.42 + 0.5 * cos(2.0 * kPi * t / wlen_t) + 0.08 * cos(4.0 * kPi * t / wlen_t);
+    const double c1 = cospi(2.0 * t / wlen_t);
+    mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
   }
   __syncthreads();
   double pw[6], ni[6];

@@ -40,7 +40,7 @@ struct BandJob {
 };
 
 inline size_t band_lds_bytes(int max_ntap) {
-  return sizeof(double) * (size_t)((max_ntap + 1) + pad8(kTile + 2 + max_ntap + 3) + 1 + pad8(kTile + 4) + 1 + 64);
+  return sizeof(double) * (size_t)((max_ntap + 1) + pad8(kTile + 2 + max_ntap + 3 + 8) + 1 + pad8(kTile + 4) + 1 + 64);
 }
 inline int band_segments(int n) { return (n + kSeg - 1) / kSeg; }
 
@@ -54,30 +54,37 @@ __device__ __forceinline__ double fine_edge(int e, double prev, double cur) { re
 __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps, int t0, double *yt, double *s) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ntap = job.ntap;
-  // in index for output k, tap j: t0 + k + shift - j  ->  yt[k + (ntap-1) - j],  yt[0] = in[t0 + shift - (ntap-1)]
+  // in index for output k, tap j: t0 + k + shift - j  ->  tile index k + (ntap-1) - j, tile[0] = in[t0 + shift - (ntap-1)].
+  // The tile is stored `org` slots into yt with org chosen so that (k0 + ntap-1 + org) = 7 (mod 8) for every
+  // thread's first output k0 (a multiple of 8): each group of 8 taps then reads 8 inputs that lie in ONE
+  // padded block of 8 -> their LDS addresses are a base plus compile-time offsets (no index arithmetic).
+  const int org = (8 - (ntap & 7)) & 7;
   const int lo = t0 + job.shift - (ntap - 1);
   const int count = kTile + 2 + ntap - 1;
   __syncthreads();
   for (int k = tid; k < count; k += nt) {
     int idx = lo + k;
-    yt[pad8(k)] = (idx >= 0 && idx < job.in_len) ? job.in[idx] : 0.0;
+    yt[pad8(k + org)] = (idx >= 0 && idx < job.in_len) ? job.in[idx] : 0.0;
   }
   __syncthreads();
   for (int k0 = tid * kOutPer; k0 < kTile; k0 += nt * kOutPer) {
     double acc[kOutPer], w[kOutPer];
-    const int base = k0 + ntap - 1;
+    const int base = k0 + ntap - 1 + org;               // = 7 (mod 8)
+    const double *top = yt + pad8(base);                // tile element base; base+q (q >= 1) is at top[1 + q]
+    acc[0] = 0.0; w[0] = top[0];
 #pragma unroll
-    for (int q = 0; q < kOutPer; ++q) { acc[q] = 0.0; w[q] = yt[pad8(base + q)]; }
-    // logical window at tap j: L_j[q] = in-tile[base + q - j] = w[(q - j) mod kOutPer].
+    for (int q = 1; q < kOutPer; ++q) { acc[q] = 0.0; w[q] = top[1 + q]; }
+    // logical window at tap j: L_j[q] = tile[base + q - j] = w[(q - j) mod kOutPer].
     // Groups of kOutPer taps: the group's kOutPer new inputs and taps are fetched
     // first (independent LDS reads in flight), then kOutPer^2 FMAs run from registers.
     const int ntap_main = ntap - (ntap % kOutPer);
-    for (int j0 = 0; j0 < ntap_main; j0 += kOutPer) {
+    const double *blk = top;                             // tile[base - j0 - u] = blk[-u] for u < 8
+    for (int j0 = 0; j0 < ntap_main; j0 += kOutPer, blk -= kOutPer + 1) {
       double fresh[kOutPer], h[kOutPer];
 #pragma unroll
       for (int u = 0; u < kOutPer; ++u) {
         h[u] = taps[j0 + u];
-        fresh[u] = yt[pad8(base - (j0 + u))];          // slot u = 0 is only needed for j0 > 0
+        fresh[u] = blk[-u];                              // slot u = 0 is only needed for j0 > 0
       }
 #pragma unroll
       for (int u = 0; u < kOutPer; ++u) {
@@ -90,18 +97,19 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
     for (int u = 0; u < kOutPer; ++u) {                 // remaining ntap % kOutPer taps
       const int j = ntap_main + u;
       if (j < ntap) {
-        if (j > 0) w[(kOutPer - u) % kOutPer] = yt[pad8(base - j)];
+        if (j > 0) w[(kOutPer - u) % kOutPer] = blk[-u];
         const double hh = taps[j];
 #pragma unroll
         for (int q = 0; q < kOutPer; ++q) acc[q] = fma(hh, w[(q + kOutPer - u) % kOutPer], acc[q]);
       }
     }
+    double *sdst = s + pad8(k0);                         // k0 = 0 (mod 8): outputs are contiguous
 #pragma unroll
-    for (int q = 0; q < kOutPer; ++q) s[pad8(k0 + q)] = acc[q];
+    for (int q = 0; q < kOutPer; ++q) sdst[q] = acc[q];
   }
   for (int e = tid; e < 2; e += nt) {              // the two look-ahead samples
     double acc = 0.0;
-    const int base = kTile + e + (ntap - 1);
+    const int base = kTile + e + (ntap - 1) + org;
     for (int j = 0; j < ntap; ++j) acc = fma(taps[j], yt[pad8(base - j)], acc);
     s[pad8(kTile + e)] = acc;
   }
@@ -123,7 +131,7 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
   const int seg_end = imin(n, seg_begin + kSeg);
   double *taps = reinterpret_cast<double *>(lds);
   double *yt = taps + (job.max_ntap + 1);
-  double *s = yt + pad8(kTile + 2 + job.max_ntap + 3) + 1;
+  double *s = yt + pad8(kTile + 2 + job.max_ntap + 3 + 8) + 1;
   double *scratch = s + pad8(kTile + 4) + 1;
   for (int j = tid; j < job.ntap; j += nt) taps[j] = job.taps[j];
 

@@ -190,15 +190,14 @@ constexpr int kSelKeys = 4096 / 2 + 1;
 constexpr int kSelKeys = (4096 / 2 + 1 + 255) / 256;    // 256-thread workgroups
 #endif
 // key[q] = bit pattern of element tid + q*T (~0 = no element).
-__device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int n, int m, int *hist,
-                                                   double *scratch, double *partial, double *total) {
+// key[q], q < mine: bit patterns of this thread's elements (n elements block-wide).
+__device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int mine, int n, int m,
+                                                   int *hist, double *scratch, double *partial, double *total) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wv = wave_in_block(), nw = waves_per_block();
   unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
-  for (int q = 0; q < kSelKeys; ++q) {
-    const int i = tid + q * nt;
-    if (i < n) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
-  }
+  for (int q = 0; q < kSelKeys; ++q)
+    if (q < mine) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
   for (int i = tid; i < 512; i += nt) hist[i] = 0;
 #ifndef WORLD_EMU
   for (int s = 32; s >= 1; s >>= 1) {
@@ -266,13 +265,13 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
   int c_lt = 0;
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q) {
-    const int i = tid + q * nt;
-    if (i < n) {
+    if (q < mine) {
       const double x = __longlong_as_double((long long)key[q]);
       s_all += x;
       if (x < thr) { s_lt += x; c_lt++; }
     }
   }
+  (void)n; (void)tid; (void)nt;
   block_sum2(s_lt, s_all, scratch);
   int tot_lt;
   block_excl_scan_int(c_lt, &tot_lt, scratch);
@@ -309,6 +308,7 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
 #endif
   double a_reg[kBinsPerThread];
   const FftPlan plan_c = make_plan(lgn);            // the packed centroid transform: 2^lgn complex points
+  const int top_bit = plan_c.rl(plan_c.ns - 1) - 1; // bit of a slot index that carries the top bit of its bin
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
   const int x_len = p.b.x_len[u];
@@ -334,11 +334,23 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
       e.im = v * (i + 1.0);                          // second transform's input (d4c.cpp:111-112)
     }
     block_cfft_dif(Z, plan_c, tw);
+    // Bins k <= H in an order that makes consecutive lanes read consecutive physical
+    // slots (conflict-free): bins below H are exactly the slots whose last-stage digit
+    // has its top bit clear.  Item `it` names the same bin in both centroid passes.
 #pragma unroll
     for (int slot = 0; slot < kBinsPerThread; ++slot) {
-      const int k = tid + slot * nt;
-      if (k > H) break;
-      cplx za = Z[fft_slot(plan_c, k)], zb = Z[fft_slot(plan_c, (N - k) & (N - 1))];
+      const int it = tid + slot * nt;
+      if (it > H) break;
+      int k, phys;
+      if (it < H) {
+        const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
+        phys = swz(pos);
+        k = fft_bin_of_slot(plan_c, phys);
+      } else {
+        k = H;
+        phys = fft_slot(plan_c, H);
+      }
+      cplx za = Z[phys], zb = Z[fft_slot(plan_c, (N - k) & (N - 1))];
       double x1r = 0.5 * (za.re + zb.re), x1i = 0.5 * (za.im - zb.im);
       double x2r = 0.5 * (za.im + zb.im), x2i = -0.5 * (za.re - zb.re);
       if (k == 0 || k == H) { x1i = 0.0; x2i = 0.0; }
@@ -349,8 +361,14 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
   __syncthreads();
 #pragma unroll
   for (int slot = 0; slot < kBinsPerThread; ++slot) {
-    const int k = tid + slot * nt;
-    if (k <= H) A[k] = a_reg[slot];
+    const int it = tid + slot * nt;
+    if (it > H) break;
+    int k = H;
+    if (it < H) {
+      const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
+      k = fft_bin_of_slot(plan_c, swz(pos));
+    }
+    A[k] = a_reg[slot];
   }
   d4c_dc_correct(A, cf0, fs, N, Zr);
 
@@ -409,7 +427,7 @@ __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
     ++filled;
   });
   double part, tot;
-  block_smallest_sum(key, H + 1, H - bnd, hist, scratch, &part, &tot);
+  block_smallest_sum(key, filled, H + 1, H - bnd, hist, scratch, &part, &tot);
   if (tid == 0) {
     double c = 10 * log10(part / tot);
     c = c + (cf0 - 100) / 50.0;                       // d4c.cpp:314-316

@@ -21,7 +21,10 @@ constexpr int kDecSpan = kDecThreads * kDecChunk;     // outputs per workgroup
 constexpr int kDecWarm = 384;     // 0.889^384 = 2e-20 (r = 12); r <= 6: 0.7985^384 = 3e-38
 constexpr int kDecBatch = 8;      // samples fetched together ahead of the serial recurrence
 constexpr int kDecPad = 9;        // kNFact
-inline size_t dec_lds_bytes() { return sizeof(double) * (size_t)(kDecSpan + kDecWarm + 8); }
+// threads read the staged span with a lane stride of kDecChunk doubles: one pad slot per
+// kDecChunk entries makes that stride odd (33) -> bank-conflict free
+__host__ __device__ __forceinline__ int dec_pad(int k) { return k + k / kDecChunk; }
+inline size_t dec_lds_bytes() { return sizeof(double) * (size_t)(dec_pad(kDecSpan + kDecWarm) + 8); }
 
 // filter coefficients, src/matlabfunctions.cpp:29-113
 inline IirCoef decimate_coef(int r) {
@@ -70,7 +73,7 @@ __device__ __forceinline__ void dec_forward_block(const double *x, int n, int la
   if (b0 >= total) return;
   const int lo = b0 - kDecWarm;                          // stage[k] = padded[lo + k]
   const int cnt = imin(total, b0 + kDecSpan) - lo;
-  for (int k = threadIdx.x; k < cnt; k += blockDim.x) stage[k] = lo + k >= 0 ? dec_padded(x, n, lag, lo + k) : 0.0;
+  for (int k = threadIdx.x; k < cnt; k += blockDim.x) stage[dec_pad(k)] = lo + k >= 0 ? dec_padded(x, n, lag, lo + k) : 0.0;
   __syncthreads();
   for (int t = threadIdx.x; t < kDecThreads; t += blockDim.x) {
     const int c0 = b0 + t * kDecChunk;
@@ -80,7 +83,7 @@ __device__ __forceinline__ void dec_forward_block(const double *x, int n, int la
     for (int j0 = imax(0, c0 - kDecWarm); j0 < c1; j0 += kDecBatch) {
       double v[kDecBatch];
 #pragma unroll
-      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 + q < c1 ? stage[j0 + q - lo] : 0.0;
+      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 + q < c1 ? stage[dec_pad(j0 + q - lo)] : 0.0;
 #pragma unroll
       for (int q = 0; q < kDecBatch; ++q) {
         const int j = j0 + q;
@@ -104,7 +107,7 @@ __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int
   const int b0 = block * kDecSpan;
   if (b0 >= total) return;
   const int hi = imin(total, b0 + kDecSpan + kDecWarm);  // stage[k] = fwd[b0 + k], k < hi - b0
-  for (int k = threadIdx.x; k < hi - b0; k += blockDim.x) stage[k] = fwd[b0 + k];
+  for (int k = threadIdx.x; k < hi - b0; k += blockDim.x) stage[dec_pad(k)] = fwd[b0 + k];
   __syncthreads();
   for (int t = threadIdx.x; t < kDecThreads; t += blockDim.x) {
     const int c0 = b0 + t * kDecChunk;
@@ -114,7 +117,7 @@ __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int
     for (int j0 = imin(total - 1, c1 - 1 + kDecWarm); j0 >= c0; j0 -= kDecBatch) {
       double v[kDecBatch];
 #pragma unroll
-      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 - q >= c0 ? stage[j0 - q - b0] : 0.0;
+      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 - q >= c0 ? stage[dec_pad(j0 - q - b0)] : 0.0;
 #pragma unroll
       for (int q = 0; q < kDecBatch; ++q) {
         const int j = j0 - q;

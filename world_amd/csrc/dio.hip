@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(kBpThreads) dio_lowcut(DioParams p) {
   job.max_ntap = job.ntap;
   double *taps = reinterpret_cast<double *>(lds);
   double *yt = taps + (job.max_ntap + 1);
-  double *s = yt + pad8(kTile + 2 + job.max_ntap + 3) + 1;
+  double *s = yt + pad8(kTile + 2 + job.max_ntap + 3 + 8) + 1;
   for (int j = threadIdx.x; j < job.ntap; j += blockDim.x) taps[j] = job.taps[j];
   fir_tile(job, taps, t0, yt, s);
   double *z = p.z + (size_t)u * p.z_stride;

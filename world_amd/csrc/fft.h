@@ -90,6 +90,19 @@ __device__ __forceinline__ int fft_slot(const FftPlan &p, int k) {
   return swz(pos);
 }
 
+// inverse of fft_slot: which bin lives in physical slot `slot` after the forward transform
+__device__ __forceinline__ int fft_bin_of_slot(const FftPlan &p, int slot) {
+  const int pos = swz(slot);                         // the swizzle is an involution
+  int k = 0, rem = p.lg, shift = 0;
+  for (int s = 0; s < p.ns; ++s) {
+    const int rl = p.rl(s);
+    rem -= rl;
+    k |= ((pos >> rem) & ((1 << rl) - 1)) << shift;
+    shift += rl;
+  }
+  return k;
+}
+
 // ---- in-register DFTs, natural order in and out; FWD: e^{-i..}, else e^{+i..} -----
 template <bool FWD> __device__ __forceinline__ cplx mul_i4(cplx a) {          // a * W4 = a * (-/+ i)
   cplx r; if (FWD) { r.re = a.im; r.im = -a.re; } else { r.re = -a.im; r.im = a.re; } return r;
@@ -237,7 +250,7 @@ __device__ __forceinline__ void block_cfft_dit(cplx *z, const FftPlan &p, const 
 // (use rfft_in() to address it).  After the call the buffer holds scrambled data;
 // emit(k, Xre, Xim) has been called once for every k in [0, N/2] (same semantics as
 // the reference's r2c: X[k] = sum x[n] e^{-2 pi i k n / N}, imaginary part of
-// DC/Nyquist = 0); thread t receives k = t, t + T, t + 2T, ...
+// DC/Nyquist = 0); every thread receives at most ceil((N/2+1)/T) bins, in slot order.
 __device__ __forceinline__ double &rfft_in(cplx *z, int n) {
   cplx &c = z[swz(n >> 1)];
   return (n & 1) ? c.im : c.re;
@@ -247,9 +260,15 @@ __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Em
   const int lgh = lgn - 1, h = 1 << lgh;
   const FftPlan plan = make_plan(lgh);
   block_cfft_dif(z, plan, tw);
-  for (int k = threadIdx.x; k <= h; k += blockDim.x) {
-    int ka = k & (h - 1), kb = (h - k) & (h - 1);
-    cplx za = z[fft_slot(plan, ka)], zb = z[fft_slot(plan, kb)];
+  // Walk the PHYSICAL slots in lane order (conflict-free wide reads) and emit whichever
+  // bin lives there; the mirrored bin h-k then sits in a nearby mirrored slot.  Slot
+  // count h, plus one extra item for the Nyquist bin k = h.  Thread t handles items
+  // t, t+T, ...: every bin exactly once, <= ceil((h+1)/T) bins per thread.
+  for (int it = threadIdx.x; it <= h; it += blockDim.x) {
+    const int k = it < h ? fft_bin_of_slot(plan, it) : h;
+    const int ka = k & (h - 1), kb = (h - k) & (h - 1);
+    cplx za = it < h ? z[it] : z[fft_slot(plan, 0)], zb = z[fft_slot(plan, kb)];
+    (void)ka;
     cplx e, o;                                         // even / odd sub-spectra
     e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
     o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);

@@ -281,22 +281,34 @@ __device__ __forceinline__ double nearest_error(double ref, const double *c, int
   }
   return err;
 }
-__global__ void hv_prune(HarvestParams p) {             // one thread per (frame, slot)
-  const int item = flat_thread_x(), u = blockIdx.y;
-  const int frame = item / p.maxc, j = item - frame * p.maxc;
+constexpr int kPruneFrames = 32;                          // frames per workgroup (+1 neighbour row each side)
+__global__ void hv_prune(HarvestParams p) {
+  DYN_LDS(lds);
+  double *rows = reinterpret_cast<double *>(lds);         // [kPruneFrames + 2][maxc] refined candidates
+  const int u = blockIdx.y, f0 = blockIdx.x * kPruneFrames;
   const int nfb = p.nfb[u];
-  if (frame >= nfb) return;
+  if (f0 >= nfb) return;
   const int nslot = p.nc[u] * 7;
-  if (j >= nslot) return;
-  const size_t row = ((size_t)u * p.fb_stride + frame) * p.maxc;
-  double ref = p.cand_b[row + j], sc = p.score_b[row + j];
-  if (frame >= 1 && frame < nfb - 1 && ref != 0) {
-    double e1 = nearest_error(ref, p.cand_b + row + p.maxc, nslot);
-    double e2 = nearest_error(ref, p.cand_b + row - p.maxc, nslot);
-    if ((e1 < e2 ? e1 : e2) > 0.05) { ref = 0; sc = 0; }
+  const int nrows = imin(kPruneFrames + 2, nfb - f0 + 1);
+  // stage rows f0-1 .. f0+kPruneFrames (coalesced); rows outside the utterance are never compared
+  for (int i = threadIdx.x; i < nrows * p.maxc; i += blockDim.x) {
+    const int r = i / p.maxc, j = i - r * p.maxc, f = f0 - 1 + r;
+    rows[i] = (f >= 0 && f < nfb && j < nslot) ? p.cand_b[((size_t)u * p.fb_stride + f) * p.maxc + j] : 0.0;
   }
-  p.cand_a[row + j] = ref;
-  p.score_a[row + j] = sc;
+  __syncthreads();
+  for (int i = threadIdx.x; i < kPruneFrames * nslot; i += blockDim.x) {
+    const int r = i / nslot, j = i - r * nslot, frame = f0 + r;
+    if (frame >= nfb) break;
+    const size_t at = ((size_t)u * p.fb_stride + frame) * p.maxc + j;
+    double ref = rows[(r + 1) * p.maxc + j], sc = p.score_b[at];
+    if (frame >= 1 && frame < nfb - 1 && ref != 0) {
+      double e1 = nearest_error(ref, rows + (r + 2) * p.maxc, nslot);
+      double e2 = nearest_error(ref, rows + r * p.maxc, nslot);
+      if ((e1 < e2 ? e1 : e2) > 0.05) { ref = 0; sc = 0; }
+    }
+    p.cand_a[at] = ref;
+    p.score_a[at] = sc;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -325,7 +337,8 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   WH_THREADS(hv_raw_candidates, max_fb, p.nch, B, stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
   WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
-  WH_THREADS(hv_prune, (long)max_fb * p.maxc, B, 1, stream, p);
+  WH_BLOCKS(hv_prune, dim3((max_fb + kPruneFrames - 1) / kPruneFrames, B), 256,
+            sizeof(double) * (size_t)(kPruneFrames + 2) * p.maxc, stream, p);
   launch_harvest_contour(p, max_fb, max_frames, stream);
 }
 

@@ -180,8 +180,17 @@ __global__ void hv_refine(HarvestParams p) {
   const double fs = p.afs;
   const double pos = frame * 1 / 1000.0;
 
-  for (int slot = 0; slot < nslot; ++slot) {
-    const int m = slot / nc, j = slot - m * nc;
+  // Slots are visited track by track (j outer, the 7 neighbouring source frames m inner):
+  // consecutive candidates then differ by a fraction of a Hz, so they usually share the
+  // window length -- and with it the window, the windowed samples and often the harmonic
+  // bin indices.  Whatever is identical to the previous candidate is reused, not recomputed.
+  constexpr int kIter = WAVE >= 8 ? 1 : 6;                        // harmonic groups processed one after another
+  int c_hw = -1, c_first = 0;                                      // window held in LDS
+  int c_idx[kIter];
+  double c_are[kIter], c_aim[kIter], c_dre[kIter], c_dim[kIter];   // reduced DFT sums of the previous candidate
+  for (int q = 0; q < kIter; ++q) c_idx[q] = -1;
+  for (int it = 0; it < nslot; ++it) {
+    const int j = it / 7, m = it - j * 7, slot = j + nc * m;
     const int sf = m == 0 ? frame : (m <= 3 ? frame - m : frame + (m - 3));
     double f0c = (sf >= 0 && sf < nfb) ? src[(size_t)sf * p.maxc + j] : 0.0;
     double rf0 = 0.0, rsc = 0.0;
@@ -193,23 +202,27 @@ __global__ void hv_refine(HarvestParams p) {
       const int N = 1 << lgN;
       const double base0 = static_cast<double>(-hw) / fs;
       const int first = mround((pos + base0) * fs + 0.001);      // GetBaseIndex, harvest.cpp:434-441
-      // main window (harvest.cpp:446-456)
-      for (int i = lane; i < blen; i += WAVE) {
-        double t = ((first + i) - 1.0) / fs - pos;
-        const double c1 = cospi(2.0 * t / wlen_t);                  // cos(2 pi t / T) without range reduction
-        mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);    // cos(2a) = 2 cos^2(a) - 1
+      const bool same_window = hw == c_hw && first == c_first;
+      if (!same_window) {
+        // main window (harvest.cpp:446-456)
+        for (int i = lane; i < blen; i += WAVE) {
+          double t = ((first + i) - 1.0) / fs - pos;
+          const double c1 = cospi(2.0 * t / wlen_t);                  // cos(2 pi t / T) without range reduction
+          mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);    // cos(2a) = 2 cos^2(a) - 1
+        }
+        wave_sync();
+        for (int i = lane; i < blen; i += WAVE) {
+          double dwv;                                              // GetDiffWindow, harvest.cpp:462-468
+          if (i == 0) dwv = -mw[1] / 2.0;
+          else if (i == blen - 1) dwv = mw[blen - 2] / 2.0;
+          else dwv = -(mw[i + 1] - mw[i - 1]) / 2.0;
+          double xv = y[imax(0, imin(y_len - 1, first + i - 1))];
+          ym[i] = xv * mw[i];
+          yd[i] = xv * dwv;
+        }
+        wave_sync();
+        c_hw = hw; c_first = first;
       }
-      wave_sync();
-      for (int i = lane; i < blen; i += WAVE) {
-        double dwv;                                              // GetDiffWindow, harvest.cpp:462-468
-        if (i == 0) dwv = -mw[1] / 2.0;
-        else if (i == blen - 1) dwv = mw[blen - 2] / 2.0;
-        else dwv = -(mw[i + 1] - mw[i - 1]) / 2.0;
-        double xv = y[imax(0, imin(y_len - 1, first + i - 1))];
-        ym[i] = xv * mw[i];
-        yd[i] = xv * dwv;
-      }
-      wave_sync();
       // 6-bin DFTs: lane = (harmonic h = lane%8, sample phase g = lane/8)
       const int nh = imin(static_cast<int>(fs / 2.0 / f0c), 6);
       const int LH = WAVE >= 8 ? 8 : 1;                           // harmonics handled side by side
@@ -218,11 +231,13 @@ __global__ void hv_refine(HarvestParams p) {
       // evaluates its own term once, the six results are then summed in harmonic order
       double inst_h[6], amp_h[6], dev_h[6];
       for (int h0 = 0; h0 < 6; h0 += LH) {
-        const int h = h0 + lane % LH, g = lane / LH;
+        const int h = h0 + lane % LH, g = lane / LH, hi = h0 / LH;
         double are = 0, aim = 0, dre = 0, dim = 0;
-        int idx = 0;
-        if (h < nh) {
-          idx = mround(f0c * N / fs * (h + 1));                  // FixF0, harvest.cpp:515
+        const int idx = h < nh ? mround(f0c * N / fs * (h + 1)) : 0;     // FixF0, harvest.cpp:515
+        const bool reuse = same_window && h < nh && idx == c_idx[hi];
+        if (reuse) {
+          if (g == 0) { are = c_are[hi]; aim = c_aim[hi]; dre = c_dre[hi]; dim = c_dim[hi]; }
+        } else if (h < nh) {
           // e^{-2 pi i idx n / N} by rotation: exact start / step from the integer phase
           const double2 w0 = p.tab.tw[(size_t)((idx * g) & (N - 1)) << (kTwLog2 - lgN)];
           const double2 st = p.tab.tw[(size_t)((idx * G) & (N - 1)) << (kTwLog2 - lgN)];
@@ -243,6 +258,8 @@ __global__ void hv_refine(HarvestParams p) {
           dre += __shfl_xor(dre, s, 64); dim += __shfl_xor(dim, s, 64);
         }
 #endif
+        c_idx[hi] = h < nh ? idx : -1;
+        c_are[hi] = are; c_aim[hi] = aim; c_dre[hi] = dre; c_dim[hi] = dim;
         const double pwv = are * are + aim * aim;                // harvest.cpp:564-569
         const double niv = are * dim - aim * dre;
         const double inst = pwv == 0.0 ? 0.0 : static_cast<double>(idx) * fs / N + niv / pwv * fs / 2.0 / kPi;

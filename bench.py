@@ -36,6 +36,48 @@ BYTES_PER_FRAME = 240 * 8 + 8 + 8 + 2 * 1025 * 8
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 
 
+def cpu_baseline_all_cores(x_np, seconds_budget=20.0):
+    """The reference is re-entrant (no globals), so the fairest whole-box CPU number is one
+    analysis per core: T threads (ctypes releases the GIL) each analyse the utterance once."""
+    import concurrent.futures as cf
+    from oracle.loader import best_oracle
+    o = best_oracle()
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+
+    def one(_):
+        tp, f0 = o.harvest(x_np, FS, frame_period=FRAME_PERIOD)
+        o.cheaptrick(x_np, FS, tp, f0, fft_size=FFT_SIZE)
+        o.d4c(x_np, FS, tp, f0, FFT_SIZE)
+        return len(f0)
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        frames = sum(ex.map(one, range(threads)))
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": threads,
+            "kind": "reference" if o.kind == "reference" else "port",
+            "sample": f"{threads} concurrent analyses of the same {len(x_np) / FS:.1f} s utterance, one per thread, "
+                      f"{dt:.1f} s wall", "host_cores_available": cores}
+
+
+def measured_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by tools_profile_summary.py).  FETCH_SIZE is
+    doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read);
+    WRITE_SIZE is used as reported (uncalibrated).  None when no matching profile exists."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("frames_per_launch") != frames_per_launch or kernel not in t["kernels"]:
+            return None
+        k = t["kernels"][kernel]
+        return int((2.0 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(x_np, reps=1):
     """Time the CPU oracle (the unmodified reference when its in-place build travelled
     here, else this repo's C restatement) on the same utterance, one host core."""
@@ -182,13 +224,15 @@ def main():
         alg_bytes = BYTES_PER_FRAME * units
         achieved = alg_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, units),
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
                     "note": "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~6 MFLOP/frame vs 18.3 kB/frame"}
 
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(xs[0].cpu().numpy())
+        x_host = xs[0].cpu().numpy()
+        cpu = cpu_baseline(x_host)
+        cpu_all = cpu_baseline_all_cores(x_host)
 
     barrier()
     if world > 1:
@@ -205,7 +249,7 @@ def main():
                        "parallelism": f"utterance-sharded x{world}" + (
                            ", async RCCL all-gather of f0/sp/ap per step" if world > 1 and not args.no_gather_cfg
                            else ", no collective")},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
                 kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "single_job_latency_ms": lat,

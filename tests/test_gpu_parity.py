@@ -113,6 +113,48 @@ def test_edge_cases(hip, oracle):
     assert_f0_close(f0, f0_o)
 
 
+def test_config2_harvest_only_batch_vs_oracle(wh, oracle):
+    """BASELINE.json configs[2] in small: a batch of 48 kHz vowels/chirps, Harvest F0 only,
+    every utterance against the CPU oracle (ragged lengths, rows beyond an utterance untouched)"""
+    import torch
+    from world_amd import synth
+    fs = 48000
+    secs = [2.0, 1.3, 1.7, 0.9, 2.0, 1.1]
+    xs = [synth.utterance(i, fs, s).numpy() for i, s in enumerate(secs)]
+    L = max(len(x) for x in xs)
+    xb = torch.zeros((len(xs), L), dtype=torch.float64)
+    for i, x in enumerate(xs):
+        xb[i, :len(x)] = torch.from_numpy(x)
+    tpos, f0, nf = wh.harvest(xb.cuda(), fs, x_len=[len(x) for x in xs])
+    torch.cuda.synchronize()
+    tpos, f0 = tpos.cpu().numpy(), f0.cpu().numpy()
+    for i, x in enumerate(xs):
+        tp_o, f0_o = oracle.harvest(x, fs)
+        n = len(f0_o)
+        assert nf[i] == n and np.array_equal(tpos[i, :n], tp_o)
+        assert_f0_close(f0[i, :n], f0_o, what=f"utterance {i}")
+        assert np.all(f0[i, n:] == 0) and np.all(tpos[i, n:] == 0)       # padding rows are not written
+
+
+def test_hard_inputs_vs_oracle(hip, oracle):
+    """DC offset, full-scale clipping and a pure sine (single dominant harmonic)"""
+    from world_amd import synth
+    fs = 16000
+    t = np.arange(int(0.8 * fs)) / fs
+    cases = {
+        "dc_offset": synth.vowel(fs, 0.8, seed=21).numpy() * 0.5 + 0.4,
+        "clipped": np.clip(synth.vowel(fs, 0.8, seed=22).numpy() * 8.0, -1.0, 32767.0 / 32768.0),
+        "sine": np.round(0.5 * np.sin(2 * np.pi * 220.0 * t) * 32768.0) / 32768.0,
+    }
+    for name, x in cases.items():
+        tp_o, f0_o = oracle.harvest(x, fs)
+        tp, f0 = hip.harvest(x, fs)
+        assert np.array_equal(tp, tp_o), name
+        assert_f0_close(f0, f0_o, what=name)
+        assert max_rel(hip.cheaptrick(x, fs, tp_o, f0_o, fft_size=1024), oracle.cheaptrick(x, fs, tp_o, f0_o, fft_size=1024)) <= RTOL, name
+        assert max_rel(hip.d4c(x, fs, tp_o, f0_o, 1024), oracle.d4c(x, fs, tp_o, f0_o, 1024)) <= RTOL, name
+
+
 def test_batched_equals_single_calls(hip, wh):
     """ragged batch through the device API == one drop-in call per utterance"""
     import torch

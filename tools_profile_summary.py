@@ -22,6 +22,8 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
         print(f"{short(r['Name']):50s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} "
               f"{float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}")
 
+import json
+traffic = {}
 print()
 print("== PMC counters, per-dispatch average by kernel ==")
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
@@ -38,3 +40,9 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         vals = "  ".join(f"{c}={v[0]/max(v[1],1):.4g}" for c, v in sorted(acc[k].items()))
         n = max(v[1] for v in acc[k].values())
         print(f"   {k:48s} n={n:<5d} {vals}")
+    for k in acc:
+        for c, v in acc[k].items():
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                traffic.setdefault(k, {})[c] = v[0] / max(v[1], 1)
+json.dump({"frames_per_launch": int(os.environ.get("PROFILE_FRAMES", "2001")), "unit": "KB per dispatch (rocprofv3)",
+           "kernels": traffic}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

@@ -170,7 +170,7 @@ class RefOracle(WorldCABI):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.flags = "-O3 -march=x86-64-v3" if name.endswith("_o3.so") else "-O1 (reference makefile:6)"
-        super().__init__(path)
+        super().__init__(path, hip_runtime=False)
 
 
 def ref_available():
@@ -180,3 +180,26 @@ def ref_available():
 def best_oracle():
     """The real reference when its prebuilt .so is present, else the port."""
     return RefOracle() if ref_available() else PortOracle()
+
+
+# ---- whole-box CPU baseline: one analysis per worker process ---------------------------
+def parallel_analyses(x, fs, frame_period, fft_size, procs, timeout=300):
+    """Run `procs` full analyses concurrently, each in its own `python oracle/cpu_worker.py`
+    process (no GPU runtime, own heap), all starting at the same wall-clock instant.
+    Returns (total frames, wall seconds from the common start to the last finish)."""
+    import tempfile
+    import time as _t
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "x.npy")
+        np.save(path, np.ascontiguousarray(x, dtype=np.float64))
+        start_at = _t.time() + 3.0 + 0.04 * procs
+        cmd = [sys.executable, os.path.join(HERE, "cpu_worker.py"), path, str(fs), str(frame_period), str(fft_size),
+               repr(start_at)]
+        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+        frames, t_end = 0, start_at
+        for p in ps:
+            out, _ = p.communicate(timeout=timeout)
+            n, t0, t1 = out.split()[-3:]
+            frames += int(n)
+            t_end = max(t_end, float(t1))
+    return frames, t_end - start_at

@@ -118,11 +118,12 @@ class HostAPI:
     libworld_hip.so (default) and on any build of the reference itself."""
     kind = "cabi"
 
-    def __init__(self, path=LIB_PATH):
+    def __init__(self, path=LIB_PATH, hip_runtime=True):
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing (python -m world_amd.build); there is no fallback.")
         self.path = path
-        _hip_runtime_first()
+        if hip_runtime:                      # False only for CPU-only libraries (the reference build)
+            _hip_runtime_first()
         self.lib = L = C.CDLL(path)
         L.Dio.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(DioOption), _dp, _dp]
         L.Harvest.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(HarvestOption), _dp, _dp]

@@ -47,26 +47,50 @@ inline int band_segments(int n) { return (n + kSeg - 1) / kSeg; }
 // sub-sample crossing time between samples e-1 and e (harvest.cpp:183-186, dio.cpp:380-382)
 __device__ __forceinline__ double fine_edge(int e, double prev, double cur) { return e - prev / (cur - prev); }
 
-// One tile: s[pad8(k)] = filtered[t0 + k] for k in [0, kTile + 2).  taps are in LDS.
-// Each thread produces kOutPer consecutive outputs from a register window that
-// slides one input sample per tap: per tap one LDS read of the input, one broadcast
-// read of the tap and kOutPer FMAs -> FP64-FMA bound instead of LDS bound.
-__device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps, int t0, double *yt, double *s) {
+// ---- one tile of one channel -------------------------------------------------------
+// s[pad8(k)] = filtered[t0 + k] for k in [0, kTile + 2); taps are in LDS.
+// Input index for output k, tap j: t0 + k + shift - j -> tile index k + (ntap-1) - j with
+// tile[0] = in[t0 + shift - (ntap-1)].  The tile is stored `org` slots into yt, org chosen so
+// that (k0 + ntap-1 + org) = 7 (mod 8) for every thread's first output k0 (a multiple of 8):
+// each group of 8 taps then reads 8 inputs that lie in ONE padded block of 8, so their LDS
+// addresses are a base plus compile-time offsets.  Each thread produces kOutPer consecutive
+// outputs from a register window that slides one input per tap: per 8 taps 16 LDS reads
+// and 64 FMAs -> FP64-FMA bound instead of LDS bound.
+__device__ __forceinline__ int tile_org(int ntap) { return (8 - (ntap & 7)) & 7; }
+
+// The tile's input is fetched into registers first (so that the NEXT tile's HBM/L2 latency
+// hides behind the current tile's FMAs) and committed to LDS later.
+constexpr int kTileRegs = 12;                             // >= (kTile + 2 + taps - 1) / kBpThreads for <= 1022 taps
+struct TileRegs { double v[kTileRegs]; };
+__device__ __forceinline__ bool tile_fits_regs(const BandJob &job) {
+  return (kTile + 2 + job.ntap - 1) <= kTileRegs * (int)blockDim.x;
+}
+__device__ __forceinline__ void tile_fetch(const BandJob &job, int t0, TileRegs &r) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lo = t0 + job.shift - (job.ntap - 1);
+  const int count = kTile + 2 + job.ntap - 1;
+#pragma unroll
+  for (int q = 0; q < kTileRegs; ++q) {
+    const int k = tid + q * nt, idx = lo + k;
+    r.v[q] = (k < count && idx >= 0 && idx < job.in_len) ? job.in[idx] : 0.0;
+  }
+}
+__device__ __forceinline__ void tile_commit(const BandJob &job, const TileRegs &r, double *yt) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int org = tile_org(job.ntap), count = kTile + 2 + job.ntap - 1;
+#pragma unroll
+  for (int q = 0; q < kTileRegs; ++q) {
+    const int k = tid + q * nt;
+    if (k < count) yt[pad8(k + org)] = r.v[q];
+  }
+}
+
+// convolution of the tile resident in yt
+__device__ __forceinline__ void fir_compute(const BandJob &job, const double *taps, const double *yt, double *s) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ntap = job.ntap;
-  // in index for output k, tap j: t0 + k + shift - j  ->  tile index k + (ntap-1) - j, tile[0] = in[t0 + shift - (ntap-1)].
-  // The tile is stored `org` slots into yt with org chosen so that (k0 + ntap-1 + org) = 7 (mod 8) for every
-  // thread's first output k0 (a multiple of 8): each group of 8 taps then reads 8 inputs that lie in ONE
-  // padded block of 8 -> their LDS addresses are a base plus compile-time offsets (no index arithmetic).
-  const int org = (8 - (ntap & 7)) & 7;
-  const int lo = t0 + job.shift - (ntap - 1);
-  const int count = kTile + 2 + ntap - 1;
-  __syncthreads();
-  for (int k = tid; k < count; k += nt) {
-    int idx = lo + k;
-    yt[pad8(k + org)] = (idx >= 0 && idx < job.in_len) ? job.in[idx] : 0.0;
-  }
-  __syncthreads();
+  const int org = tile_org(ntap);
+
   for (int k0 = tid * kOutPer; k0 < kTile; k0 += nt * kOutPer) {
     double acc[kOutPer], w[kOutPer];
     const int base = k0 + ntap - 1 + org;               // = 7 (mod 8)
@@ -116,6 +140,21 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
   __syncthreads();
 }
 
+// unpipelined variant (one-off tiles, e.g. DIO's low-cut stage)
+__device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps, int t0, double *yt, double *s) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int org = tile_org(job.ntap);
+  const int lo = t0 + job.shift - (job.ntap - 1);
+  const int count = kTile + 2 + job.ntap - 1;
+  __syncthreads();
+  for (int k = tid; k < count; k += nt) {
+    int idx = lo + k;
+    yt[pad8(k + org)] = (idx >= 0 && idx < job.in_len) ? job.in[idx] : 0.0;
+  }
+  __syncthreads();
+  fir_compute(job, taps, yt, s);
+}
+
 // Whole segment `seg` of one channel: filter tile by tile and append the crossing
 // times of the four families (falling, rising, peaks, dips) to the segment's lists.
 __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg) {
@@ -138,8 +177,19 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
   double *ev = job.seg_events + (size_t)seg * kSegCap;
   const size_t fam_stride = (size_t)job.nseg * kSegCap;
   int count[4] = {0, 0, 0, 0};
+  const bool pipelined = tile_fits_regs(job);
+  TileRegs pre;
+  if (pipelined) tile_fetch(job, seg_begin, pre);
   for (int t0 = seg_begin; t0 < seg_end; t0 += kTile) {
-    fir_tile(job, taps, t0, yt, s);
+    if (pipelined) {
+      __syncthreads();                               // everyone is done with the previous tile's yt and s
+      tile_commit(job, pre, yt);
+      __syncthreads();
+      if (t0 + kTile < seg_end) tile_fetch(job, t0 + kTile, pre);   // in flight during this tile's FMAs
+      fir_compute(job, taps, yt, s);
+    } else {
+      fir_tile(job, taps, t0, yt, s);
+    }
     // events: every thread inspects kOutPer consecutive samples (time order).  Pass 1
     // counts the crossings of all four families (16-bit counters packed in one word),
     // ONE block scan turns the counts into list positions, pass 2 re-detects and writes.

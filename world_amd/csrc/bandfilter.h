@@ -131,11 +131,13 @@ __device__ __forceinline__ void fir_compute(const BandJob &job, const double *ta
 #pragma unroll
     for (int q = 0; q < kOutPer; ++q) sdst[q] = acc[q];
   }
-  for (int e = tid; e < 2; e += nt) {              // the two look-ahead samples
+  // the two look-ahead samples: one wave each, taps spread over the lanes
+  for (int e = wave_in_block(); e < 2; e += waves_per_block()) {
     double acc = 0.0;
     const int base = kTile + e + (ntap - 1) + org;
-    for (int j = 0; j < ntap; ++j) acc = fma(taps[j], yt[pad8(base - j)], acc);
-    s[pad8(kTile + e)] = acc;
+    for (int j = lane_id(); j < ntap; j += WAVE) acc = fma(taps[j], yt[pad8(base - j)], acc);
+    acc = wave_sum(acc);
+    if (lane_id() == 0) s[pad8(kTile + e)] = acc;
   }
   __syncthreads();
 }
@@ -190,42 +192,42 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
     } else {
       fir_tile(job, taps, t0, yt, s);
     }
-    // events: every thread inspects kOutPer consecutive samples (time order).  Pass 1
-    // counts the crossings of all four families (16-bit counters packed in one word),
-    // ONE block scan turns the counts into list positions, pass 2 re-detects and writes.
+    // events: every thread inspects kOutPer consecutive samples (time order) and records
+    // the crossings of each family as a bit mask; ONE block scan of the four packed counts
+    // gives the list positions; the sub-sample times (one FP64 division each) are then
+    // evaluated only for the set bits.
     for (int sub = 0; sub < kTile; sub += nt * kOutPer) {
       const int kbase = sub + tid * kOutPer;
       double sv[kOutPer + 2];
 #pragma unroll
       for (int q = 0; q < kOutPer + 2; ++q) sv[q] = kbase + q < kTile + 2 ? s[pad8(kbase + q)] : 0.0;
-      auto crossing = [&](int fam, int q, double &a, double &b) {
+      unsigned mask[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < kOutPer; ++q) {
         const int i = t0 + kbase + q;
-        bool in_range;
-        if (fam < 2) { a = sv[q]; b = sv[q + 1]; in_range = i <= n - 2; }
-        else { a = sv[q + 1] - sv[q]; b = sv[q + 2] - sv[q + 1]; in_range = i <= n - 3; }
-        const bool hit = fam % 2 == 0 ? (0.0 < a && b <= 0.0) : (a < 0.0 && 0.0 <= b);
-        return in_range && hit && kbase + q < kTile;
-      };
+        const bool live = kbase + q < kTile;
+        const double a = sv[q], b = sv[q + 1], c = sv[q + 2];
+        const double da = b - a, db = c - b;
+        const bool r01 = live && i <= n - 2, r23 = live && i <= n - 3;
+        if (r01 && 0.0 < a && b <= 0.0) mask[0] |= 1u << q;
+        if (r01 && a < 0.0 && 0.0 <= b) mask[1] |= 1u << q;
+        if (r23 && 0.0 < da && db <= 0.0) mask[2] |= 1u << q;
+        if (r23 && da < 0.0 && 0.0 <= db) mask[3] |= 1u << q;
+      }
       unsigned long long packed = 0;
 #pragma unroll
-      for (int fam = 0; fam < 4; ++fam) {
-        int c = 0;
-#pragma unroll
-        for (int q = 0; q < kOutPer; ++q) { double a, b; c += crossing(fam, q, a, b) ? 1 : 0; }
-        packed |= (unsigned long long)c << (16 * fam);
-      }
+      for (int fam = 0; fam < 4; ++fam) packed |= (unsigned long long)__builtin_popcount(mask[fam]) << (16 * fam);
       unsigned long long total, off = block_excl_scan_u64(packed, &total, scratch);
 #pragma unroll
       for (int fam = 0; fam < 4; ++fam) {
         double *dst = ev + fam * fam_stride;
         int at = count[fam] + (int)((off >> (16 * fam)) & 0xFFFF);
-#pragma unroll
-        for (int q = 0; q < kOutPer; ++q) {
-          double a, b;
-          if (crossing(fam, q, a, b)) {
-            if (at < kSegCap) dst[at] = fine_edge(t0 + kbase + q + 1, a, b);
-            ++at;
-          }
+        for (unsigned m = mask[fam]; m != 0; m &= m - 1) {
+          const int q = __builtin_ctz(m);
+          double a = sv[q], b = sv[q + 1];
+          if (fam >= 2) { const double c = sv[q + 2]; a = b - a; b = c - b; }
+          if (at < kSegCap) dst[at] = fine_edge(t0 + kbase + q + 1, a, b);
+          ++at;
         }
         count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
       }

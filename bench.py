@@ -114,11 +114,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one rank per GPU; (for a functional check of the N > 1 path on a 1-GPU box, ranks may share a
+    # device with WORLD_HIP_BENCH_BACKEND=gloo -- never used for numbers of record)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("WORLD_HIP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     def barrier():
         if world > 1:

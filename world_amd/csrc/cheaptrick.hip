@@ -126,8 +126,21 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   }
   __syncthreads();
   if (tid == 0) {                       // the order-sensitive serial prefix sum
-    double acc = seg[0];
-    for (int i = 1; i < seg_len; ++i) { acc = seg[i] + acc; seg[i] = acc; }
+    // strictly left-to-right FP64 additions; only the LDS traffic is batched (16 loads in
+    // flight, 16 dependent adds, 16 stores) so the chain runs at add latency, not LDS latency
+    constexpr int kB = 16;
+    double acc = 0.0;
+    for (int i0 = 0; i0 < seg_len; i0 += kB) {
+      double v[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) v[q] = i0 + q < seg_len ? seg[i0 + q] : 0.0;
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        if (i0 + q < seg_len) { acc = (i0 + q == 0) ? v[q] : v[q] + acc; v[q] = acc; }
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) if (i0 + q < seg_len) seg[i0 + q] = v[q];
+    }
   }
   __syncthreads();
   {

@@ -242,9 +242,12 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
         acc += c;
       }
     }
-    digit = wave_max_int(digit);
-    below = wave_max_int(below);
-    hsel = wave_max_int(hsel);
+    // exactly one lane found the bin: two max-reductions broadcast (digit, below) and hsel
+    {
+      const int got = wave_max_int(digit < 0 ? -1 : (digit << 12) | below);     // below <= 2049 < 2^12
+      hsel = wave_max_int(hsel);
+      digit = got >> 12; below = got & 4095;
+    }
     remaining -= below;
     bucket = hsel;
     prefix |= (unsigned long long)digit << shift;

@@ -205,9 +205,10 @@ __global__ void hv_refine(HarvestParams p) {
       const bool same_window = hw == c_hw && first == c_first;
       if (!same_window) {
         // main window (harvest.cpp:446-456)
+        const double inv_fs = 1.0 / fs, two_over_t = 2.0 / wlen_t;   // reciprocals: the window is not rounding-critical
         for (int i = lane; i < blen; i += WAVE) {
-          double t = ((first + i) - 1.0) / fs - pos;
-          const double c1 = cospi(2.0 * t / wlen_t);                  // cos(2 pi t / T) without range reduction
+          double t = ((first + i) - 1.0) * inv_fs - pos;
+          const double c1 = cospi(t * two_over_t);                    // cos(2 pi t / T) without range reduction
           mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);    // cos(2a) = 2 cos^2(a) - 1
         }
         wave_sync();

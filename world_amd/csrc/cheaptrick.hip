@@ -129,18 +129,18 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
     // strictly left-to-right FP64 additions; only the LDS traffic is batched (16 loads in
     // flight, 16 dependent adds, 16 stores) so the chain runs at add latency, not LDS latency
     constexpr int kB = 16;
-    double acc = 0.0;
-    for (int i0 = 0; i0 < seg_len; i0 += kB) {
+    double acc = seg[0];
+    int i0 = 1;
+    for (; i0 + kB <= seg_len; i0 += kB) {
       double v[kB];
 #pragma unroll
-      for (int q = 0; q < kB; ++q) v[q] = i0 + q < seg_len ? seg[i0 + q] : 0.0;
+      for (int q = 0; q < kB; ++q) v[q] = seg[i0 + q];
 #pragma unroll
-      for (int q = 0; q < kB; ++q) {
-        if (i0 + q < seg_len) { acc = (i0 + q == 0) ? v[q] : v[q] + acc; v[q] = acc; }
-      }
+      for (int q = 0; q < kB; ++q) { acc = v[q] + acc; v[q] = acc; }
 #pragma unroll
-      for (int q = 0; q < kB; ++q) if (i0 + q < seg_len) seg[i0 + q] = v[q];
+      for (int q = 0; q < kB; ++q) seg[i0 + q] = v[q];
     }
+    for (; i0 < seg_len; ++i0) { acc = seg[i0] + acc; seg[i0] = acc; }
   }
   __syncthreads();
   {

@@ -212,23 +212,27 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 #else
   (void)lane; (void)wv; (void)nw;
 #endif
-  int pass = 0;
-  while (pass < 8 && ((kmin ^ kmax) >> (56 - 8 * pass)) == 0) ++pass;
-  unsigned long long prefix = pass ? (kmin >> (64 - 8 * pass)) << (64 - 8 * pass) : 0ull;
+  // Digits are taken from the first bit in which any two keys differ (not from byte
+  // boundaries): the first histogram then spans exactly [kmin, kmax], so the keys spread
+  // over up to 256 bins instead of piling into the two or three exponent bytes present.
+  const unsigned long long diff = kmin ^ kmax;
+  int hi = diff ? 64 - __clzll((long long)diff) : 0;    // bits >= hi are common to every key
+  unsigned long long prefix = hi >= 64 ? 0ull : (kmin >> hi) << hi;
   int remaining = m - 1;                           // rank (0-based, ascending) of the threshold element
   int bucket = n;                                   // keys that still match the prefix
-  for (int it = 0; pass < 8 && bucket > 1; ++pass, ++it) {
-    const int shift = 56 - 8 * pass;
+  for (int it = 0; hi > 0 && bucket > 1; ++it) {
+    const int shift = hi > 8 ? hi - 8 : 0;
+    const unsigned long long mask = (1ull << (hi - shift)) - 1ull;
     int *h = hist + (it & 1) * 256;                 // this pass's histogram (already zero)
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q) {
-      const bool in = key[q] != ~0ull && (pass == 0 || (key[q] >> (shift + 8)) == (prefix >> (shift + 8)));
-      if (in) atomicAdd(&h[(int)((key[q] >> shift) & 255ull)], 1);
+      const bool in = q < mine && (it == 0 || (key[q] >> hi) == (prefix >> hi));
+      if (in) atomicAdd(&h[(int)((key[q] >> shift) & mask)], 1);
     }
     __syncthreads();
     for (int i = tid; i < 256; i += nt) hist[((it & 1) ^ 1) * 256 + i] = 0;   // next pass's histogram
-    // every wave locates the byte redundantly: each lane sums its bins, a wave scan finds the rank
+    // every wave locates the digit redundantly: each lane sums its bins, a wave scan finds the rank
     const int per_lane = 256 / WAVE;
     int local = 0;
     for (int j = 0; j < per_lane; ++j) local += h[lane_id() * per_lane + j];
@@ -251,34 +255,32 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     remaining -= below;
     bucket = hsel;
     prefix |= (unsigned long long)digit << shift;
+    hi = shift;
   }
-  if (pass < 8) {
+  if (hi > 0) {
     // the bucket holds exactly one key: it is the threshold; its owner publishes it
-    const int fixed = 64 - 8 * pass;               // low bits not yet decided
     unsigned long long *ks2 = reinterpret_cast<unsigned long long *>(scratch) + 48;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q)
-      if (key[q] != ~0ull && (fixed == 64 || (key[q] >> fixed) == (prefix >> fixed))) ks2[0] = key[q];
+      if (q < mine && (key[q] >> hi) == (prefix >> hi)) ks2[0] = key[q];
     __syncthreads();
     prefix = ks2[0];
   }
+  // keys strictly below the threshold: every key of the lower buckets, i.e. (m-1) - remaining
   const double thr = __longlong_as_double((long long)prefix);
   double s_lt = 0.0, s_all = 0.0;
-  int c_lt = 0;
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q) {
     if (q < mine) {
       const double x = __longlong_as_double((long long)key[q]);
       s_all += x;
-      if (x < thr) { s_lt += x; c_lt++; }
+      if (x < thr) s_lt += x;
     }
   }
   (void)n; (void)tid; (void)nt;
   block_sum2(s_lt, s_all, scratch);
-  int tot_lt;
-  block_excl_scan_int(c_lt, &tot_lt, scratch);
-  *partial = s_lt + (m - tot_lt) * thr;
+  *partial = s_lt + (remaining + 1) * thr;
   *total = s_all;
 }
 

@@ -43,6 +43,7 @@ typedef void *hipStream_t;
 #define hipSuccess 0
 #define WAVE 1
 #define DYN_LDS(name) char *name = emu_lds_base
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline unsigned __brev(unsigned v) {
   unsigned r = 0;
   for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);

@@ -169,32 +169,51 @@ __global__ void hv_refine(HarvestParams p) {
   const int frame = wave_item_x(), u = blockIdx.y;
   if (frame >= p.nfb[u]) return;
   const int lane = lane_id();
-  double *mw = reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * 3 * p.refine_cap;
-  double *ym = mw + p.refine_cap, *yd = ym + p.refine_cap;      // y*main window, y*diff window
-  const int nfb = p.nfb[u], nc = p.nc[u], nslot = nc * 7;
+  const int cap = p.refine_cap;
+  double *yc = reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * 3 * cap;
+  double *ym = yc + cap, *yd = ym + cap;            // signal around the frame | y*main window | y*diff window
+  const int nfb = p.nfb[u], nc = p.nc[u];
   const double *src = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
   double *dst_f0 = p.cand_b + ((size_t)u * p.fb_stride + frame) * p.maxc;
   double *dst_sc = p.score_b + ((size_t)u * p.fb_stride + frame) * p.maxc;
   const double *y = p.y + (size_t)u * p.y_stride;
   const int y_len = p.y_len[u];
-  const double fs = p.afs;
+  const double fs = p.afs, inv_fs = 1.0 / fs;
   const double pos = frame * 1 / 1000.0;
 
-  // Slots are visited track by track (j outer, the 7 neighbouring source frames m inner):
-  // consecutive candidates then differ by a fraction of a Hz, so they usually share the
-  // window length -- and with it the window, the windowed samples and often the harmonic
-  // bin indices.  Whatever is identical to the previous candidate is reused, not recomputed.
-  constexpr int kIter = WAVE >= 8 ? 1 : 6;                        // harmonic groups processed one after another
+  // Every window of this frame is centred on `pos`, so the samples any of them can touch
+  // (clamped at the signal ends like GetBaseIndex's safe_index, harvest.cpp:434-441) are
+  // fetched from HBM once and kept in LDS.
+  const int origin = mround(pos * fs) - cap / 2;
+  for (int k = lane; k < cap; k += WAVE) yc[k] = y[imax(0, imin(y_len - 1, origin + k))];
+  wave_sync();
+
+  // Lane roles: harmonic h = lane % LH, sample phase g = lane / LH.  Slots are visited
+  // track by track (j outer, the 7 neighbouring source frames m inner): consecutive
+  // candidates then differ by a fraction of a Hz, so they usually share the window length
+  // -- and with it the windowed samples and often the harmonic bin indices.  Whatever is
+  // identical to the previous candidate is reused.  The per-candidate tail (FixF0's
+  // instantaneous-frequency arithmetic) is deferred: phase group g keeps the DFT sums of
+  // slot m == g, and one vectorised tail per track finishes all seven slots at once.
+  constexpr int LH = WAVE >= 8 ? 8 : 1;                           // harmonics handled side by side
+  constexpr int G = WAVE / LH;                                    // sample phases
+  constexpr int kIter = (6 + LH - 1) / LH;                        // harmonic groups per lane (1 on the GPU)
+  constexpr int kM = (7 + G - 1) / G;                             // deferred slots per lane (1 on the GPU)
+  const int hl = lane % LH, g = lane / LH;
   int c_hw = -1, c_first = 0;                                      // window held in LDS
   int c_idx[kIter];
   double c_are[kIter], c_aim[kIter], c_dre[kIter], c_dim[kIter];   // reduced DFT sums of the previous candidate
   for (int q = 0; q < kIter; ++q) c_idx[q] = -1;
-  for (int it = 0; it < nslot; ++it) {
-    const int j = it / 7, m = it - j * 7, slot = j + nc * m;
-    const int sf = m == 0 ? frame : (m <= 3 ? frame - m : frame + (m - 3));
-    double f0c = (sf >= 0 && sf < nfb) ? src[(size_t)sf * p.maxc + j] : 0.0;
-    double rf0 = 0.0, rsc = 0.0;
-    if (f0c > 0.0) {                                             // GetRefinedF0, harvest.cpp:589-617
+
+  for (int j = 0; j < nc; ++j) {
+    double k_are[kM][kIter], k_aim[kM][kIter], k_dre[kM][kIter], k_dim[kM][kIter], k_f0[kM];
+    int k_idx[kM][kIter], k_lgn[kM];
+    for (int q = 0; q < kM; ++q) k_f0[q] = 0.0;
+    for (int m = 0; m < 7; ++m) {
+      const int sf = m == 0 ? frame : (m <= 3 ? frame - m : frame + (m - 3));
+      const double f0c = (sf >= 0 && sf < nfb) ? src[(size_t)sf * p.maxc + j] : 0.0;
+      if (!(f0c > 0.0)) continue;
+      // GetRefinedF0, harvest.cpp:589-617
       const int hw = static_cast<int>(1.5 * fs / f0c + 1.0);
       const int blen = 2 * hw + 1;
       const double wlen_t = (2.0 * hw + 1.0) / fs;
@@ -204,86 +223,117 @@ __global__ void hv_refine(HarvestParams p) {
       const int first = mround((pos + base0) * fs + 0.001);      // GetBaseIndex, harvest.cpp:434-441
       const bool same_window = hw == c_hw && first == c_first;
       if (!same_window) {
-        // main window (harvest.cpp:446-456)
-        const double inv_fs = 1.0 / fs, two_over_t = 2.0 / wlen_t;   // reciprocals: the window is not rounding-critical
+        // Blackman main window (harvest.cpp:446-456) and its central difference
+        // (GetDiffWindow, :462-468).  w[i+1]-w[i-1] follows from the angle-addition
+        // identities, so no neighbour values are exchanged.
+        const double two_over_t = 2.0 / wlen_t;
+        double sd, cd;
+        sincospi(inv_fs * two_over_t, &sd, &cd);
+        const double s2d = 2.0 * sd * cd, c2d = 2.0 * cd * cd - 1.0;
+        wave_sync();                                             // the previous candidate's reads are done
         for (int i = lane; i < blen; i += WAVE) {
-          double t = ((first + i) - 1.0) * inv_fs - pos;
-          const double c1 = cospi(t * two_over_t);                    // cos(2 pi t / T) without range reduction
-          mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);    // cos(2a) = 2 cos^2(a) - 1
-        }
-        wave_sync();
-        for (int i = lane; i < blen; i += WAVE) {
-          double dwv;                                              // GetDiffWindow, harvest.cpp:462-468
-          if (i == 0) dwv = -mw[1] / 2.0;
-          else if (i == blen - 1) dwv = mw[blen - 2] / 2.0;
-          else dwv = -(mw[i + 1] - mw[i - 1]) / 2.0;
-          double xv = y[imax(0, imin(y_len - 1, first + i - 1))];
-          ym[i] = xv * mw[i];
+          const double t = ((first + i) - 1.0) * inv_fs - pos;
+          double sa, ca;
+          sincospi(t * two_over_t, &sa, &ca);
+          const double c2a = 2.0 * ca * ca - 1.0, s2a = 2.0 * sa * ca;
+          const double w = 0.42 + 0.5 * ca + 0.08 * c2a;
+          double dwv;
+          if (i == 0) dwv = -(0.42 + 0.5 * (ca * cd - sa * sd) + 0.08 * (c2a * c2d - s2a * s2d)) / 2.0;
+          else if (i == blen - 1) dwv = (0.42 + 0.5 * (ca * cd + sa * sd) + 0.08 * (c2a * c2d + s2a * s2d)) / 2.0;
+          else dwv = 0.5 * sa * sd + 0.08 * s2a * s2d;
+          const int k = first + i - 1 - origin;
+          const double xv = (k >= 0 && k < cap) ? yc[k] : y[imax(0, imin(y_len - 1, first + i - 1))];
+          ym[i] = xv * w;
           yd[i] = xv * dwv;
         }
         wave_sync();
         c_hw = hw; c_first = first;
       }
-      // 6-bin DFTs: lane = (harmonic h = lane%8, sample phase g = lane/8)
+      // 6-bin DFTs of both windowed signals, one Goertzel recurrence per (harmonic, phase)
       const int nh = imin(static_cast<int>(fs / 2.0 / f0c), 6);
-      const int LH = WAVE >= 8 ? 8 : 1;                           // harmonics handled side by side
-      const int G = WAVE / LH;                                    // sample phases
-      // per-harmonic terms of FixF0 (harvest.cpp:507-536); each harmonic's lane group
-      // evaluates its own term once, the six results are then summed in harmonic order
-      double inst_h[6], amp_h[6], dev_h[6];
-      for (int h0 = 0; h0 < 6; h0 += LH) {
-        const int h = h0 + lane % LH, g = lane / LH, hi = h0 / LH;
+      for (int hi = 0; hi < kIter; ++hi) {
+        const int h = hi * LH + hl;
         double are = 0, aim = 0, dre = 0, dim = 0;
         const int idx = h < nh ? mround(f0c * N / fs * (h + 1)) : 0;     // FixF0, harvest.cpp:515
         const bool reuse = same_window && h < nh && idx == c_idx[hi];
         if (reuse) {
           if (g == 0) { are = c_are[hi]; aim = c_aim[hi]; dre = c_dre[hi]; dim = c_dim[hi]; }
-        } else if (h < nh) {
-          // e^{-2 pi i idx n / N} by rotation: exact start / step from the integer phase
-          const double2 w0 = p.tab.tw[(size_t)((idx * g) & (N - 1)) << (kTwLog2 - lgN)];
+        } else if (h < nh && g < blen) {
+          // sum_n v[g+nG] e^{-i theta n}, theta = 2 pi idx G / N:  s[n] = v[n] + 2cos(theta) s[n-1] - s[n-2]
           const double2 st = p.tab.tw[(size_t)((idx * G) & (N - 1)) << (kTwLog2 - lgN)];
-          double wc = w0.x, ws = w0.y;
-          const double rc = st.x, rs = st.y;
-          for (int i = g; i < blen; i += G) {
-            double a = ym[i], d = yd[i];
-            are = fma(a, wc, are); aim = fma(-a, ws, aim);
-            dre = fma(d, wc, dre); dim = fma(-d, ws, dim);
-            const double nc = wc * rc - ws * rs;
-            ws = ws * rc + wc * rs;
-            wc = nc;
+          const double c2 = 2.0 * st.x;
+          double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
+          int i = g;
+          for (; i + G < blen; i += 2 * G) {
+            const double a0 = ym[i], d0 = yd[i], a1 = ym[i + G], d1 = yd[i + G];
+            const double sa = fma(c2, s1, a0) - s2, ta = fma(c2, t1, d0) - t2;
+            s2 = sa; t2 = ta;
+            s1 = fma(c2, sa, a1) - s1; t1 = fma(c2, ta, d1) - t1;
           }
+          if (i < blen) {
+            const double sa = fma(c2, s1, ym[i]) - s2, ta = fma(c2, t1, yd[i]) - t2;
+            s2 = s1; t2 = t1; s1 = sa; t1 = ta;
+            i += G;
+          }
+          // i - G is the last sample taken; its phase e^{-2 pi i idx (i-G) / N} closes the sum
+          const double2 wl = p.tab.tw[(size_t)((idx * (i - G)) & (N - 1)) << (kTwLog2 - lgN)];
+          const double A = s1 - st.x * s2, B = st.y * s2, C = t1 - st.x * t2, D = st.y * t2;
+          are = A * wl.x + B * wl.y; aim = B * wl.x - A * wl.y;
+          dre = C * wl.x + D * wl.y; dim = D * wl.x - C * wl.y;
         }
 #ifndef WORLD_EMU
-        for (int s = 8; s < 64; s <<= 1) {
+        for (int s = LH; s < WAVE; s <<= 1) {
           are += __shfl_xor(are, s, 64); aim += __shfl_xor(aim, s, 64);
           dre += __shfl_xor(dre, s, 64); dim += __shfl_xor(dim, s, 64);
         }
 #endif
         c_idx[hi] = h < nh ? idx : -1;
         c_are[hi] = are; c_aim[hi] = aim; c_dre[hi] = dre; c_dim[hi] = dim;
-        const double pwv = are * are + aim * aim;                // harvest.cpp:564-569
-        const double niv = are * dim - aim * dre;
-        const double inst = pwv == 0.0 ? 0.0 : static_cast<double>(idx) * fs / N + niv / pwv * fs / 2.0 / kPi;
-        const double amp = sqrt(pwv);
-        const double dev = fabs((inst / (h + 1.0) - f0c) / f0c);
-        for (int k = 0; k < LH && h0 + k < 6; ++k) {
-          inst_h[h0 + k] = wave_bcast(inst, k);
-          amp_h[h0 + k] = wave_bcast(amp, k);
-          dev_h[h0 + k] = wave_bcast(dev, k);
+        if (m % G == g) {
+          const int q = m / G;
+          k_are[q][hi] = are; k_aim[q][hi] = aim; k_dre[q][hi] = dre; k_dim[q][hi] = dim;
+          k_idx[q][hi] = idx; k_lgn[q] = lgN; k_f0[q] = f0c;
         }
       }
-      double num = 0.0, den = 0.0, sc = 0.0;
-      for (int h = 0; h < nh; ++h) {
-        num += amp_h[h] * inst_h[h];
-        den += amp_h[h] * (h + 1.0);
-        sc += dev_h[h];
-      }
-      rf0 = num / (den + kTiny);
-      rsc = 1.0 / (sc / nh + kTiny);
-      if (rf0 < p.f0_floor || rf0 > p.f0_ceil || rsc < 2.5) { rf0 = 0.0; rsc = 0.0; }
-      wave_sync();
     }
-    if (lane == 0) { dst_f0[slot] = rf0; dst_sc[slot] = rsc; }
+    // deferred tail: lane (h, g) finishes harmonic h of slot m = g (+ q*G)
+    for (int q = 0; q < kM; ++q) {
+      const int m = q * G + g;
+      const double f0c = k_f0[q];
+      double num = 0.0, den = 0.0, sc = 0.0;
+      int nh = 1;
+      if (f0c > 0.0) {
+        nh = imin(static_cast<int>(fs / 2.0 / f0c), 6);
+        const int N = 1 << k_lgn[q];
+        for (int hi = 0; hi < kIter; ++hi) {
+          const int h = hi * LH + hl;
+          if (h >= nh) continue;
+          const double are = k_are[q][hi], aim = k_aim[q][hi], dre = k_dre[q][hi], dim = k_dim[q][hi];
+          const double pwv = are * are + aim * aim;                // harvest.cpp:564-569
+          const double niv = are * dim - aim * dre;
+          const double inst = pwv == 0.0 ? 0.0 : static_cast<double>(k_idx[q][hi]) * fs / N + niv / pwv * fs / 2.0 / kPi;
+          const double amp = sqrt(pwv);
+          num += amp * inst;                                        // FixF0, harvest.cpp:507-536
+          den += amp * (h + 1.0);
+          sc += fabs((inst / (h + 1.0) - f0c) / f0c);
+        }
+      }
+#ifndef WORLD_EMU
+      for (int s = 1; s < LH; s <<= 1) {
+        num += __shfl_xor(num, s, 64); den += __shfl_xor(den, s, 64); sc += __shfl_xor(sc, s, 64);
+      }
+#endif
+      if (hl == 0 && m < 7) {
+        double rf0 = 0.0, rsc = 0.0;
+        if (f0c > 0.0) {
+          rf0 = num / (den + kTiny);
+          rsc = 1.0 / (sc / nh + kTiny);
+          if (rf0 < p.f0_floor || rf0 > p.f0_ceil || rsc < 2.5) { rf0 = 0.0; rsc = 0.0; }
+        }
+        const int slot = j + nc * m;
+        dst_f0[slot] = rf0; dst_sc[slot] = rsc;
+      }
+    }
   }
 }
 

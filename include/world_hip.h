@@ -89,6 +89,19 @@ WORLD_HIP_API void D4C(const double *x, int x_length, int fs, const double *temp
                        double **aperiodicity);
 WORLD_HIP_API void InitializeD4COption(D4COption *option);
 
+/* reference src/world/codec.h:33,47,60,74,88 (src/codec.cpp:212-324) -- SURVEY.md 8f.1.
+ * All five public symbols of codec.o are defined so that the object is never pulled from
+ * a reference archive linked behind this library. */
+WORLD_HIP_API int GetNumberOfAperiodicities(int fs);
+WORLD_HIP_API void CodeAperiodicity(const double *const *aperiodicity, int f0_length, int fs, int fft_size,
+                                    double **coded_aperiodicity);
+WORLD_HIP_API void DecodeAperiodicity(const double *const *coded_aperiodicity, int f0_length, int fs,
+                                      int fft_size, double **aperiodicity);
+WORLD_HIP_API void CodeSpectralEnvelope(const double *const *spectrogram, int f0_length, int fs, int fft_size,
+                                        int number_of_dimensions, double **coded_spectral_envelope);
+WORLD_HIP_API void DecodeSpectralEnvelope(const double *const *coded_spectral_envelope, int f0_length, int fs,
+                                          int fft_size, int number_of_dimensions, double **spectrogram);
+
 /* ------------------------------------------------------------------------- */
 /* Part 2: batched device-resident API                                        */
 /* ------------------------------------------------------------------------- */
@@ -138,6 +151,23 @@ WORLD_HIP_API int world_hip_d4c_batch(WorldHipContext *ctx, int n_utt, int fs, c
                                       int x_stride, const int *x_length, const int *n_frames,
                                       int f_stride, const double *d_tpos, const double *d_f0,
                                       int fft_size, const D4COption *option, double *d_aperiodicity);
+
+/* Coders on dense device rows (reference src/codec.cpp:217-324).  Rows are independent:
+ *   spectrogram / aperiodicity  [rows][fft_size/2+1]
+ *   coded spectral envelope     [rows][number_of_dimensions]
+ *   coded aperiodicity          [rows][GetNumberOfAperiodicities(fs)]
+ * A batch's [n_utt][f_stride][...] output of the calls above is one such array with
+ * rows = n_utt * f_stride (padding rows must then hold finite positive values). */
+WORLD_HIP_API int world_hip_code_spectral_envelope(WorldHipContext *ctx, int rows, int fs, int fft_size,
+                                                   int number_of_dimensions, const double *d_spectrogram,
+                                                   double *d_coded);
+WORLD_HIP_API int world_hip_decode_spectral_envelope(WorldHipContext *ctx, int rows, int fs, int fft_size,
+                                                     int number_of_dimensions, const double *d_coded,
+                                                     double *d_spectrogram);
+WORLD_HIP_API int world_hip_code_aperiodicity(WorldHipContext *ctx, int rows, int fs, int fft_size,
+                                              const double *d_aperiodicity, double *d_coded);
+WORLD_HIP_API int world_hip_decode_aperiodicity(WorldHipContext *ctx, int rows, int fs, int fft_size,
+                                                const double *d_coded, double *d_aperiodicity);
 
 #ifdef __cplusplus
 }

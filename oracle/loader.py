@@ -73,6 +73,11 @@ class PortOracle(_Base):
         L.wo_dc_correction.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
         L.wo_round.argtypes = [C.c_double]
         L.wo_nuttall.argtypes = [C.c_int, _dp]
+        L.wo_number_of_aperiodicities.argtypes = [C.c_int]
+        L.wo_code_aperiodicity.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
+        L.wo_decode_aperiodicity.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
+        L.wo_code_spectral_envelope.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+        L.wo_decode_spectral_envelope.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
 
     # -- primitives --
     def randn(self, count):
@@ -142,6 +147,30 @@ class PortOracle(_Base):
         ap = np.zeros((len(f0), fft_size // 2 + 1))
         self.lib.wo_d4c(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, threshold, _p(ap))
         return ap
+
+    # -- codec --
+    def number_of_aperiodicities(self, fs):
+        return self.lib.wo_number_of_aperiodicities(fs)
+
+    def code_aperiodicity(self, ap, fs, fft_size):
+        ap = _f64(ap); out = np.zeros((ap.shape[0], self.number_of_aperiodicities(fs)))
+        self.lib.wo_code_aperiodicity(_p(ap), ap.shape[0], fs, fft_size, _p(out))
+        return out
+
+    def decode_aperiodicity(self, coded, fs, fft_size):
+        coded = _f64(coded); out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.wo_decode_aperiodicity(_p(coded), coded.shape[0], fs, fft_size, _p(out))
+        return out
+
+    def code_spectral_envelope(self, sp, fs, fft_size, ndim):
+        sp = _f64(sp); out = np.zeros((sp.shape[0], ndim))
+        self.lib.wo_code_spectral_envelope(_p(sp), sp.shape[0], fs, fft_size, ndim, _p(out))
+        return out
+
+    def decode_spectral_envelope(self, coded, fs, fft_size):
+        coded = _f64(coded); out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.wo_decode_spectral_envelope(_p(coded), coded.shape[0], fs, fft_size, coded.shape[1], _p(out))
+        return out
 
 
 # The generic binding of the reference's 13-symbol C ABI lives in the product's

@@ -1184,3 +1184,113 @@ void wo_d4c(const double *x, int x_length, int fs, const double *tpos, const dou
   free(nut); free(ap0); free(coarse); free(caxis); free(faxis);
   free(wave); free(c1); free(c2); free(sc); free(sp); free(gd); free(sg); free(re); free(im); free(ps);
 }
+
+/* ------------------------------------------------------------------ */
+/* codec.cpp: band aperiodicity / mel-cepstral envelope coders          */
+/* ------------------------------------------------------------------ */
+static const double K_M0 = 1127.01048, K_F0 = 700.0;   /* constantnumbers.h:45-46 */
+static double mel_of(double f) { return K_M0 * log(f / K_F0 + 1.0); }        /* codec.cpp:59-61 */
+static double freq_of(double m) { return K_F0 * (exp(m / K_M0) - 1.0); }      /* codec.cpp:66-68 */
+
+int wo_number_of_aperiodicities(int fs) {
+  return (int)(dmin(15000.0, fs / 2.0 - 3000.0) / 3000.0);
+}
+
+void wo_code_aperiodicity(const double *ap, int nf, int fs, int fft_size, double *coded) {
+  int nap = wo_number_of_aperiodicities(fs), nb = fft_size / 2 + 1;
+  double *axis = dalloc(nap), *lg = dalloc(nb);
+  for (int i = 0; i < nap; ++i) axis[i] = 3000.0 * (i + 1.0);
+  for (int f = 0; f < nf; ++f) {
+    for (int j = 0; j < nb; ++j) lg[j] = 20 * log10(ap[(size_t)f * nb + j]);
+    wo_interp1q(0, (double)fs / fft_size, lg, nb, axis, nap, coded + (size_t)f * nap);
+  }
+  free(axis); free(lg);
+}
+
+void wo_decode_aperiodicity(const double *coded, int nf, int fs, int fft_size, double *ap) {
+  int nap = wo_number_of_aperiodicities(fs), nb = fft_size / 2 + 1;
+  double *faxis = dalloc(nb), *caxis = dalloc(nap + 2), *coarse = dalloc(nap + 2);
+  for (int i = 0; i < nb; ++i) faxis[i] = (double)fs / fft_size * i;
+  for (int i = 0; i <= nap; ++i) caxis[i] = i * 3000.0;
+  caxis[nap + 1] = fs / 2.0;
+  coarse[0] = -60.0;
+  coarse[nap + 1] = -K_TINY;
+  for (int f = 0; f < nf; ++f) {
+    double *row = ap + (size_t)f * nb, mean = 0.0;
+    for (int j = 0; j < nb; ++j) row[j] = 1.0 - K_TINY;              /* codec.cpp:21-26 */
+    /* CheckVUV (codec.cpp:31-41): note that it stores the frame's values BEFORE deciding,
+     * so `coarse` always holds the current frame's bands */
+    for (int i = 0; i < nap; ++i) { mean += coded[(size_t)f * nap + i]; coarse[i + 1] = coded[(size_t)f * nap + i]; }
+    mean /= nap;
+    if (mean > -0.5) continue;
+    wo_interp1(caxis, coarse, nap + 2, faxis, nb, row);
+    for (int j = 0; j < nb; ++j) row[j] = pow(10.0, row[j] / 20.0);
+  }
+  free(faxis); free(caxis); free(coarse);
+}
+
+void wo_code_spectral_envelope(const double *sp, int nf, int fs, int fft_size, int ndim, double *coded) {
+  int md = fft_size / 2, nb = md + 1;
+  double fm = mel_of(40.0), cm = mel_of(dmin(fs / 2.0, 20000.0));
+  double *mel_axis = dalloc(md), *faxis = dalloc(nb), *wr = dalloc(md), *wi = dalloc(md);
+  /* the reference's r2c leaves bins above md/2 unwritten (fft.cpp:49-60), so dimensions beyond
+   * md/2+1 read stale memory there: meaningful only for ndim <= md/2+1; zero here */
+  double *lg = dalloc(nb), *mel = dalloc(md), *wave = dalloc(md), *re = dalloc(md + 1), *im = dalloc(md + 1);
+  for (int i = 0; i < md; ++i) {                                       /* codec.cpp:162-180 */
+    mel_axis[i] = (cm - fm) * i / md + fm;
+    wr[i] = 2.0 * cos(i * K_PI / fft_size) / sqrt(fft_size);
+    wi[i] = 2.0 * sin(i * K_PI / fft_size) / sqrt(fft_size);
+  }
+  wr[0] /= sqrt(2.0);
+  for (int i = 0; i <= md; ++i) faxis[i] = mel_of((double)i * fs / fft_size);
+  double norm = sqrt(md);
+  for (int f = 0; f < nf; ++f) {
+    for (int j = 0; j < nb; ++j) lg[j] = log(sp[(size_t)f * nb + j]);
+    wo_interp1(faxis, lg, nb, mel_axis, md, mel);                       /* codec.cpp:120-130 */
+    for (int i = 0; i < md / 2; ++i) {                                  /* codec.cpp:73-87 */
+      wave[i] = mel[i * 2];
+      wave[i + md / 2] = mel[md - (i * 2) - 1];
+    }
+    wo_rfft(md, wave, re, im);
+    for (int i = 0; i < ndim; ++i)
+      coded[(size_t)f * ndim + i] = (re[i] * wr[i] - im[i] * wi[i]) / norm;
+  }
+  free(mel_axis); free(faxis); free(wr); free(wi); free(lg); free(mel); free(wave); free(re); free(im);
+}
+
+void wo_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_size, int ndim, double *sp) {
+  int md = fft_size / 2, nb = md + 1;
+  double fm = mel_of(40.0), cm = mel_of(dmin(fs / 2.0, 20000.0));
+  double *mel_axis = dalloc(md + 2), *faxis = dalloc(nb), *wr = dalloc(md), *wi = dalloc(md);
+  double *mel = dalloc(md + 2), *zr = dalloc(md), *zi = dalloc(md);
+  for (int i = 0; i < ndim; ++i) {                                     /* codec.cpp:185-207 */
+    wr[i] = cos(i * K_PI / fft_size) * sqrt(fft_size);
+    wi[i] = sin(i * K_PI / fft_size) * sqrt(fft_size);
+  }
+  wr[0] /= sqrt(2.0);
+  for (int i = 0; i < md; ++i) mel_axis[i + 1] = freq_of((cm - fm) * i / md + fm);
+  mel_axis[0] = 0;
+  mel_axis[md + 1] = fs / 2.0;
+  for (int i = 0; i < nb; ++i) faxis[i] = (double)i * fs / fft_size;
+  double norm = sqrt(md);
+  for (int f = 0; f < nf; ++f) {
+    const double *c = coded + (size_t)f * ndim;
+    for (int i = 0; i < md; ++i) {                                     /* codec.cpp:93-115 */
+      zr[i] = i < ndim ? c[i] * wr[i] * norm : 0.0;
+      zi[i] = i < ndim ? -c[i] * wi[i] * norm : 0.0;
+    }
+    /* the reference's backward c2c (fft.cpp:36-45) returns conj(sum in[j] e^{-2 pi i jk/n});
+     * only its real part is read here */
+    cfft(md, zr, zi, -1);
+    for (int i = 0; i < md / 2; ++i) {
+      mel[1 + i * 2] = zr[i];
+      mel[1 + i * 2 + 1] = zr[md - i - 1];
+    }
+    mel[0] = mel[1];
+    mel[md + 1] = mel[md];
+    double *row = sp + (size_t)f * nb;
+    wo_interp1(mel_axis, mel, md + 2, faxis, nb, row);                  /* codec.cpp:138-156 */
+    for (int j = 0; j < nb; ++j) row[j] = exp(row[j] / md);
+  }
+  free(mel_axis); free(faxis); free(wr); free(wi); free(mel); free(zr); free(zi);
+}

@@ -58,6 +58,18 @@ void wo_d4c(const double *x, int x_length, int fs, const double *tpos,
             const double *f0, int nf, int fft_size, double threshold,
             double *aperiodicity);
 
+
+/* codec: contiguous row-major [nf][*] arrays in and out */
+int  wo_number_of_aperiodicities(int fs);                              /* codec.cpp:212-215 */
+void wo_code_aperiodicity(const double *ap, int nf, int fs, int fft_size,
+                          double *coded);                              /* codec.cpp:217-236 */
+void wo_decode_aperiodicity(const double *coded, int nf, int fs, int fft_size,
+                            double *ap);                               /* codec.cpp:238-266 */
+void wo_code_spectral_envelope(const double *sp, int nf, int fs, int fft_size,
+                               int ndim, double *coded);               /* codec.cpp:268-297 */
+void wo_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_size,
+                                 int ndim, double *sp);                /* codec.cpp:299-324 */
+
 #ifdef __cplusplus
 }
 #endif

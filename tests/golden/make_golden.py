@@ -51,9 +51,33 @@ def analyse(R, q, fs, f0_method, f0_floor_est, row_step, frame_period=5.0, q1=-0
     return out
 
 
+def codec_fixture(R):
+    """Reference codec (src/codec.cpp) outputs for rows of the analysis fixtures above."""
+    out = {}
+    for name in ("vaiueo2d_harvest", "vowel48k_harvest", "vowel16k_dio"):
+        g = dict(np.load(os.path.join(OUT, name + ".npz")))
+        fs, fft = int(g["fs"]), int(g["fft_size"])
+        sp, ap = g["sp_rows"][:12], g["ap_rows"][:12]
+        for nd in (24, 60):
+            coded = R.code_spectral_envelope(sp, fs, fft, nd)
+            out[f"{name}.mcep{nd}"] = coded
+            out[f"{name}.sp_from_mcep{nd}"] = R.decode_spectral_envelope(coded, fs, fft)[:4]
+        bap = R.code_aperiodicity(ap, fs, fft)
+        bap_in = bap.copy()
+        bap_in[::5] = -0.2                         # frames CheckVUV treats as aperiodic (codec.cpp:31-41)
+        out[f"{name}.bap"] = bap
+        out[f"{name}.bap_in"] = bap_in
+        out[f"{name}.ap_from_bap"] = R.decode_aperiodicity(bap_in, fs, fft)
+    np.savez_compressed(os.path.join(OUT, "codec.npz"), **out)
+
+
 def main():
     build()
     R = RefOracle()
+    if "--codec-only" in sys.argv:
+        codec_fixture(R)
+        print("codec.npz", os.path.getsize(os.path.join(OUT, "codec.npz")) // 1024, "KiB")
+        return
     q, fs = wav_int16("/root/reference/test/vaiueo2d.wav")
     # config 0 plumbing of test/test.cpp:89-219 (DIO floor 40 + StoneMask) and its Harvest variant
     np.savez_compressed(os.path.join(OUT, "vaiueo2d_dio.npz"), **analyse(R, q, fs, "dio", 40.0, 4))
@@ -75,6 +99,7 @@ def main():
                          1.1797650642693043, -0.25188251212239265]),
         interp_x=np.array([1., 2., 4., 7.]), interp_xi=np.array([-1, .5, 1, 1.5, 2, 3.9, 4, 7, 9.]),
         interp_yi=np.array([-10, 5, 10, 15, 20, 39, 40, 70, 90.]))
+    codec_fixture(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -29,6 +29,9 @@ def test_header_declares_the_reference_api():
                  "GetSamplesForHarvest", "StoneMask", "CheapTrick", "InitializeCheapTrickOption",
                  "GetFFTSizeForCheapTrick", "GetF0FloorForCheapTrick", "D4C", "InitializeD4COption"]:
         assert must in names          # the 13 symbols of SURVEY.md 8b
+    for must in ["GetNumberOfAperiodicities", "CodeAperiodicity", "DecodeAperiodicity", "CodeSpectralEnvelope",
+                 "DecodeSpectralEnvelope"]:
+        assert must in names          # every public symbol of codec.o
 
 
 def test_library_exports_every_declared_symbol(lib_path):

@@ -203,3 +203,29 @@ def test_full_size_properties(wh):
     f_true = 140.0 + 40.0 * torch.sin(2 * np.pi * 0.7 * t) + 3.0 * torch.sin(2 * np.pi * 5.5 * t)
     err = ((f0[0] - f_true).abs() / f_true)[voiced]
     assert err.median().item() < 0.01
+
+
+def test_concurrent_dropin_calls_from_host_threads(hip):
+    """the reference is re-entrant, so callers may analyse from several host
+    threads at once; the drop-in serialises them on its context and every thread must get
+    exactly the single-threaded result."""
+    import threading
+    from world_amd import synth
+    xs = [synth.vowel(16000, 0.4 + 0.05 * i, seed=100 + i, base_f0=120.0 + 15 * i).numpy() for i in range(6)]
+    want = []
+    for x in xs:
+        tp, f0 = hip.dio(x, 16000)
+        want.append((tp, f0, hip.cheaptrick(x, 16000, tp, f0, fft_size=1024)))
+    got = [None] * len(xs)
+
+    def work(i):
+        tp, f0 = hip.dio(xs[i], 16000)
+        got[i] = (tp, f0, hip.cheaptrick(xs[i], 16000, tp, f0, fft_size=1024))
+
+    for _ in range(3):
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        for w, g in zip(want, got):
+            for a, b in zip(w, g):
+                assert np.array_equal(a, b)

@@ -74,6 +74,11 @@ def load_library(path=LIB_PATH):
                                                C.POINTER(CheapTrickOption), vp]
     lib.world_hip_d4c_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp, C.c_int,
                                         C.POINTER(D4COption), vp]
+    lib.world_hip_code_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.world_hip_decode_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.world_hip_code_aperiodicity.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.world_hip_decode_aperiodicity.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.GetNumberOfAperiodicities.argtypes = [C.c_int]
     lib.GetFFTSizeForCheapTrick.argtypes = [C.c_int, C.POINTER(CheapTrickOption)]
     lib.world_hip_profile_enable.argtypes = [C.c_int]
     lib.world_hip_profile_collect.argtypes = [C.c_char_p, C.c_int]
@@ -137,6 +142,12 @@ class HostAPI:
         L.GetF0FloorForCheapTrick.argtypes = [C.c_int, C.c_int]
         L.GetF0FloorForCheapTrick.restype = C.c_double
         L.InitializeCheapTrickOption.argtypes = [C.c_int, C.POINTER(CheapTrickOption)]
+        rows = C.POINTER(_dp)                # codec.h:33-88
+        L.GetNumberOfAperiodicities.argtypes = [C.c_int]
+        L.CodeAperiodicity.argtypes = [rows, C.c_int, C.c_int, C.c_int, rows]
+        L.DecodeAperiodicity.argtypes = [rows, C.c_int, C.c_int, C.c_int, rows]
+        L.CodeSpectralEnvelope.argtypes = [rows, C.c_int, C.c_int, C.c_int, C.c_int, rows]
+        L.DecodeSpectralEnvelope.argtypes = [rows, C.c_int, C.c_int, C.c_int, C.c_int, rows]
 
     def frame_count(self, fs, n, frame_period):
         return frame_count(fs, n, frame_period)
@@ -186,6 +197,34 @@ class HostAPI:
         ap = np.zeros((len(f0), fft_size // 2 + 1))
         self.lib.D4C(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, C.byref(opt), _rows(ap))
         return ap
+
+    # -- codec (reference codec.h) --
+    def number_of_aperiodicities(self, fs):
+        return self.lib.GetNumberOfAperiodicities(fs)
+
+    def code_aperiodicity(self, ap, fs, fft_size):
+        ap = _f64(ap)
+        out = np.zeros((ap.shape[0], self.number_of_aperiodicities(fs)))
+        self.lib.CodeAperiodicity(_rows(ap), ap.shape[0], fs, fft_size, _rows(out))
+        return out
+
+    def decode_aperiodicity(self, coded, fs, fft_size):
+        coded = _f64(coded)
+        out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.DecodeAperiodicity(_rows(coded), coded.shape[0], fs, fft_size, _rows(out))
+        return out
+
+    def code_spectral_envelope(self, sp, fs, fft_size, ndim):
+        sp = _f64(sp)
+        out = np.zeros((sp.shape[0], ndim))
+        self.lib.CodeSpectralEnvelope(_rows(sp), sp.shape[0], fs, fft_size, ndim, _rows(out))
+        return out
+
+    def decode_spectral_envelope(self, coded, fs, fft_size):
+        coded = _f64(coded)
+        out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.DecodeSpectralEnvelope(_rows(coded), coded.shape[0], fs, fft_size, coded.shape[1], _rows(out))
+        return out
 
 
 class WorldHip:
@@ -318,6 +357,31 @@ class WorldHip:
                                                  nf.ctypes.data_as(_ip), F, tpos.data_ptr(), f0.data_ptr(),
                                                  fft_size, C.byref(opt), ap.data_ptr()), "d4c")
         return ap
+
+    # ---- coders (reference codec.h): dense [..., cols] tensors, leading dims are rows ----
+    def _codec(self, fn, what, src, fs, fft_size, out_cols, *dims):
+        t = self.torch
+        src = src.contiguous()
+        rows = int(src.numel() // src.shape[-1])
+        out = t.empty(tuple(src.shape[:-1]) + (out_cols,), dtype=t.float64, device=src.device)
+        self._check(fn(self._context(), rows, fs, fft_size, *dims, src.data_ptr(), out.data_ptr()), what)
+        return out
+
+    def code_spectral_envelope(self, sp, fs, fft_size, number_of_dimensions):
+        return self._codec(self.lib.world_hip_code_spectral_envelope, "code_spectral_envelope", sp, fs, fft_size,
+                           number_of_dimensions, number_of_dimensions)
+
+    def decode_spectral_envelope(self, coded, fs, fft_size):
+        return self._codec(self.lib.world_hip_decode_spectral_envelope, "decode_spectral_envelope", coded, fs,
+                           fft_size, fft_size // 2 + 1, int(coded.shape[-1]))
+
+    def code_aperiodicity(self, ap, fs, fft_size):
+        return self._codec(self.lib.world_hip_code_aperiodicity, "code_aperiodicity", ap, fs, fft_size,
+                           self.lib.GetNumberOfAperiodicities(fs))
+
+    def decode_aperiodicity(self, coded, fs, fft_size):
+        return self._codec(self.lib.world_hip_decode_aperiodicity, "decode_aperiodicity", coded, fs, fft_size,
+                           fft_size // 2 + 1)
 
     def analyze(self, x, fs, x_len=None, f0_method="harvest", frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
                 q1=-0.15, threshold=0.85, sp_out=None, ap_out=None):

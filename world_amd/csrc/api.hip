@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "bandfilter.h"
+#include "codec.h"
 #include "decimate.h"
 #include "dio.h"
 #include "harvest.h"
@@ -69,6 +70,7 @@ struct WorldHipContext {
   double *d_nuttall = nullptr;   // D4C band window
   int nuttall_len = 0;
   void *dio_bands = nullptr;     // world_hip::DioBands (cached DIO filter tables)
+  void *codec_tables = nullptr;  // world_hip::CodecTableSet (cached interp1 / DCT tables of the coders)
   double *d_noise = nullptr;     // noise[k] = k-th randn() after reseed (grow-only constant table)
   size_t noise_len = 0;
   // pinned, double-buffered staging for the small per-call host arrays
@@ -535,6 +537,152 @@ static void run_stonemask(WorldHipContext *c, int n_utt, int fs, const double *d
 }
 
 // ---------------------------------------------------------------------------
+// Codec (reference src/codec.cpp): every table depends on (fs, fft_size) only
+// ---------------------------------------------------------------------------
+struct CodecTables {
+  int fs = 0, fft_size = 0;
+  int *d_knot_code = nullptr, *d_knot_dec = nullptr, *d_knot_ap = nullptr;
+  double *d_frac_code = nullptr, *d_frac_dec = nullptr, *d_frac_ap = nullptr;
+  double *d_wc_re = nullptr, *d_wc_im = nullptr, *d_wd_re = nullptr, *d_wd_im = nullptr;
+};
+struct CodecTableSet { std::vector<CodecTables> sets; };
+
+// interp1's histc + weights (matlabfunctions.cpp:136-176) for fixed knots x and queries xi
+static void interp1_tables(const std::vector<double> &x, const std::vector<double> &xi, std::vector<int> *knot,
+                           std::vector<double> *frac) {
+  const int n = (int)x.size();
+  knot->resize(xi.size()); frac->resize(xi.size());
+  for (size_t i = 0; i < xi.size(); ++i) {
+    int c = 0;
+    while (c < n && x[c] <= xi[i]) ++c;
+    const int k = c < 1 ? 1 : (c > n - 1 ? n - 1 : c);
+    (*knot)[i] = k;
+    (*frac)[i] = (xi[i] - x[k - 1]) / (x[k] - x[k - 1]);
+  }
+}
+
+template <class T> static T *to_device(WorldHipContext *c, const std::vector<T> &v) {
+  T *d = static_cast<T *>(devrt::dmalloc(sizeof(T) * std::max<size_t>(v.size(), 1)));
+  if (!v.empty()) devrt::h2d(d, v.data(), sizeof(T) * v.size(), c->stream);
+  return d;
+}
+
+static const CodecTables &codec_tables(WorldHipContext *c, int fs, int fft_size) {
+  CodecTableSet *set = static_cast<CodecTableSet *>(c->codec_tables);
+  for (const CodecTables &t : set->sets)
+    if (t.fs == fs && t.fft_size == fft_size) return t;
+  const int md = fft_size / 2, nb = md + 1;
+  const double kM0 = 1127.01048, kF0 = 700.0;                          // constantnumbers.h:45-46
+  auto mel_of = [&](double f) { return kM0 * log(f / kF0 + 1.0); };    // codec.cpp:59-61
+  auto freq_of = [&](double m) { return kF0 * (exp(m / kM0) - 1.0); }; // codec.cpp:66-68
+  const double floor_mel = mel_of(40.0), ceil_mel = mel_of(std::min(fs / 2.0, 20000.0));
+  std::vector<int> knot;
+  std::vector<double> frac;
+  CodecTables t;
+  t.fs = fs; t.fft_size = fft_size;
+  {  // GetParametersForCoding, codec.cpp:162-180
+    std::vector<double> mel_axis(md), faxis(nb), wr(md), wi(md);
+    for (int i = 0; i < md; ++i) {
+      mel_axis[i] = (ceil_mel - floor_mel) * i / md + floor_mel;
+      wr[i] = 2.0 * cos(i * kPi / fft_size) / sqrt(static_cast<double>(fft_size));
+      wi[i] = 2.0 * sin(i * kPi / fft_size) / sqrt(static_cast<double>(fft_size));
+    }
+    wr[0] /= sqrt(2.0);
+    for (int i = 0; i <= md; ++i) faxis[i] = mel_of(static_cast<double>(i) * fs / fft_size);
+    interp1_tables(faxis, mel_axis, &knot, &frac);
+    t.d_knot_code = to_device(c, knot); t.d_frac_code = to_device(c, frac);
+    t.d_wc_re = to_device(c, wr); t.d_wc_im = to_device(c, wi);
+    devrt::sync(c->stream);
+  }
+  {  // GetParametersForDecoding, codec.cpp:185-207
+    std::vector<double> mel_axis(md + 2), faxis(nb), wr(md), wi(md);
+    for (int i = 0; i < md; ++i) {
+      wr[i] = cos(i * kPi / fft_size) * sqrt(static_cast<double>(fft_size));
+      wi[i] = sin(i * kPi / fft_size) * sqrt(static_cast<double>(fft_size));
+      mel_axis[i + 1] = freq_of((ceil_mel - floor_mel) * i / md + floor_mel);
+    }
+    wr[0] /= sqrt(2.0);
+    mel_axis[0] = 0;
+    mel_axis[md + 1] = fs / 2.0;
+    for (int i = 0; i < nb; ++i) faxis[i] = static_cast<double>(i) * fs / fft_size;
+    interp1_tables(mel_axis, faxis, &knot, &frac);
+    t.d_knot_dec = to_device(c, knot); t.d_frac_dec = to_device(c, frac);
+    t.d_wd_re = to_device(c, wr); t.d_wd_im = to_device(c, wi);
+    devrt::sync(c->stream);
+  }
+  {  // DecodeAperiodicity's axes, codec.cpp:242-250
+    const int nap = static_cast<int>(std::min(15000.0, fs / 2.0 - 3000.0) / 3000.0);
+    std::vector<double> caxis(std::max(nap, 0) + 2), faxis(nb);
+    for (int i = 0; i <= nap; ++i) caxis[i] = i * 3000.0;
+    caxis[std::max(nap, 0) + 1] = fs / 2.0;
+    for (int i = 0; i < nb; ++i) faxis[i] = static_cast<double>(fs) / fft_size * i;
+    interp1_tables(caxis, faxis, &knot, &frac);
+    t.d_knot_ap = to_device(c, knot); t.d_frac_ap = to_device(c, frac);
+    devrt::sync(c->stream);
+  }
+  set->sets.push_back(t);
+  return set->sets.back();
+}
+
+static void free_codec_tables(WorldHipContext *c) {
+  CodecTableSet *set = static_cast<CodecTableSet *>(c->codec_tables);
+  if (!set) return;
+  for (CodecTables &t : set->sets) {
+    devrt::dfree(t.d_knot_code); devrt::dfree(t.d_knot_dec); devrt::dfree(t.d_knot_ap);
+    devrt::dfree(t.d_frac_code); devrt::dfree(t.d_frac_dec); devrt::dfree(t.d_frac_ap);
+    devrt::dfree(t.d_wc_re); devrt::dfree(t.d_wc_im); devrt::dfree(t.d_wd_re); devrt::dfree(t.d_wd_im);
+  }
+  delete set;
+  c->codec_tables = nullptr;
+}
+
+static int number_of_aperiodicities(int fs) {                          // codec.cpp:212-215
+  return static_cast<int>(std::min(15000.0, fs / 2.0 - 3000.0) / 3000.0);
+}
+
+enum CodecOp { kCodeSp, kDecodeSp, kCodeAp, kDecodeAp };
+static void run_codec(WorldHipContext *c, CodecOp op, int rows, int fs, int fft_size, int ndim, const double *d_in,
+                      double *d_out) {
+  if (rows < 0) fail("negative row count");
+  if (rows == 0) return;
+  if (fs <= 0) fail("fs must be positive");
+  if (!d_in || !d_out) fail("null buffer");
+  const int lg = ilog2_exact(fft_size);
+  CodecParams p;
+  p.in = d_in; p.out = d_out; p.rows = rows; p.fs = fs; p.fft_size = fft_size; p.lg_md = lg - 1; p.ndim = ndim;
+  p.tab = c->tab;
+  p.knot = nullptr; p.frac = nullptr; p.w_re = nullptr; p.w_im = nullptr;
+  if (op == kCodeSp || op == kDecodeSp) {
+    if (lg < 7 || lg > 13) fail("codec: fft_size %d unsupported (128..8192)", fft_size);
+    // the DCT is one real FFT of fft_size/2 points: it has fft_size/4+1 bins (the reference reads
+    // never-written plan memory beyond them, codec.cpp:84-86)
+    if (ndim < 1 || ndim > fft_size / 4 + 1) fail("codec: number_of_dimensions %d outside [1, fft_size/4+1]", ndim);
+  } else {
+    p.ndim = number_of_aperiodicities(fs);
+    if (p.ndim < 1) fail("codec: fs=%d has no aperiodicity band (needs fs >= 12 kHz)", fs);
+    if (3000.0 * p.ndim > fs / 2.0) fail("codec: band centre beyond fs/2");
+  }
+  const CodecTables &t = codec_tables(c, fs, fft_size);
+  switch (op) {
+    case kCodeSp:
+      p.knot = t.d_knot_code; p.frac = t.d_frac_code; p.w_re = t.d_wc_re; p.w_im = t.d_wc_im;
+      launch_code_spectral_envelope(p, c->stream);
+      break;
+    case kDecodeSp:
+      p.knot = t.d_knot_dec; p.frac = t.d_frac_dec; p.w_re = t.d_wd_re; p.w_im = t.d_wd_im;
+      launch_decode_spectral_envelope(p, c->stream);
+      break;
+    case kCodeAp:
+      launch_code_aperiodicity(p, c->stream);
+      break;
+    case kDecodeAp:
+      p.knot = t.d_knot_ap; p.frac = t.d_frac_ap;
+      launch_decode_aperiodicity(p, c->stream);
+      break;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // error plumbing for the C ABI
 // ---------------------------------------------------------------------------
 template <class F> static int guarded(WorldHipContext *c, F f) {
@@ -576,6 +724,7 @@ WorldHipContext *world_hip_create(int device, void *stream) {
     c->tab.tw = d_tw;
     c->tab.jump = d_jump;
     c->dio_bands = new DioBands;
+    c->codec_tables = new CodecTableSet;
     return c;
   } catch (const std::exception &e) {
     g_last_error = e.what();
@@ -600,6 +749,7 @@ void world_hip_destroy(WorldHipContext *c) {
       }
       delete db;
     }
+    free_codec_tables(c);
     for (int k = 0; k < 2; ++k) {
       if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
       if (c->stage_ev[k]) devrt::event_destroy(c->stage_ev[k]);
@@ -684,6 +834,23 @@ int world_hip_d4c_batch(WorldHipContext *c, int n_utt, int fs, const double *d_x
   return guarded(c, [&] {
     run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, true);
   });
+}
+
+int world_hip_code_spectral_envelope(WorldHipContext *c, int rows, int fs, int fft_size, int number_of_dimensions,
+                                     const double *d_spectrogram, double *d_coded) {
+  return guarded(c, [&] { run_codec(c, kCodeSp, rows, fs, fft_size, number_of_dimensions, d_spectrogram, d_coded); });
+}
+int world_hip_decode_spectral_envelope(WorldHipContext *c, int rows, int fs, int fft_size, int number_of_dimensions,
+                                       const double *d_coded, double *d_spectrogram) {
+  return guarded(c, [&] { run_codec(c, kDecodeSp, rows, fs, fft_size, number_of_dimensions, d_coded, d_spectrogram); });
+}
+int world_hip_code_aperiodicity(WorldHipContext *c, int rows, int fs, int fft_size, const double *d_aperiodicity,
+                                double *d_coded) {
+  return guarded(c, [&] { run_codec(c, kCodeAp, rows, fs, fft_size, 0, d_aperiodicity, d_coded); });
+}
+int world_hip_decode_aperiodicity(WorldHipContext *c, int rows, int fs, int fft_size, const double *d_coded,
+                                  double *d_aperiodicity) {
+  return guarded(c, [&] { run_codec(c, kDecodeAp, rows, fs, fft_size, 0, d_coded, d_aperiodicity); });
 }
 
 }  // extern "C"

@@ -40,7 +40,7 @@ __device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2
   __syncthreads();
   TwLds t; t.q = q; t.lg = lg; return t;
 }
-__device__ __forceinline__ size_t twiddle_lds_doubles(int lg) { return (size_t)(1 << (lg - 2)) + 2; }
+__host__ __device__ __forceinline__ size_t twiddle_lds_doubles(int lg) { return (size_t)(1 << (lg - 2)) + 2; }
 
 // e^{-2 pi i k / 2^lg} (forward, sign=-1) or its conjugate (sign=+1), 0 <= k < 2^lg
 __device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign) {

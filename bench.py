@@ -225,6 +225,39 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
                     "note": "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~6 MFLOP/frame vs 18.3 kB/frame"}
 
+    # ---- coders behind the path: reported beside the metric, never part of `value` ----
+    codec = None
+    if rank == 0:
+        sp, ap = sp_bufs[0], ap_bufs[0]
+        with torch.cuda.stream(streams[0]):
+            for _ in range(2):
+                mcep = wh.code_spectral_envelope(sp, FS, FFT_SIZE, 60)
+                bap = wh.code_aperiodicity(ap, FS, FFT_SIZE)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                mcep = wh.code_spectral_envelope(sp, FS, FFT_SIZE, 60)
+                bap = wh.code_aperiodicity(ap, FS, FFT_SIZE)
+            e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        cbytes = nf * B * 8 * (2 * (FFT_SIZE // 2 + 1) + mcep.shape[-1] + bap.shape[-1])
+        codec = {"workload": f"CodeSpectralEnvelope(60 dims) + CodeAperiodicity on the step's {nf * B} frames",
+                 "ms": ms, "frames_per_s": nf * B / (ms * 1e-3),
+                 "roofline": {"bound": "hbm", "achieved": cbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": cbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_bytes": cbytes}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.loader import best_oracle
+            orc = best_oracle()
+            sp_h, ap_h = sp[0].cpu().numpy(), ap[0].cpu().numpy()
+            t1 = time.perf_counter()
+            orc.code_spectral_envelope(sp_h, FS, FFT_SIZE, 60)
+            orc.code_aperiodicity(ap_h, FS, FFT_SIZE)
+            codec["cpu_baseline"] = {"value": nf / (time.perf_counter() - t1), "unit": "frames/s", "cores": 1,
+                                     "kind": orc.kind, "sample": f"the same {nf} frames, one call each"}
+
     cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x_host = xs[0].cpu().numpy()
@@ -249,7 +282,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
                 kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-            "single_job_latency_ms": lat,
+            "single_job_latency_ms": lat, "codec": codec,
             "workspace_bytes": sum(w.workspace_bytes() for w in whs),
         }
         print(json.dumps(out))

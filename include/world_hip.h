@@ -152,6 +152,10 @@ WORLD_HIP_API int world_hip_d4c_batch(WorldHipContext *ctx, int n_utt, int fs, c
                                       int f_stride, const double *d_tpos, const double *d_f0,
                                       int fft_size, const D4COption *option, double *d_aperiodicity);
 
+/* 16-bit PCM (as stored in a WAV file) -> the doubles the reference's wavread() produces,
+ * x = q / 32768 (tools/audioio.cpp:236-249), on the device: upload int16, not FP64. */
+WORLD_HIP_API int world_hip_pcm16_to_double(WorldHipContext *ctx, long long n, const short *d_pcm, double *d_x);
+
 /* Coders on dense device rows (reference src/codec.cpp:217-324).  Rows are independent:
  *   spectrogram / aperiodicity  [rows][fft_size/2+1]
  *   coded spectral envelope     [rows][number_of_dimensions]

@@ -229,3 +229,46 @@ def test_concurrent_dropin_calls_from_host_threads(hip):
         for w, g in zip(want, got):
             for a, b in zip(w, g):
                 assert np.array_equal(a, b)
+
+
+def test_pcm16_upload_path(wh):
+    """int16 widened on the device is bit-identical to wavread()'s q / 32768 (audioio.cpp:236-249)"""
+    import torch
+    q = torch.randint(-32768, 32768, (3, 48000), dtype=torch.int16)
+    q[0, :4] = torch.tensor([-32768, 32767, 0, -1], dtype=torch.int16)
+    x = wh.pcm16_to_double(q.cuda())
+    assert torch.equal(x.cpu(), q.double() / 32768.0)
+
+
+def test_unmodified_reference_test_program_runs_on_the_drop_in(tmp_path):
+    """INTEGRATION.md's link recipe, executed: the reference's own test/test.cpp, compiled
+    unmodified (oracle/Makefile), once against the reference archive alone and once with
+    libworld_hip.so supplying Harvest / CheapTrick / D4C.  Both analyse-and-resynthesise the
+    same WAV; the three output files must agree to the 16-bit LSB."""
+    import os
+    import subprocess
+    import wave
+    ref_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    exe_ref, exe_hip = os.path.join(ref_dir, "test_ref"), os.path.join(ref_dir, "test_hip")
+    if not (os.path.exists(exe_ref) and os.path.exists(exe_hip)):
+        pytest.skip("oracle/_ref test programs were not prebuilt (needs /root/reference at build time)")
+    g = load_golden("vaiueo2d_harvest")
+    src = str(tmp_path / "in.wav")
+    with wave.open(src, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(g["fs"])
+        w.writeframes(g["q"].astype("<i2").tobytes())
+    outs = {}
+    for tag, exe in (("ref", exe_ref), ("hip", exe_hip)):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([exe, src, "out.wav"], cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "complete." in r.stdout, r.stdout + r.stderr
+        outs[tag] = []
+        for k in ("01", "02", "03"):
+            with wave.open(str(d / f"{k}out.wav")) as w:
+                outs[tag].append(np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.int32))
+    for a, b in zip(outs["ref"], outs["hip"]):
+        assert a.shape == b.shape and a.size > 0
+        diff = np.abs(a - b)
+        assert diff.max() <= 1, f"max sample difference {diff.max()} LSB"
+        assert np.mean(diff > 0) < 1e-3

@@ -74,6 +74,7 @@ def load_library(path=LIB_PATH):
                                                C.POINTER(CheapTrickOption), vp]
     lib.world_hip_d4c_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp, C.c_int,
                                         C.POINTER(D4COption), vp]
+    lib.world_hip_pcm16_to_double.argtypes = [vp, C.c_longlong, vp, vp]
     lib.world_hip_code_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.world_hip_decode_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.world_hip_code_aperiodicity.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -357,6 +358,16 @@ class WorldHip:
                                                  nf.ctypes.data_as(_ip), F, tpos.data_ptr(), f0.data_ptr(),
                                                  fft_size, C.byref(opt), ap.data_ptr()), "d4c")
         return ap
+
+    def pcm16_to_double(self, pcm):
+        """int16 samples (any shape) -> float64 / 32768, wavread()'s convention, on the device"""
+        t = self.torch
+        assert pcm.dtype == t.int16
+        pcm = pcm.contiguous()
+        x = t.empty(pcm.shape, dtype=t.float64, device=pcm.device)
+        self._check(self.lib.world_hip_pcm16_to_double(self._context(), pcm.numel(), pcm.data_ptr(), x.data_ptr()),
+                    "pcm16_to_double")
+        return x
 
     # ---- coders (reference codec.h): dense [..., cols] tensors, leading dims are rows ----
     def _codec(self, fn, what, src, fs, fft_size, out_cols, *dims):

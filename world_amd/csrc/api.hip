@@ -640,6 +640,8 @@ static int number_of_aperiodicities(int fs) {                          // codec.
   return static_cast<int>(std::min(15000.0, fs / 2.0 - 3000.0) / 3000.0);
 }
 
+void launch_pcm16_to_double(const short *d_pcm, double *d_x, long n, hipStream_t stream);   // pcm.hip
+
 enum CodecOp { kCodeSp, kDecodeSp, kCodeAp, kDecodeAp };
 static void run_codec(WorldHipContext *c, CodecOp op, int rows, int fs, int fft_size, int ndim, const double *d_in,
                       double *d_out) {
@@ -833,6 +835,14 @@ int world_hip_d4c_batch(WorldHipContext *c, int n_utt, int fs, const double *d_x
                         const double *d_f0, int fft_size, const D4COption *option, double *d_ap) {
   return guarded(c, [&] {
     run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, true);
+  });
+}
+
+int world_hip_pcm16_to_double(WorldHipContext *c, long long n, const short *d_pcm, double *d_x) {
+  return guarded(c, [&] {
+    if (n < 0) fail("negative sample count");
+    if (n > 0 && (!d_pcm || !d_x)) fail("null buffer");
+    if (n > 0) launch_pcm16_to_double(d_pcm, d_x, (long)n, c->stream);
   });
 }
 

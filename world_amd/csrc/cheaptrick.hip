@@ -24,6 +24,13 @@ __device__ __forceinline__ double ct_effective_f0(double f0, double floor_f0) {
   return f0 <= floor_f0 ? kDefaultF0 : f0;              // cheaptrick.cpp:218
 }
 
+// doubles reserved for Z and the smoothing work area that overlays it (even)
+__host__ __device__ __forceinline__ int ct_seg_cap(int N) {
+  const int need = N / 2 + 1 + 2 * (N / 3 + 2) + 1;
+  const int cap = need > N ? need : N;
+  return cap + (cap & 1);
+}
+
 // ---------------------------------------------------------------------------
 __global__ void ct_prepare(CtParams p) {
   DYN_LDS(lds);
@@ -48,20 +55,26 @@ __global__ void ct_prepare(CtParams p) {
 }
 
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ct_frame(CtParams p) {
+#ifdef WORLD_EMU
+constexpr int kCtPerThread = 4096;                    // one emulated thread owns the whole window
+#else
+constexpr int kCtPerThread = 4096 / 256;
+#endif
+__global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   DYN_LDS(lds);
   const int lgn = p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
 
-  // LDS carve-up (bytes): Z: 8N | P: 8(nb+1) | seg: 8*seg_len | scratch: 512
+  // LDS carve-up (doubles): Z: N | seg overflow | P: nb+1 | scratch: 64 | twiddles.  The smoothing
+  // work area `seg` (up to nb + 2(N/3+2) + 1 values) starts on top of Z, which is dead whenever
+  // seg is live, and runs into the small overflow strip behind it: 32 KB per frame instead of 48.
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
-  double *P = Zr + N;
-  const int seg_cap = nb + 2 * (N / 3 + 2) + 1;
-  double *seg = P + (nb + 1);
-  double *scratch = seg + seg_cap + (seg_cap & 1);
+  double *seg = Zr;
+  double *P = Zr + ct_seg_cap(N);
+  double *scratch = P + (nb + 1) + ((nb + 1) & 1);
   const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
@@ -75,26 +88,42 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
   const int hw = mround(1.5 * fs / cf0);
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
-  // window shape into seg; the frame's draws (sample order) come from the noise stream
+  // window shape: every thread keeps the values of its own samples in registers (the FFT
+  // butterflies, not this phase, set the register budget); the frame's draws (sample order)
+  // come from the noise stream
+  double wreg[kCtPerThread];
   double e = 0.0;
-  for (int i = tid; i < wlen; i += nt) {
-    double position = (i - hw) / 1.5 / fs;
-    double w = 0.5 * cospi(position * cf0) + 0.5;       // cos(pi * position * f0), cheaptrick.cpp:101-102
-    seg[i] = w;
+#pragma unroll
+  for (int q = 0; q < kCtPerThread; ++q) {
+    const int i = tid + q * nt;
+    double w = 0.0;
+    if (i < wlen) {
+      double position = (i - hw) / 1.5 / fs;
+      w = 0.5 * cospi(position * cf0) + 0.5;            // cos(pi * position * f0), cheaptrick.cpp:101-102
+    }
+    wreg[q] = w;
     e += w * w;
   }
   e = sqrt(block_sum(e, scratch));
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < wlen; i += nt) {
-    double w = seg[i] / e;
-    seg[i] = w;
-    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kTiny;
-    rfft_in(Z, i) = v;
-    s1 += v; s2 += w;
+#pragma unroll
+  for (int q = 0; q < kCtPerThread; ++q) {
+    const int i = tid + q * nt;
+    if (i < wlen) {
+      const double w = wreg[q] / e;
+      wreg[q] = w;
+      double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kTiny;
+      rfft_in(Z, i) = v;
+      s1 += v; s2 += w;
+    }
   }
   block_sum2(s1, s2, scratch);
   const double coef = s1 / s2;
-  for (int i = tid; i < N; i += nt) rfft_in(Z, i) = i < wlen ? rfft_in(Z, i) - seg[i] * coef : 0.0;
+#pragma unroll
+  for (int q = 0; q < kCtPerThread; ++q) {
+    const int i = tid + q * nt;
+    if (i < N) rfft_in(Z, i) = i < wlen ? rfft_in(Z, i) - wreg[q] * coef : 0.0;
+  }
 
   // ---- GetPowerSpectrum (cheaptrick.cpp:64-82): r2c, |X|^2 -----------------
   block_rfft(Z, lgn, tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
@@ -184,8 +213,7 @@ __global__ void __launch_bounds__(256) ct_frame(CtParams p) {
 // ---------------------------------------------------------------------------
 size_t ct_frame_lds_bytes(int lg_fft) {
   int N = 1 << lg_fft, nb = N / 2 + 1;
-  int seg_cap = nb + 2 * (N / 3 + 2) + 1;
-  return sizeof(double) * (size_t)(N + nb + 1 + seg_cap + (seg_cap & 1) + 64 + N / 4 + 2);
+  return sizeof(double) * (size_t)(ct_seg_cap(N) + nb + 1 + ((nb + 1) & 1) + 64 + N / 4 + 2);
 }
 
 size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size / 2 + 1; }   // window < fft_size, + bins

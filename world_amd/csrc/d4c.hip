@@ -414,23 +414,33 @@ __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
   double *Zr = reinterpret_cast<double *>(lds);
   int *hist = reinterpret_cast<int *>(Zr + N);
   double *scratch = reinterpret_cast<double *>(hist + 512);
-  const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
+  // table for the inner N/2-point complex transform only (the merge step derives its odd twiddles)
+  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   const int bnd = mround(N * 8.0 / p.wl);
   const int hwl = p.wl / 2;
   const int center = static_cast<int>(3000.0 * (band + 1) * N / fs);
-  const double *gd = p.gd + fi * p.gd_stride;
-  for (int i = tid; i < N; i += nt)
-    rfft_in(Z, i) = i <= 2 * hwl ? gd[center - hwl + i] * p.nuttall[i] : 0.0;
+  const double *gd = p.gd + fi * p.gd_stride + (center - hwl);
+  const double *nut = p.nuttall;
+  const int wl = 2 * hwl + 1;
   unsigned long long key[kSelKeys];
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q) key[q] = ~0ull;
   int filled = 0;
-  block_rfft(Z, lgn, tw, [&](int k, double re, double im) {
-    (void)k;
-    key[filled < kSelKeys ? filled : kSelKeys - 1] = (unsigned long long)__double_as_longlong(re * re + im * im);
-    ++filled;
-  });
+  // the windowed slice is short (wl of N samples): the first FFT stage reads it straight from HBM
+  block_rfft_from(Z, lgn, tw,
+    [&](int n) {
+      cplx v; v.re = 0.0; v.im = 0.0;
+      const int i = 2 * n;
+      if (i < wl) v.re = gd[i] * nut[i];
+      if (i + 1 < wl) v.im = gd[i + 1] * nut[i + 1];
+      return v;
+    },
+    [&](int k, double re, double im) {
+      (void)k;
+      key[filled < kSelKeys ? filled : kSelKeys - 1] = (unsigned long long)__double_as_longlong(re * re + im * im);
+      ++filled;
+    });
   double part, tot;
   block_smallest_sum(key, filled, H + 1, H - bnd, hist, scratch, &part, &tot);
   if (tid == 0) {
@@ -481,7 +491,7 @@ size_t d4c_groupdelay_lds_bytes(int lg) {
 }
 size_t d4c_band_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(N + 256 + 64 + N / 4 + 2);
+  return sizeof(double) * (size_t)(N + 256 + 64 + N / 8 + 2);
 }
 
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz

@@ -31,19 +31,25 @@ __device__ __forceinline__ cplx cconj(cplx a) { a.im = -a.im; return a; }
 // Twiddles come from a quarter-wave cosine table staged in LDS by the owning kernel:
 // q[r] = cos(2 pi r / 2^lg), r = 0 .. 2^lg/4.  (A butterfly needs three twiddles; from
 // the HBM table each was an L2-latency gather on the critical path between barriers.)
-struct TwLds { const double *q; int lg; };
+struct TwLds {
+  const double *q; int lg;
+  double fine_c, fine_s;     // cos/sin(2 pi / 2^(lg+1)): one level finer than the table (see twiddle())
+};
 
 // stage the table for transforms up to 2^lg points; call before the first transform
 __device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2 *global_tw) {
   const int quarter = 1 << (lg - 2);
   for (int i = threadIdx.x; i <= quarter; i += blockDim.x) q[i] = global_tw[(size_t)i << (kTwLog2 - lg)].x;
   __syncthreads();
-  TwLds t; t.q = q; t.lg = lg; return t;
+  TwLds t; t.q = q; t.lg = lg;
+  const double2 f = global_tw[lg + 1 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 1) : 0];
+  t.fine_c = f.x; t.fine_s = f.y;
+  return t;
 }
 __host__ __device__ __forceinline__ size_t twiddle_lds_doubles(int lg) { return (size_t)(1 << (lg - 2)) + 2; }
 
 // e^{-2 pi i k / 2^lg} (forward, sign=-1) or its conjugate (sign=+1), 0 <= k < 2^lg
-__device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign) {
+__device__ __forceinline__ cplx twiddle_table(const TwLds &tw, int k, int lg, int sign) {
   const int K = k << (tw.lg - lg);
   const int quarter = 1 << (tw.lg - 2);
   const int quad = K >> (tw.lg - 2), r = K & (quarter - 1);
@@ -54,6 +60,16 @@ __device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign
   else if (quad == 2) { c = -a; s = -b; }
   else { c = b; s = -a; }
   cplx w; w.re = c; w.im = sign > 0 ? s : -s; return w;
+}
+// A real transform of 2^(tw.lg+1) points needs the table's resolution only for its inner complex
+// transform; its merge step asks for lg = tw.lg + 1 and gets w^k = W^(k>>1) * (k odd ? w^1 : 1).
+__device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign) {
+  if (lg > tw.lg) {
+    cplx a = twiddle_table(tw, k >> 1, tw.lg, sign);
+    if (k & 1) { cplx f; f.re = tw.fine_c; f.im = sign > 0 ? tw.fine_s : -tw.fine_s; a = cmul(a, f); }
+    return a;
+  }
+  return twiddle_table(tw, k, lg, sign);
 }
 // ---------------------------------------------------------------------------
 // Mixed-radix plan: radix-16 stages, then one radix-8/4/2 stage for the remainder.
@@ -196,6 +212,23 @@ template <int LR> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int
     for (int k = 0; k < R; ++k) z[swz(base + k * q)] = a[k];
   }
 }
+// the first DIF stage with its inputs taken from src(n) (element n of the transform) instead of LDS:
+// a caller whose input is computed on the fly, or mostly zero, skips the staging pass and its barrier
+template <int LR, class Src>
+__device__ __forceinline__ void dif_first_stage(cplx *z, int lg, const TwLds &tw, Src src) {
+  constexpr int R = 1 << LR;
+  const int q = 1 << (lg - LR);
+  for (int j = threadIdx.x; j < q; j += blockDim.x) {
+    cplx a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = src(j + r * q);
+    dft_reg<true, LR>(a);
+    if (q > 1) mul_powers<LR>(a, twiddle(tw, j, lg, -1));
+#pragma unroll
+    for (int k = 0; k < R; ++k) z[swz(j + k * q)] = a[k];
+  }
+}
+
 // one decimation-in-time stage: R finished sub-transforms of length 2^done are merged
 template <int LR> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
   constexpr int R = 1 << LR;
@@ -217,6 +250,29 @@ template <int LR> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int
 __device__ __forceinline__ void block_cfft_dif(cplx *z, const FftPlan &p, const TwLds &tw) {
   int lev = p.lg;
   for (int s = 0; s < p.ns; ++s) {
+    __syncthreads();
+    switch (p.rl(s)) {
+      case 4: dif_stage<4>(z, p.lg, lev, tw); break;
+      case 3: dif_stage<3>(z, p.lg, lev, tw); break;
+      case 2: dif_stage<2>(z, p.lg, lev, tw); break;
+      default: dif_stage<1>(z, p.lg, lev, tw); break;
+    }
+    lev -= p.rl(s);
+  }
+  __syncthreads();
+}
+
+template <class Src>
+__device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, const TwLds &tw, Src src) {
+  __syncthreads();                                   // earlier readers of z are done
+  switch (p.rl(0)) {
+    case 4: dif_first_stage<4>(z, p.lg, tw, src); break;
+    case 3: dif_first_stage<3>(z, p.lg, tw, src); break;
+    case 2: dif_first_stage<2>(z, p.lg, tw, src); break;
+    default: dif_first_stage<1>(z, p.lg, tw, src); break;
+  }
+  int lev = p.lg - p.rl(0);
+  for (int s = 1; s < p.ns; ++s) {
     __syncthreads();
     switch (p.rl(s)) {
       case 4: dif_stage<4>(z, p.lg, lev, tw); break;
@@ -256,10 +312,24 @@ __device__ __forceinline__ double &rfft_in(cplx *z, int n) {
   return (n & 1) ? c.im : c.re;
 }
 template <class Emit>
+__device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit);
+
+template <class Emit>
 __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Emit emit) {
-  const int lgh = lgn - 1, h = 1 << lgh;
-  const FftPlan plan = make_plan(lgh);
+  const FftPlan plan = make_plan(lgn - 1);
   block_cfft_dif(z, plan, tw);
+  rfft_merge(z, lgn, plan, tw, emit);
+}
+// same transform with the packed input supplied by src(n) = (x[2n], x[2n+1]), n < N/2: z is pure workspace
+template <class Src, class Emit>
+__device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &tw, Src src, Emit emit) {
+  const FftPlan plan = make_plan(lgn - 1);
+  block_cfft_dif_from(z, plan, tw, src);
+  rfft_merge(z, lgn, plan, tw, emit);
+}
+template <class Emit>
+__device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit) {
+  const int lgh = lgn - 1, h = 1 << lgh;
   // Walk the PHYSICAL slots in lane order (conflict-free wide reads) and emit whichever
   // bin lives there; the mirrored bin h-k then sits in a nearby mirrored slot.  Slot
   // count h, plus one extra item for the Nyquist bin k = h.  Thread t handles items

@@ -186,13 +186,14 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
       double lg = log(smoothed + fabs(noise[wlen + i]) * kEps);
       P[i] = lg;
     }
-    __syncthreads();
-    for (int i = tid; i < N; i += nt) rfft_in(Z, i) = i <= half ? P[i] : P[N - i];
   }
 
   // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
+  // the symmetric extension of the log spectrum is read by the first FFT stage directly from P
   const double q1 = p.q1;
-  block_rfft(Z, lgn, tw, [&](int k, double re, double im) {
+  auto mirrored = [&](int i) { return i <= half ? P[i] : P[N - i]; };
+  block_rfft_from(Z, lgn, tw, [&](int n) { cplx v; v.re = mirrored(2 * n); v.im = mirrored(2 * n + 1); return v; },
+                  [&](int k, double re, double im) {
     (void)im;
     double sl, cl;
     if (k == 0) {

@@ -179,18 +179,20 @@ __device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, 
 }
 
 // Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them: a radix
-// select on the IEEE bit patterns (monotone for non-negative doubles), one byte per
-// pass, histogram in LDS.  Keys stay in registers; bytes shared by all keys (common
-// sign/exponent prefix, found from the block min/max) are skipped, and the walk stops
-// as soon as the bucket holding the threshold contains a single key -- typically after
-// two or three passes instead of eight.  hist: 2 x 256 ints of LDS (ping-pong).
+// select on the IEEE bit patterns (monotone for non-negative doubles), 8 bits per pass,
+// histogram in LDS.  Keys stay in registers.  Digits start at the first bit in which any
+// two keys differ (found from the block min/max), so the first histogram spans exactly
+// [kmin, kmax]; the walk stops as soon as the bucket holding the threshold contains a
+// single key -- typically after two passes.  Barriers: two for min/max, ONE per pass (the
+// first kSelHists histograms are zeroed up front), two for the final sums.
 #ifdef WORLD_EMU
 constexpr int kSelKeys = 4096 / 2 + 1;
 #else
 constexpr int kSelKeys = (4096 / 2 + 1 + 255) / 256;    // 256-thread workgroups
 #endif
-// key[q] = bit pattern of element tid + q*T (~0 = no element).
+constexpr int kSelHists = 3;
 // key[q], q < mine: bit patterns of this thread's elements (n elements block-wide).
+// hist: kSelHists x 256 ints of LDS.
 __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int mine, int n, int m,
                                                    int *hist, double *scratch, double *partial, double *total) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wv = wave_in_block(), nw = waves_per_block();
@@ -198,7 +200,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q)
     if (q < mine) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
-  for (int i = tid; i < 512; i += nt) hist[i] = 0;
+  for (int i = tid; i < kSelHists * 256; i += nt) hist[i] = 0;
 #ifndef WORLD_EMU
   for (int s = 32; s >= 1; s >>= 1) {
     unsigned long long a = __shfl_xor(kmin, s, 64), b = __shfl_xor(kmax, s, 64);
@@ -212,9 +214,6 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 #else
   (void)lane; (void)wv; (void)nw;
 #endif
-  // Digits are taken from the first bit in which any two keys differ (not from byte
-  // boundaries): the first histogram then spans exactly [kmin, kmax], so the keys spread
-  // over up to 256 bins instead of piling into the two or three exponent bytes present.
   const unsigned long long diff = kmin ^ kmax;
   int hi = diff ? 64 - __clzll((long long)diff) : 0;    // bits >= hi are common to every key
   unsigned long long prefix = hi >= 64 ? 0ull : (kmin >> hi) << hi;
@@ -223,15 +222,18 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
   for (int it = 0; hi > 0 && bucket > 1; ++it) {
     const int shift = hi > 8 ? hi - 8 : 0;
     const unsigned long long mask = (1ull << (hi - shift)) - 1ull;
-    int *h = hist + (it & 1) * 256;                 // this pass's histogram (already zero)
-    __syncthreads();
+    int *h = hist + (it % kSelHists) * 256;
+    if (it >= kSelHists) {                          // rare: recycle a histogram
+      __syncthreads();
+      for (int i = tid; i < 256; i += nt) h[i] = 0;
+      __syncthreads();
+    }
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q) {
       const bool in = q < mine && (it == 0 || (key[q] >> hi) == (prefix >> hi));
       if (in) atomicAdd(&h[(int)((key[q] >> shift) & mask)], 1);
     }
     __syncthreads();
-    for (int i = tid; i < 256; i += nt) hist[((it & 1) ^ 1) * 256 + i] = 0;   // next pass's histogram
     // every wave locates the digit redundantly: each lane sums its bins, a wave scan finds the rank
     const int per_lane = 256 / WAVE;
     int local = 0;
@@ -257,29 +259,25 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     prefix |= (unsigned long long)digit << shift;
     hi = shift;
   }
-  if (hi > 0) {
-    // the bucket holds exactly one key: it is the threshold; its owner publishes it
-    unsigned long long *ks2 = reinterpret_cast<unsigned long long *>(scratch) + 48;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kSelKeys; ++q)
-      if (q < mine && (key[q] >> hi) == (prefix >> hi)) ks2[0] = key[q];
-    __syncthreads();
-    prefix = ks2[0];
-  }
-  // keys strictly below the threshold: every key of the lower buckets, i.e. (m-1) - remaining
-  const double thr = __longlong_as_double((long long)prefix);
-  double s_lt = 0.0, s_all = 0.0;
+  // Bits >= hi of the threshold are known.  If hi > 0 the bucket holds exactly one key (the
+  // threshold itself), every other key differs from it above bit hi, and its owner
+  // contributes it through the third sum; if hi == 0 the prefix IS the threshold (possibly
+  // shared by several equal keys, `remaining` of which lie below the rank).
+  const unsigned long long pfx = hi >= 64 ? 0ull : prefix >> hi;
+  double s_lt = 0.0, s_all = 0.0, s_thr = 0.0;
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q) {
     if (q < mine) {
       const double x = __longlong_as_double((long long)key[q]);
+      const unsigned long long top = hi >= 64 ? 0ull : key[q] >> hi;
       s_all += x;
-      if (x < thr) s_lt += x;
+      if (top < pfx) s_lt += x;
+      else if (top == pfx && hi > 0) s_thr += x;
     }
   }
-  (void)n; (void)tid; (void)nt;
-  block_sum2(s_lt, s_all, scratch);
+  (void)n;
+  block_sum3(s_lt, s_all, s_thr, scratch);
+  const double thr = hi > 0 ? s_thr : __longlong_as_double((long long)prefix);
   *partial = s_lt + (remaining + 1) * thr;
   *total = s_all;
 }
@@ -413,7 +411,7 @@ __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   int *hist = reinterpret_cast<int *>(Zr + N);
-  double *scratch = reinterpret_cast<double *>(hist + 512);
+  double *scratch = reinterpret_cast<double *>(hist + kSelHists * 256);
   // table for the inner N/2-point complex transform only (the merge step derives its odd twiddles)
   const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
@@ -491,7 +489,7 @@ size_t d4c_groupdelay_lds_bytes(int lg) {
 }
 size_t d4c_band_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(N + 256 + 64 + N / 8 + 2);
+  return sizeof(double) * (size_t)(N + kSelHists * 128 + 64 + N / 8 + 2);
 }
 
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz

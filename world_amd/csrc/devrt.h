@@ -257,6 +257,21 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch
   (void)scratch;
 #endif
 }
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *scratch) {
+#ifndef WORLD_EMU
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  int nw = waves_per_block();
+  if (nw == 1) return;
+  __syncthreads();
+  if (lane_id() == 0) { scratch[wave_in_block()] = a; scratch[16 + wave_in_block()] = b; scratch[32 + wave_in_block()] = c; }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0, tc = 0.0;
+  for (int w = 0; w < nw; ++w) { ta += scratch[w]; tb += scratch[16 + w]; tc += scratch[32 + w]; }
+  a = ta; b = tb; c = tc;
+#else
+  (void)scratch;
+#endif
+}
 // exclusive scan of one int per thread over the block (thread order); *total = block sum
 __device__ __forceinline__ int block_excl_scan_int(int v, int *total, double *scratch) {
 #ifndef WORLD_EMU
@@ -314,6 +329,32 @@ __device__ __forceinline__ void block_scan_incl_double(double *a, int n, double 
   int chunk = (n + nt - 1) / nt;
   int lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
   __syncthreads();
+#ifndef WORLD_EMU
+  // the thread's chunk is scanned in registers (loads first, then the dependent adds) and
+  // written back once, already offset by everything to its left
+  constexpr int kRegChunk = 12;
+  if (chunk <= kRegChunk) {
+    double v[kRegChunk];
+#pragma unroll
+    for (int q = 0; q < kRegChunk; ++q) v[q] = lo + q < hi ? a[lo + q] : 0.0;
+#pragma unroll
+    for (int q = 1; q < kRegChunk; ++q) v[q] += v[q - 1];
+    const double s = v[kRegChunk - 1];
+    double inc = s;
+    const int lane = lane_id(), w = wave_in_block();
+    for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    __syncthreads();
+    if (lane == 63) scratch[w] = inc;
+    __syncthreads();
+    double base = 0.0;
+    for (int k = 0; k < w; ++k) base += scratch[k];
+    const double off = base + (inc - s);
+#pragma unroll
+    for (int q = 0; q < kRegChunk; ++q) if (lo + q < hi) a[lo + q] = v[q] + off;
+    __syncthreads();
+    return;
+  }
+#endif
   double s = 0.0;
   for (int i = lo; i < hi; ++i) { s += a[i]; a[i] = s; }
 #ifndef WORLD_EMU

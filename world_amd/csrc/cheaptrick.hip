@@ -91,26 +91,24 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   // window shape: every thread keeps the values of its own samples in registers (the FFT
   // butterflies, not this phase, set the register budget); the frame's draws (sample order)
   // come from the noise stream
+  const double win_scale = 1.0 / 1.5 / fs * cf0;        // position * f0 = (i - hw) / 1.5 / fs * f0
   double wreg[kCtPerThread];
   double e = 0.0;
 #pragma unroll
   for (int q = 0; q < kCtPerThread; ++q) {
     const int i = tid + q * nt;
     double w = 0.0;
-    if (i < wlen) {
-      double position = (i - hw) / 1.5 / fs;
-      w = 0.5 * cospi(position * cf0) + 0.5;            // cos(pi * position * f0), cheaptrick.cpp:101-102
-    }
+    if (i < wlen) w = 0.5 * cospi(win_scale * (i - hw)) + 0.5;   // cos(pi * position * f0), cheaptrick.cpp:101-102
     wreg[q] = w;
     e += w * w;
   }
-  e = sqrt(block_sum(e, scratch));
+  e = 1.0 / sqrt(block_sum(e, scratch));
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int q = 0; q < kCtPerThread; ++q) {
     const int i = tid + q * nt;
     if (i < wlen) {
-      const double w = wreg[q] / e;
+      const double w = wreg[q] * e;
       wreg[q] = w;
       double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kTiny;
       rfft_in(Z, i) = v;
@@ -146,12 +144,13 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   const double width = cf0 * 2.0 / 3.0;
   const int bnd = static_cast<int>(width * N / fs) + 1;
   const int seg_len = half + 2 * bnd + 1;
+  const double inv_n = 1.0 / N;
   for (int i = tid; i < seg_len; i += nt) {
     double m;
     if (i < bnd) m = P[bnd - i];
     else if (i < half + bnd) m = P[i - bnd];
     else m = P[half - (i - (half + bnd))];
-    seg[i] = m * fs / N;
+    seg[i] = m * fs * inv_n;                           // == m * fs / N: N is a power of two
   }
   __syncthreads();
   if (tid == 0) {                       // the order-sensitive serial prefix sum
@@ -175,8 +174,11 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   {
     const double origin_axis = -(bnd - 0.5) * fs / N;
     const double step = static_cast<double>(fs) / N;
+    // hi - lo cancels up to 12 digits where the envelope sits at the noise floor:
+    // the interpolation weights and the final quotient keep the reference's exact operations
+    // (true divisions), so that every product rounds as it does there.
     for (int i = tid; i <= half; i += nt) {
-      double fa = static_cast<double>(i) / N * fs - width / 2.0;
+      double fa = static_cast<double>(i) * inv_n * fs - width / 2.0;
       double lo = interp_uniform(origin_axis, step, seg, seg_len, fa);
       fa += width;
       double hi = interp_uniform(origin_axis, step, seg, seg_len, fa);
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
 
   // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
   // the symmetric extension of the log spectrum is read by the first FFT stage directly from P
-  const double q1 = p.q1;
+  const double q1 = p.q1, inv_fs = 1.0 / fs;
   auto mirrored = [&](int i) { return i <= half ? P[i] : P[N - i]; };
   block_rfft_from(Z, lgn, tw, [&](int n) { cplx v; v.re = mirrored(2 * n); v.im = mirrored(2 * n + 1); return v; },
                   [&](int k, double re, double im) {
@@ -200,11 +202,11 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
       sl = 1.0;
       cl = (1.0 - 2.0 * q1) + 2.0 * q1;
     } else {
-      double quef = static_cast<double>(k) / fs;
+      double quef = static_cast<double>(k) * inv_fs;
       sl = sin(kPi * cf0 * quef) / (kPi * cf0 * quef);
       cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * quef * cf0);
     }
-    P[k] = re * sl * cl / N;
+    P[k] = re * sl * cl * inv_n;                        // == .. / N: N is a power of two
   });
   block_irfft(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   double *out = p.spectrogram + ((size_t)u * p.b.f_stride + f) * nb;

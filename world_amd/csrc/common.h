@@ -34,6 +34,18 @@ __device__ __forceinline__ double interp_uniform(double x0, double dx, const dou
   return y[b] + dy * frac;
 }
 
+// Same, with the caller's 1/dx: one FP64 division per query is the dominant cost of the
+// smoothing loops.  (xi - x0) * (1/dx) differs from (xi - x0) / dx by at most an ulp, i.e. the
+// interpolation weight moves by ~1e-13 -- and the interpolant is continuous across knots, so
+// even a flipped bin index changes the value by no more than that.
+__device__ __forceinline__ double interp_uniform_rcp(double x0, double inv_dx, const double *y, int n, double xi) {
+  double p = (xi - x0) * inv_dx;
+  int b = static_cast<int>(p);
+  double frac = p - b;
+  double dy = b < n - 1 ? y[b + 1] - y[b] : 0.0;
+  return y[b] + dy * frac;
+}
+
 // NuttallWindow(), src/common.cpp:113-121
 __device__ __forceinline__ double nuttall_at(int i, int len) {
   double t = i / (len - 1.0);

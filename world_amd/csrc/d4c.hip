@@ -25,14 +25,25 @@
 
 namespace world_hip {
 
+// Development aid (-DWH_TRACE, see tools_trace.py): cycle-counter stamps of one workgroup's
+// phases, read back through world_hip_trace_read().  Compiled out of the product.
+#if defined(WH_TRACE) && !defined(WORLD_EMU)
+__device__ long long wh_trace[128];
+#define WH_STAMP(base, k) do { if (trace_me && threadIdx.x == 0) wh_trace[(base) + (k)] = clock64(); } while (0)
+#else
+#define WH_STAMP(base, k) do { } while (0)
+#endif
+
 constexpr int kHanning = 1, kBlackman = 2;
 
-__device__ __forceinline__ double d4c_window_at(int i, int hw, int kind, double ratio, int fs, double f0) {
-  double position = (2.0 * (i - hw) / ratio) / fs;                  // d4c.cpp:36,41
-  const double c1 = cospi(position * f0);                           // cos(pi * position * f0)
+// window value of sample i; scale = 2 / ratio / fs * f0, so that scale * (i - hw) is
+// position * f0 of d4c.cpp:36,41 (the two divisions hoisted out of the per-sample loop)
+__device__ __forceinline__ double d4c_window_at(int i, int hw, int kind, double scale) {
+  const double c1 = cospi(scale * (i - hw));                        // cos(pi * position * f0)
   if (kind == kHanning) return 0.5 * c1 + 0.5;
   return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);             // cos(2a) = 2 cos^2(a) - 1
 }
+
 
 // ---------------------------------------------------------------------------
 __global__ void d4c_prepare1(D4cParams p) {
@@ -87,18 +98,26 @@ __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, 
   const int hw = mround(ratio * fs / f0 / 2.0);
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
-  auto at = [&](int i) -> double & { return packed ? z[swz(i)].re : rfft_in(z, i); };
+  // Second pass needs each sample's window value again.  The packed layout has a free slot for
+  // it (the imaginary half, overwritten by the caller afterwards); the r2c layout has none, so
+  // the value is recomputed (one cospi, no division).
+  const double scale = 2.0 / ratio / fs * f0;
   double s1 = 0.0, s2 = 0.0;
   for (int i = tid; i < wlen; i += nt) {
-    const double w = d4c_window_at(i, hw, kind, ratio, fs, f0);
+    const double w = d4c_window_at(i, hw, kind, scale);
     // noise[i]: the window's draws in sample order (d4c.cpp:67-69)
     double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kSafeGuardD4C;
-    at(i) = v;
+    if (packed) { cplx e; e.re = v; e.im = w; z[swz(i)] = e; }
+    else rfft_in(z, i) = v;
     s1 += v; s2 += w;
   }
   block_sum2(s1, s2, scratch);
   const double coef = s1 / s2;
-  for (int i = tid; i < wlen; i += nt) at(i) -= d4c_window_at(i, hw, kind, ratio, fs, f0) * coef;
+  if (packed) {
+    for (int i = tid; i < wlen; i += nt) { cplx &e = z[swz(i)]; e.re -= e.im * coef; }
+  } else {
+    for (int i = tid; i < wlen; i += nt) rfft_in(z, i) -= d4c_window_at(i, hw, kind, scale) * coef;
+  }
   __syncthreads();
   return wlen;
 }
@@ -143,23 +162,24 @@ __device__ __forceinline__ void d4c_smooth(const double *in, double width, int f
   const int tid = threadIdx.x, nt = blockDim.x, half = N / 2;
   const int bnd = static_cast<int>(width * N / fs) + 1;
   const int seg_len = half + 2 * bnd + 1;
+  const double inv_n = 1.0 / N;
   __syncthreads();
   for (int i = tid; i < seg_len; i += nt) {
     double m;
     if (i < bnd) m = in[bnd - i];
     else if (i < half + bnd) m = in[i - bnd];
     else m = in[half - (i - (half + bnd))];
-    seg[i] = m * fs / N;
+    seg[i] = m * fs * inv_n;                           // == m * fs / N: N is a power of two
   }
   block_scan_incl_double(seg, seg_len, scratch);
   const double origin_axis = -(bnd - 0.5) * fs / N;
-  const double step = static_cast<double>(fs) / N;
+  const double inv_step = static_cast<double>(N) / fs, inv_width = 1.0 / width;
   for (int i = tid; i <= half; i += nt) {
-    double fa = static_cast<double>(i) / N * fs - width / 2.0;
-    double lo = interp_uniform(origin_axis, step, seg, seg_len, fa);
+    double fa = static_cast<double>(i) * inv_n * fs - width / 2.0;
+    double lo = interp_uniform_rcp(origin_axis, inv_step, seg, seg_len, fa);
     fa += width;
-    double hi = interp_uniform(origin_axis, step, seg, seg_len, fa);
-    out[i] = (hi - lo) / width;
+    double hi = interp_uniform_rcp(origin_axis, inv_step, seg, seg_len, fa);
+    out[i] = (hi - lo) * inv_width;
   }
   __syncthreads();
 }
@@ -188,13 +208,15 @@ __device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, 
 #ifdef WORLD_EMU
 constexpr int kSelKeys = 4096 / 2 + 1;
 #else
-constexpr int kSelKeys = (4096 / 2 + 1 + 255) / 256;    // 256-thread workgroups
+constexpr int kSelKeys = 2 * ((4096 / 4 + 1 + 255) / 256);   // 256-thread workgroups: what block_rfft hands one thread
 #endif
 constexpr int kSelHists = 3;
 // key[q], q < mine: bit patterns of this thread's elements (n elements block-wide).
 // hist: kSelHists x 256 ints of LDS.
 __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int mine, int n, int m,
-                                                   int *hist, double *scratch, double *partial, double *total) {
+                                                   int *hist, double *scratch, double *partial, double *total,
+                                                   bool trace_me = false) {
+  (void)trace_me;
   const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wv = wave_in_block(), nw = waves_per_block();
   unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
@@ -214,6 +236,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 #else
   (void)lane; (void)wv; (void)nw;
 #endif
+  WH_STAMP(0, 3);
   const unsigned long long diff = kmin ^ kmax;
   int hi = diff ? 64 - __clzll((long long)diff) : 0;    // bits >= hi are common to every key
   unsigned long long prefix = hi >= 64 ? 0ull : (kmin >> hi) << hi;
@@ -258,6 +281,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     bucket = hsel;
     prefix |= (unsigned long long)digit << shift;
     hi = shift;
+    WH_STAMP(0, 4 + (it < 3 ? it : 3));
   }
   // Bits >= hi of the threshold are known.  If hi > 0 the bucket holds exactly one key (the
   // threshold itself), every other key differs from it above bit hi, and its owner
@@ -276,6 +300,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     }
   }
   (void)n;
+  WH_STAMP(0, 8);
   block_sum3(s_lt, s_all, s_thr, scratch);
   const double thr = hi > 0 ? s_thr : __longlong_as_double((long long)prefix);
   *partial = s_lt + (remaining + 1) * thr;
@@ -293,6 +318,8 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
+  const bool trace_me = f == 1000; (void)trace_me;
+  WH_STAMP(32, 0);
   const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
   // LDS: Z (N complex + 8) | scratch (64) | twiddles.  The packed centroid transform
   // needs all of Z; afterwards Z is re-carved into the real-FFT / prefix-sum work area
@@ -324,19 +351,23 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
   for (int c = 0; c < 2; ++c) {
     const double cpos = c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
     __syncthreads();
+    WH_STAMP(32, 1 + 5 * c);
     const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
                                   Z, true, scratch);
+    WH_STAMP(32, 2 + 5 * c);
     double pw = 0.0;
     for (int i = tid; i < wlen; i += nt) { const double v = Z[swz(i)].re; pw += v * v; }
     pw = block_sum(pw, scratch);
-    const double nrm = sqrt(pw);
+    const double inv_nrm = 1.0 / sqrt(pw);
     for (int i = tid; i < N; i += nt) {
       cplx &e = Z[swz(i)];
-      double v = i < wlen ? e.re / nrm : 0.0;
+      double v = i < wlen ? e.re * inv_nrm : 0.0;
       e.re = v;
       e.im = v * (i + 1.0);                          // second transform's input (d4c.cpp:111-112)
     }
+    WH_STAMP(32, 3 + 5 * c);
     block_cfft_dif(Z, plan_c, tw);
+    WH_STAMP(32, 4 + 5 * c);
     // Bins k <= H in an order that makes consecutive lanes read consecutive physical
     // slots (conflict-free): bins below H are exactly the slots whose last-stage digit
     // has its top bit clear.  Item `it` names the same bin in both centroid passes.
@@ -360,6 +391,7 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
       double cen = x2r * x1r + x1i * x2i;            // d4c.cpp:115-116
       a_reg[slot] = c == 0 ? cen : a_reg[slot] + cen;
     }
+    WH_STAMP(32, 5 + 5 * c);
   }
   __syncthreads();
 #pragma unroll
@@ -373,24 +405,34 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
     }
     A[k] = a_reg[slot];
   }
+  WH_STAMP(32, 11);
   d4c_dc_correct(A, cf0, fs, N, Zr);
+  WH_STAMP(32, 12);
 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
   {
     const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
                                   Z, false, scratch);
     for (int i = wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
+    WH_STAMP(32, 13);
     block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+    WH_STAMP(32, 14);
   }
   d4c_dc_correct(B, cf0, fs, N, Zr);
+  WH_STAMP(32, 15);
   d4c_smooth(B, cf0, fs, N, Zr, B, scratch);
+  WH_STAMP(32, 16);
 
   // ---- GetStaticGroupDelay (d4c.cpp:172-188) ----------------------------------
   for (int i = tid; i <= H; i += nt) A[i] = A[i] / B[i];
+  WH_STAMP(32, 17);
   d4c_smooth(A, cf0 / 2.0, fs, N, Zr, A, scratch);
+  WH_STAMP(32, 18);
   d4c_smooth(A, cf0, fs, N, Zr, B, scratch);
+  WH_STAMP(32, 19);
   double *gd = p.gd + fi * p.gd_stride;
   for (int i = tid; i <= H; i += nt) gd[i] = A[i] - B[i];
+  WH_STAMP(32, 20);
 }
 
 // ---------------------------------------------------------------------------
@@ -407,6 +449,8 @@ __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const bool trace_me = band == 2 && f == 1000; (void)trace_me;
+  WH_STAMP(0, 0);
   const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
@@ -414,6 +458,7 @@ __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
   double *scratch = reinterpret_cast<double *>(hist + kSelHists * 256);
   // table for the inner N/2-point complex transform only (the merge step derives its odd twiddles)
   const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
+  WH_STAMP(0, 1);
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   const int bnd = mround(N * 8.0 / p.wl);
   const int hwl = p.wl / 2;
@@ -439,8 +484,10 @@ __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
       key[filled < kSelKeys ? filled : kSelKeys - 1] = (unsigned long long)__double_as_longlong(re * re + im * im);
       ++filled;
     });
+  WH_STAMP(0, 2);
   double part, tot;
-  block_smallest_sum(key, filled, H + 1, H - bnd, hist, scratch, &part, &tot);
+  block_smallest_sum(key, filled, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
+  WH_STAMP(0, 9);
   if (tid == 0) {
     double c = 10 * log10(part / tot);
     c = c + (cf0 - 100) / 50.0;                       // d4c.cpp:314-316
@@ -496,6 +543,14 @@ size_t d4c_band_lds_bytes(int lg) {
 size_t d4c_max_draws_per_frame(int fs) {
   return (size_t)(2 * mround(3.0 * fs / 40.0 / 2.0) + 1) + 3 * (size_t)(2 * mround(4.0 * fs / kFloorF0D4C / 2.0) + 1);
 }
+
+}  // namespace world_hip
+#if defined(WH_TRACE) && !defined(WORLD_EMU)
+extern "C" __attribute__((visibility("default"))) int world_hip_trace_read(long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(world_hip::wh_trace), sizeof(long long) * n);
+}
+#endif
+namespace world_hip {
 
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);

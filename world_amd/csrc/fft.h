@@ -306,7 +306,7 @@ __device__ __forceinline__ void block_cfft_dit(cplx *z, const FftPlan &p, const 
 // (use rfft_in() to address it).  After the call the buffer holds scrambled data;
 // emit(k, Xre, Xim) has been called once for every k in [0, N/2] (same semantics as
 // the reference's r2c: X[k] = sum x[n] e^{-2 pi i k n / N}, imaginary part of
-// DC/Nyquist = 0); every thread receives at most ceil((N/2+1)/T) bins, in slot order.
+// DC/Nyquist = 0); every thread receives at most 2 ceil((N/4+1)/T) bins.
 __device__ __forceinline__ double &rfft_in(cplx *z, int n) {
   cplx &c = z[swz(n >> 1)];
   return (n & 1) ? c.im : c.re;
@@ -329,25 +329,36 @@ __device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &t
 }
 template <class Emit>
 __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit) {
-  const int lgh = lgn - 1, h = 1 << lgh;
-  // Walk the PHYSICAL slots in lane order (conflict-free wide reads) and emit whichever
-  // bin lives there; the mirrored bin h-k then sits in a nearby mirrored slot.  Slot
-  // count h, plus one extra item for the Nyquist bin k = h.  Thread t handles items
-  // t, t+T, ...: every bin exactly once, <= ceil((h+1)/T) bins per thread.
-  for (int it = threadIdx.x; it <= h; it += blockDim.x) {
-    const int k = it < h ? fft_bin_of_slot(plan, it) : h;
-    const int ka = k & (h - 1), kb = (h - k) & (h - 1);
-    cplx za = it < h ? z[it] : z[fft_slot(plan, 0)], zb = z[fft_slot(plan, kb)];
-    (void)ka;
-    cplx e, o;                                         // even / odd sub-spectra
-    e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
-    o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
-    cplx w;
-    if (k < h) w = twiddle(tw, k, lgn, -1); else { w.re = -1.0; w.im = 0.0; }
-    cplx ow = cmul(o, w);
-    double xr = e.re + ow.re, xi = e.im + ow.im;
-    if (k == 0 || k == h) xi = 0.0;
-    emit(k, xr, xi);
+  const int lgh = lgn - 1, h = 1 << lgh, q = h >> 1;
+  // Bins are produced in conjugate pairs: with e / o the even / odd sub-spectra at bin k,
+  //   X[k] = e + w_k o   and   X[h-k] = conj(e - w_k o)          (w_{h-k} = -conj(w_k)),
+  // so one pair of LDS reads, one twiddle and one complex product yield two bins.  Items walk
+  // the PHYSICAL slots whose bin is below h/2 in lane order (conflict-free wide reads): those
+  // are the slots whose last-stage digit has its top bit clear.  Item h/2 is the self-paired
+  // bin k = h/2.  Every bin in [0, h] is emitted exactly once, <= 2 ceil((h/2+1)/T) per thread.
+  const int top_bit = plan.rl(plan.ns - 1) - 1;
+  for (int it = threadIdx.x; it <= q; it += blockDim.x) {
+    if (it < q) {
+      const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
+      const int slot = swz(pos);
+      const int k = fft_bin_of_slot(plan, slot);
+      const cplx za = z[slot];
+      if (k == 0) {
+        emit(0, za.re + za.im, 0.0);
+        emit(h, za.re - za.im, 0.0);
+      } else {
+        const cplx zb = z[fft_slot(plan, h - k)];
+        cplx e, o;
+        e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
+        o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
+        const cplx ow = cmul(o, twiddle(tw, k, lgn, -1));
+        emit(k, e.re + ow.re, e.im + ow.im);
+        emit(h - k, e.re - ow.re, ow.im - e.im);
+      }
+    } else {
+      const cplx za = z[fft_slot(plan, q)];            // k = h/2: w = -i, X = conj(z)
+      emit(q, za.re, -za.im);
+    }
   }
   __syncthreads();
 }
@@ -360,15 +371,33 @@ __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, S
   const int lgh = lgn - 1, h = 1 << lgh;
   const FftPlan plan = make_plan(lgh);
   __syncthreads();
-  for (int k = threadIdx.x; k < h; k += blockDim.x) {
-    cplx x = spec(k), y = spec(h - k);
-    if (k == 0) { x.im = 0.0; y.im = 0.0; }
-    y.im = -y.im;                                       // conj(X[h-k])
-    cplx s = cadd(x, y), d = csub(x, y);
-    cplx w = twiddle(tw, k, lgn, +1);
-    cplx t = cmul(d, w);
-    cplx r; r.re = s.re - t.im; r.im = s.im + t.re;     // s + i*w*d
-    z[fft_slot(plan, k)] = r;
+  // Pre-twiddle in conjugate pairs, walking physical slots like rfft_merge: with s = X[k] +
+  // conj(X[h-k]), t = w_k (X[k] - conj(X[h-k])):  Z[k] = s + i t  and  Z[h-k] = conj(s - i t).
+  const int q = h >> 1, top_bit = plan.rl(plan.ns - 1) - 1;
+  for (int it = threadIdx.x; it <= q; it += blockDim.x) {
+    if (it < q) {
+      const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
+      const int slot = swz(pos);
+      const int k = fft_bin_of_slot(plan, slot);
+      cplx x = spec(k), y = spec(h - k);
+      if (k == 0) {
+        cplx r; r.re = x.re + y.re; r.im = x.re - y.re;  // imaginary parts of DC / Nyquist ignored
+        z[slot] = r;
+      } else {
+        y.im = -y.im;                                     // conj(X[h-k])
+        const cplx s = cadd(x, y), d = csub(x, y);
+        const cplx t = cmul(d, twiddle(tw, k, lgn, +1));
+        cplx r, rm;
+        r.re = s.re - t.im; r.im = s.im + t.re;
+        rm.re = s.re + t.im; rm.im = t.re - s.im;
+        z[slot] = r;
+        z[fft_slot(plan, h - k)] = rm;
+      }
+    } else {
+      const cplx x = spec(q);                             // k = h/2: w = +i
+      cplx r; r.re = 2.0 * x.re; r.im = -2.0 * x.im;
+      z[fft_slot(plan, q)] = r;
+    }
   }
   block_cfft_dit(z, plan, tw);
 }

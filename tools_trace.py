@@ -1,0 +1,33 @@
+"""Development aid: build with -DWH_TRACE, run one analysis, print the cycle stamps one
+workgroup of d4c_band / d4c_groupdelay recorded (deltas in shader-clock cycles)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+os.environ["WORLD_HIP_EXTRA_FLAGS"] = "-DWH_TRACE"
+subprocess.run([sys.executable, "-m", "world_amd.build", "--force"], check=True, capture_output=True)
+import torch
+from world_amd import synth
+from world_amd.api import WorldHip
+wh = WorldHip()
+x = synth.vowel(48000, 10.0, seed=12345, device=torch.device("cuda", 0))[None]
+for _ in range(3):
+    wh.analyze(x, 48000)
+torch.cuda.synchronize()
+def stamps(unit):
+    buf = (C.c_longlong * 128)()
+    fn = getattr(wh.lib, "world_hip_trace_read_" + unit)
+    fn.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+    assert fn(buf, 128) == 0
+    return list(buf)
+
+
+for unit, name, base, n in (("d4c", "d4c_band", 0, 10), ("d4c", "d4c_groupdelay", 32, 21), ("ct", "ct_frame", 0, 11)):
+    t = stamps(unit)[base:base + n]
+    print(name, "total", t[-1] - t[0], "cycles")
+    prev = t[0]
+    for k in range(1, n):
+        if t[k]:
+            print(f"  stamp {k:2d}: +{t[k] - prev}")
+            prev = t[k]

@@ -17,6 +17,8 @@
 // HBM traffic per frame: the window's samples of x (L2-resident: adjacent
 // frames overlap ~97%) and one row of the spectrogram written once.
 #include "stage_params.h"
+#include "trace.h"
+WH_TRACE_DEFINE(ct)
 
 namespace world_hip {
 
@@ -55,17 +57,16 @@ __global__ void ct_prepare(CtParams p) {
 }
 
 // ---------------------------------------------------------------------------
-#ifdef WORLD_EMU
-constexpr int kCtPerThread = 4096;                    // one emulated thread owns the whole window
-#else
-constexpr int kCtPerThread = 4096 / 256;
-#endif
+// PER: samples of the window a thread owns (fft_size / 256 on the GPU)
+template <int PER>
 __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   DYN_LDS(lds);
   const int lgn = p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
+  const bool trace_me = f == 1000; (void)trace_me;
+  WH_STAMP(0, 0);
 
   // LDS carve-up (doubles): Z: N | seg overflow | P: nb+1 | scratch: 64 | twiddles.  The smoothing
   // work area `seg` (up to nb + 2(N/3+2) + 1 values) starts on top of Z, which is dead whenever
@@ -84,48 +85,44 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   const double *noise = p.noise + p.offsets[(size_t)u * p.b.f_stride + f];
   const int tid = threadIdx.x, nt = blockDim.x;
 
+  WH_STAMP(0, 1);
   // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) -------------------------
   const int hw = mround(1.5 * fs / cf0);
   const int wlen = 2 * hw + 1;
   const int origin = mround(pos * fs + 0.001);
-  // window shape: every thread keeps the values of its own samples in registers (the FFT
-  // butterflies, not this phase, set the register budget); the frame's draws (sample order)
-  // come from the noise stream
+  // One pass, one block reduction: with w the raw window, a = x w and n the dither, the
+  // reference's normalised window is c w (c = 1/sqrt(sum w^2)), its waveform v = c a + n, and
+  // the DC-balanced result v - c w (sum v / sum c w) -- all linear in four sums.  A thread keeps
+  // the three values of each of its samples in registers (the FFT butterflies, not this phase,
+  // set the register budget); the frame's draws (sample order) come from the noise stream.
   const double win_scale = 1.0 / 1.5 / fs * cf0;        // position * f0 = (i - hw) / 1.5 / fs * f0
-  double wreg[kCtPerThread];
-  double e = 0.0;
+  double wv[PER], av[PER], nv[PER];
+  double s_ww = 0.0, s_a = 0.0, s_n = 0.0, s_w = 0.0;
 #pragma unroll
-  for (int q = 0; q < kCtPerThread; ++q) {
+  for (int q = 0; q < PER; ++q) {
     const int i = tid + q * nt;
-    double w = 0.0;
-    if (i < wlen) w = 0.5 * cospi(win_scale * (i - hw)) + 0.5;   // cos(pi * position * f0), cheaptrick.cpp:101-102
-    wreg[q] = w;
-    e += w * w;
-  }
-  e = 1.0 / sqrt(block_sum(e, scratch));
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int q = 0; q < kCtPerThread; ++q) {
-    const int i = tid + q * nt;
+    wv[q] = 0.0; av[q] = 0.0; nv[q] = 0.0;
     if (i < wlen) {
-      const double w = wreg[q] * e;
-      wreg[q] = w;
-      double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kTiny;
-      rfft_in(Z, i) = v;
-      s1 += v; s2 += w;
+      const double w = 0.5 * cospi(win_scale * (i - hw)) + 0.5;   // cos(pi * position * f0), cheaptrick.cpp:101-102
+      const double a = x[imin(x_len - 1, imax(0, origin + i - hw))] * w, n = noise[i] * kTiny;
+      wv[q] = w; av[q] = a; nv[q] = n;
+      s_ww += w * w; s_a += a; s_n += n; s_w += w;
     }
   }
-  block_sum2(s1, s2, scratch);
-  const double coef = s1 / s2;
+  block_sum4(s_ww, s_a, s_n, s_w, scratch);
+  const double c = 1.0 / sqrt(s_ww);
+  const double cc = c * ((c * s_a + s_n) / (c * s_w));
 #pragma unroll
-  for (int q = 0; q < kCtPerThread; ++q) {
+  for (int q = 0; q < PER; ++q) {
     const int i = tid + q * nt;
-    if (i < N) rfft_in(Z, i) = i < wlen ? rfft_in(Z, i) - wreg[q] * coef : 0.0;
+    if (i < N) rfft_in(Z, i) = i < wlen ? av[q] * c + nv[q] - wv[q] * cc : 0.0;
   }
 
+  WH_STAMP(0, 2);
   // ---- GetPowerSpectrum (cheaptrick.cpp:64-82): r2c, |X|^2 -----------------
   block_rfft(Z, lgn, tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
 
+  WH_STAMP(0, 3);
   // DCCorrection (common.cpp:56-75); replica staged in seg, then added
   {
     const int upper = 2 + static_cast<int>(cf0 * N / fs);
@@ -140,6 +137,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     __syncthreads();
   }
 
+  WH_STAMP(0, 4);
   // ---- LinearSmoothing (common.cpp:27-111), width = 2/3 f0 -----------------
   const double width = cf0 * 2.0 / 3.0;
   const int bnd = static_cast<int>(width * N / fs) + 1;
@@ -153,7 +151,15 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     seg[i] = m * fs * inv_n;                           // == m * fs / N: N is a power of two
   }
   __syncthreads();
-  if (tid == 0) {                       // the order-sensitive serial prefix sum
+  WH_STAMP(0, 5);
+  if (tid < WAVE) {                     // the order-sensitive serial prefix sum (one lane)
+#ifndef WORLD_EMU
+    // the rest of the workgroup waits for this dependent chain: let its wave issue ahead of the
+    // other workgroups' waves that share the SIMD
+    __builtin_amdgcn_s_setprio(3);
+#endif
+  }
+  if (tid == 0) {
     // strictly left-to-right FP64 additions; only the LDS traffic is batched (16 loads in
     // flight, 16 dependent adds, 16 stores) so the chain runs at add latency, not LDS latency
     constexpr int kB = 16;
@@ -170,7 +176,11 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     }
     for (; i0 < seg_len; ++i0) { acc = seg[i0] + acc; seg[i0] = acc; }
   }
+#ifndef WORLD_EMU
+  if (tid < WAVE) __builtin_amdgcn_s_setprio(0);
+#endif
   __syncthreads();
+  WH_STAMP(0, 6);
   {
     const double origin_axis = -(bnd - 0.5) * fs / N;
     const double step = static_cast<double>(fs) / N;
@@ -190,6 +200,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     }
   }
 
+  WH_STAMP(0, 7);
   // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
   // the symmetric extension of the log spectrum is read by the first FFT stage directly from P
   const double q1 = p.q1, inv_fs = 1.0 / fs;
@@ -208,9 +219,12 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     }
     P[k] = re * sl * cl * inv_n;                        // == .. / N: N is a power of two
   });
+  WH_STAMP(0, 8);
   block_irfft(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
+  WH_STAMP(0, 9);
   double *out = p.spectrogram + ((size_t)u * p.b.f_stride + f) * nb;
   for (int i = tid; i <= half; i += nt) out[i] = exp(rfft_in(Z, i));
+  WH_STAMP(0, 10);
 }
 
 // ---------------------------------------------------------------------------
@@ -223,7 +237,12 @@ size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size
 
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(ct_frame, dim3(max_frames, p.b.n_utt), 256, ct_frame_lds_bytes(p.lg_fft), stream, p);
+#ifdef WORLD_EMU
+  devrt::launch_blocks("ct_frame", ct_frame<4096>, dim3(max_frames, p.b.n_utt), 256, ct_frame_lds_bytes(p.lg_fft), stream, p);
+#else
+  if (p.lg_fft <= 11) devrt::launch_blocks("ct_frame", ct_frame<8>, dim3(max_frames, p.b.n_utt), 256, ct_frame_lds_bytes(p.lg_fft), stream, p);
+  else devrt::launch_blocks("ct_frame", ct_frame<16>, dim3(max_frames, p.b.n_utt), 256, ct_frame_lds_bytes(p.lg_fft), stream, p);
+#endif
 }
 
 }  // namespace world_hip

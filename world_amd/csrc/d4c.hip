@@ -22,17 +22,10 @@
 //                   smallest powers is used) -> one coarse aperiodicity value.
 //   d4c_finish    : the 3 kHz-grid interpolation, every row written once to HBM.
 #include "stage_params.h"
+#include "trace.h"
+WH_TRACE_DEFINE(d4c)
 
 namespace world_hip {
-
-// Development aid (-DWH_TRACE, see tools_trace.py): cycle-counter stamps of one workgroup's
-// phases, read back through world_hip_trace_read().  Compiled out of the product.
-#if defined(WH_TRACE) && !defined(WORLD_EMU)
-__device__ long long wh_trace[128];
-#define WH_STAMP(base, k) do { if (trace_me && threadIdx.x == 0) wh_trace[(base) + (k)] = clock64(); } while (0)
-#else
-#define WH_STAMP(base, k) do { } while (0)
-#endif
 
 constexpr int kHanning = 1, kBlackman = 2;
 
@@ -543,14 +536,6 @@ size_t d4c_band_lds_bytes(int lg) {
 size_t d4c_max_draws_per_frame(int fs) {
   return (size_t)(2 * mround(3.0 * fs / 40.0 / 2.0) + 1) + 3 * (size_t)(2 * mround(4.0 * fs / kFloorF0D4C / 2.0) + 1);
 }
-
-}  // namespace world_hip
-#if defined(WH_TRACE) && !defined(WORLD_EMU)
-extern "C" __attribute__((visibility("default"))) int world_hip_trace_read(long long *out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(world_hip::wh_trace), sizeof(long long) * n);
-}
-#endif
-namespace world_hip {
 
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);

@@ -272,6 +272,24 @@ __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, doub
   (void)scratch;
 #endif
 }
+__device__ __forceinline__ void block_sum4(double &a, double &b, double &c, double &d, double *scratch) {
+#ifndef WORLD_EMU
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+  int nw = waves_per_block();
+  if (nw == 1) return;
+  __syncthreads();
+  if (lane_id() == 0) {
+    double *s = scratch + 4 * wave_in_block();
+    s[0] = a; s[1] = b; s[2] = c; s[3] = d;
+  }
+  __syncthreads();
+  double ta = 0.0, tb = 0.0, tc = 0.0, td = 0.0;
+  for (int w = 0; w < nw; ++w) { ta += scratch[4 * w]; tb += scratch[4 * w + 1]; tc += scratch[4 * w + 2]; td += scratch[4 * w + 3]; }
+  a = ta; b = tb; c = tc; d = td;
+#else
+  (void)scratch;
+#endif
+}
 // exclusive scan of one int per thread over the block (thread order); *total = block sum
 __device__ __forceinline__ int block_excl_scan_int(int v, int *total, double *scratch) {
 #ifndef WORLD_EMU

@@ -1,0 +1,16 @@
+// trace.h -- development aid, compiled out of the product.  With -DWH_TRACE a kernel can
+// stamp the shader clock at phase boundaries of ONE chosen workgroup (`trace_me`); the stamps
+// are read back through world_hip_trace_read_<unit>() (tools_trace.py prints the deltas).
+// In-situ phase latencies are what rocprofv3's per-kernel totals cannot show.
+#pragma once
+#if defined(WH_TRACE) && !defined(WORLD_EMU)
+#define WH_TRACE_DEFINE(unit)                                                                        \
+  namespace world_hip { __device__ long long wh_trace[128]; }                                          \
+  extern "C" __attribute__((visibility("default"))) int world_hip_trace_read_##unit(long long *out, int n) { \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(world_hip::wh_trace), sizeof(long long) * n);      \
+  }
+#define WH_STAMP(base, k) do { if (trace_me && threadIdx.x == 0) wh_trace[(base) + (k)] = clock64(); } while (0)
+#else
+#define WH_TRACE_DEFINE(unit)
+#define WH_STAMP(base, k) do { } while (0)
+#endif

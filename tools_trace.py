@@ -31,3 +31,7 @@ for unit, name, base, n in (("d4c", "d4c_band", 0, 10), ("d4c", "d4c_groupdelay"
         if t[k]:
             print(f"  stamp {k:2d}: +{t[k] - prev}")
             prev = t[k]
+
+t = stamps("hv")[:8]
+print("hv_refine (one wave, frame 5000): cache fill", t[0], "window rebuilds", t[1], "DFT+reduce", t[2], "tails", t[3],
+      "refined candidates", t[4])

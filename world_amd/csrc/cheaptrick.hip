@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   }
   if (tid == 0) {
     // strictly left-to-right FP64 additions; only the LDS traffic is batched (16 loads in
-    // flight, 16 dependent adds, 16 stores) so the chain runs at add latency, not LDS latency
+    // flight, 16 dependent adds, 16 stores).  The chain runs at the FP64 add's dependent-issue
+    // latency (~38 cycles measured in situ): ~40k cycles per frame, the largest single phase.
     constexpr int kB = 16;
     double acc = seg[0];
     int i0 = 1;

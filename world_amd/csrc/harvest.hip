@@ -21,6 +21,8 @@
 #include "bandfilter.h"
 #include "decimate.h"
 #include "harvest.h"
+#include "trace.h"
+WH_TRACE_DEFINE(hv)
 
 namespace world_hip {
 
@@ -184,9 +186,13 @@ __global__ void hv_refine(HarvestParams p) {
   // Every window of this frame is centred on `pos`, so the samples any of them can touch
   // (clamped at the signal ends like GetBaseIndex's safe_index, harvest.cpp:434-441) are
   // fetched from HBM once and kept in LDS.
+  const bool trace_me = frame == 5000; (void)trace_me;
+  WH_ACC_DECL;
+  WH_ACC_BEGIN;
   const int origin = mround(pos * fs) - cap / 2;
   for (int k = lane; k < cap; k += WAVE) yc[k] = y[imax(0, imin(y_len - 1, origin + k))];
   wave_sync();
+  WH_ACC_END(0);
 
   // Lane roles: harmonic h = lane % LH, sample phase g = lane / LH.  Slots are visited
   // track by track (j outer, the 7 neighbouring source frames m inner): consecutive
@@ -223,6 +229,7 @@ __global__ void hv_refine(HarvestParams p) {
       const int first = mround((pos + base0) * fs + 0.001);      // GetBaseIndex, harvest.cpp:434-441
       const bool same_window = hw == c_hw && first == c_first;
       if (!same_window) {
+        WH_ACC_BEGIN;
         // Blackman main window (harvest.cpp:446-456) and its central difference
         // (GetDiffWindow, :462-468).  w[i+1]-w[i-1] follows from the angle-addition
         // identities, so no neighbour values are exchanged.
@@ -231,10 +238,13 @@ __global__ void hv_refine(HarvestParams p) {
         sincospi(inv_fs * two_over_t, &sd, &cd);
         const double s2d = 2.0 * sd * cd, c2d = 2.0 * cd * cd - 1.0;
         wave_sync();                                             // the previous candidate's reads are done
+        // a lane's samples are WAVE apart: one sincospi for its first sample, then a rotation
+        // by WAVE * delta per further sample
+        double sD, cD;
+        sincospi(WAVE * (inv_fs * two_over_t), &sD, &cD);
+        double sa, ca;
+        sincospi((((first + lane) - 1.0) * inv_fs - pos) * two_over_t, &sa, &ca);
         for (int i = lane; i < blen; i += WAVE) {
-          const double t = ((first + i) - 1.0) * inv_fs - pos;
-          double sa, ca;
-          sincospi(t * two_over_t, &sa, &ca);
           const double c2a = 2.0 * ca * ca - 1.0, s2a = 2.0 * sa * ca;
           const double w = 0.42 + 0.5 * ca + 0.08 * c2a;
           double dwv;
@@ -245,12 +255,17 @@ __global__ void hv_refine(HarvestParams p) {
           const double xv = (k >= 0 && k < cap) ? yc[k] : y[imax(0, imin(y_len - 1, first + i - 1))];
           ym[i] = xv * w;
           yd[i] = xv * dwv;
+          const double cn = ca * cD - sa * sD;
+          sa = sa * cD + ca * sD;
+          ca = cn;
         }
         wave_sync();
         c_hw = hw; c_first = first;
+        WH_ACC_END(1);
       }
       // 6-bin DFTs of both windowed signals, one Goertzel recurrence per (harmonic, phase)
       const int nh = imin(static_cast<int>(fs / 2.0 / f0c), 6);
+      WH_ACC_BEGIN;
       for (int hi = 0; hi < kIter; ++hi) {
         const int h = hi * LH + hl;
         double are = 0, aim = 0, dre = 0, dim = 0;
@@ -295,7 +310,10 @@ __global__ void hv_refine(HarvestParams p) {
           k_idx[q][hi] = idx; k_lgn[q] = lgN; k_f0[q] = f0c;
         }
       }
+      WH_ACC_END(2);
+      WH_ACC_COUNT(4);
     }
+    WH_ACC_BEGIN;
     // deferred tail: lane (h, g) finishes harmonic h of slot m = g (+ q*G)
     for (int q = 0; q < kM; ++q) {
       const int m = q * G + g;
@@ -334,7 +352,9 @@ __global__ void hv_refine(HarvestParams p) {
         dst_f0[slot] = rf0; dst_sc[slot] = rsc;
       }
     }
+    WH_ACC_END(3);
   }
+  WH_ACC_FLUSH(0, lane == 0);
 }
 
 // ---------------------------------------------------------------------------

@@ -10,7 +10,18 @@
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(world_hip::wh_trace), sizeof(long long) * n);      \
   }
 #define WH_STAMP(base, k) do { if (trace_me && threadIdx.x == 0) wh_trace[(base) + (k)] = clock64(); } while (0)
+// accumulating form for phases that repeat inside loops: WH_ACC_DECL once, then BEGIN/END pairs
+#define WH_ACC_DECL long long wh_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wh_t0 = 0; (void)wh_t0
+#define WH_ACC_BEGIN do { if (trace_me) wh_t0 = clock64(); } while (0)
+#define WH_ACC_END(k) do { if (trace_me) wh_acc[k] += clock64() - wh_t0; } while (0)
+#define WH_ACC_COUNT(k) do { if (trace_me) wh_acc[k] += 1; } while (0)
+#define WH_ACC_FLUSH(base, lane0) do { if (trace_me && (lane0)) for (int k_ = 0; k_ < 8; ++k_) wh_trace[(base) + k_] = wh_acc[k_]; } while (0)
 #else
+#define WH_ACC_DECL
+#define WH_ACC_BEGIN do { } while (0)
+#define WH_ACC_END(k) do { } while (0)
+#define WH_ACC_COUNT(k) do { } while (0)
+#define WH_ACC_FLUSH(base, lane0) do { } while (0)
 #define WH_TRACE_DEFINE(unit)
 #define WH_STAMP(base, k) do { } while (0)
 #endif

@@ -1,12 +1,13 @@
-"""Ablation timing on the GPU box (development aid): patch a kernel source, rebuild, time, restore."""
-import json, subprocess, sys
+"""Ablation timing on the GPU box (development aid): swap in alternative source files, rebuild, time, restore."""
+import json, subprocess, sys, shutil
 VARIANTS = {
-  'base': ('world_amd/csrc/cheaptrick.hip', []),
-  'ct_lb3': ('world_amd/csrc/cheaptrick.hip', [("__global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {", "__global__ void __launch_bounds__(256) ct_frame(CtParams p) {")]),
-  'base2': ('world_amd/csrc/cheaptrick.hip', []),
-  'ct_noprio': ('world_amd/csrc/cheaptrick.hip', [("    __builtin_amdgcn_s_setprio(3);\n", "")]),
+  'base': {},
+  'd4c_old': {'world_amd/csrc/d4c.hip': 'tools_old_d4c.txt'},
+  'fft_old': {'world_amd/csrc/fft.h': 'tools_old_fft.txt'},
+  'both_old': {'world_amd/csrc/d4c.hip': 'tools_old_d4c.txt', 'world_amd/csrc/fft.h': 'tools_old_fft.txt'},
+  'base2': {},
 }
-KERNELS = ('ct_frame', 'd4c_groupdelay', 'd4c_band', 'hv_refine')
+KERNELS = ('ct_frame', 'd4c_groupdelay', 'd4c_band', 'd4c_lovetrain', 'hv_refine')
 def run(name):
     out = subprocess.run([sys.executable, 'bench.py', '--steps', '30', '--warmup', '3', '--streams', '1', '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]
@@ -14,17 +15,14 @@ def run(name):
     k = d['kernels_ms_per_step']
     print(name, 'ms/step %.3f' % d['ms_per_step'], {n: k[n] for n in KERNELS}, flush=True)
 for name in (sys.argv[1:] or VARIANTS):
-    src, edits = VARIANTS[name]
-    orig = open(src).read()
+    saved = {dst: open(dst).read() for dst in VARIANTS[name]}
     try:
-        s = orig
-        for a, b in edits:
-            assert a in s, (name, a)
-            s = s.replace(a, b, 1)
-        open(src, 'w').write(s)
-        r = subprocess.run([sys.executable, '-m', 'world_amd.build'], capture_output=True, text=True)
+        for dst, src in VARIANTS[name].items():
+            shutil.copy(src, dst)
+        r = subprocess.run([sys.executable, '-m', 'world_amd.build', '--force'], capture_output=True, text=True)
         if r.returncode: print(name, 'BUILD FAILED', r.stderr[-800:]); continue
         run(name)
     finally:
-        open(src, 'w').write(orig)
-subprocess.run([sys.executable, '-m', 'world_amd.build'], capture_output=True, text=True)
+        for dst, text in saved.items():
+            open(dst, 'w').write(text)
+subprocess.run([sys.executable, '-m', 'world_amd.build', '--force'], capture_output=True, text=True)

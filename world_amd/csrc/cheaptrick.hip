@@ -143,13 +143,15 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   const int bnd = static_cast<int>(width * N / fs) + 1;
   const int seg_len = half + 2 * bnd + 1;
   const double inv_n = 1.0 / N;
-  for (int i = tid; i < seg_len; i += nt) {
-    double m;
-    if (i < bnd) m = P[bnd - i];
-    else if (i < half + bnd) m = P[i - bnd];
-    else m = P[half - (i - (half + bnd))];
-    seg[i] = m * fs * inv_n;                           // == m * fs / N: N is a power of two
-  }
+  block_map<4, double>(seg_len,
+    [&](int i) {
+      double m;
+      if (i < bnd) m = P[bnd - i];
+      else if (i < half + bnd) m = P[i - bnd];
+      else m = P[half - (i - (half + bnd))];
+      return m * fs * inv_n;                           // == m * fs / N: N is a power of two
+    },
+    [&](int i, double v) { seg[i] = v; });
   __syncthreads();
   WH_STAMP(0, 5);
   if (tid < WAVE) {                     // the order-sensitive serial prefix sum (one lane)
@@ -188,17 +190,18 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     // hi - lo cancels up to 12 digits where the envelope sits at the noise floor:
     // the interpolation weights and the final quotient keep the reference's exact operations
     // (true divisions), so that every product rounds as it does there.
-    for (int i = tid; i <= half; i += nt) {
-      double fa = static_cast<double>(i) * inv_n * fs - width / 2.0;
-      double lo = interp_uniform(origin_axis, step, seg, seg_len, fa);
-      fa += width;
-      double hi = interp_uniform(origin_axis, step, seg, seg_len, fa);
-      double smoothed = (hi - lo) / width;
-      // AddInfinitesimalNoise: the per-bin draws continue the frame's stream after the
-      // window draws (cheaptrick.cpp:147-151); then the log of SmoothingWithRecovery (:39-42)
-      double lg = log(smoothed + fabs(noise[wlen + i]) * kEps);
-      P[i] = lg;
-    }
+    block_map<4, double>(half + 1,
+      [&](int i) {
+        double fa = static_cast<double>(i) * inv_n * fs - width / 2.0;
+        double lo = interp_uniform(origin_axis, step, seg, seg_len, fa);
+        fa += width;
+        double hi = interp_uniform(origin_axis, step, seg, seg_len, fa);
+        double smoothed = (hi - lo) / width;
+        // AddInfinitesimalNoise: the per-bin draws continue the frame's stream after the
+        // window draws (cheaptrick.cpp:147-151); then the log of SmoothingWithRecovery (:39-42)
+        return log(smoothed + fabs(noise[wlen + i]) * kEps);
+      },
+      [&](int i, double lg) { P[i] = lg; });
   }
 
   WH_STAMP(0, 7);
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   block_irfft(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   WH_STAMP(0, 9);
   double *out = p.spectrogram + ((size_t)u * p.b.f_stride + f) * nb;
-  for (int i = tid; i <= half; i += nt) out[i] = exp(rfft_in(Z, i));
+  block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = v; });
   WH_STAMP(0, 10);
 }
 

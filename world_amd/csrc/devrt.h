@@ -290,6 +290,24 @@ __device__ __forceinline__ void block_sum4(double &a, double &b, double &c, doub
   (void)scratch;
 #endif
 }
+// Element-wise pass over n items, K per thread at a time: all K `produce(i)` calls (loads +
+// arithmetic, returning a value) are issued before any `consume(i, value)` (the stores).
+// A plain `for (i = tid; i < n; i += T) out[i] = f(in[i])` cannot overlap its iterations -- the
+// compiler must keep each store ahead of the next iteration's loads -- and a dependent FP64 op
+// costs 36 cycles on gfx950 (tools/microbench_fp64.hip), so with 2-4 waves per SIMD such loops
+// run at latency, not throughput.  K independent chains per thread close most of that gap.
+template <int K, class T, class Produce, class Consume>
+__device__ __forceinline__ void block_map(int n, Produce produce, Consume consume) {
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+  for (int base = tid; base < n; base += K * nt) {
+    T v[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { const int i = base + q * nt; if (i < n) v[q] = produce(i); }
+#pragma unroll
+    for (int q = 0; q < K; ++q) { const int i = base + q * nt; if (i < n) consume(i, v[q]); }
+  }
+}
+
 // exclusive scan of one int per thread over the block (thread order); *total = block sum
 __device__ __forceinline__ int block_excl_scan_int(int v, int *total, double *scratch) {
 #ifndef WORLD_EMU

@@ -337,29 +337,36 @@ __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan
   // are the slots whose last-stage digit has its top bit clear.  Item h/2 is the self-paired
   // bin k = h/2.  Every bin in [0, h] is emitted exactly once, <= 2 ceil((h/2+1)/T) per thread.
   const int top_bit = plan.rl(plan.ns - 1) - 1;
-  for (int it = threadIdx.x; it <= q; it += blockDim.x) {
-    if (it < q) {
-      const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
-      const int slot = swz(pos);
-      const int k = fft_bin_of_slot(plan, slot);
-      const cplx za = z[slot];
-      if (k == 0) {
-        emit(0, za.re + za.im, 0.0);
-        emit(h, za.re - za.im, 0.0);
+  struct Pair { int k; double ar, ai, br, bi; };      // bins k and h-k (k = 0: DC and Nyquist; k = h/2: a only)
+  block_map<2, Pair>(q + 1,
+    [&](int it) {
+      Pair r;
+      if (it < q) {
+        const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
+        const int slot = swz(pos);
+        const int k = fft_bin_of_slot(plan, slot);
+        const cplx za = z[slot];
+        r.k = k;
+        if (k == 0) {
+          r.ar = za.re + za.im; r.ai = 0.0; r.br = za.re - za.im; r.bi = 0.0;
+        } else {
+          const cplx zb = z[fft_slot(plan, h - k)];
+          cplx e, o;
+          e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
+          o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
+          const cplx ow = cmul(o, twiddle(tw, k, lgn, -1));
+          r.ar = e.re + ow.re; r.ai = e.im + ow.im; r.br = e.re - ow.re; r.bi = ow.im - e.im;
+        }
       } else {
-        const cplx zb = z[fft_slot(plan, h - k)];
-        cplx e, o;
-        e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
-        o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
-        const cplx ow = cmul(o, twiddle(tw, k, lgn, -1));
-        emit(k, e.re + ow.re, e.im + ow.im);
-        emit(h - k, e.re - ow.re, ow.im - e.im);
+        const cplx za = z[fft_slot(plan, q)];          // k = h/2: w = -i, X = conj(z)
+        r.k = q; r.ar = za.re; r.ai = -za.im; r.br = 0.0; r.bi = 0.0;
       }
-    } else {
-      const cplx za = z[fft_slot(plan, q)];            // k = h/2: w = -i, X = conj(z)
-      emit(q, za.re, -za.im);
-    }
-  }
+      return r;
+    },
+    [&](int, Pair r) {
+      emit(r.k, r.ar, r.ai);
+      if (r.k != q) emit(h - r.k, r.br, r.bi);
+    });
   __syncthreads();
 }
 
@@ -374,31 +381,37 @@ __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, S
   // Pre-twiddle in conjugate pairs, walking physical slots like rfft_merge: with s = X[k] +
   // conj(X[h-k]), t = w_k (X[k] - conj(X[h-k])):  Z[k] = s + i t  and  Z[h-k] = conj(s - i t).
   const int q = h >> 1, top_bit = plan.rl(plan.ns - 1) - 1;
-  for (int it = threadIdx.x; it <= q; it += blockDim.x) {
-    if (it < q) {
-      const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
-      const int slot = swz(pos);
-      const int k = fft_bin_of_slot(plan, slot);
-      cplx x = spec(k), y = spec(h - k);
-      if (k == 0) {
-        cplx r; r.re = x.re + y.re; r.im = x.re - y.re;  // imaginary parts of DC / Nyquist ignored
-        z[slot] = r;
+  struct Pair { int slot, mslot; cplx r, rm; };
+  block_map<2, Pair>(q + 1,
+    [&](int it) {
+      Pair o;
+      o.mslot = -1;
+      if (it < q) {
+        const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
+        o.slot = swz(pos);
+        const int k = fft_bin_of_slot(plan, o.slot);
+        cplx x = spec(k), y = spec(h - k);
+        if (k == 0) {
+          o.r.re = x.re + y.re; o.r.im = x.re - y.re;    // imaginary parts of DC / Nyquist ignored
+        } else {
+          y.im = -y.im;                                   // conj(X[h-k])
+          const cplx s = cadd(x, y), d = csub(x, y);
+          const cplx t = cmul(d, twiddle(tw, k, lgn, +1));
+          o.r.re = s.re - t.im; o.r.im = s.im + t.re;
+          o.rm.re = s.re + t.im; o.rm.im = t.re - s.im;
+          o.mslot = fft_slot(plan, h - k);
+        }
       } else {
-        y.im = -y.im;                                     // conj(X[h-k])
-        const cplx s = cadd(x, y), d = csub(x, y);
-        const cplx t = cmul(d, twiddle(tw, k, lgn, +1));
-        cplx r, rm;
-        r.re = s.re - t.im; r.im = s.im + t.re;
-        rm.re = s.re + t.im; rm.im = t.re - s.im;
-        z[slot] = r;
-        z[fft_slot(plan, h - k)] = rm;
+        const cplx x = spec(q);                           // k = h/2: w = +i
+        o.slot = fft_slot(plan, q);
+        o.r.re = 2.0 * x.re; o.r.im = -2.0 * x.im;
       }
-    } else {
-      const cplx x = spec(q);                             // k = h/2: w = +i
-      cplx r; r.re = 2.0 * x.re; r.im = -2.0 * x.im;
-      z[fft_slot(plan, q)] = r;
-    }
-  }
+      return o;
+    },
+    [&](int, Pair o) {
+      z[o.slot] = o.r;
+      if (o.mslot >= 0) z[o.mslot] = o.rm;
+    });
   block_cfft_dit(z, plan, tw);
 }
 

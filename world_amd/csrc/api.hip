@@ -61,6 +61,11 @@ struct HarvestBands {            // cached per (fs, f0_floor, f0_ceil)
 
 }  // namespace world_hip
 
+// Calls reuse a staging buffer only kStageRing calls later, so the host never waits for the GPU
+// in steady state (with two buffers, D4C's call waited for the same job's Harvest to finish:
+// ~1.2 ms of host stall per job, which also kept concurrent jobs from overlapping).
+constexpr int kStageRing = 12;
+
 struct WorldHipContext {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -73,9 +78,9 @@ struct WorldHipContext {
   void *codec_tables = nullptr;  // world_hip::CodecTableSet (cached interp1 / DCT tables of the coders)
   double *d_noise = nullptr;     // noise[k] = k-th randn() after reseed (grow-only constant table)
   size_t noise_len = 0;
-  // pinned, double-buffered staging for the small per-call host arrays
-  char *stage[2] = {nullptr, nullptr};
-  void *stage_ev[2] = {nullptr, nullptr};
+  // pinned ring of staging buffers for the small per-call host arrays
+  char *stage[kStageRing] = {};
+  void *stage_ev[kStageRing] = {};
   size_t stage_cap = 0, stage_used = 0;
   int stage_cur = 0;
   std::mutex lock;               // one call at a time per context
@@ -117,21 +122,21 @@ static const double *ensure_noise(WorldHipContext *c, size_t draws) {
 }
 
 // Small host arrays travel through pinned staging so the async copy never reads
-// memory the caller (or a destroyed std::vector) owns.  Two buffers alternate per
-// call; a buffer is reused only after the event recorded behind its copies fired.
+// memory the caller (or a destroyed std::vector) owns.  The buffers form a ring, one
+// per call; a buffer is reused only after the event recorded behind its copies fired.
 struct CallScope {
   WorldHipContext *c;
   explicit CallScope(WorldHipContext *ctx, size_t staging_bytes) : c(ctx) {
     if (staging_bytes > c->stage_cap) {
       devrt::sync(c->stream);
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < kStageRing; ++k) {
         if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
         c->stage[k] = static_cast<char *>(devrt::hmalloc_pinned(staging_bytes * 2));
         if (!c->stage_ev[k]) c->stage_ev[k] = devrt::event_create();
       }
       c->stage_cap = staging_bytes * 2;
     }
-    c->stage_cur ^= 1;
+    c->stage_cur = (c->stage_cur + 1) % kStageRing;
     devrt::event_sync(c->stage_ev[c->stage_cur]);
     c->stage_used = 0;
   }
@@ -752,7 +757,7 @@ void world_hip_destroy(WorldHipContext *c) {
       delete db;
     }
     free_codec_tables(c);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kStageRing; ++k) {
       if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
       if (c->stage_ev[k]) devrt::event_destroy(c->stage_ev[k]);
     }

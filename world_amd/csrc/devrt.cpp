@@ -1,11 +1,45 @@
 // devrt.cpp -- HIP runtime plumbing for the product build (gfx950).
 #include "devrt.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 namespace devrt {
+
+// ---- host-side cost of every runtime call (WORLD_HIP_HOST_TRACE=1): printed at exit ----
+bool g_host_trace = getenv("WORLD_HIP_HOST_TRACE") != nullptr;
+namespace {
+struct HostTrace {
+  std::map<std::string, std::pair<double, long>> acc;
+  ~HostTrace() {
+    if (!g_host_trace) return;
+    double total = 0;
+    for (auto &kv : acc) total += kv.second.first;
+    fprintf(stderr, "[world_hip host trace] total %.1f us in %zu call sites\n", total, acc.size());
+    for (auto &kv : acc)
+      fprintf(stderr, "  %-28s %8ld calls %10.1f us  %7.2f us/call\n", kv.first.c_str(), kv.second.second, kv.second.first,
+              kv.second.first / kv.second.second);
+  }
+} g_trace;
+struct Timed {
+  const char *name;
+  std::chrono::steady_clock::time_point t0;
+  explicit Timed(const char *n) : name(n) { if (g_host_trace) t0 = std::chrono::steady_clock::now(); }
+  ~Timed() {
+    if (g_host_trace) host_trace_add(name, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+}  // namespace
+void host_trace_add(const char *name, double us) {
+  auto &e = g_trace.acc[name];
+  e.first += us; e.second += 1;
+}
 
 void check(hipError_t e, const char *what) {
   if (e != hipSuccess)
@@ -17,10 +51,10 @@ void *dmalloc(size_t bytes) {
   return p;
 }
 void dfree(void *p) { if (p) check(hipFree(p), "hipFree"); }
-void h2d(void *dst, const void *src, size_t n, hipStream_t s) {
+void h2d(void *dst, const void *src, size_t n, hipStream_t s) { Timed t_("api:h2d");
   if (n) check(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s), "hipMemcpyAsync H2D");
 }
-void d2h(void *dst, const void *src, size_t n, hipStream_t s) {
+void d2h(void *dst, const void *src, size_t n, hipStream_t s) { Timed t_("api:d2h");
   if (n) check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s), "hipMemcpyAsync D2H");
 }
 void d2d(void *dst, const void *src, size_t n, hipStream_t s) {
@@ -29,7 +63,7 @@ void d2d(void *dst, const void *src, size_t n, hipStream_t s) {
 void dzero(void *dst, size_t n, hipStream_t s) {
   if (n) check(hipMemsetAsync(dst, 0, n, s), "hipMemsetAsync");
 }
-void sync(hipStream_t s) { check(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+void sync(hipStream_t s) { Timed t_("api:stream_sync"); check(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 void set_device(int device) {
   int count = 0;
   check(hipGetDeviceCount(&count), "hipGetDeviceCount");
@@ -48,9 +82,20 @@ void *event_create() {
   return ev;
 }
 void event_destroy(void *ev) { if (ev) check(hipEventDestroy(static_cast<hipEvent_t>(ev)), "hipEventDestroy"); }
-void event_record(void *ev, hipStream_t s) { check(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord"); }
-void event_sync(void *ev) { check(hipEventSynchronize(static_cast<hipEvent_t>(ev)), "hipEventSynchronize"); }
+void event_record(void *ev, hipStream_t s) { Timed t_("api:event_record"); check(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord"); }
+void event_sync(void *ev) { Timed t_("api:event_sync"); check(hipEventSynchronize(static_cast<hipEvent_t>(ev)), "hipEventSynchronize"); }
 
+
+void allow_large_lds(const void *kernel, size_t lds, const char *name) {
+  static std::mutex lock;
+  static std::map<const void *, size_t> granted;
+  std::lock_guard<std::mutex> g(lock);
+  size_t &have = granted[kernel];
+  if (lds <= have) return;
+  Timed t_("api:func_set_attribute");
+  check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
+  have = lds;
+}
 
 // ---- per-kernel event timing ---------------------------------------------------
 bool g_profiling = false;

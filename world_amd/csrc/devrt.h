@@ -117,18 +117,28 @@ void prof_begin(const char *name, hipStream_t s);
 void prof_end(hipStream_t s);
 extern bool g_profiling;
 void prof_enable(bool on);
+// opt a kernel in to more than 48 KiB of dynamic LDS (up to the 160 KiB of a gfx950 CU); the
+// attribute is set once per kernel and size, not per launch
+void allow_large_lds(const void *kernel, size_t lds, const char *name);
+extern bool g_host_trace;                      // WORLD_HIP_HOST_TRACE=1: host cost per call site, printed at exit
+void host_trace_add(const char *name, double us);
 }  // namespace devrt
+#include <chrono>
 #include <string>
 namespace devrt {
 std::string prof_collect();
 template <class K, class... A>
 void launch_blocks(const char *name, K kernel, dim3 grid, int threads, size_t lds, hipStream_t s, A... args) {
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;
-  if (lds > 48 * 1024)   // opt in to the full 160 KiB LDS of a gfx950 CU
-    check(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (lds > 48 * 1024) allow_large_lds(reinterpret_cast<const void *>(kernel), lds, name);
   if (g_profiling) prof_begin(name, s);
-  hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, args...);
+  if (g_host_trace) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, args...);
+    host_trace_add(name, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  } else {
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, args...);
+  }
   check(hipGetLastError(), name);
   if (g_profiling) prof_end(s);
 }

@@ -91,13 +91,13 @@ def cpu_baseline(x_np, reps=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=6,
                     help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
                          "stream with its own workspace; 1 = strictly one after the other)")
     args = ap.parse_args()

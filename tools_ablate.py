@@ -2,9 +2,7 @@
 import json, subprocess, sys, shutil
 VARIANTS = {
   'base': {},
-  'd4c_old': {'world_amd/csrc/d4c.hip': 'tools_old_d4c.txt'},
-  'fft_old': {'world_amd/csrc/fft.h': 'tools_old_fft.txt'},
-  'both_old': {'world_amd/csrc/d4c.hip': 'tools_old_d4c.txt', 'world_amd/csrc/fft.h': 'tools_old_fft.txt'},
+  # 'name': {'world_amd/csrc/<unit>': 'path/to/alternative/source'},
   'base2': {},
 }
 KERNELS = ('ct_frame', 'd4c_groupdelay', 'd4c_band', 'd4c_lovetrain', 'hv_refine')

@@ -87,6 +87,15 @@ __host__ __device__ __forceinline__ FftPlan make_plan(int lg) {
   if (r) p.stages |= (unsigned)r << (4 * p.ns++);
   return p;
 }
+// the same with radix-8 stages: twice the butterflies per stage (every thread of a 256-thread
+// workgroup stays busy on a 2048-point transform) and half the registers, for one more LDS pass
+__host__ __device__ __forceinline__ FftPlan make_plan_r8(int lg) {
+  FftPlan p; p.lg = lg; p.ns = 0; p.stages = 0;
+  int r = lg;
+  while (r >= 3) { p.stages |= 3u << (4 * p.ns++); r -= 3; }
+  if (r) p.stages |= (unsigned)r << (4 * p.ns++);
+  return p;
+}
 // LDS slot swizzle: XOR the 16-byte slot index with bits 4..7 of itself.  With the
 // butterfly->thread mapping below every ds_read_b128 of every stage of every plan
 // (256..4096 points) is conflict-free in the gfx950 bank model (MI355X_MICROARCH.md
@@ -322,8 +331,8 @@ __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Em
 }
 // same transform with the packed input supplied by src(n) = (x[2n], x[2n+1]), n < N/2: z is pure workspace
 template <class Src, class Emit>
-__device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &tw, Src src, Emit emit) {
-  const FftPlan plan = make_plan(lgn - 1);
+__device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &tw, Src src, Emit emit, bool radix8 = false) {
+  const FftPlan plan = radix8 ? make_plan_r8(lgn - 1) : make_plan(lgn - 1);
   block_cfft_dif_from(z, plan, tw, src);
   rfft_merge(z, lgn, plan, tw, emit);
 }

@@ -2,7 +2,7 @@
 import json, subprocess, sys, shutil
 VARIANTS = {
   'base': {},
-  # 'name': {'world_amd/csrc/<unit>': 'path/to/alternative/source'},
+  'ct_r8': {'world_amd/csrc/cheaptrick.hip': 'tools_alt_ct_r8.txt'},
   'base2': {},
 }
 KERNELS = ('ct_frame', 'd4c_groupdelay', 'd4c_band', 'd4c_lovetrain', 'hv_refine')

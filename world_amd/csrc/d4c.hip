@@ -303,7 +303,11 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 // ---------------------------------------------------------------------------
 // Stage A of D4CGeneralBody: static group delay of one selected frame -> HBM.
 // (GetStaticCentroid, GetSmoothedPowerSpectrum, GetStaticGroupDelay: d4c.cpp:126-188)
-__global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
+// Workgroup shape of d4c_groupdelay: 256 threads with radix-16 butterflies, or 512 threads with
+// radix-8 butterflies (every thread busy in every FFT stage, half the registers per thread).
+constexpr int kGdThreads = 512;
+constexpr bool kGdRadix8 = true;
+__global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_groupdelay(D4cParams p) {
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
@@ -327,10 +331,10 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
 #ifdef WORLD_EMU
   constexpr int kBinsPerThread = 4096 / 2 + 1;          // one emulated thread owns every bin
 #else
-  constexpr int kBinsPerThread = (4096 / 2 + 1 + 255) / 256;
+  constexpr int kBinsPerThread = (4096 / 2 + 1 + kGdThreads - 1) / kGdThreads;
 #endif
   double a_reg[kBinsPerThread];
-  const FftPlan plan_c = make_plan(lgn);            // the packed centroid transform: 2^lgn complex points
+  const FftPlan plan_c = kGdRadix8 ? make_plan_r8(lgn) : make_plan(lgn);            // the packed centroid transform: 2^lgn complex points
   const int top_bit = plan_c.rl(plan_c.ns - 1) - 1; // bit of a slot index that carries the top bit of its bin
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
@@ -359,7 +363,7 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
       e.im = v * (i + 1.0);                          // second transform's input (d4c.cpp:111-112)
     }
     WH_STAMP(32, 3 + 5 * c);
-    block_cfft_dif(Z, plan_c, tw);
+    block_cfft_dif<kGdRadix8>(Z, plan_c, tw);
     WH_STAMP(32, 4 + 5 * c);
     // Bins k <= H in an order that makes consecutive lanes read consecutive physical
     // slots (conflict-free): bins below H are exactly the slots whose last-stage digit
@@ -408,7 +412,7 @@ __global__ void __launch_bounds__(256) d4c_groupdelay(D4cParams p) {
                                   Z, false, scratch);
     for (int i = wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
     WH_STAMP(32, 13);
-    block_rfft(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+    block_rfft<kGdRadix8>(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
     WH_STAMP(32, 14);
   }
   d4c_dc_correct(B, cf0, fs, N, Zr);
@@ -541,7 +545,7 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), 256, d4c_love_lds_bytes(p.lg_love), stream, p);
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(d4c_groupdelay, dim3(max_frames, p.b.n_utt), 256, d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
+  WH_BLOCKS(d4c_groupdelay, dim3(max_frames, p.b.n_utt), kGdThreads, d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
   WH_BLOCKS(d4c_band, dim3(p.nap, max_frames, p.b.n_utt), 256, d4c_band_lds_bytes(p.lg_d4c), stream, p);
   WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 0, stream, p);
 }

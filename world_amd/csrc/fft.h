@@ -256,12 +256,15 @@ template <int LR> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int
 }
 
 // ---- forward: element n at slot swz(n) in -> bin k at slot fft_slot(plan, k) out ----
+// R8: the plan is known to hold no radix-16 stage (make_plan_r8), so that butterfly -- and its
+// register footprint -- is compiled out of the instantiation.
+template <bool R8 = false>
 __device__ __forceinline__ void block_cfft_dif(cplx *z, const FftPlan &p, const TwLds &tw) {
   int lev = p.lg;
   for (int s = 0; s < p.ns; ++s) {
     __syncthreads();
     switch (p.rl(s)) {
-      case 4: dif_stage<4>(z, p.lg, lev, tw); break;
+      case 4: if (!R8) dif_stage<4>(z, p.lg, lev, tw); break;
       case 3: dif_stage<3>(z, p.lg, lev, tw); break;
       case 2: dif_stage<2>(z, p.lg, lev, tw); break;
       default: dif_stage<1>(z, p.lg, lev, tw); break;
@@ -271,11 +274,11 @@ __device__ __forceinline__ void block_cfft_dif(cplx *z, const FftPlan &p, const 
   __syncthreads();
 }
 
-template <class Src>
+template <bool R8 = false, class Src>
 __device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, const TwLds &tw, Src src) {
   __syncthreads();                                   // earlier readers of z are done
   switch (p.rl(0)) {
-    case 4: dif_first_stage<4>(z, p.lg, tw, src); break;
+    case 4: if (!R8) dif_first_stage<4>(z, p.lg, tw, src); break;
     case 3: dif_first_stage<3>(z, p.lg, tw, src); break;
     case 2: dif_first_stage<2>(z, p.lg, tw, src); break;
     default: dif_first_stage<1>(z, p.lg, tw, src); break;
@@ -284,7 +287,7 @@ __device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, c
   for (int s = 1; s < p.ns; ++s) {
     __syncthreads();
     switch (p.rl(s)) {
-      case 4: dif_stage<4>(z, p.lg, lev, tw); break;
+      case 4: if (!R8) dif_stage<4>(z, p.lg, lev, tw); break;
       case 3: dif_stage<3>(z, p.lg, lev, tw); break;
       case 2: dif_stage<2>(z, p.lg, lev, tw); break;
       default: dif_stage<1>(z, p.lg, lev, tw); break;
@@ -323,17 +326,17 @@ __device__ __forceinline__ double &rfft_in(cplx *z, int n) {
 template <class Emit>
 __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit);
 
-template <class Emit>
+template <bool R8 = false, class Emit>
 __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Emit emit) {
-  const FftPlan plan = make_plan(lgn - 1);
-  block_cfft_dif(z, plan, tw);
+  const FftPlan plan = R8 ? make_plan_r8(lgn - 1) : make_plan(lgn - 1);
+  block_cfft_dif<R8>(z, plan, tw);
   rfft_merge(z, lgn, plan, tw, emit);
 }
 // same transform with the packed input supplied by src(n) = (x[2n], x[2n+1]), n < N/2: z is pure workspace
-template <class Src, class Emit>
-__device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &tw, Src src, Emit emit, bool radix8 = false) {
-  const FftPlan plan = radix8 ? make_plan_r8(lgn - 1) : make_plan(lgn - 1);
-  block_cfft_dif_from(z, plan, tw, src);
+template <bool R8 = false, class Src, class Emit>
+__device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &tw, Src src, Emit emit) {
+  const FftPlan plan = R8 ? make_plan_r8(lgn - 1) : make_plan(lgn - 1);
+  block_cfft_dif_from<R8>(z, plan, tw, src);
   rfft_merge(z, lgn, plan, tw, emit);
 }
 template <class Emit>

@@ -57,6 +57,9 @@ __global__ void ct_prepare(CtParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Largest butterfly of ct_frame's transforms (log2): a 1024-point complex transform has only 64
+// radix-16 butterflies for 256 threads; smaller butterflies keep more threads busy per stage.
+constexpr int kCtMaxLr = 3;
 // PER: samples of the window a thread owns (fft_size / 256 on the GPU)
 template <int PER>
 __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
 
   WH_STAMP(0, 2);
   // ---- GetPowerSpectrum (cheaptrick.cpp:64-82): r2c, |X|^2 -----------------
-  block_rfft(Z, lgn, tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
+  block_rfft<kCtMaxLr>(Z, lgn, tw, [&](int k, double re, double im) { P[k] = re * re + im * im; });
 
   WH_STAMP(0, 3);
   // DCCorrection (common.cpp:56-75); replica staged in seg, then added
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   // the symmetric extension of the log spectrum is read by the first FFT stage directly from P
   const double q1 = p.q1, inv_fs = 1.0 / fs;
   auto mirrored = [&](int i) { return i <= half ? P[i] : P[N - i]; };
-  block_rfft_from(Z, lgn, tw, [&](int n) { cplx v; v.re = mirrored(2 * n); v.im = mirrored(2 * n + 1); return v; },
+  block_rfft_from<kCtMaxLr>(Z, lgn, tw, [&](int n) { cplx v; v.re = mirrored(2 * n); v.im = mirrored(2 * n + 1); return v; },
                   [&](int k, double re, double im) {
     (void)im;
     double sl, cl;
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     P[k] = re * sl * cl * inv_n;                        // == .. / N: N is a power of two
   });
   WH_STAMP(0, 8);
-  block_irfft(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
+  block_irfft<kCtMaxLr>(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   WH_STAMP(0, 9);
   double *out = p.spectrogram + ((size_t)u * p.b.f_stride + f) * nb;
   block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = v; });

@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_gro
       e.im = v * (i + 1.0);                          // second transform's input (d4c.cpp:111-112)
     }
     WH_STAMP(32, 3 + 5 * c);
-    block_cfft_dif<kGdRadix8>(Z, plan_c, tw);
+    block_cfft_dif<kGdRadix8 ? 3 : 4>(Z, plan_c, tw);
     WH_STAMP(32, 4 + 5 * c);
     // Bins k <= H in an order that makes consecutive lanes read consecutive physical
     // slots (conflict-free): bins below H are exactly the slots whose last-stage digit
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_gro
                                   Z, false, scratch);
     for (int i = wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
     WH_STAMP(32, 13);
-    block_rfft<kGdRadix8>(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+    block_rfft<kGdRadix8 ? 3 : 4>(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
     WH_STAMP(32, 14);
   }
   d4c_dc_correct(B, cf0, fs, N, Zr);

@@ -87,15 +87,16 @@ __host__ __device__ __forceinline__ FftPlan make_plan(int lg) {
   if (r) p.stages |= (unsigned)r << (4 * p.ns++);
   return p;
 }
-// the same with radix-8 stages: twice the butterflies per stage (every thread of a 256-thread
+// the same with smaller butterflies (max_lr = 3: radix 8): twice the butterflies per stage (every thread of a 256-thread
 // workgroup stays busy on a 2048-point transform) and half the registers, for one more LDS pass
-__host__ __device__ __forceinline__ FftPlan make_plan_r8(int lg) {
+__host__ __device__ __forceinline__ FftPlan make_plan_max(int lg, int max_lr) {
   FftPlan p; p.lg = lg; p.ns = 0; p.stages = 0;
   int r = lg;
-  while (r >= 3) { p.stages |= 3u << (4 * p.ns++); r -= 3; }
+  while (r >= max_lr) { p.stages |= (unsigned)max_lr << (4 * p.ns++); r -= max_lr; }
   if (r) p.stages |= (unsigned)r << (4 * p.ns++);
   return p;
 }
+__host__ __device__ __forceinline__ FftPlan make_plan_r8(int lg) { return make_plan_max(lg, 3); }
 // LDS slot swizzle: XOR the 16-byte slot index with bits 4..7 of itself.  With the
 // butterfly->thread mapping below every ds_read_b128 of every stage of every plan
 // (256..4096 points) is conflict-free in the gfx950 bank model (MI355X_MICROARCH.md
@@ -256,16 +257,16 @@ template <int LR> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int
 }
 
 // ---- forward: element n at slot swz(n) in -> bin k at slot fft_slot(plan, k) out ----
-// R8: the plan is known to hold no radix-16 stage (make_plan_r8), so that butterfly -- and its
-// register footprint -- is compiled out of the instantiation.
-template <bool R8 = false>
+// MAXLR: the plan is known to hold no stage above radix 2^MAXLR (make_plan_max), so the larger
+// butterflies -- and their register footprint -- are compiled out of the instantiation.
+template <int MAXLR = 4>
 __device__ __forceinline__ void block_cfft_dif(cplx *z, const FftPlan &p, const TwLds &tw) {
   int lev = p.lg;
   for (int s = 0; s < p.ns; ++s) {
     __syncthreads();
     switch (p.rl(s)) {
-      case 4: if (!R8) dif_stage<4>(z, p.lg, lev, tw); break;
-      case 3: dif_stage<3>(z, p.lg, lev, tw); break;
+      case 4: if (MAXLR >= 4) dif_stage<4>(z, p.lg, lev, tw); break;
+      case 3: if (MAXLR >= 3) dif_stage<3>(z, p.lg, lev, tw); break;
       case 2: dif_stage<2>(z, p.lg, lev, tw); break;
       default: dif_stage<1>(z, p.lg, lev, tw); break;
     }
@@ -274,12 +275,12 @@ __device__ __forceinline__ void block_cfft_dif(cplx *z, const FftPlan &p, const 
   __syncthreads();
 }
 
-template <bool R8 = false, class Src>
+template <int MAXLR = 4, class Src>
 __device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, const TwLds &tw, Src src) {
   __syncthreads();                                   // earlier readers of z are done
   switch (p.rl(0)) {
-    case 4: if (!R8) dif_first_stage<4>(z, p.lg, tw, src); break;
-    case 3: dif_first_stage<3>(z, p.lg, tw, src); break;
+    case 4: if (MAXLR >= 4) dif_first_stage<4>(z, p.lg, tw, src); break;
+    case 3: if (MAXLR >= 3) dif_first_stage<3>(z, p.lg, tw, src); break;
     case 2: dif_first_stage<2>(z, p.lg, tw, src); break;
     default: dif_first_stage<1>(z, p.lg, tw, src); break;
   }
@@ -287,8 +288,8 @@ __device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, c
   for (int s = 1; s < p.ns; ++s) {
     __syncthreads();
     switch (p.rl(s)) {
-      case 4: if (!R8) dif_stage<4>(z, p.lg, lev, tw); break;
-      case 3: dif_stage<3>(z, p.lg, lev, tw); break;
+      case 4: if (MAXLR >= 4) dif_stage<4>(z, p.lg, lev, tw); break;
+      case 3: if (MAXLR >= 3) dif_stage<3>(z, p.lg, lev, tw); break;
       case 2: dif_stage<2>(z, p.lg, lev, tw); break;
       default: dif_stage<1>(z, p.lg, lev, tw); break;
     }
@@ -298,13 +299,14 @@ __device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, c
 }
 
 // ---- inverse (unscaled): bin k at slot fft_slot(plan, k) in -> element n at slot swz(n) out ----
+template <int MAXLR = 4>
 __device__ __forceinline__ void block_cfft_dit(cplx *z, const FftPlan &p, const TwLds &tw) {
   int done = 0;
   for (int s = p.ns - 1; s >= 0; --s) {
     __syncthreads();
     switch (p.rl(s)) {
-      case 4: dit_stage<4>(z, p.lg, done, tw); break;
-      case 3: dit_stage<3>(z, p.lg, done, tw); break;
+      case 4: if (MAXLR >= 4) dit_stage<4>(z, p.lg, done, tw); break;
+      case 3: if (MAXLR >= 3) dit_stage<3>(z, p.lg, done, tw); break;
       case 2: dit_stage<2>(z, p.lg, done, tw); break;
       default: dit_stage<1>(z, p.lg, done, tw); break;
     }
@@ -326,17 +328,17 @@ __device__ __forceinline__ double &rfft_in(cplx *z, int n) {
 template <class Emit>
 __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit);
 
-template <bool R8 = false, class Emit>
+template <int MAXLR = 4, class Emit>
 __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Emit emit) {
-  const FftPlan plan = R8 ? make_plan_r8(lgn - 1) : make_plan(lgn - 1);
-  block_cfft_dif<R8>(z, plan, tw);
+  const FftPlan plan = make_plan_max(lgn - 1, MAXLR);
+  block_cfft_dif<MAXLR>(z, plan, tw);
   rfft_merge(z, lgn, plan, tw, emit);
 }
 // same transform with the packed input supplied by src(n) = (x[2n], x[2n+1]), n < N/2: z is pure workspace
-template <bool R8 = false, class Src, class Emit>
+template <int MAXLR = 4, class Src, class Emit>
 __device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &tw, Src src, Emit emit) {
-  const FftPlan plan = R8 ? make_plan_r8(lgn - 1) : make_plan(lgn - 1);
-  block_cfft_dif_from<R8>(z, plan, tw, src);
+  const FftPlan plan = make_plan_max(lgn - 1, MAXLR);
+  block_cfft_dif_from<MAXLR>(z, plan, tw, src);
   rfft_merge(z, lgn, plan, tw, emit);
 }
 template <class Emit>
@@ -385,10 +387,10 @@ __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan
 // ---- real inverse transform (unscaled: N * irfft, like the reference's c2r) ----
 // spec(k) returns X[k] for k in [0, N/2] (the imaginary part of DC and Nyquist
 // is ignored, src/fft.cpp:28-29).  On return real output n is rfft_in(z, n).
-template <class Spec>
+template <int MAXLR = 4, class Spec>
 __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, Spec spec) {
   const int lgh = lgn - 1, h = 1 << lgh;
-  const FftPlan plan = make_plan(lgh);
+  const FftPlan plan = make_plan_max(lgh, MAXLR);
   __syncthreads();
   // Pre-twiddle in conjugate pairs, walking physical slots like rfft_merge: with s = X[k] +
   // conj(X[h-k]), t = w_k (X[k] - conj(X[h-k])):  Z[k] = s + i t  and  Z[h-k] = conj(s - i t).
@@ -424,7 +426,7 @@ __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, S
       z[o.slot] = o.r;
       if (o.mslot >= 0) z[o.mslot] = o.rm;
     });
-  block_cfft_dit(z, plan, tw);
+  block_cfft_dit<MAXLR>(z, plan, tw);
 }
 
 }  // namespace world_hip

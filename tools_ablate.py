@@ -1,9 +1,8 @@
 """Ablation timing on the GPU box (development aid): swap in alternative source files, rebuild, time, restore."""
 import json, subprocess, sys, shutil
 VARIANTS = {
-  'base_r8': {},
-  'ct_r4': {'world_amd/csrc/cheaptrick.hip': 'tools_alt_ct_r4.txt'},
-  'ct_r16': {'world_amd/csrc/cheaptrick.hip': 'tools_alt_ct_r16.txt'},
+  'base': {},
+  'band_r8': {'world_amd/csrc/d4c.hip': 'tools_alt_band_r8.txt'},
   'base2': {},
 }
 KERNELS = ('ct_frame', 'd4c_groupdelay', 'd4c_band', 'd4c_lovetrain', 'hv_refine')

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   double *scratch = Zr + M;
-  const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
+  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);    // inner complex transform's table
   const double cf0 = f0 > 40.0 ? f0 : 40.0;
   const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
                                 kBlackman, 3.0, p.noise + p.offsets1[fi], Z, false, scratch);
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
   const int b2 = static_cast<int>(ceil(7900.0 * M / fs));
   double lo = 0.0, hi = 0.0;     // cumulative power (b0, b1] and (b0, b2]   (d4c.cpp:241-249)
-  block_rfft(Z, lgn, tw, [&](int k, double re, double im) {
+  block_rfft<3>(Z, lgn, tw, [&](int k, double re, double im) {
     if (k > b0 && k <= b2) {
       double pw = re * re + im * im;
       hi += pw;
@@ -526,7 +526,7 @@ __global__ void d4c_finish(D4cParams p) {
 }
 
 // ---------------------------------------------------------------------------
-size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 4 + 2); }
+size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 8 + 2); }
 size_t d4c_groupdelay_lds_bytes(int lg) {
   int N = 1 << lg;
   return sizeof(double) * (size_t)(2 * N + 8 + 64 + N / 4 + 2);

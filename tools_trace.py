@@ -35,3 +35,6 @@ for unit, name, base, n in (("d4c", "d4c_band", 0, 10), ("d4c", "d4c_groupdelay"
 t = stamps("hv")[:8]
 print("hv_refine (one wave, frame 5000): cache fill", t[0], "window rebuilds", t[1], "DFT+reduce", t[2], "tails", t[3],
       "refined candidates", t[4])
+
+t = stamps("hv")[16:24]
+print("hv_band_events (workgroup seg 5, band 20): setup", t[0], "tile fetch/commit", t[1], "FIR", t[2], "events", t[3], "taps", t[4])

@@ -11,6 +11,7 @@
 // of the reference scales the signal by a power of two, which cancels exactly in
 // the crossing-time ratio below.)
 #pragma once
+#include "trace.h"
 #include "common.h"
 
 namespace world_hip {
@@ -170,6 +171,9 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
     return;
   }
   const int seg_end = imin(n, seg_begin + kSeg);
+  const bool trace_me = blockIdx.x == 5 && blockIdx.y == 20; (void)trace_me;
+  WH_ACC_DECL;
+  WH_ACC_BEGIN;
   double *taps = reinterpret_cast<double *>(lds);
   double *yt = taps + (job.max_ntap + 1);
   double *s = yt + pad8(kTile + 2 + job.max_ntap + 3 + 8) + 1;
@@ -182,16 +186,22 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
   const bool pipelined = tile_fits_regs(job);
   TileRegs pre;
   if (pipelined) tile_fetch(job, seg_begin, pre);
+  WH_ACC_END(0);
   for (int t0 = seg_begin; t0 < seg_end; t0 += kTile) {
+    WH_ACC_BEGIN;
     if (pipelined) {
       __syncthreads();                               // everyone is done with the previous tile's yt and s
       tile_commit(job, pre, yt);
       __syncthreads();
       if (t0 + kTile < seg_end) tile_fetch(job, t0 + kTile, pre);   // in flight during this tile's FMAs
+      WH_ACC_END(1);
+      WH_ACC_BEGIN;
       fir_compute(job, taps, yt, s);
     } else {
       fir_tile(job, taps, t0, yt, s);
     }
+    WH_ACC_END(2);
+    WH_ACC_BEGIN;
     // events: every thread inspects kOutPer consecutive samples (time order) and records
     // the crossings of each family as a bit mask; ONE block scan of the four packed counts
     // gives the list positions; the sub-sample times (one FP64 division each) are then
@@ -232,7 +242,10 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
         count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
       }
     }
+    WH_ACC_END(3);
   }
+  WH_ACC_SET(4, job.ntap);
+  WH_ACC_FLUSH(16, tid == 0);
   if (tid == 0)
     for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * job.nseg] = imin(count[fam], kSegCap);
 }

@@ -11,6 +11,8 @@
 #include "bandfilter.h"
 #include "decimate.h"
 #include "dio.h"
+#include "trace.h"
+WH_TRACE_DEFINE(dio)
 
 namespace world_hip {
 

@@ -4,8 +4,8 @@
 // In-situ phase latencies are what rocprofv3's per-kernel totals cannot show.
 #pragma once
 #if defined(WH_TRACE) && !defined(WORLD_EMU)
+namespace world_hip { static __device__ long long wh_trace[128]; }   // one per translation unit
 #define WH_TRACE_DEFINE(unit)                                                                        \
-  namespace world_hip { __device__ long long wh_trace[128]; }                                          \
   extern "C" __attribute__((visibility("default"))) int world_hip_trace_read_##unit(long long *out, int n) { \
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(world_hip::wh_trace), sizeof(long long) * n);      \
   }
@@ -15,12 +15,14 @@
 #define WH_ACC_BEGIN do { if (trace_me) wh_t0 = clock64(); } while (0)
 #define WH_ACC_END(k) do { if (trace_me) wh_acc[k] += clock64() - wh_t0; } while (0)
 #define WH_ACC_COUNT(k) do { if (trace_me) wh_acc[k] += 1; } while (0)
+#define WH_ACC_SET(k, v) do { if (trace_me) wh_acc[k] = (v); } while (0)
 #define WH_ACC_FLUSH(base, lane0) do { if (trace_me && (lane0)) for (int k_ = 0; k_ < 8; ++k_) wh_trace[(base) + k_] = wh_acc[k_]; } while (0)
 #else
 #define WH_ACC_DECL
 #define WH_ACC_BEGIN do { } while (0)
 #define WH_ACC_END(k) do { } while (0)
 #define WH_ACC_COUNT(k) do { } while (0)
+#define WH_ACC_SET(k, v) do { } while (0)
 #define WH_ACC_FLUSH(base, lane0) do { } while (0)
 #define WH_TRACE_DEFINE(unit)
 #define WH_STAMP(base, k) do { } while (0)

@@ -2,10 +2,10 @@
 import json, subprocess, sys, shutil
 VARIANTS = {
   'base': {},
-  'band_r8': {'world_amd/csrc/d4c.hip': 'tools_alt_band_r8.txt'},
+  # 'name': {'world_amd/csrc/<unit>': 'path/to/alternative/source'},
   'base2': {},
 }
-KERNELS = ('ct_frame', 'd4c_groupdelay', 'd4c_band', 'd4c_lovetrain', 'hv_refine')
+KERNELS = ('hv_raw_candidates', 'hv_band_events', 'hv_detect', 'hv_refine', 'hv_prune')
 def run(name):
     out = subprocess.run([sys.executable, 'bench.py', '--steps', '30', '--warmup', '3', '--streams', '1', '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]

@@ -270,7 +270,30 @@ __device__ __forceinline__ double interval_f0(const double *e, int k, double fs)
 // interp1 (matlabfunctions.cpp:136-176) of the n_int intervals of one family at time t:
 // the bin is clamp(#{locations <= t}, 1, n-1), so both ends extrapolate linearly.
 __device__ __forceinline__ double interp_intervals(const double *e, int n_int, double fs, double t) {
-  int lo = 0, hi = n_int;                       // count of locations <= t
+  // count of locations <= t.  Crossings of a band-passed signal are nearly uniform in time, so a
+  // proportional guess lands within a few intervals of the answer: bracket it by doubling steps
+  // from the guess, then bisect the bracket (same result as bisecting [0, n_int), ~4 probes, not 10).
+  int lo = 0, hi = n_int;
+  if (n_int > 8) {
+    const double first = interval_loc(e, 0, fs), last = interval_loc(e, n_int - 1, fs);
+    const double r = (t - first) / (last - first) * (n_int - 1);
+    int g = r < 0.0 ? 0 : (r > n_int - 1.0 ? n_int - 1 : static_cast<int>(r));
+    if (interval_loc(e, g, fs) <= t) {            // every index <= g is <= t
+      lo = g + 1;
+      for (int step = 1, q = g + 1; ; q += step, step <<= 1) {
+        if (q >= n_int) break;                    // hi stays n_int
+        if (interval_loc(e, q, fs) > t) { hi = q; break; }
+        lo = q + 1;
+      }
+    } else {                                      // every index >= g is > t
+      hi = g;
+      for (int step = 1, q = g - 1; ; q -= step, step <<= 1) {
+        if (q < 0) break;                         // lo stays 0
+        if (interval_loc(e, q, fs) <= t) { lo = q + 1; break; }
+        hi = q;
+      }
+    }
+  }
   while (lo < hi) {
     int mid = (lo + hi) >> 1;
     if (interval_loc(e, mid, fs) <= t) lo = mid + 1; else hi = mid;

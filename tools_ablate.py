@@ -2,7 +2,7 @@
 import json, subprocess, sys, shutil
 VARIANTS = {
   'base': {},
-  # 'name': {'world_amd/csrc/<unit>': 'path/to/alternative/source'},
+  'old_refine': {'world_amd/csrc/harvest.hip': 'tools_old_harvest.txt'},
   'base2': {},
 }
 KERNELS = ('hv_raw_candidates', 'hv_band_events', 'hv_detect', 'hv_refine', 'hv_prune')

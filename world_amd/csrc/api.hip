@@ -56,6 +56,8 @@ struct HarvestBands {            // cached per (fs, f0_floor, f0_ceil)
   int nch = 0, max_half = 0;
   double *d_band_f0 = nullptr, *d_taps = nullptr;
   int *d_half = nullptr, *d_off = nullptr;
+  double *d_win_tab = nullptr;   // refinement-window angle steps per half length (hv_refine)
+  int win_tab_len = 0;
   std::vector<double> band_f0;
 };
 
@@ -310,6 +312,21 @@ static void prepare_bands(WorldHipContext *c, int fs, double f0_floor, double f0
   devrt::sync(c->stream);
   hb.fs = fs; hb.f0_floor = f0_floor; hb.f0_ceil = f0_ceil; hb.nch = nch; hb.max_half = max_half;
   hb.band_f0 = fb;
+  // GetMainWindow's angle step for every window half length hv_refine can meet (harvest.cpp:446-456):
+  // cos/sin of pi*d and of pi*WAVE*d with d = 2/(2hw+1), so the kernel needs one sincospi per rebuild
+  const int hw_max = static_cast<int>(1.5 * afs / f0_floor + 1.0) + 2;
+  std::vector<double> wt((size_t)(hw_max + 1) * 4);
+  for (int hw = 0; hw <= hw_max; ++hw) {
+    const double wlen_t = (2.0 * hw + 1.0) / afs;
+    const double d = (1.0 / afs) * (2.0 / wlen_t);
+    wt[4 * hw + 0] = sin(kPi * d); wt[4 * hw + 1] = cos(kPi * d);
+    wt[4 * hw + 2] = sin(kPi * (WAVE * d)); wt[4 * hw + 3] = cos(kPi * (WAVE * d));
+  }
+  if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
+  hb.d_win_tab = static_cast<double *>(devrt::dmalloc(sizeof(double) * wt.size()));
+  devrt::h2d(hb.d_win_tab, wt.data(), sizeof(double) * wt.size(), c->stream);
+  devrt::sync(c->stream);
+  hb.win_tab_len = hw_max + 1;
 }
 
 static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride,
@@ -375,6 +392,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.y_len = upload(c, yl);
   p.nfb = upload(c, nfb);
   p.band_f0 = hb.d_band_f0; p.band_half = hb.d_half; p.band_off = hb.d_off; p.band_taps = hb.d_taps;
+  p.win_tab = hb.d_win_tab;
   p.fwd = c->arena.take<double>(B * p.m_stride);
   p.y = c->arena.take<double>(B * p.y_stride);
   p.events = c->arena.take<double>(B * p.nch * 4 * p.ev_cap);
@@ -763,6 +781,7 @@ void world_hip_destroy(WorldHipContext *c) {
     }
     HarvestBands &hb = c->bands;
     if (hb.d_band_f0) { devrt::dfree(hb.d_band_f0); devrt::dfree(hb.d_taps); devrt::dfree(hb.d_half); devrt::dfree(hb.d_off); }
+    if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
   } catch (...) {
   }
   delete c;

@@ -28,6 +28,7 @@ struct HarvestParams {
   const int *band_off;     // [nch]  offset of the band's taps in band_taps
   const double *band_taps; // Nuttall * cos band-pass FIRs (harvest.cpp:101-108), built on the host
   int max_half;            // max L
+  const double *win_tab;   // [hw][4] = sin/cos(pi d), sin/cos(pi WAVE d), d = 2/(2hw+1): refinement window steps
   Tables tab;
   // ---- workspace (device) ----
   double *fwd;             // [n_utt][m_stride] forward-filtered padded signal

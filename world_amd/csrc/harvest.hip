@@ -222,10 +222,10 @@ __global__ void hv_refine(HarvestParams p) {
       // GetRefinedF0, harvest.cpp:589-617
       const int hw = static_cast<int>(1.5 * fs / f0c + 1.0);
       const int blen = 2 * hw + 1;
-      const double wlen_t = (2.0 * hw + 1.0) / fs;
+      const double wlen_t = (2.0 * hw + 1.0) * inv_fs;
       const int lgN = 2 + floor_log2_int(blen);                  // fft_size = 2^(2+floor(log2(2hw+1)))
       const int N = 1 << lgN;
-      const double base0 = static_cast<double>(-hw) / fs;
+      const double base0 = static_cast<double>(-hw) * inv_fs;   // first = round(..) + 0.001 margin absorbs the ulp
       const int first = mround((pos + base0) * fs + 0.001);      // GetBaseIndex, harvest.cpp:434-441
       const bool same_window = hw == c_hw && first == c_first;
       if (!same_window) {
@@ -234,14 +234,13 @@ __global__ void hv_refine(HarvestParams p) {
         // (GetDiffWindow, :462-468).  w[i+1]-w[i-1] follows from the angle-addition
         // identities, so no neighbour values are exchanged.
         const double two_over_t = 2.0 / wlen_t;
-        double sd, cd;
-        sincospi(inv_fs * two_over_t, &sd, &cd);
+        // sin/cos of one sample's and of WAVE samples' angle step: host table indexed by hw
+        const double *wt = p.win_tab + 4 * hw;
+        const double sd = wt[0], cd = wt[1], sD = wt[2], cD = wt[3];
         const double s2d = 2.0 * sd * cd, c2d = 2.0 * cd * cd - 1.0;
         wave_sync();                                             // the previous candidate's reads are done
         // a lane's samples are WAVE apart: one sincospi for its first sample, then a rotation
         // by WAVE * delta per further sample
-        double sD, cD;
-        sincospi(WAVE * (inv_fs * two_over_t), &sD, &cD);
         double sa, ca;
         sincospi((((first + lane) - 1.0) * inv_fs - pos) * two_over_t, &sa, &ca);
         for (int i = lane; i < blen; i += WAVE) {

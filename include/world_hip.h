@@ -102,6 +102,12 @@ WORLD_HIP_API void CodeSpectralEnvelope(const double *const *spectrogram, int f0
 WORLD_HIP_API void DecodeSpectralEnvelope(const double *const *coded_spectral_envelope, int f0_length, int fs,
                                           int fft_size, int number_of_dimensions, double **spectrogram);
 
+/* reference src/world/synthesis.h:30 (src/synthesis.cpp:339-399) -- SURVEY.md 8f.3.  The only public
+ * symbol of synthesis.o; SynthesisRealtime (synthesisrealtime.o) is not provided. */
+WORLD_HIP_API void Synthesis(const double *f0, int f0_length, const double *const *spectrogram,
+                             const double *const *aperiodicity, int fft_size, double frame_period, int fs,
+                             int y_length, double *y);
+
 /* ------------------------------------------------------------------------- */
 /* Part 2: batched device-resident API                                        */
 /* ------------------------------------------------------------------------- */
@@ -151,6 +157,15 @@ WORLD_HIP_API int world_hip_d4c_batch(WorldHipContext *ctx, int n_utt, int fs, c
                                       int x_stride, const int *x_length, const int *n_frames,
                                       int f_stride, const double *d_tpos, const double *d_f0,
                                       int fft_size, const D4COption *option, double *d_aperiodicity);
+
+/* Waveform synthesis from analysis parameters (reference src/synthesis.cpp:339-399):
+ *   f0 [n_utt][f_stride], spectrogram / aperiodicity [n_utt][f_stride][fft_size/2+1] (device),
+ *   n_frames, y_length [n_utt] (HOST), y [n_utt][y_stride] (device).  frame_period in ms.
+ * Pulses beyond a mean rate of 1200 Hz over the longest utterance are dropped. */
+WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int fs, double frame_period,
+                                            int fft_size, const int *n_frames, int f_stride, const double *d_f0,
+                                            const double *d_spectrogram, const double *d_aperiodicity,
+                                            const int *y_length, int y_stride, double *d_y);
 
 /* 16-bit PCM (as stored in a WAV file) -> the doubles the reference's wavread() produces,
  * x = q / 32768 (tools/audioio.cpp:236-249), on the device: upload int16, not FP64. */

@@ -73,6 +73,7 @@ class PortOracle(_Base):
         L.wo_dc_correction.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
         L.wo_round.argtypes = [C.c_double]
         L.wo_nuttall.argtypes = [C.c_int, _dp]
+        L.wo_synthesis.argtypes = [_dp, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp]
         L.wo_number_of_aperiodicities.argtypes = [C.c_int]
         L.wo_code_aperiodicity.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
         L.wo_decode_aperiodicity.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
@@ -147,6 +148,13 @@ class PortOracle(_Base):
         ap = np.zeros((len(f0), fft_size // 2 + 1))
         self.lib.wo_d4c(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, threshold, _p(ap))
         return ap
+
+    # -- synthesis --
+    def synthesis(self, f0, sp, ap, fft_size, frame_period, fs, y_length):
+        f0, sp, ap = _f64(f0), _f64(sp), _f64(ap)
+        y = np.zeros(y_length)
+        self.lib.wo_synthesis(_p(f0), len(f0), _p(sp), _p(ap), fft_size, frame_period, fs, y_length, _p(y))
+        return y
 
     # -- codec --
     def number_of_aperiodicities(self, fs):

@@ -1294,3 +1294,151 @@ void wo_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_si
   }
   free(mel_axis); free(faxis); free(wr); free(wi); free(mel); free(zr); free(zi);
 }
+
+/* ------------------------------------------------------------------ */
+/* synthesis.cpp                                                        */
+/* ------------------------------------------------------------------ */
+/* GetMinimumPhaseSpectrum (common.cpp:182-220).  lg[0..N/2] in; (mr, mi)[0..N/2] out.
+ * The reference's forward c2c plan computes FFT(conj(x)) (fft.cpp:62-71). */
+static void minimum_phase(const double *lg, int N, double *mr, double *mi) {
+  int H = N / 2;
+  double *full = dalloc(N), *cr = dalloc(H + 1), *ci = dalloc(H + 1), *zr = dalloc(N), *zi = dalloc(N);
+  for (int i = 0; i <= H; ++i) full[i] = lg[i];
+  for (int i = H + 1; i < N; ++i) full[i] = lg[N - i];
+  wo_rfft(N, full, cr, ci);
+  zr[0] = cr[0]; zi[0] = -ci[0];
+  for (int i = 1; i < H; ++i) { zr[i] = cr[i] * 2.0; zi[i] = ci[i] * -2.0; }
+  zr[H] = cr[H]; zi[H] = -ci[H];
+  for (int i = H + 1; i < N; ++i) { zr[i] = 0.0; zi[i] = 0.0; }
+  for (int i = 0; i < N; ++i) zi[i] = -zi[i];            /* conj of the input ... */
+  cfft(N, zr, zi, -1);                                   /* ... forward transform */
+  for (int i = 0; i <= H; ++i) {
+    double t = exp(zr[i] / N);
+    mr[i] = t * cos(zi[i] / N);
+    mi[i] = t * sin(zi[i] / N);
+  }
+  free(full); free(cr); free(ci); free(zr); free(zi);
+}
+
+static void fft_shift(const double *x, int n, double *y) {          /* matlabfunctions.cpp:129-134 */
+  for (int i = 0; i < n / 2; ++i) { y[i] = x[i + n / 2]; y[i + n / 2] = x[i]; }
+}
+
+static double safe_ap(double x) { return dmax(0.001, dmin(0.999999999999, x)); }   /* common.h:111-113 */
+
+void wo_synthesis(const double *f0, int nf, const double *sp, const double *ap, int fft_size,
+                  double frame_period, int fs, int y_length, double *y) {
+  const int N = fft_size, H = N / 2, nb = H + 1;
+  const double two_pi = 2.0 * K_PI;
+  uint32_t rng[4];
+  wo_randn_seed(rng);
+  for (int i = 0; i < y_length; ++i) y[i] = 0.0;
+  double fp = frame_period / 1000.0;
+  /* ---- GetTimeBase (synthesis.cpp:225-318) ---- */
+  double lowest_f0 = fs / fft_size + 1.0;                /* integer division, as in the reference's call (:361) */
+  double *time_axis = dalloc(y_length), *ctime = dalloc(nf + 1), *cf0 = dalloc(nf + 1), *cvuv = dalloc(nf + 1);
+  double *if0 = dalloc(y_length), *ivuv = dalloc(y_length);
+  for (int i = 0; i < y_length; ++i) time_axis[i] = i / (double)fs;
+  for (int i = 0; i < nf; ++i) {
+    ctime[i] = i * fp;
+    cf0[i] = f0[i] < lowest_f0 ? 0.0 : f0[i];
+    cvuv[i] = cf0[i] == 0.0 ? 0.0 : 1.0;
+  }
+  ctime[nf] = nf * fp;
+  cf0[nf] = cf0[nf - 1] * 2 - cf0[nf - 2];
+  cvuv[nf] = cvuv[nf - 1] * 2 - cvuv[nf - 2];
+  wo_interp1(ctime, cf0, nf + 1, time_axis, y_length, if0);
+  wo_interp1(ctime, cvuv, nf + 1, time_axis, y_length, ivuv);
+  for (int i = 0; i < y_length; ++i) {
+    ivuv[i] = ivuv[i] > 0.5 ? 1.0 : 0.0;
+    if0[i] = ivuv[i] == 0.0 ? 500.0 : if0[i];
+  }
+  double *total = dalloc(y_length), *wrap = dalloc(y_length);
+  double *ploc = dalloc(y_length), *pshift = dalloc(y_length);
+  int *pidx = ialloc(y_length);
+  total[0] = two_pi * if0[0] / fs;
+  wrap[0] = fmod(total[0], two_pi);
+  for (int i = 1; i < y_length; ++i) {
+    total[i] = total[i - 1] + two_pi * if0[i] / fs;
+    wrap[i] = fmod(total[i], two_pi);
+  }
+  int np = 0;
+  for (int i = 0; i < y_length - 1; ++i) {
+    if (fabs(wrap[i + 1] - wrap[i]) > K_PI) {
+      ploc[np] = time_axis[i];
+      pidx[np] = i;
+      double y1 = wrap[i] - two_pi, y2 = wrap[i + 1];
+      pshift[np] = (-y1 / (y2 - y1)) / fs;
+      ++np;
+    }
+  }
+  /* ---- GetDCRemover (:320-335) ---- */
+  double *rem = dalloc(N), dcsum = 0.0;
+  for (int i = 0; i < H; ++i) {
+    rem[i] = 0.5 - 0.5 * cos(two_pi * (i + 1.0) / (1.0 + N));
+    rem[N - i - 1] = rem[i];
+    dcsum += rem[i] * 2.0;
+  }
+  for (int i = 0; i < H; ++i) { rem[i] /= dcsum; rem[N - i - 1] = rem[i]; }
+
+  double *env = dalloc(nb), *ratio = dalloc(nb), *lg = dalloc(nb), *mr = dalloc(nb), *mi = dalloc(nb);
+  double *sr = dalloc(nb), *si = dalloc(nb), *wave = dalloc(N), *per = dalloc(N), *aper = dalloc(N), *tmp = dalloc(N);
+  double *nr = dalloc(nb), *ni = dalloc(nb);
+  for (int p = 0; p < np; ++p) {
+    int nxt = p + 1 < np - 1 ? p + 1 : np - 1;
+    int noise_size = pidx[nxt] - pidx[p];
+    double vuv = ivuv[pidx[p]], t = ploc[p];
+    /* GetSpectralEnvelope / GetAperiodicRatio (:140-180) */
+    int ff = imin(nf - 1, (int)floor(t / fp)), fc = imin(nf - 1, (int)ceil(t / fp));
+    double w = t / fp - ff;
+    for (int i = 0; i < nb; ++i) {
+      double a0 = fabs(sp[(size_t)ff * nb + i]), a1 = fabs(sp[(size_t)fc * nb + i]);
+      double b0 = safe_ap(ap[(size_t)ff * nb + i]), b1 = safe_ap(ap[(size_t)fc * nb + i]);
+      if (ff == fc) { env[i] = a0; ratio[i] = pow(b0, 2.0); }
+      else { env[i] = (1.0 - w) * a0 + w * a1; ratio[i] = pow((1.0 - w) * b0 + w * b1, 2.0); }
+    }
+    /* GetPeriodicResponse (:103-135) */
+    if (vuv <= 0.5 || ratio[0] > 0.999) {
+      for (int i = 0; i < N; ++i) per[i] = 0.0;
+    } else {
+      for (int i = 0; i < nb; ++i) lg[i] = log(env[i] * (1.0 - ratio[i]) + K_TINY) / 2.0;
+      minimum_phase(lg, N, mr, mi);
+      double coef = two_pi * pshift[p] * fs / N;
+      for (int i = 0; i < nb; ++i) {                     /* GetSpectrumWithFractionalTimeShift (:86-98) */
+        double re2 = cos(coef * i), im2 = sqrt(1.0 - re2 * re2);
+        sr[i] = mr[i] * re2 + mi[i] * im2;
+        si[i] = mi[i] * re2 - mr[i] * im2;
+      }
+      wo_irfft_unscaled(N, sr, si, tmp);
+      fft_shift(tmp, N, per);
+      double dc = 0.0;                                   /* RemoveDCComponent in place (:72-80) */
+      for (int i = H; i < N; ++i) dc += per[i];
+      for (int i = 0; i < H; ++i) per[i] = -dc * rem[i];
+      for (int i = H; i < N; ++i) per[i] -= dc * rem[i];
+    }
+    /* GetAperiodicResponse (:38-66) with GetNoiseSpectrum (:19-33) */
+    double avg = 0.0;
+    for (int i = 0; i < noise_size; ++i) { wave[i] = wo_randn(rng); avg += wave[i]; }
+    avg /= noise_size;
+    for (int i = 0; i < noise_size; ++i) wave[i] -= avg;
+    for (int i = noise_size > 0 ? noise_size : 0; i < N; ++i) wave[i] = 0.0;
+    wo_rfft(N, wave, nr, ni);
+    if (vuv != 0.0) for (int i = 0; i < nb; ++i) lg[i] = log(env[i] * ratio[i]) / 2.0;
+    else for (int i = 0; i < nb; ++i) lg[i] = log(env[i]) / 2.0;
+    minimum_phase(lg, N, mr, mi);
+    for (int i = 0; i < nb; ++i) {
+      sr[i] = mr[i] * nr[i] - mi[i] * ni[i];
+      si[i] = mr[i] * ni[i] + mi[i] * nr[i];
+    }
+    wo_irfft_unscaled(N, sr, si, tmp);
+    fft_shift(tmp, N, aper);
+    /* GetOneFrameSegment (:213-218) and the overlap-add (:376-385) */
+    double sq = sqrt((double)noise_size);
+    int offset = pidx[p] - H + 1;
+    int lo = imax(0, -offset), hi = imin(N, y_length - offset);
+    for (int j = lo; j < hi; ++j) y[j + offset] += (per[j] * sq + aper[j]) / N;
+  }
+  free(time_axis); free(ctime); free(cf0); free(cvuv); free(if0); free(ivuv); free(total); free(wrap);
+  free(ploc); free(pshift); free(pidx); free(rem); free(env); free(ratio); free(lg); free(mr); free(mi);
+  free(sr); free(si); free(wave); free(per); free(aper); free(tmp); free(nr); free(ni);
+}

@@ -70,6 +70,10 @@ void wo_code_spectral_envelope(const double *sp, int nf, int fs, int fft_size,
 void wo_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_size,
                                  int ndim, double *sp);                /* codec.cpp:299-324 */
 
+/* synthesis: dense [nf][fft_size/2+1] spectrogram / aperiodicity */
+void wo_synthesis(const double *f0, int nf, const double *sp, const double *ap, int fft_size,
+                  double frame_period, int fs, int y_length, double *y);   /* synthesis.cpp:339-399 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,9 +71,28 @@ def codec_fixture(R):
     np.savez_compressed(os.path.join(OUT, "codec.npz"), **out)
 
 
+SYNTH_CASES = {"syn16k": (16000, 180, 1024, 5.0, 14400, 0), "syn48k": (48000, 120, 2048, 5.0, 28000, 1),
+               "syn22k_hop10": (22050, 90, 1024, 10.0, 19000, 2)}
+
+
+def synthesis_fixture(R):
+    """Reference Synthesis() (src/synthesis.cpp) on the deterministic parameters of tests/util.synth_params."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import synth_params
+    out = {}
+    for name, (fs, nf, fft, fp, ylen, seed) in SYNTH_CASES.items():
+        f0, sp, ap = synth_params(fs, nf, fft, seed)
+        out[name] = R.synthesis(f0, sp, ap, fft, fp, fs, ylen)
+    np.savez_compressed(os.path.join(OUT, "synthesis.npz"), **out)
+
+
 def main():
     build()
     R = RefOracle()
+    if "--synthesis-only" in sys.argv:
+        synthesis_fixture(R)
+        print("synthesis.npz", os.path.getsize(os.path.join(OUT, "synthesis.npz")) // 1024, "KiB")
+        return
     if "--codec-only" in sys.argv:
         codec_fixture(R)
         print("codec.npz", os.path.getsize(os.path.join(OUT, "codec.npz")) // 1024, "KiB")
@@ -100,6 +119,7 @@ def main():
         interp_x=np.array([1., 2., 4., 7.]), interp_xi=np.array([-1, .5, 1, 1.5, 2, 3.9, 4, 7, 9.]),
         interp_yi=np.array([-10, 5, 10, 15, 20, 39, 40, 70, 90.]))
     codec_fixture(R)
+    synthesis_fixture(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

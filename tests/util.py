@@ -71,3 +71,22 @@ def check_against_golden(backend, g, rtol=RTOL, given_f0=False):
     assert max_rel(ap[rows], g["ap_rows"]) <= rtol, f"aperiodicity rel err {max_rel(ap[rows], g['ap_rows'])}"
     assert max_rel(np.log(sp).sum(axis=1), g["sp_row_sums"]) <= rtol
     assert max_rel(ap.sum(axis=1), g["ap_row_sums"]) <= rtol
+
+
+def synth_params(fs, nf, fft_size, seed=0):
+    """Deterministic analysis-like parameters for the synthesis tests: an f0 contour with unvoiced
+    gaps, a formant-shaped envelope, a rising aperiodicity (plain numpy arithmetic only)."""
+    nb = fft_size // 2 + 1
+    i = np.arange(nf, dtype=np.float64)
+    f0 = 130.0 + 45.0 * np.sin(2 * np.pi * i / 83.0 + seed) + 8.0 * np.sin(2 * np.pi * i / 11.0)
+    f0[(i % 67) < 12] = 0.0                                   # unvoiced stretches
+    f0[-5:] = 0.0
+    k = np.arange(nb, dtype=np.float64) * fs / fft_size
+    env = np.zeros((nf, nb))
+    for c, bw, a in ((700.0, 130.0, 1.0), (1220.0, 170.0, 0.5), (2600.0, 240.0, 0.25), (3500.0, 300.0, 0.1)):
+        centre = c * (1.0 + 0.1 * np.sin(2 * np.pi * i / 140.0 + seed))[:, None]
+        env += a / (1.0 + ((k[None, :] - centre) / bw) ** 2)
+    sp = 1e-3 * env ** 2 + 1e-9
+    ap = np.clip(0.02 + 0.9 * (k[None, :] / (fs / 2.0)) ** 1.5 * (1.0 + 0.2 * np.sin(i / 9.0))[:, None], 0.0, 1.0)
+    ap[f0 == 0.0] = 1.0 - 1e-12
+    return f0, sp, ap

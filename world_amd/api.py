@@ -74,6 +74,8 @@ def load_library(path=LIB_PATH):
                                                C.POINTER(CheapTrickOption), vp]
     lib.world_hip_d4c_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp, C.c_int,
                                         C.POINTER(D4COption), vp]
+    lib.world_hip_synthesis_batch.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, _ip, C.c_int, vp, vp, vp,
+                                              _ip, C.c_int, vp]
     lib.world_hip_pcm16_to_double.argtypes = [vp, C.c_longlong, vp, vp]
     lib.world_hip_code_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.world_hip_decode_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -143,7 +145,9 @@ class HostAPI:
         L.GetF0FloorForCheapTrick.argtypes = [C.c_int, C.c_int]
         L.GetF0FloorForCheapTrick.restype = C.c_double
         L.InitializeCheapTrickOption.argtypes = [C.c_int, C.POINTER(CheapTrickOption)]
-        rows = C.POINTER(_dp)                # codec.h:33-88
+        rows = C.POINTER(_dp)
+        L.Synthesis.argtypes = [_dp, C.c_int, rows, rows, C.c_int, C.c_double, C.c_int, C.c_int, _dp]   # synthesis.h:30
+        # codec.h:33-88
         L.GetNumberOfAperiodicities.argtypes = [C.c_int]
         L.CodeAperiodicity.argtypes = [rows, C.c_int, C.c_int, C.c_int, rows]
         L.DecodeAperiodicity.argtypes = [rows, C.c_int, C.c_int, C.c_int, rows]
@@ -198,6 +202,13 @@ class HostAPI:
         ap = np.zeros((len(f0), fft_size // 2 + 1))
         self.lib.D4C(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), fft_size, C.byref(opt), _rows(ap))
         return ap
+
+    # -- synthesis (reference synthesis.h:30) --
+    def synthesis(self, f0, sp, ap, fft_size, frame_period, fs, y_length):
+        f0, sp, ap = _f64(f0), _f64(sp), _f64(ap)
+        y = np.zeros(y_length)
+        self.lib.Synthesis(_p(f0), len(f0), _rows(sp), _rows(ap), fft_size, frame_period, fs, y_length, _p(y))
+        return y
 
     # -- codec (reference codec.h) --
     def number_of_aperiodicities(self, fs):
@@ -358,6 +369,22 @@ class WorldHip:
                                                  nf.ctypes.data_as(_ip), F, tpos.data_ptr(), f0.data_ptr(),
                                                  fft_size, C.byref(opt), ap.data_ptr()), "d4c")
         return ap
+
+    def synthesis(self, f0, sp, ap, n_frames, fft_size, frame_period, fs, y_length):
+        """reference Synthesis() on a batch: f0 [B, F], sp / ap [B, F, fft/2+1] (float64, device);
+        n_frames and y_length are per-utterance ints; returns y [B, max(y_length)]"""
+        t = self.torch
+        f0, sp, ap = f0.contiguous(), sp.contiguous(), ap.contiguous()
+        B, F = f0.shape
+        nf = np.ascontiguousarray(np.broadcast_to(n_frames, (B,)), dtype=np.int32)
+        yl = np.ascontiguousarray(np.broadcast_to(y_length, (B,)), dtype=np.int32)
+        Y = int(yl.max())
+        y = t.zeros((B, Y), dtype=t.float64, device=f0.device)
+        self._check(self.lib.world_hip_synthesis_batch(self._context(), B, fs, float(frame_period), fft_size,
+                                                       nf.ctypes.data_as(_ip), F, f0.data_ptr(), sp.data_ptr(),
+                                                       ap.data_ptr(), yl.ctypes.data_as(_ip), Y, y.data_ptr()),
+                    "synthesis")
+        return y
 
     def pcm16_to_double(self, pcm):
         """int16 samples (any shape) -> float64 / 32768, wavread()'s convention, on the device"""

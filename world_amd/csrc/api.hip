@@ -22,6 +22,7 @@
 #include "dio.h"
 #include "harvest.h"
 #include "stage_params.h"
+#include "synthesis.h"
 
 namespace world_hip {
 
@@ -77,6 +78,8 @@ struct WorldHipContext {
   double *d_nuttall = nullptr;   // D4C band window
   int nuttall_len = 0;
   void *dio_bands = nullptr;     // world_hip::DioBands (cached DIO filter tables)
+  double *d_dc_remover = nullptr; // GetDCRemover(fft_size) of the synthesiser
+  int dc_remover_len = 0;
   void *codec_tables = nullptr;  // world_hip::CodecTableSet (cached interp1 / DCT tables of the coders)
   double *d_noise = nullptr;     // noise[k] = k-th randn() after reseed (grow-only constant table)
   size_t noise_len = 0;
@@ -708,6 +711,71 @@ static void run_codec(WorldHipContext *c, CodecOp op, int rows, int fs, int fft_
 }
 
 // ---------------------------------------------------------------------------
+// Synthesis (reference src/synthesis.cpp:339-399)
+// ---------------------------------------------------------------------------
+static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_period, int fft_size, const int *n_frames,
+                          int f_stride, const double *d_f0, const double *d_sp, const double *d_ap,
+                          const int *y_length, int y_stride, double *d_y) {
+  if (n_utt <= 0) fail("n_utt must be positive");
+  if (fs <= 0 || frame_period <= 0) fail("fs and frame_period must be positive");
+  if (!d_f0 || !d_sp || !d_ap || !d_y || !n_frames || !y_length) fail("null buffer");
+  const int lg = ilog2_exact(fft_size);
+  if (lg < 7 || lg > 12) fail("Synthesis: fft_size %d unsupported (128..4096: one pulse must fit LDS)", fft_size);
+  int max_y = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    if (n_frames[u] < 2 || n_frames[u] > f_stride) fail("n_frames[%d]=%d outside [2, f_stride]", u, n_frames[u]);
+    if (y_length[u] < 1 || y_length[u] > y_stride) fail("y_length[%d]=%d outside [1, y_stride]", u, y_length[u]);
+    max_y = std::max(max_y, y_length[u]);
+  }
+  if (c->dc_remover_len != fft_size) {                                 // GetDCRemover, synthesis.cpp:320-335
+    std::vector<double> rem(fft_size);
+    double dc = 0.0;
+    for (int i = 0; i < fft_size / 2; ++i) {
+      rem[i] = 0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft_size));
+      rem[fft_size - i - 1] = rem[i];
+      dc += rem[i] * 2.0;
+    }
+    for (int i = 0; i < fft_size / 2; ++i) { rem[i] /= dc; rem[fft_size - i - 1] = rem[i]; }
+    devrt::sync(c->stream);
+    if (c->d_dc_remover) devrt::dfree(c->d_dc_remover);
+    c->d_dc_remover = static_cast<double *>(devrt::dmalloc(sizeof(double) * fft_size));
+    devrt::h2d(c->d_dc_remover, rem.data(), sizeof(double) * fft_size, c->stream);
+    devrt::sync(c->stream);
+    c->dc_remover_len = fft_size;
+  }
+  SynthParams p;
+  p.n_utt = n_utt; p.fs = fs; p.fft_size = fft_size; p.lg_fft = lg;
+  p.frame_period = frame_period / 1000.0;
+  p.lowest_f0 = fs / fft_size + 1.0;                                   // integer division (synthesis.cpp:361)
+  p.f0 = d_f0; p.sp = d_sp; p.ap = d_ap; p.f_stride = f_stride; p.y = d_y; p.y_stride = y_stride;
+  p.nblk = (max_y + kSyTile - 1) / kSyTile;
+  // room for a mean pulse rate of 1200 Hz over the longest utterance (voiced pulses come at f0,
+  // unvoiced ones at 500 Hz); pulses beyond it are dropped and np is clamped
+  p.pulse_cap = static_cast<int>(static_cast<double>(max_y) * 1200.0 / fs) + 16;
+  const size_t B = n_utt;
+  size_t need = 2 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * y_stride) + pad256(B * y_stride) +
+                pad256(sizeof(double) * B * p.nblk) + pad256(sizeof(int) * B * p.nblk) +
+                pad256(sizeof(int) * B * p.pulse_cap) + pad256(sizeof(double) * B * p.pulse_cap) + pad256(sizeof(int) * B) +
+                pad256(sizeof(double) * B * p.pulse_cap * fft_size);
+  ensure_arena(c, need);
+  c->arena.reset();
+  CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
+  p.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
+  p.y_len = upload(c, std::vector<int>(y_length, y_length + n_utt));
+  p.inc = c->arena.take<double>(B * y_stride);
+  p.flags = c->arena.take<unsigned char>(B * y_stride);
+  p.blk_cnt = c->arena.take<int>(B * p.nblk);
+  p.pidx = c->arena.take<int>(B * p.pulse_cap);
+  p.pshift = c->arena.take<double>(B * p.pulse_cap);
+  p.np = c->arena.take<int>(B);
+  p.resp = c->arena.take<double>(B * p.pulse_cap * fft_size);
+  p.dc_remover = c->d_dc_remover;
+  p.noise = ensure_noise(c, (size_t)max_y + 8);
+  p.tab = c->tab;
+  launch_synthesis(p, max_y, c->stream);
+}
+
+// ---------------------------------------------------------------------------
 // error plumbing for the C ABI
 // ---------------------------------------------------------------------------
 template <class F> static int guarded(WorldHipContext *c, F f) {
@@ -775,6 +843,7 @@ void world_hip_destroy(WorldHipContext *c) {
       delete db;
     }
     free_codec_tables(c);
+    if (c->d_dc_remover) devrt::dfree(c->d_dc_remover);
     for (int k = 0; k < kStageRing; ++k) {
       if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
       if (c->stage_ev[k]) devrt::event_destroy(c->stage_ev[k]);
@@ -859,6 +928,15 @@ int world_hip_d4c_batch(WorldHipContext *c, int n_utt, int fs, const double *d_x
                         const double *d_f0, int fft_size, const D4COption *option, double *d_ap) {
   return guarded(c, [&] {
     run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, true);
+  });
+}
+
+int world_hip_synthesis_batch(WorldHipContext *c, int n_utt, int fs, double frame_period, int fft_size,
+                              const int *n_frames, int f_stride, const double *d_f0, const double *d_spectrogram,
+                              const double *d_aperiodicity, const int *y_length, int y_stride, double *d_y) {
+  return guarded(c, [&] {
+    run_synthesis(c, n_utt, fs, frame_period, fft_size, n_frames, f_stride, d_f0, d_spectrogram, d_aperiodicity,
+                  y_length, y_stride, d_y);
   });
 }
 

@@ -1,0 +1,45 @@
+// synthesis.h -- parameter block of the waveform synthesiser (synthesis.hip).
+// Reference: Synthesis(), src/synthesis.cpp:339-399.
+#pragma once
+#include "common.h"
+
+namespace world_hip {
+
+#ifdef WORLD_EMU
+constexpr int kSyThreads = 1;                    // the host emulation runs one thread per workgroup
+#else
+constexpr int kSyThreads = 256;
+#endif
+constexpr int kSyPer = 8;                       // consecutive samples per thread in the time-base kernels
+constexpr int kSyTile = kSyThreads * kSyPer;    // samples per workgroup
+
+struct SynthParams {
+  int n_utt, fs, fft_size, lg_fft;
+  double frame_period;      // seconds (the reference divides by 1000 on entry, synthesis.cpp:360,366)
+  double lowest_f0;         // fs / fft_size + 1.0 with the reference's integer division (synthesis.cpp:361)
+  const double *f0;         // [n_utt][f_stride]
+  const double *sp, *ap;    // [n_utt][f_stride][fft_size/2+1]
+  int f_stride;
+  const int *n_frames;      // [n_utt] (device)
+  const int *y_len;         // [n_utt] (device)
+  double *y;                // [n_utt][y_stride]
+  int y_stride;
+  // ---- workspace ----
+  double *inc;              // [n_utt][y_stride] phase increments, then (in place) the running phase
+  unsigned char *flags;     // [n_utt][y_stride] bit0 = interpolated vuv, bit1 = a pulse sits at this sample
+  int *blk_cnt;             // [n_utt][nblk] pulses of each tile
+  int nblk;
+  int *pidx;                // [n_utt][pulse_cap] pulse_locations_index
+  double *pshift;           // [n_utt][pulse_cap] pulse_locations_time_shift
+  int *np;                  // [n_utt] number_of_pulses (clamped to pulse_cap)
+  int pulse_cap;
+  double *resp;             // [n_utt][pulse_cap][fft_size] impulse response of every pulse
+  const double *dc_remover; // [fft_size] GetDCRemover(), host-built
+  const double *noise;      // noise[k] = k-th randn() after reseed
+  Tables tab;
+};
+
+void launch_synthesis(const SynthParams &p, int max_y, hipStream_t stream);
+size_t synth_pulse_lds_bytes(int lg_fft);
+
+}  // namespace world_hip

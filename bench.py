@@ -258,6 +258,33 @@ def main():
             codec["cpu_baseline"] = {"value": nf / (time.perf_counter() - t1), "unit": "frames/s", "cores": 1,
                                      "kind": orc.kind, "sample": f"the same {nf} frames, one call each"}
 
+    # ---- synthesis from the step's device-resident parameters: beside the metric ----
+    synthesis = None
+    if rank == 0:
+        with torch.cuda.stream(streams[0]):
+            tpos1, f01, sp1, ap1, nf1 = whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0],
+                                                        ap_out=ap_bufs[0])
+            y = wh.synthesis(f01, sp1, ap1, nf1, FFT_SIZE, FRAME_PERIOD, FS, n)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                y = wh.synthesis(f01, sp1, ap1, nf1, FFT_SIZE, FRAME_PERIOD, FS, n)
+            e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        synthesis = {"workload": f"Synthesis() of {B} x {args.seconds:g} s from the analysis outputs in HBM",
+                     "ms": ms, "x_realtime": B * args.seconds / (ms * 1e-3),
+                     "note": "bound by the bit-faithful serial phase accumulation (one FP64 add per sample, "
+                             "36-cycle dependent issue); utterances of a batch share that latency"}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.loader import best_oracle
+            orc = best_oracle()
+            f0_h, sp_h, ap_h = f01[0].cpu().numpy(), sp1[0].cpu().numpy(), ap1[0].cpu().numpy()
+            t1 = time.perf_counter()
+            orc.synthesis(f0_h, sp_h, ap_h, FFT_SIZE, FRAME_PERIOD, FS, n)
+            synthesis["cpu_baseline"] = {"ms": (time.perf_counter() - t1) * 1e3, "cores": 1, "kind": orc.kind,
+                                         "sample": "the same utterance, one call"}
+
     cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x_host = xs[0].cpu().numpy()
@@ -282,7 +309,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
                 kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-            "single_job_latency_ms": lat, "codec": codec,
+            "single_job_latency_ms": lat, "codec": codec, "synthesis": synthesis,
             "workspace_bytes": sum(w.workspace_bytes() for w in whs),
         }
         print(json.dumps(out))

@@ -30,7 +30,7 @@ def test_header_declares_the_reference_api():
                  "GetFFTSizeForCheapTrick", "GetF0FloorForCheapTrick", "D4C", "InitializeD4COption"]:
         assert must in names          # the 13 symbols of SURVEY.md 8b
     for must in ["GetNumberOfAperiodicities", "CodeAperiodicity", "DecodeAperiodicity", "CodeSpectralEnvelope",
-                 "DecodeSpectralEnvelope"]:
+                 "DecodeSpectralEnvelope", "Synthesis"]:
         assert must in names          # every public symbol of codec.o
 
 

@@ -17,8 +17,8 @@
 // run at the default 500 Hz, and at fs = 16 / 32 / 48 kHz that is an exact divisor of the
 // sampling rate, so every unvoiced pulse lands within an ulp of the wrap boundary and which
 // sample it is detected at depends on the last bit of the running sum.  A dependent FP64 add
-// issues every 36 cycles on gfx950 (tools/microbench_fp64.hip): 7 ms of latency for 10 s of
-// 48 kHz audio on one lane -- but 64 utterances per wavefront cost the same, and everything
+// issues every ~30-36 cycles on gfx950 (tools/microbench_fp64.hip): 5.8 ms of latency for 10 s
+// of 48 kHz audio on one lane -- but 64 utterances per wavefront cost the same, and everything
 // else here is parallel.  The randn stream is consumed strictly in pulse order, noise_size draws per pulse, so pulse
 // p starts at draw pidx[p] - pidx[0].
 #include "synthesis.h"
@@ -72,13 +72,17 @@ __global__ void __launch_bounds__(kSyThreads) sy_increments(SynthParams p) {
   }
 }
 
-// total_phase[i] = total_phase[i-1] + increment[i], in place, one lane per utterance
-__global__ void sy_phase_serial(SynthParams p) {
+// total_phase[i] = total_phase[i-1] + increment[i], in place, one lane per utterance.  The add
+// chain is the floor (36 cycles per sample); memory traffic comes in batches of 64 values so that
+// the load latency exposed between batches is a few percent of a batch's chain.  (Staging through
+// LDS with cooperative loads, or software-pipelining the batches, measured slower: on a lone
+// wavefront every extra instruction lands on the critical path.)
+__global__ void __launch_bounds__(WAVE) sy_phase_serial(SynthParams p) {
   const int u = flat_thread_x();
   if (u >= p.n_utt) return;
   const int n = p.y_len[u];
   double *a = p.inc + (size_t)u * p.y_stride;
-  constexpr int kB = 16;                             // loads / stores in batches; the add chain is the floor
+  constexpr int kB = 64;
   double acc = 0.0;
   int i0 = 0;
   for (; i0 + kB <= n; i0 += kB) {
@@ -326,7 +330,7 @@ __global__ void sy_overlap_add(SynthParams p) {
 void launch_synthesis(const SynthParams &p, int max_y, hipStream_t stream) {
   const size_t small = sizeof(double) * 80;
   WH_BLOCKS(sy_increments, dim3(p.nblk, p.n_utt), kSyThreads, 0, stream, p);
-  WH_THREADS(sy_phase_serial, p.n_utt, 1, 1, stream, p);
+  WH_BLOCKS(sy_phase_serial, dim3((p.n_utt + WAVE - 1) / WAVE), WAVE, 0, stream, p);
   WH_BLOCKS(sy_detect, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
   WH_BLOCKS(sy_compact, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
   WH_BLOCKS(sy_pulse, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);

@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x;
   const bool trace_me = band == 2 && f == 1000; (void)trace_me;
   WH_STAMP(0, 0);
   const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;

@@ -18,7 +18,9 @@ struct IirCoef { double a0, a1, a2, b0, b1; };
 constexpr int kDecThreads = 256;
 constexpr int kDecChunk = 32;                         // outputs per thread
 constexpr int kDecSpan = kDecThreads * kDecChunk;     // outputs per workgroup
-constexpr int kDecWarm = 384;     // 0.889^384 = 2e-20 (r = 12); r <= 6: 0.7985^384 = 3e-38
+constexpr int kDecWarm = 384;     // longest warm-up (LDS is carved for it): 0.889^384 = 2e-20 at r = 12
+// warm-up actually run: the pole radius is <= 0.7985 for r <= 6, and 0.7985^160 = 2e-16
+__host__ __device__ __forceinline__ int dec_warm(int r) { return r <= 6 ? 160 : kDecWarm; }
 constexpr int kDecBatch = 8;      // samples fetched together ahead of the serial recurrence
 constexpr int kDecPad = 9;        // kNFact
 // threads read the staged span with a lane stride of kDecChunk doubles: one pad slot per
@@ -56,9 +58,15 @@ __device__ __forceinline__ double dec_padded(const double *x, int n, int lag, in
   return px(j - kDecPad);
 }
 
+// One step of the 3rd-order recurrence w[n] = in + a0 w[n-1] + a1 w[n-2] + a2 w[n-3] (FilterForDecimate,
+// matlabfunctions.cpp:115-125).  The terms that do not involve w[n-1] are summed first, so the
+// dependent chain from one step to the next is a single FMA (a dependent FP64 op issues every 36
+// cycles on gfx950; left-to-right evaluation would put four of them on the chain).  The different
+// association moves the filtered signal by ~1e-16 relative.
 __device__ __forceinline__ double iir_step(const IirCoef &c, double in, double &w0, double &w1, double &w2) {
-  double wt = in + c.a0 * w0 + c.a1 * w1 + c.a2 * w2;
-  double out = c.b0 * wt + c.b1 * w0 + c.b1 * w1 + c.b0 * w2;
+  const double t = fma(c.a2, w2, fma(c.a1, w1, in));
+  const double wt = fma(c.a0, w0, t);
+  const double out = c.b0 * wt + c.b1 * w0 + c.b1 * w1 + c.b0 * w2;
   w2 = w1; w1 = w0; w0 = wt;
   return out;
 }
@@ -67,11 +75,11 @@ __device__ __forceinline__ double iir_step(const IirCoef &c, double in, double &
 // stages its span (+ warm-up) in LDS with coalesced loads, then every thread runs
 // the recurrence over its warm-up and its chunk out of LDS.
 __device__ __forceinline__ void dec_forward_block(const double *x, int n, int lag, IirCoef c, int block, double *fwd,
-                                                  double *stage) {
+                                                  double *stage, int warm) {
   const int total = n + 2 * lag + 2 * kDecPad;
   const int b0 = block * kDecSpan;
   if (b0 >= total) return;
-  const int lo = b0 - kDecWarm;                          // stage[k] = padded[lo + k]
+  const int lo = b0 - warm;                              // stage[k] = padded[lo + k]
   const int cnt = imin(total, b0 + kDecSpan) - lo;
   for (int k = threadIdx.x; k < cnt; k += blockDim.x) stage[dec_pad(k)] = lo + k >= 0 ? dec_padded(x, n, lag, lo + k) : 0.0;
   __syncthreads();
@@ -80,7 +88,7 @@ __device__ __forceinline__ void dec_forward_block(const double *x, int n, int la
     if (c0 >= total) break;
     const int c1 = imin(total, c0 + kDecChunk);
     double w0 = 0, w1 = 0, w2 = 0;
-    for (int j0 = imax(0, c0 - kDecWarm); j0 < c1; j0 += kDecBatch) {
+    for (int j0 = imax(0, c0 - warm); j0 < c1; j0 += kDecBatch) {
       double v[kDecBatch];
 #pragma unroll
       for (int q = 0; q < kDecBatch; ++q) v[q] = j0 + q < c1 ? stage[dec_pad(j0 + q - lo)] : 0.0;
@@ -98,7 +106,7 @@ __device__ __forceinline__ void dec_forward_block(const double *x, int n, int la
 // backward sweep over fwd; every r-th output starting at `first` is a decimated sample.
 // out[k] = decimated[skip + k] for k < out_len   (matlabfunctions.cpp:195-200, harvest.cpp:62)
 __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int lag, int r, IirCoef c, int block,
-                                                   int skip, int out_len, double *out, double *stage) {
+                                                   int skip, int out_len, double *out, double *stage, int warm) {
   const int total = n + 2 * lag + 2 * kDecPad;
   const int m = n + 2 * lag;
   const int nout = (m - 1) / r + 1;
@@ -106,7 +114,7 @@ __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int
   const int first = nbeg + kDecPad - 1;         // index (in padded coordinates) of decimated[0]
   const int b0 = block * kDecSpan;
   if (b0 >= total) return;
-  const int hi = imin(total, b0 + kDecSpan + kDecWarm);  // stage[k] = fwd[b0 + k], k < hi - b0
+  const int hi = imin(total, b0 + kDecSpan + warm);      // stage[k] = fwd[b0 + k], k < hi - b0
   for (int k = threadIdx.x; k < hi - b0; k += blockDim.x) stage[dec_pad(k)] = fwd[b0 + k];
   __syncthreads();
   for (int t = threadIdx.x; t < kDecThreads; t += blockDim.x) {
@@ -114,7 +122,7 @@ __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int
     if (c0 >= total) break;
     const int c1 = imin(total, c0 + kDecChunk);
     double w0 = 0, w1 = 0, w2 = 0;
-    for (int j0 = imin(total - 1, c1 - 1 + kDecWarm); j0 >= c0; j0 -= kDecBatch) {
+    for (int j0 = imin(total - 1, c1 - 1 + warm); j0 >= c0; j0 -= kDecBatch) {
       double v[kDecBatch];
 #pragma unroll
       for (int q = 0; q < kDecBatch; ++q) v[q] = j0 - q >= c0 ? stage[dec_pad(j0 - q - b0)] : 0.0;

@@ -21,13 +21,13 @@ __global__ void __launch_bounds__(kDecThreads) dio_decimate_fwd(DioParams p, Iir
   DYN_LDS(lds);
   const int u = blockIdx.y;
   dec_forward_block(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], 0, c, blockIdx.x, p.fwd + (size_t)u * p.m_stride,
-                    reinterpret_cast<double *>(lds));
+                    reinterpret_cast<double *>(lds), dec_warm(p.ratio));
 }
 __global__ void __launch_bounds__(kDecThreads) dio_decimate_bwd(DioParams p, IirCoef c) {
   DYN_LDS(lds);
   const int u = blockIdx.y;
   dec_backward_block(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], 0, p.ratio, c, blockIdx.x, 0, p.y_len[u],
-                     p.y + (size_t)u * p.y_stride, reinterpret_cast<double *>(lds));
+                     p.y + (size_t)u * p.y_stride, reinterpret_cast<double *>(lds), dec_warm(p.ratio));
 }
 __global__ void dio_copy_signal(DioParams p) {              // dio.cpp:71-72
   int u = blockIdx.y, i = flat_thread_x();

@@ -32,13 +32,14 @@ __global__ void __launch_bounds__(kDecThreads) hv_decimate_fwd(HarvestParams p, 
   DYN_LDS(lds);
   const int u = blockIdx.y;
   dec_forward_block(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], p.lag, c, blockIdx.x,
-                    p.fwd + (size_t)u * p.m_stride, reinterpret_cast<double *>(lds));
+                    p.fwd + (size_t)u * p.m_stride, reinterpret_cast<double *>(lds), dec_warm(p.ratio));
 }
 __global__ void __launch_bounds__(kDecThreads) hv_decimate_bwd(HarvestParams p, IirCoef c) {
   DYN_LDS(lds);
   const int u = blockIdx.y;
   dec_backward_block(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], p.lag, p.ratio, c, blockIdx.x,
-                     p.lag / p.ratio, p.y_len[u], p.y + (size_t)u * p.y_stride, reinterpret_cast<double *>(lds));
+                     p.lag / p.ratio, p.y_len[u], p.y + (size_t)u * p.y_stride, reinterpret_cast<double *>(lds),
+                     dec_warm(p.ratio));
 }
 __global__ void hv_copy_signal(HarvestParams p) {          // ratio == 1 (harvest.cpp:45-48)
   int u = blockIdx.y, i = flat_thread_x();

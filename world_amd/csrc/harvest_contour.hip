@@ -357,7 +357,7 @@ __global__ void hc_smooth(HarvestParams p) {
 #pragma unroll
       for (int q = 0; q < kBatch; ++q) {
         if (j + q >= j1) break;
-        double wt = v[q] + a0 * w0 + a1 * w1;
+        double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
         double y = b0 * wt + b1 * w0 + b0 * w1;
         w1 = w0; w0 = wt;
         if (j + q >= j0) tmp[j + q] = y;
@@ -377,7 +377,7 @@ __global__ void hc_smooth(HarvestParams p) {
 #pragma unroll
       for (int q = 0; q < kBatch; ++q) {
         if (j - q < j0) break;
-        double wt = v[q] + a0 * w0 + a1 * w1;
+        double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
         double y = b0 * wt + b1 * w0 + b0 * w1;
         w1 = w0; w0 = wt;
         if (j - q < j1 && j - q < len) out[st + j - q] = y;

@@ -171,24 +171,40 @@ __global__ void hc_extend(HarvestParams p) {
       for (int a = 0; a < kAhead; ++a) {
         if (i0 + a > dist || stop) break;
         const int t = origin + shift * (i0 + a) + shift;
-        // nearest candidate within 18 %, ties -> the LAST slot (SelectBestF0, :636-650)
-        double best_e = 0.18, best_v = 0.0;
+        // nearest candidate within 18 %, ties -> the LAST slot (SelectBestF0, :636-650).  The
+        // reference compares err = |cur - c| / cur; cur is common to all slots, so the distances
+        // are ordered first (no division on the frame-to-frame chain) and the 18 % test is made
+        // once, for the winner -- by a product unless it is within 1e-12 of the boundary.
+        double best_d = 1e300, best_v = 0.0;
         int best_i = -1;
 #pragma unroll
         for (int r = 0; r < kSlotsPerLane; ++r) {
           const int sl = lane + r * WAVE;
           if (sl < nslot) {
-            double err = fabs(cur - row[a][r]) / cur;
-            if (!(err > best_e)) { best_e = err; best_i = sl; best_v = row[a][r]; }
+            const double d = fabs(cur - row[a][r]);
+            if (!(d > best_d)) { best_d = d; best_i = sl; best_v = row[a][r]; }
           }
         }
 #ifndef WORLD_EMU
-        for (int m = 32; m >= 1; m >>= 1) {
-          double oe = __shfl_xor(best_e, m, 64), ov = __shfl_xor(best_v, m, 64);
-          int oi = __shfl_xor(best_i, m, 64);
-          if (oe < best_e || (oe == best_e && oi > best_i)) { best_e = oe; best_i = oi; best_v = ov; }
+        {
+          double dmin = best_d;
+          for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(dmin, m, 64); dmin = o < dmin ? o : dmin; }
+          const int mine = best_d == dmin ? best_i : -1;        // several lanes tie only exceptionally
+          const unsigned long long tied = __ballot(mine >= 0);
+          int win = -1;
+          if (__popcll(tied) > 1) win = wave_max_int(mine);
+          else if (tied) win = __shfl(mine, __ffsll((long long)tied) - 1, 64);
+          best_v = __shfl(best_v, win < 0 ? 0 : win % WAVE, 64);   // that lane's local best IS slot `win`
+          best_i = win;
+          best_d = dmin;
         }
 #endif
+        if (best_i >= 0) {
+          const double bound = 0.18 * cur;
+          bool ok = best_d <= bound;
+          if (fabs(best_d - bound) <= 1e-12 * cur) ok = !(best_d / cur > 0.18);
+          if (!ok) best_i = -1;
+        }
         const double v = best_i < 0 ? 0.0 : best_v;
         if (lane == 0) e[t - lo] = v;
         if (v == 0.0) { miss++; } else { cur = v; miss = 0; moved = t; }

@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
+    ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis legs reported beside the metric")
     ap.add_argument("--streams", type=int, default=6,
                     help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
                          "stream with its own workspace; 1 = strictly one after the other)")
@@ -227,7 +228,7 @@ def main():
 
     # ---- coders behind the path: reported beside the metric, never part of `value` ----
     codec = None
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         sp, ap = sp_bufs[0], ap_bufs[0]
         with torch.cuda.stream(streams[0]):
             for _ in range(2):
@@ -260,7 +261,7 @@ def main():
 
     # ---- synthesis from the step's device-resident parameters: beside the metric ----
     synthesis = None
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         with torch.cuda.stream(streams[0]):
             tpos1, f01, sp1, ap1, nf1 = whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0],
                                                         ap_out=ap_bufs[0])

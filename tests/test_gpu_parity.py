@@ -275,7 +275,7 @@ def test_unmodified_reference_test_program_runs_on_the_drop_in(tmp_path):
 
 
 def test_randomised_sweep_vs_oracle(hip, oracle):
-    """A slice of tools_fuzz_parity.py (which ran 810 cases -- six sampling rates, four signal kinds,
+    """A slice of tests/fuzz_parity.py (which ran 810 cases -- six sampling rates, four signal kinds,
     every stage including synthesis -- without a single divergence above 1e-6): random rates,
     durations, pitch and noise levels; every stage against the oracle."""
     from world_amd import synth

@@ -251,8 +251,9 @@ __global__ void hv_refine(HarvestParams p) {
           if (i == 0) dwv = -(0.42 + 0.5 * (ca * cd - sa * sd) + 0.08 * (c2a * c2d - s2a * s2d)) / 2.0;
           else if (i == blen - 1) dwv = (0.42 + 0.5 * (ca * cd + sa * sd) + 0.08 * (c2a * c2d + s2a * s2d)) / 2.0;
           else dwv = 0.5 * sa * sd + 0.08 * s2a * s2d;
-          const int k = first + i - 1 - origin;
-          const double xv = (k >= 0 && k < cap) ? yc[k] : y[imax(0, imin(y_len - 1, first + i - 1))];
+          // the frame-wide cache covers every window by construction (cap = 2 hw_max + 4 around the
+          // frame centre); the clamp only keeps a violated precondition from reading outside LDS
+          const double xv = yc[imax(0, imin(cap - 1, first + i - 1 - origin))];
           ym[i] = xv * w;
           yd[i] = xv * dwv;
           const double cn = ca * cD - sa * sD;

@@ -299,3 +299,22 @@ def test_randomised_sweep_vs_oracle(hip, oracle):
         y_o = oracle.synthesis(f0_o, sp_o, ap_o, fft, 5.0, fs, len(x))
         y = hip.synthesis(f0_o, sp_o, ap_o, fft, 5.0, fs, len(x))
         assert np.max(np.abs(y - y_o)) <= 1e-6 * max(np.max(np.abs(y_o)), 1e-9)
+
+
+def test_fft_size_4096_paths(hip, oracle):
+    """f0_floor 40 at 48 kHz makes CheapTrick pick fft_size 4096 (cheaptrick.cpp:191-194): the largest
+    transforms CheapTrick, D4C's output rows, the coders and Synthesis handle"""
+    from world_amd import synth
+    fs = 48000
+    x = synth.vowel(fs, 0.6, seed=9, base_f0=95.0).numpy()
+    tp, f0 = oracle.harvest(x, fs, f0_floor=40.0)
+    fft = hip.cheaptrick_fft_size(fs, 40.0)
+    assert fft == 4096
+    sp_o = oracle.cheaptrick(x, fs, tp, f0, f0_floor=40.0, fft_size=fft)
+    ap_o = oracle.d4c(x, fs, tp, f0, fft)
+    assert max_rel(hip.cheaptrick(x, fs, tp, f0, f0_floor=40.0, fft_size=fft), sp_o) <= RTOL
+    assert max_rel(hip.d4c(x, fs, tp, f0, fft), ap_o) <= RTOL
+    y_o = oracle.synthesis(f0, sp_o, ap_o, fft, 5.0, fs, len(x))
+    assert np.max(np.abs(hip.synthesis(f0, sp_o, ap_o, fft, 5.0, fs, len(x)) - y_o)) <= 1e-8 * np.max(np.abs(y_o))
+    c_o = oracle.code_spectral_envelope(sp_o, fs, fft, 60)
+    assert np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, 60) - c_o)) <= 1e-9 * np.max(np.abs(c_o))

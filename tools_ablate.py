@@ -2,10 +2,10 @@
 import json, subprocess, sys, shutil
 VARIANTS = {
   'base': {},
-  'old_iir': {'world_amd/csrc/decimate.h': 'tools_old_dec.txt', 'world_amd/csrc/harvest_contour.hip': 'tools_old_hc.txt'},
+  # 'name': {'world_amd/csrc/<unit>': 'path/to/alternative/source'},
   'base2': {},
 }
-KERNELS = ('hv_decimate_fwd', 'hv_decimate_bwd', 'hc_smooth', 'hc_extend', 'hc_merge')
+KERNELS = ('hv_refine', 'hv_band_events', 'hv_raw_candidates')
 def run(name):
     out = subprocess.run([sys.executable, 'bench.py', '--steps', '30', '--warmup', '3', '--streams', '1', '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]

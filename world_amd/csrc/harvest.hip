@@ -174,7 +174,7 @@ __global__ void hv_refine(HarvestParams p) {
   const int lane = lane_id();
   const int cap = p.refine_cap;
   double *yc = reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * 3 * cap;
-  double *ym = yc + cap, *yd = ym + cap;            // signal around the frame | y*main window | y*diff window
+  cplx *yw = reinterpret_cast<cplx *>(yc + cap);    // signal around the frame | (y*main window, y*diff window) pairs
   const int nfb = p.nfb[u], nc = p.nc[u];
   const double *src = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
   double *dst_f0 = p.cand_b + ((size_t)u * p.fb_stride + frame) * p.maxc;
@@ -254,8 +254,8 @@ __global__ void hv_refine(HarvestParams p) {
           // the frame-wide cache covers every window by construction (cap = 2 hw_max + 4 around the
           // frame centre); the clamp only keeps a violated precondition from reading outside LDS
           const double xv = yc[imax(0, imin(cap - 1, first + i - 1 - origin))];
-          ym[i] = xv * w;
-          yd[i] = xv * dwv;
+          cplx pr; pr.re = xv * w; pr.im = xv * dwv;
+          yw[i] = pr;                                            // one 16-byte store, one 16-byte load per DFT step
           const double cn = ca * cD - sa * sD;
           sa = sa * cD + ca * sD;
           ca = cn;
@@ -281,13 +281,15 @@ __global__ void hv_refine(HarvestParams p) {
           double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
           int i = g;
           for (; i + G < blen; i += 2 * G) {
-            const double a0 = ym[i], d0 = yd[i], a1 = ym[i + G], d1 = yd[i + G];
+            const cplx p0 = yw[i], p1 = yw[i + G];
+            const double a0 = p0.re, d0 = p0.im, a1 = p1.re, d1 = p1.im;
             const double sa = fma(c2, s1, a0) - s2, ta = fma(c2, t1, d0) - t2;
             s2 = sa; t2 = ta;
             s1 = fma(c2, sa, a1) - s1; t1 = fma(c2, ta, d1) - t1;
           }
           if (i < blen) {
-            const double sa = fma(c2, s1, ym[i]) - s2, ta = fma(c2, t1, yd[i]) - t2;
+            const cplx p0 = yw[i];
+            const double sa = fma(c2, s1, p0.re) - s2, ta = fma(c2, t1, p0.im) - t2;
             s2 = s1; t2 = t1; s1 = sa; t1 = ta;
             i += G;
           }

@@ -318,3 +318,30 @@ def test_fft_size_4096_paths(hip, oracle):
     assert np.max(np.abs(hip.synthesis(f0, sp_o, ap_o, fft, 5.0, fs, len(x)) - y_o)) <= 1e-8 * np.max(np.abs(y_o))
     c_o = oracle.code_spectral_envelope(sp_o, fs, fft, 60)
     assert np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, 60) - c_o)) <= 1e-9 * np.max(np.abs(c_o))
+
+
+def test_batched_api_reports_errors_instead_of_computing(wh):
+    """Part 2 of include/world_hip.h returns non-zero and a reason (world_hip_last_error) for requests it
+    cannot serve; nothing falls back to another path and the context stays usable afterwards."""
+    import torch
+    from world_amd import synth
+    x = synth.vowel(48000, 0.3, seed=1).cuda()[None]
+    tpos, f0, nf = wh.harvest(x, 48000)
+    with pytest.raises(RuntimeError, match="power of two"):
+        wh.cheaptrick(x, 48000, tpos, f0, nf, fft_size=2000)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        wh.cheaptrick(x, 48000, tpos, f0, nf, fft_size=16384)
+    x96 = synth.vowel(96000, 0.3, seed=1).cuda()[None]
+    t96, f96, n96 = wh.harvest(x96, 96000)                      # Harvest itself is fine at 96 kHz (ratio 12)
+    with pytest.raises(RuntimeError, match="48 kHz"):
+        wh.d4c(x96, 96000, t96, f96, n96, 4096)
+    with pytest.raises(RuntimeError, match="x_length"):
+        wh.harvest(x, 48000, x_len=np.array([x.shape[1] + 1], dtype=np.int32))
+    sp = wh.cheaptrick(x, 48000, tpos, f0, nf, fft_size=2048)
+    with pytest.raises(RuntimeError, match="number_of_dimensions"):
+        wh.code_spectral_envelope(sp, 48000, 2048, 2048)
+    with pytest.raises(RuntimeError, match="n_frames"):
+        wh.synthesis(f0[:, :1], sp[:, :1], sp[:, :1], 1, 2048, 5.0, 48000, 1000)
+    # still healthy
+    tpos2, f02, _ = wh.harvest(x, 48000)
+    assert torch.equal(f0, f02)

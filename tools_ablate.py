@@ -5,7 +5,7 @@ VARIANTS = {
   # 'name': {'world_amd/csrc/<unit>': 'path/to/alternative/source'},
   'base2': {},
 }
-KERNELS = ('hv_refine', 'hv_band_events', 'hv_raw_candidates')
+KERNELS = ('d4c_groupdelay', 'd4c_band', 'd4c_lovetrain', 'ct_frame')
 def run(name):
     out = subprocess.run([sys.executable, 'bench.py', '--steps', '30', '--warmup', '3', '--streams', '1', '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]

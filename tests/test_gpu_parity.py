@@ -331,10 +331,9 @@ def test_batched_api_reports_errors_instead_of_computing(wh):
         wh.cheaptrick(x, 48000, tpos, f0, nf, fft_size=2000)
     with pytest.raises(RuntimeError, match="unsupported"):
         wh.cheaptrick(x, 48000, tpos, f0, nf, fft_size=16384)
-    x96 = synth.vowel(96000, 0.3, seed=1).cuda()[None]
-    t96, f96, n96 = wh.harvest(x96, 96000)                      # Harvest itself is fine at 96 kHz (ratio 12)
-    with pytest.raises(RuntimeError, match="48 kHz"):
-        wh.d4c(x96, 96000, t96, f96, n96, 4096)
+    x192 = synth.vowel(192000, 0.2, seed=1).cuda()[None]
+    with pytest.raises(RuntimeError, match="96 kHz"):
+        wh.d4c(x192, 192000, tpos, f0, nf, 4096)                # D4C's internal FFT would need 16384 points
     with pytest.raises(RuntimeError, match="x_length"):
         wh.harvest(x, 48000, x_len=np.array([x.shape[1] + 1], dtype=np.int32))
     sp = wh.cheaptrick(x, 48000, tpos, f0, nf, fft_size=2048)
@@ -345,3 +344,18 @@ def test_batched_api_reports_errors_instead_of_computing(wh):
     # still healthy
     tpos2, f02, _ = wh.harvest(x, 48000)
     assert torch.equal(f0, f02)
+
+
+@pytest.mark.parametrize("fs", [64000, 96000])
+def test_above_48khz(hip, oracle, fs):
+    """D4C's internal transforms grow to 8192 points above 48 kHz (d4c.cpp:350-363); Harvest decimates
+    by 8 / 12; CheapTrick stays at 4096"""
+    from world_amd import synth
+    x = synth.vowel(fs, 0.4, seed=fs // 1000, base_f0=150.0).numpy()
+    tp_o, f0_o = oracle.harvest(x, fs)
+    tp, f0 = hip.harvest(x, fs)
+    assert np.array_equal(tp, tp_o)
+    assert_f0_close(f0, f0_o, what="harvest")
+    fft = hip.cheaptrick_fft_size(fs)
+    assert max_rel(hip.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft), oracle.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft)) <= RTOL
+    assert max_rel(hip.d4c(x, fs, tp_o, f0_o, fft), oracle.d4c(x, fs, tp_o, f0_o, fft)) <= RTOL

@@ -227,7 +227,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   // d4c.cpp:350-363 and :264-265
   const int fft_d4c = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(4.0 * fs / kFloorF0D4C + 1) / kLog2)));
   const int fft_love = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(3.0 * fs / 40.0 + 1) / kLog2)));
-  if (fft_d4c > 4096) fail("D4C: fs=%d needs an internal FFT of %d > 4096 points (LDS budget); fs <= 48 kHz supported", fs, fft_d4c);
+  if (fft_d4c > 8192) fail("D4C: fs=%d needs an internal FFT of %d > 8192 points (LDS budget); fs <= 96 kHz supported", fs, fft_d4c);
   if (fs < 15800) fail("D4C: fs=%d is below the 15.8 kHz the reference's LoveTrain band edges require", fs);
   const int nap = static_cast<int>(std::min(15000.0, fs / 2.0 - 3000.0) / 3000.0);
   const int wl = static_cast<int>(3000.0 * fft_d4c / fs) * 2 + 1;

@@ -198,14 +198,18 @@ __device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, 
 // [kmin, kmax]; the walk stops as soon as the bucket holding the threshold contains a
 // single key -- typically after two passes.  Barriers: two for min/max, ONE per pass (the
 // first kSelHists histograms are zeroed up front), two for the final sums.
+// keys one thread of a 256-thread workgroup receives from block_rfft of NMAX points
+template <int NMAX> struct SelKeys {
 #ifdef WORLD_EMU
-constexpr int kSelKeys = 4096 / 2 + 1;
+  static constexpr int n = NMAX / 2 + 1;
 #else
-constexpr int kSelKeys = 2 * ((4096 / 4 + 1 + 255) / 256);   // 256-thread workgroups: what block_rfft hands one thread
+  static constexpr int n = 2 * ((NMAX / 4 + 1 + 255) / 256);
 #endif
+};
 constexpr int kSelHists = 3;
 // key[q], q < mine: bit patterns of this thread's elements (n elements block-wide).
 // hist: kSelHists x 256 ints of LDS.
+template <int kSelKeys>
 __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int mine, int n, int m,
                                                    int *hist, double *scratch, double *partial, double *total,
                                                    bool trace_me = false) {
@@ -307,6 +311,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 // radix-8 butterflies (every thread busy in every FFT stage, half the registers per thread).
 constexpr int kGdThreads = 512;
 constexpr bool kGdRadix8 = true;
+template <int NMAX>
 __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_groupdelay(D4cParams p) {
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
@@ -329,9 +334,9 @@ __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_gro
   double *scratch = Zr + 2 * N + 8;
   const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
 #ifdef WORLD_EMU
-  constexpr int kBinsPerThread = 4096 / 2 + 1;          // one emulated thread owns every bin
+  constexpr int kBinsPerThread = NMAX / 2 + 1;          // one emulated thread owns every bin
 #else
-  constexpr int kBinsPerThread = (4096 / 2 + 1 + kGdThreads - 1) / kGdThreads;
+  constexpr int kBinsPerThread = (NMAX / 2 + 1 + kGdThreads - 1) / kGdThreads;
 #endif
   double a_reg[kBinsPerThread];
   const FftPlan plan_c = kGdRadix8 ? make_plan_r8(lgn) : make_plan(lgn);            // the packed centroid transform: 2^lgn complex points
@@ -438,7 +443,9 @@ __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_gro
 // share of the N/2-boundary smallest bins.  The power values never touch LDS: the
 // transform's merge step hands bin tid + q*T to thread tid, which is exactly the key
 // layout of the radix select.
+template <int NMAX>
 __global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
+  constexpr int kSelKeys = SelKeys<NMAX>::n;
   DYN_LDS(lds);
   const int band = blockIdx.x, f = blockIdx.y, u = blockIdx.z;
   if (f >= p.b.n_frames[u]) return;
@@ -545,8 +552,18 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), 256, d4c_love_lds_bytes(p.lg_love), stream, p);
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(d4c_groupdelay, dim3(max_frames, p.b.n_utt), kGdThreads, d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
-  WH_BLOCKS(d4c_band, dim3(p.nap, max_frames, p.b.n_utt), 256, d4c_band_lds_bytes(p.lg_d4c), stream, p);
+  // per-thread register arrays are sized for the internal FFT: 4096 points up to 48 kHz, 8192 up to 96 kHz
+  if (p.lg_d4c <= 12) {
+    devrt::launch_blocks("d4c_groupdelay", d4c_groupdelay<4096>, dim3(max_frames, p.b.n_utt), kGdThreads,
+                         d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
+    devrt::launch_blocks("d4c_band", d4c_band<4096>, dim3(p.nap, max_frames, p.b.n_utt), 256,
+                         d4c_band_lds_bytes(p.lg_d4c), stream, p);
+  } else {
+    devrt::launch_blocks("d4c_groupdelay", d4c_groupdelay<8192>, dim3(max_frames, p.b.n_utt), kGdThreads,
+                         d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
+    devrt::launch_blocks("d4c_band", d4c_band<8192>, dim3(p.nap, max_frames, p.b.n_utt), 256,
+                         d4c_band_lds_bytes(p.lg_d4c), stream, p);
+  }
   WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 0, stream, p);
 }
 

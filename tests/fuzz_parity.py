@@ -14,7 +14,7 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
-    fs = int(rng.choice([16000, 22050, 24000, 32000, 44100, 48000]))
+    fs = int(rng.choice([16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000]))
     dur = float(rng.uniform(0.25, 1.2))
     kind = rng.choice(['vowel', 'utt', 'noise', 'mix'])
     seed = int(rng.integers(1, 10**6))
@@ -26,17 +26,22 @@ for case in range(n_cases):
         x = np.round((x + rng.normal(size=len(x)) * float(rng.uniform(0.001, 0.05))) * 32768) / 32768
     x = np.clip(x, -1, 32767 / 32768)
     msg = []
-    tp_o, f0_o = orc.harvest(x, fs)
-    tp, f0 = hip.harvest(x, fs)
+    hopt = dict(f0_floor=float(rng.choice([50.0, 71.0, 90.0])), f0_ceil=float(rng.choice([500.0, 800.0, 1000.0])),
+                frame_period=float(rng.choice([1.0, 2.5, 5.0, 10.0])))
+    tp_o, f0_o = orc.harvest(x, fs, **hopt)
+    tp, f0 = hip.harvest(x, fs, **hopt)
     if not np.array_equal(tp, tp_o): msg.append('tp')
     flips = int(np.sum((f0 > 0) != (f0_o > 0)))
     v = f0_o > 0
     e = max_rel(f0[v & (f0 > 0)], f0_o[v & (f0 > 0)]) if v.any() else 0.0
     if flips or e > 1e-6: msg.append(f'harvest flips={flips} rel={e:.1e}')
-    tpd_o, fd_o = orc.dio(x, fs); tpd, fd = hip.dio(x, fs)
+    dopt = dict(f0_floor=float(rng.choice([50.0, 71.0])), f0_ceil=float(rng.choice([600.0, 800.0])),
+                channels_in_octave=float(rng.choice([2.0, 3.0])), frame_period=hopt['frame_period'],
+                speed=int(rng.choice([1, 2, 4, 11])), allowed_range=float(rng.choice([0.05, 0.1, 0.2])))
+    tpd_o, fd_o = orc.dio(x, fs, **dopt); tpd, fd = hip.dio(x, fs, **dopt)
     flips = int(np.sum((fd > 0) != (fd_o > 0)))
     if flips or max_rel(fd[fd_o > 0], fd_o[fd_o > 0]) > 1e-6: msg.append(f'dio flips={flips}')
-    sm_o, sm = orc.stonemask(x, fs, tp_o, fd_o), hip.stonemask(x, fs, tp_o, fd_o)
+    sm_o, sm = orc.stonemask(x, fs, tpd_o, fd_o), hip.stonemask(x, fs, tpd_o, fd_o)
     if np.sum((sm > 0) != (sm_o > 0)) or max_rel(sm[sm_o > 0], sm_o[sm_o > 0]) > 1e-6: msg.append('stonemask')
     fft = hip.cheaptrick_fft_size(fs)
     sp_o, sp = orc.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft), hip.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft)
@@ -45,7 +50,7 @@ for case in range(n_cases):
     ap_o, ap = orc.d4c(x, fs, tp_o, f0_o, fft), hip.d4c(x, fs, tp_o, f0_o, fft)
     e = max_rel(ap, ap_o)
     if e > 1e-5: msg.append(f'd4c rel={e:.1e}')
-    y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, 5.0, fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, 5.0, fs, len(x))
+    y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
     e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
     if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
     if msg:

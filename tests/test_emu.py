@@ -37,6 +37,20 @@ def test_emulated_dio_with_decimation(emu, port_oracle):
         assert np.array_equal(f0 > 0, f0_o > 0) and np.allclose(f0, f0_o, rtol=1e-9, atol=0)
 
 
+def test_emulated_dio_heavy_decimation_on_low_rates(emu, port_oracle):
+    """speed 11-12 on 16-22 kHz input leaves 4..8-tap channel filters, where the reference's mirror
+    store in GetFilteredSignal (dio.cpp:310-337) is no longer negligible: found by tests/fuzz_parity.py
+    (F0 off by up to 1.6e-2 before the term was added to the FIR path)"""
+    from world_amd import synth
+    for fs, speed, fp in ((16000, 12, 1.0), (22050, 11, 5.0)):
+        x = synth.vowel(fs, 0.6, seed=607455, base_f0=200.0).numpy()
+        tp_o, f0_o = port_oracle.dio(x, fs, speed=speed, frame_period=fp, channels_in_octave=3.0)
+        tp, f0 = emu.dio(x, fs, speed=speed, frame_period=fp, channels_in_octave=3.0)
+        assert np.array_equal(tp, tp_o) and np.array_equal(f0 > 0, f0_o > 0)
+        v = f0_o > 0
+        assert np.max(np.abs(f0[v] - f0_o[v]) / f0_o[v]) <= 1e-10
+
+
 def test_emulated_ragged_and_tiny_inputs(emu, port_oracle):
     """very short and odd-length inputs (edge clamping, single voiced run at the border)"""
     from world_amd import synth

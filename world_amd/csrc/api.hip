@@ -424,6 +424,7 @@ struct DioBands {                // cached per (fs, f0_floor, f0_ceil, channels,
   int fs = 0, ratio = 0;
   double f0_floor = 0, f0_ceil = 0, cpo = 0;
   int nb = 0, cut = 0, max_ntap = 0;
+  double band_f0_first = 0;      // boundary_f0_list[0]
   double *d_band_f0 = nullptr, *d_taps = nullptr, *d_lowcut = nullptr;
   int *d_hal = nullptr, *d_off = nullptr;
 };
@@ -477,6 +478,7 @@ static void prepare_dio_bands(WorldHipContext *c, DioBands &db, int fs, const Di
   devrt::sync(c->stream);
   db.fs = fs; db.ratio = ratio; db.f0_floor = opt->f0_floor; db.f0_ceil = opt->f0_ceil;
   db.cpo = opt->channels_in_octave; db.nb = nb; db.cut = cut; db.max_ntap = max_ntap;
+  db.band_f0_first = fb[0];
 }
 
 static void run_dio(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
@@ -494,10 +496,13 @@ static void run_dio(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.allowed_range = opt->allowed_range;
   p.nb = db.nb; p.cut = db.cut; p.max_ntap = db.max_ntap;
   p.vrm = static_cast<int>(0.5 + 1000.0 / opt->frame_period / opt->f0_floor) * 2 + 1;   // dio.cpp:263-264
-  std::vector<int> xl(x_length, x_length + n_utt), yl(n_utt), nfr(n_utt);
+  std::vector<int> xl(x_length, x_length + n_utt), yl(n_utt), nfr(n_utt), rfft(n_utt);
   int max_x = 0, max_y = 0, max_fr = 0;
   for (int u = 0; u < n_utt; ++u) {
     yl[u] = 1 + xl[u] / p.ratio;                                      // dio.cpp:590
+    // the reference's transform length (dio.cpp:592-594, GetSuitableFFTSize = common.cpp:51-54)
+    const int span = yl[u] + mround(p.afs / 50.0) * 2 + 1 + 4 * static_cast<int>(1.0 + p.afs / db.band_f0_first / 2.0);
+    rfft[u] = static_cast<int>(pow(2.0, static_cast<int>(log(static_cast<double>(span)) / kLog2) + 1.0));
     nfr[u] = frame_count(fs, xl[u], opt->frame_period);
     if (nfr[u] > f_stride) fail("f_stride %d too small for %d frames", f_stride, nfr[u]);
     max_x = std::max(max_x, xl[u]); max_y = std::max(max_y, yl[u]); max_fr = std::max(max_fr, nfr[u]);
@@ -509,7 +514,7 @@ static void run_dio(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.ev_cap = max_y / 2 + 2;
   const size_t B = n_utt;
   const size_t seg_list = (size_t)p.nseg * kSegCap;
-  size_t need = 4 * pad256(sizeof(int) * B);
+  size_t need = 5 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * 4) + pad256(sizeof(double) * B * p.nb * 4);
   need += pad256(sizeof(double) * B * p.m_stride) + pad256(sizeof(double) * B * p.y_stride) +
           pad256(sizeof(double) * B * p.z_stride);
   need += pad256(sizeof(double) * B * p.nb * 4 * seg_list) + pad256(sizeof(int) * B * p.nb * 4 * p.nseg);
@@ -517,11 +522,14 @@ static void run_dio(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   need += 2 * pad256(sizeof(double) * B * p.nb * f_stride) + 2 * pad256(sizeof(double) * B * f_stride);
   ensure_arena(c, need);
   c->arena.reset();
-  CallScope scope(c, 3 * sizeof(int) * n_utt + 512);
+  CallScope scope(c, 4 * sizeof(int) * n_utt + 512);
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, xl);
   p.b.n_frames = upload(c, nfr);
   p.y_len = upload(c, yl);
+  p.ref_fft = upload(c, rfft);
+  p.nyq = c->arena.take<double>(B * 4);
+  p.quirk = c->arena.take<double>(B * p.nb * 4);
   p.band_f0 = db.d_band_f0; p.band_hal = db.d_hal; p.band_off = db.d_off; p.band_taps = db.d_taps;
   p.lowcut_taps = db.d_lowcut;
   p.fwd = c->arena.take<double>(B * p.m_stride);

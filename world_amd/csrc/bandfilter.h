@@ -38,6 +38,11 @@ struct BandJob {
   int nseg;
   double *seg_events;     // [4][nseg][kSegCap]
   int *seg_count;         // [4][nseg]
+  // Optional additive term of the reference's FFT filtering (see dio.hip: dio_band_quirk):
+  // filtered[i] += (-1)^n (q[0] cos(2 pi n/N) + q[1] sin(2 pi n/N) + q[2]) with n = i + quirk_delay,
+  // q[3] = 2/N.  nullptr = none.
+  const double *quirk = nullptr;
+  int quirk_delay = 0;
 };
 
 inline size_t band_lds_bytes(int max_ntap) {
@@ -199,6 +204,17 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
       fir_compute(job, taps, yt, s);
     } else {
       fir_tile(job, taps, t0, yt, s);
+    }
+    if (job.quirk) {
+      const double qc = job.quirk[0], qs = job.quirk[1], q0 = job.quirk[2], w = job.quirk[3];
+      for (int k = tid; k < kTile + 2; k += nt) {
+        const int nn = t0 + k + job.quirk_delay;
+        double sn, cs;
+        sincospi(nn * w, &sn, &cs);
+        const double d = qc * cs + qs * sn + q0;
+        s[pad8(k)] += (nn & 1) ? -d : d;
+      }
+      __syncthreads();
     }
     WH_ACC_END(2);
     WH_ACC_BEGIN;

@@ -23,6 +23,9 @@ struct DioParams {
   const int *band_off;      // [nb]
   const double *band_taps;  // NuttallWindow(4*hal) per channel (dio.cpp:301)
   const double *lowcut_taps;  // centred low-cut FIR, 2*cut+1 taps (dio.cpp:40-53)
+  const int *ref_fft;       // [n_utt] the reference's FFT length for this utterance (dio.cpp:592-594)
+  double *nyq;              // [n_utt][4]: Y[N/2], Re/Im Y[N/2-1] of the low-cut filtered spectrum
+  double *quirk;            // [n_utt][nb][4] per-channel constants of the mirror-store term
   // workspace
   double *fwd;              // decimation scratch
   double *y;                // [n_utt][y_stride]

@@ -69,6 +69,79 @@ __global__ void __launch_bounds__(kBpThreads) dio_lowcut(DioParams p) {
     if (t0 + k < out_len) z[t0 + k] = s[pad8(k)];
 }
 
+// ---- the reference's mirror store (dio.cpp:310-337) ---------------------------------
+// GetFilteredSignal multiplies the spectra bin by bin and mirrors every product to bin
+// N-i-1 -- one off the Hermitian partner.  Two of those stores land inside the half spectrum
+// the inverse transform reads: at i = N/2-1 the product P = Y[N/2-1] H[N/2-1] overwrites the
+// filter's Nyquist bin BEFORE it is multiplied, and at i = N/2 the product Y[N/2] P overwrites
+// bin N/2-1.  Both bins end up holding Y[N/2] P instead of P and Y[N/2] H[N/2], which adds
+//   (-1)^n [ 2 Re((Y[N/2] - 1) P e^{-2 pi i n / N}) + Y[N/2] (Re P - H[N/2]) ]
+// to the (unnormalised) filtered signal.  With the long filters of an undecimated signal P is
+// ~1e-10 of the spectrum and the term is invisible (Harvest: < 1e-15 on F0); with speed = 11-12
+// on 16-22 kHz input the upper channels are 4..8-tap filters, P is not small, and leaving the
+// term out moved DIO's F0 by up to 1.6e-2.  It is added to the FIR output before the
+// zero-crossing search.  Y = spectrum of the mean-free decimated signal times the low-cut
+// filter's, N = the reference's transform length for this utterance.
+__global__ void dio_nyquist_bins(DioParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  const int u = blockIdx.x, n = p.y_len[u], N = p.ref_fft[u];
+  const double *y = p.y + (size_t)u * p.y_stride;
+  const double w = 2.0 / N;
+  double s0 = 0.0, s1r = 0.0, s1i = 0.0;               // sum y (-1)^n, sum y (-1)^n e^{+2 pi i n / N}
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double v = (i & 1) ? -y[i] : y[i];
+    double sn, cs;
+    sincospi(i * w, &sn, &cs);
+    s0 += v; s1r += v * cs; s1i += v * sn;
+  }
+  block_sum3(s0, s1r, s1i, scratch);
+  // low-cut spectrum at the two bins (real: the filter is symmetric about its centre tap)
+  double l0 = 0.0, l1 = 0.0;
+  for (int m = 1 + threadIdx.x; m <= p.cut; m += blockDim.x) {
+    const double t = p.lowcut_taps[p.cut + m], sgn = (m & 1) ? -1.0 : 1.0;
+    l0 += 2.0 * t * sgn;
+    l1 += 2.0 * t * sgn * cospi(m * w);
+  }
+  block_sum2(l0, l1, scratch);
+  if (threadIdx.x == 0) {
+    const double c = p.lowcut_taps[p.cut];
+    double *o = p.nyq + (size_t)u * 4;
+    o[0] = (c + l0) * s0;
+    o[1] = (c + l1) * s1r;
+    o[2] = (c + l1) * s1i;
+    o[3] = w;
+  }
+}
+
+__global__ void dio_band_quirk(DioParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  const int band = blockIdx.x, u = blockIdx.y;
+  const double *h = p.band_taps + p.band_off[band];
+  const int L = 4 * p.band_hal[band];
+  const double *ny = p.nyq + (size_t)u * 4;
+  const double w = ny[3];
+  double h0 = 0.0, h1r = 0.0, h1i = 0.0;               // H[N/2], H[N/2-1]
+  for (int m = threadIdx.x; m < L; m += blockDim.x) {
+    const double v = (m & 1) ? -h[m] : h[m];
+    double sn, cs;
+    sincospi(m * w, &sn, &cs);
+    h0 += v; h1r += v * cs; h1i += v * sn;
+  }
+  block_sum3(h0, h1r, h1i, scratch);
+  if (threadIdx.x == 0) {
+    const double y0 = ny[0];
+    const double pr = ny[1] * h1r - ny[2] * h1i, pi = ny[1] * h1i + ny[2] * h1r;   // P
+    const double inv_n = 0.5 * w;                       // the FIR path works on signal / N
+    double *q = p.quirk + ((size_t)u * p.nb + band) * 4;
+    q[0] = 2.0 * (y0 - 1.0) * pr * inv_n;               // Re(A e^{-i t}) = A.re cos t + A.im sin t
+    q[1] = 2.0 * (y0 - 1.0) * pi * inv_n;
+    q[2] = y0 * (pr - h0) * inv_n;
+    q[3] = w;
+  }
+}
+
 // ---- channels: Nuttall low-pass + zero-crossing events ----------------------------
 __global__ void __launch_bounds__(kBpThreads) dio_band_events(DioParams p) {
   const int seg = blockIdx.x, band = blockIdx.y, u = blockIdx.z;
@@ -84,6 +157,8 @@ __global__ void __launch_bounds__(kBpThreads) dio_band_events(DioParams p) {
   job.nseg = p.nseg;
   job.seg_events = p.seg_events + ((size_t)(u * p.nb + band) * 4) * p.nseg * kSegCap;
   job.seg_count = p.seg_count + ((size_t)(u * p.nb + band) * 4) * p.nseg;
+  job.quirk = p.quirk + ((size_t)u * p.nb + band) * 4;
+  job.quirk_delay = 2 * hal;                      // the term is a function of the undelayed index
   band_events_segment(job, seg);
 }
 __global__ void dio_compact_events(DioParams p) {
@@ -258,6 +333,8 @@ void launch_dio(const DioParams &p, int max_x_len, int max_y_len, int max_frames
   WH_BLOCKS(dio_remove_mean, dim3(B), 256, 64 * sizeof(double), stream, p);
   const int lc_tiles = (max_y_len + 2 * p.cut + kTile - 1) / kTile;
   WH_BLOCKS(dio_lowcut, dim3(lc_tiles, B), kBpThreads, band_lds_bytes(2 * p.cut + 1), stream, p);
+  WH_BLOCKS(dio_nyquist_bins, dim3(B), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(dio_band_quirk, dim3(p.nb, B), 64, 64 * sizeof(double), stream, p);
   WH_BLOCKS(dio_band_events, dim3(p.nseg, p.nb, B), kBpThreads, band_lds_bytes(p.max_ntap), stream, p);
   WH_BLOCKS(dio_compact_events, dim3(p.nb * 4, B), 256, 0, stream, p);
   WH_THREADS(dio_candidates, max_frames, p.nb, B, stream, p);

@@ -17,6 +17,7 @@
 #include "world_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -729,16 +730,29 @@ static void harvest_body(const double *x, int n, int fs, int frame_period, doubl
     raw[j] = dalloc(nf);
     harvest_band(fb[j], afs, Yr, Yi, y_len, fft_size, f0_floor, f0_ceil, tpos, nf, raw[j]);
   }
+  const char *dump = getenv("WO_DUMP");              /* test infrastructure: intermediate stages for debugging */
+  if (dump) { char fn[512]; snprintf(fn, sizeof fn, "%s_raw.bin", dump); FILE *f = fopen(fn, "wb");
+    for (int j = 0; j < nch; ++j) fwrite(raw[j], sizeof(double), nf, f); fclose(f);
+    snprintf(fn, sizeof fn, "%s_y.bin", dump); f = fopen(fn, "wb"); fwrite(y, sizeof(double), y_len, f); fclose(f); }
   int nc = harvest_detect(raw, nch, nf, maxc, cands);
+  if (dump) { char fn[512]; snprintf(fn, sizeof fn, "%s_det.bin", dump); FILE *f = fopen(fn, "wb");
+    for (int i = 0; i < nf; ++i) fwrite(cands[i], sizeof(double), maxc, f); fclose(f); }
   harvest_overlap(nf, nc, cands);
   nc *= 7;
   for (int i = 0; i < nf; ++i)
     for (int j = 0; j < nc; ++j)
       harvest_refine_one(y, y_len, afs, tpos[i], cands[i][j], f0_floor, f0_ceil,
                          &cands[i][j], &scores[i][j]);
+  if (dump) { char fn[512]; snprintf(fn, sizeof fn, "%s_ref.bin", dump); FILE *f = fopen(fn, "wb");
+    for (int i = 0; i < nf; ++i) fwrite(cands[i], sizeof(double), maxc, f);
+    for (int i = 0; i < nf; ++i) fwrite(scores[i], sizeof(double), maxc, f); fclose(f); }
   harvest_prune(nf, nc, cands, scores);
+  if (dump) { char fn[512]; snprintf(fn, sizeof fn, "%s_prune.bin", dump); FILE *f = fopen(fn, "wb");
+    for (int i = 0; i < nf; ++i) fwrite(cands[i], sizeof(double), maxc, f); fclose(f); }
   double *best = dalloc(nf);
   harvest_fix_contour(cands, scores, nf, nc, best);
+  if (dump) { char fn[512]; snprintf(fn, sizeof fn, "%s_best.bin", dump); FILE *f = fopen(fn, "wb");
+    fwrite(best, sizeof(double), nf, f); fclose(f); }
   harvest_smooth(best, nf, f0);
 
   for (int j = 0; j < nch; ++j) free(raw[j]);

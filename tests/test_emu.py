@@ -51,6 +51,23 @@ def test_emulated_dio_heavy_decimation_on_low_rates(emu, port_oracle):
         assert np.max(np.abs(f0[v] - f0_o[v]) / f0_o[v]) <= 1e-10
 
 
+def test_emulated_digital_silence_inside_a_signal(emu, port_oracle):
+    """a hole of exact zeros (or a held level) longer than the band filters: the reference's filtered
+    signal there is its mirror-store ripple (bandfilter.h), whose zero crossings end the interval-F0
+    interpolation at the hole; found by tests/fuzz_parity.py (Harvest off by 1.5e-2 plus a
+    voiced/unvoiced flip before the term was added)"""
+    from world_amd import synth
+    for fs, hole, level in ((32000, (9557, 10260), 0.0), (16000, (6000, 7100), 1.0 / 32768), (48000, (20000, 26000), 0.0)):
+        x = synth.vowel(fs, 0.6, seed=245779, base_f0=170.0).numpy()
+        x[hole[0]:hole[1]] = level
+        for opt in (dict(), dict(f0_floor=50.0, f0_ceil=500.0, frame_period=1.0)):
+            tp_o, f0_o = port_oracle.harvest(x, fs, **opt)
+            tp, f0 = emu.harvest(x, fs, **opt)
+            assert np.array_equal(f0 > 0, f0_o > 0)
+            v = f0_o > 0
+            assert np.max(np.abs(f0[v] - f0_o[v]) / f0_o[v]) <= 1e-9
+
+
 def test_emulated_ragged_and_tiny_inputs(emu, port_oracle):
     """very short and odd-length inputs (edge clamping, single voiced run at the border)"""
     from world_amd import synth

@@ -360,3 +360,15 @@ def test_above_48khz(hip, oracle, fs):
     fft = hip.cheaptrick_fft_size(fs)
     assert max_rel(hip.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft), oracle.cheaptrick(x, fs, tp_o, f0_o, fft_size=fft)) <= RTOL
     assert max_rel(hip.d4c(x, fs, tp_o, f0_o, fft), oracle.d4c(x, fs, tp_o, f0_o, fft)) <= RTOL
+
+
+def test_digital_silence_inside_a_signal(hip, oracle):
+    """see tests/test_emu.py::test_emulated_digital_silence_inside_a_signal"""
+    from world_amd import synth
+    for fs, hole, level in ((32000, (9557, 10260), 0.0), (16000, (6000, 7100), 1.0 / 32768), (48000, (20000, 26000), 0.0)):
+        x = synth.vowel(fs, 0.6, seed=245779, base_f0=170.0).numpy()
+        x[hole[0]:hole[1]] = level
+        for opt in (dict(), dict(f0_floor=50.0, f0_ceil=500.0, frame_period=1.0)):
+            tp_o, f0_o = oracle.harvest(x, fs, **opt)
+            tp, f0 = hip.harvest(x, fs, **opt)
+            assert_f0_close(f0, f0_o, rtol=1e-9, what=f"fs {fs} hole {hole}")

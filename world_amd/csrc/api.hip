@@ -348,10 +348,13 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.maxc = mround(hb.nch / 10.0) * 7;                                  // harvest.cpp:1179-1181
   if (p.maxc > 256) fail("Harvest: %d candidate slots per frame exceed the 256 the tracking kernel handles", p.maxc);
   p.lag = static_cast<int>(ceil(140.0 / p.ratio) * p.ratio);           // harvest.cpp:50-51
-  std::vector<int> xl(x_length, x_length + n_utt), yl(n_utt), nfb(n_utt), nfr(n_utt);
+  std::vector<int> xl(x_length, x_length + n_utt), yl(n_utt), nfb(n_utt), nfr(n_utt), rfft(n_utt);
   int max_x = 0, max_y = 0, max_fb = 0, max_fr = 0;
   for (int u = 0; u < n_utt; ++u) {
     yl[u] = static_cast<int>(ceil(static_cast<double>(xl[u]) / p.ratio));   // harvest.cpp:1161-1162
+    // the reference's transform length (harvest.cpp:1164-1165, GetSuitableFFTSize = common.cpp:51-54)
+    const int span = yl[u] + 5 + 2 * static_cast<int>(2.0 * p.afs / hb.band_f0[0]);
+    rfft[u] = static_cast<int>(pow(2.0, static_cast<int>(log(static_cast<double>(span)) / kLog2) + 1.0));
     nfb[u] = frame_count(fs, xl[u], 1);
     nfr[u] = frame_count(fs, xl[u], opt->frame_period);
     if (nfr[u] > f_stride) fail("f_stride %d too small for %d frames", f_stride, nfr[u]);
@@ -372,7 +375,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   const size_t B = n_utt;
   const size_t cand_elems = B * p.fb_stride * p.maxc;
   size_t need = 0;
-  need += 4 * pad256(sizeof(int) * B);
+  need += 5 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * 4) + pad256(sizeof(double) * B * p.nch * 4);
   need += pad256(sizeof(double) * B * p.m_stride);
   need += pad256(sizeof(double) * B * p.y_stride);
   need += pad256(sizeof(double) * B * p.nch * 4 * p.ev_cap);
@@ -387,13 +390,16 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   need += pad256(sizeof(double) * B * p.ext_cap);
   ensure_arena(c, need);
   c->arena.reset();
-  CallScope scope(c, 4 * sizeof(int) * n_utt + 512);
+  CallScope scope(c, 5 * sizeof(int) * n_utt + 512);
 
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, xl);
   p.b.n_frames = upload(c, nfr);
   p.y_len = upload(c, yl);
   p.nfb = upload(c, nfb);
+  p.ref_fft = upload(c, rfft);
+  p.nyq = c->arena.take<double>(B * 4);
+  p.quirk = c->arena.take<double>(B * p.nch * 4);
   p.band_f0 = hb.d_band_f0; p.band_half = hb.d_half; p.band_off = hb.d_off; p.band_taps = hb.d_taps;
   p.win_tab = hb.d_win_tab;
   p.fwd = c->arena.take<double>(B * p.m_stride);
@@ -415,6 +421,25 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.ext = c->arena.take<double>(B * p.ext_cap);
   p.tpos = d_tpos; p.f0 = d_f0;
   launch_harvest(p, max_x, max_y, max_fb, max_fr, c->stream);
+#ifdef WORLD_EMU
+  // host emulation only (synchronous): intermediate stages for debugging against the oracle's WO_DUMP
+  if (const char *dump = getenv("WORLD_EMU_DUMP")) {
+    auto put = [&](const char *tag, const void *ptr, size_t bytes) {
+      std::string fn = std::string(dump) + "_" + tag + ".bin";
+      FILE *f = fopen(fn.c_str(), "wb"); fwrite(ptr, 1, bytes, f); fclose(f);
+    };
+    int hdr[6] = {p.nch, p.fb_stride, p.maxc, max_fb, p.y_stride, yl[0]};
+    put("hdr", hdr, sizeof hdr);
+    put("y", p.y, sizeof(double) * p.y_stride);
+    put("raw", p.raw, sizeof(double) * p.nch * p.fb_stride);
+    put("cand_a", p.cand_a, sizeof(double) * p.fb_stride * p.maxc);
+    put("cand_b", p.cand_b, sizeof(double) * p.fb_stride * p.maxc);
+    put("score_a", p.score_a, sizeof(double) * p.fb_stride * p.maxc);
+    put("score_b", p.score_b, sizeof(double) * p.fb_stride * p.maxc);
+    put("basic", p.basic_f0, sizeof(double) * p.fb_stride);
+    put("nc", p.nc, sizeof(int));
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -558,7 +583,6 @@ static void run_stonemask(WorldHipContext *c, int n_utt, int fs, const double *d
   }
   StoneMaskParams p;
   p.win_cap = 2 * static_cast<int>(1.5 * fs / 40.0 + 1.0) + 4;       // longest window: f0 just above 40 Hz
-  if (2 * p.win_cap > kTwN * 2) fail("StoneMask: fs=%d needs an FFT beyond %d points", fs, kTwN);
   ensure_arena(c, 2 * pad256(sizeof(int) * n_utt));
   c->arena.reset();
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);

@@ -38,12 +38,54 @@ struct BandJob {
   int nseg;
   double *seg_events;     // [4][nseg][kSegCap]
   int *seg_count;         // [4][nseg]
-  // Optional additive term of the reference's FFT filtering (see dio.hip: dio_band_quirk):
+  // Optional additive term of the reference's FFT filtering (mirror_store_constants above):
   // filtered[i] += (-1)^n (q[0] cos(2 pi n/N) + q[1] sin(2 pi n/N) + q[2]) with n = i + quirk_delay,
   // q[3] = 2/N.  nullptr = none.
   const double *quirk = nullptr;
   int quirk_delay = 0;
 };
+
+// ---- the reference's mirror store (harvest.cpp:121-132, dio.cpp:317-330) -------------------
+// Both GetFilteredSignal functions multiply the spectra bin by bin and copy every product to bin
+// N-i-1 -- one off the Hermitian partner.  Two of those stores land inside the half spectrum the
+// inverse transform reads: at i = N/2-1 the product P = Y[N/2-1] H[N/2-1] overwrites the filter's
+// Nyquist bin BEFORE it is multiplied, and at i = N/2 the product Y[N/2] P overwrites bin N/2-1.
+// Both bins end up holding Y[N/2] P instead of P and Y[N/2] H[N/2], which adds
+//   (-1)^n [ 2 Re((Y[N/2] - 1) P e^{-2 pi i n / N}) + Y[N/2] (Re P - H[N/2]) ]
+// to the (unnormalised) filtered signal -- a Nyquist-rate ripple some ten orders of magnitude
+// below speech level.  It decides results in two situations: (1) DIO's 4..8-tap channels after
+// speed = 8-12 on 16-22 kHz input, where P is not small (F0 off by up to 1.6e-2 without it);
+// (2) stretches where the input is exactly constant (digital silence), where the true filtered
+// signal vanishes and the ripple alone produces the zero crossings, so the interval-F0
+// interpolation of the neighbouring frames ends at the stretch instead of bridging it (Harvest off
+// by 1.5e-2 and a voiced/unvoiced flip next to a 22 ms hole without it).  The FIR paths therefore
+// add the term before the zero-crossing search.  Y = spectrum of the (mean-free, zero-padded)
+// signal, N = the reference's transform length for this utterance, both per utterance.
+
+// block-wide: s0 = sum v[i] (-1)^i, (s1r, s1i) = sum v[i] (-1)^i e^{+2 pi i i / N}, w = 2 / N
+__device__ __forceinline__ void nyquist_pair(const double *v, int n, double w, double *scratch, double *s0, double *s1r,
+                                             double *s1i) {
+  double a = 0.0, br = 0.0, bi = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = (i & 1) ? -v[i] : v[i];
+    double sn, cs;
+    sincospi(i * w, &sn, &cs);
+    a += x; br += x * cs; bi += x * sn;
+  }
+  block_sum3(a, br, bi, scratch);
+  *s0 = a; *s1r = br; *s1i = bi;
+}
+// constants of the term for one channel, scaled by 1/N (the FIR paths work on signal / N):
+// q = {A.re, A.im, B, w} with term(n) = (-1)^n (A.re cos(pi w n) + A.im sin(pi w n) + B)
+__device__ __forceinline__ void mirror_store_constants(double y0, double y1r, double y1i, double h0, double h1r,
+                                                       double h1i, double w, double *q) {
+  const double pr = y1r * h1r - y1i * h1i, pi = y1r * h1i + y1i * h1r;   // P
+  const double inv_n = 0.5 * w;
+  q[0] = 2.0 * (y0 - 1.0) * pr * inv_n;
+  q[1] = 2.0 * (y0 - 1.0) * pi * inv_n;
+  q[2] = y0 * (pr - h0) * inv_n;
+  q[3] = w;
+}
 
 inline size_t band_lds_bytes(int max_ntap) {
   return sizeof(double) * (size_t)((max_ntap + 1) + pad8(kTile + 2 + max_ntap + 3 + 8) + 1 + pad8(kTile + 4) + 1 + 64);

@@ -69,33 +69,16 @@ __global__ void __launch_bounds__(kBpThreads) dio_lowcut(DioParams p) {
     if (t0 + k < out_len) z[t0 + k] = s[pad8(k)];
 }
 
-// ---- the reference's mirror store (dio.cpp:310-337) ---------------------------------
-// GetFilteredSignal multiplies the spectra bin by bin and mirrors every product to bin
-// N-i-1 -- one off the Hermitian partner.  Two of those stores land inside the half spectrum
-// the inverse transform reads: at i = N/2-1 the product P = Y[N/2-1] H[N/2-1] overwrites the
-// filter's Nyquist bin BEFORE it is multiplied, and at i = N/2 the product Y[N/2] P overwrites
-// bin N/2-1.  Both bins end up holding Y[N/2] P instead of P and Y[N/2] H[N/2], which adds
-//   (-1)^n [ 2 Re((Y[N/2] - 1) P e^{-2 pi i n / N}) + Y[N/2] (Re P - H[N/2]) ]
-// to the (unnormalised) filtered signal.  With the long filters of an undecimated signal P is
-// ~1e-10 of the spectrum and the term is invisible (Harvest: < 1e-15 on F0); with speed = 11-12
-// on 16-22 kHz input the upper channels are 4..8-tap filters, P is not small, and leaving the
-// term out moved DIO's F0 by up to 1.6e-2.  It is added to the FIR output before the
-// zero-crossing search.  Y = spectrum of the mean-free decimated signal times the low-cut
-// filter's, N = the reference's transform length for this utterance.
+// ---- the reference's mirror store (bandfilter.h): the utterance's two spectrum bins, with the
+// low-cut filter's spectrum applied (dio.cpp:85-101), and the per-channel constants ----------
 __global__ void dio_nyquist_bins(DioParams p) {
   DYN_LDS(lds);
   double *scratch = reinterpret_cast<double *>(lds);
   const int u = blockIdx.x, n = p.y_len[u], N = p.ref_fft[u];
   const double *y = p.y + (size_t)u * p.y_stride;
   const double w = 2.0 / N;
-  double s0 = 0.0, s1r = 0.0, s1i = 0.0;               // sum y (-1)^n, sum y (-1)^n e^{+2 pi i n / N}
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double v = (i & 1) ? -y[i] : y[i];
-    double sn, cs;
-    sincospi(i * w, &sn, &cs);
-    s0 += v; s1r += v * cs; s1i += v * sn;
-  }
-  block_sum3(s0, s1r, s1i, scratch);
+  double s0, s1r, s1i;
+  nyquist_pair(y, n, w, scratch, &s0, &s1r, &s1i);
   // low-cut spectrum at the two bins (real: the filter is symmetric about its centre tap)
   double l0 = 0.0, l1 = 0.0;
   for (int m = 1 + threadIdx.x; m <= p.cut; m += blockDim.x) {
@@ -122,24 +105,10 @@ __global__ void dio_band_quirk(DioParams p) {
   const int L = 4 * p.band_hal[band];
   const double *ny = p.nyq + (size_t)u * 4;
   const double w = ny[3];
-  double h0 = 0.0, h1r = 0.0, h1i = 0.0;               // H[N/2], H[N/2-1]
-  for (int m = threadIdx.x; m < L; m += blockDim.x) {
-    const double v = (m & 1) ? -h[m] : h[m];
-    double sn, cs;
-    sincospi(m * w, &sn, &cs);
-    h0 += v; h1r += v * cs; h1i += v * sn;
-  }
-  block_sum3(h0, h1r, h1i, scratch);
-  if (threadIdx.x == 0) {
-    const double y0 = ny[0];
-    const double pr = ny[1] * h1r - ny[2] * h1i, pi = ny[1] * h1i + ny[2] * h1r;   // P
-    const double inv_n = 0.5 * w;                       // the FIR path works on signal / N
-    double *q = p.quirk + ((size_t)u * p.nb + band) * 4;
-    q[0] = 2.0 * (y0 - 1.0) * pr * inv_n;               // Re(A e^{-i t}) = A.re cos t + A.im sin t
-    q[1] = 2.0 * (y0 - 1.0) * pi * inv_n;
-    q[2] = y0 * (pr - h0) * inv_n;
-    q[3] = w;
-  }
+  double h0, h1r, h1i;                                 // H[N/2], H[N/2-1]
+  nyquist_pair(h, L, w, scratch, &h0, &h1r, &h1i);
+  if (threadIdx.x == 0)
+    mirror_store_constants(ny[0], ny[1], ny[2], h0, h1r, h1i, w, p.quirk + ((size_t)u * p.nb + band) * 4);
 }
 
 // ---- channels: Nuttall low-pass + zero-crossing events ----------------------------

@@ -28,6 +28,9 @@ struct HarvestParams {
   const int *band_off;     // [nch]  offset of the band's taps in band_taps
   const double *band_taps; // Nuttall * cos band-pass FIRs (harvest.cpp:101-108), built on the host
   int max_half;            // max L
+  const int *ref_fft;      // [n_utt] the reference's FFT length for this utterance (harvest.cpp:1164-1165)
+  double *nyq;             // [n_utt][4]: Y[N/2], Re/Im Y[N/2-1] of the mean-free signal's spectrum, 2/N
+  double *quirk;           // [n_utt][nch][4] per-band constants of the mirror-store term (bandfilter.h)
   const double *win_tab;   // [hw][4] = sin/cos(pi d), sin/cos(pi WAVE d), d = 2/(2hw+1): refinement window steps
   Tables tab;
   // ---- workspace (device) ----

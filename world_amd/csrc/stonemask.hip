@@ -27,7 +27,12 @@ __device__ __forceinline__ void sm_harmonic_bins(const double *x, int x_len, con
       else dwv = -(mw[i + 1] - mw[i - 1]) / 2.0;
       const double xv = x[imax(0, imin(x_len - 1, raw[i] - 1))];   // GetSpectra (:67-70)
       const double a = xv * mw[i], d = xv * dwv;
-      const double2 w = tw[(size_t)(((long long)idx * i) & (N - 1)) << (kTwLog2 - lgN)];
+      // e^{-2 pi i idx i / N}: phase reduced exactly in integers, then the table -- or, for the
+      // transforms beyond its resolution (f0 < 70 Hz above 48 kHz), sincospi of the exact fraction
+      const long long ph = ((long long)idx * i) & (N - 1);
+      double2 w;
+      if (lgN <= kTwLog2) w = tw[(size_t)ph << (kTwLog2 - lgN)];
+      else { double sn, cs; sincospi(2.0 * static_cast<double>(ph) / N, &sn, &cs); w.x = cs; w.y = sn; }
       are = fma(a, w.x, are); aim = fma(-a, w.y, aim);
       dre = fma(d, w.x, dre); dim = fma(-d, w.y, dim);
     }

@@ -375,7 +375,8 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   const size_t B = n_utt;
   const size_t cand_elems = B * p.fb_stride * p.maxc;
   size_t need = 0;
-  need += 5 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * 4) + pad256(sizeof(double) * B * p.nch * 4);
+  need += 5 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * ((max_y + 4095) / 4096) * 4) +
+          pad256(sizeof(double) * B * p.nch * 4);
   need += pad256(sizeof(double) * B * p.m_stride);
   need += pad256(sizeof(double) * B * p.y_stride);
   need += pad256(sizeof(double) * B * p.nch * 4 * p.ev_cap);
@@ -398,7 +399,8 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.y_len = upload(c, yl);
   p.nfb = upload(c, nfb);
   p.ref_fft = upload(c, rfft);
-  p.nyq = c->arena.take<double>(B * 4);
+  p.nyq_slices = (max_y + 4095) / 4096;                                // kMeanSlice of harvest.hip
+  p.nyq = c->arena.take<double>(B * p.nyq_slices * 4);
   p.quirk = c->arena.take<double>(B * p.nch * 4);
   p.band_f0 = hb.d_band_f0; p.band_half = hb.d_half; p.band_off = hb.d_off; p.band_taps = hb.d_taps;
   p.win_tab = hb.d_win_tab;

@@ -63,14 +63,21 @@ struct BandJob {
 // signal, N = the reference's transform length for this utterance, both per utterance.
 
 // block-wide: s0 = sum v[i] (-1)^i, (s1r, s1i) = sum v[i] (-1)^i e^{+2 pi i i / N}, w = 2 / N
+// (the sums run over i in [lo, hi): a long signal is split over several workgroups)
 __device__ __forceinline__ void nyquist_pair(const double *v, int n, double w, double *scratch, double *s0, double *s1r,
-                                             double *s1i) {
+                                             double *s1i, int lo = 0, int hi = -1) {
+  if (hi < 0 || hi > n) hi = n;
   double a = 0.0, br = 0.0, bi = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  // thread-strided samples: one sincospi each for the first phase and the stride, then rotations
+  double sn, cs, sr, cr;
+  sincospi((double)(lo + (int)threadIdx.x) * w, &sn, &cs);
+  sincospi((double)blockDim.x * w, &sr, &cr);
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const double x = (i & 1) ? -v[i] : v[i];
-    double sn, cs;
-    sincospi(i * w, &sn, &cs);
     a += x; br += x * cs; bi += x * sn;
+    const double c2 = cs * cr - sn * sr;
+    sn = sn * cr + cs * sr;
+    cs = c2;
   }
   block_sum3(a, br, bi, scratch);
   *s0 = a; *s1r = br; *s1i = bi;
@@ -248,13 +255,20 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
       fir_tile(job, taps, t0, yt, s);
     }
     if (job.quirk) {
+      // a thread's samples are nt apart: one sincospi for its first sample, then a rotation by nt
+      // samples' phase per further one
       const double qc = job.quirk[0], qs = job.quirk[1], q0 = job.quirk[2], w = job.quirk[3];
-      for (int k = tid; k < kTile + 2; k += nt) {
-        const int nn = t0 + k + job.quirk_delay;
-        double sn, cs;
-        sincospi(nn * w, &sn, &cs);
-        const double d = qc * cs + qs * sn + q0;
-        s[pad8(k)] += (nn & 1) ? -d : d;
+      const int n0 = t0 + tid + job.quirk_delay;
+      double sn, cs, sr, cr;
+      sincospi(n0 * w, &sn, &cs);
+      sincospi(nt * w, &sr, &cr);
+      const double sign = (n0 & 1) ? -1.0 : 1.0;
+      for (int k = tid, j = 0; k < kTile + 2; k += nt, ++j) {
+        const double flip = ((nt & 1) && (j & 1)) ? -sign : sign;     // (-1)^(n0 + j nt)
+        s[pad8(k)] += flip * (qc * cs + qs * sn + q0);
+        const double c2 = cs * cr - sn * sr;
+        sn = sn * cr + cs * sr;
+        cs = c2;
       }
       __syncthreads();
     }

@@ -29,7 +29,8 @@ struct HarvestParams {
   const double *band_taps; // Nuttall * cos band-pass FIRs (harvest.cpp:101-108), built on the host
   int max_half;            // max L
   const int *ref_fft;      // [n_utt] the reference's FFT length for this utterance (harvest.cpp:1164-1165)
-  double *nyq;             // [n_utt][4]: Y[N/2], Re/Im Y[N/2-1] of the mean-free signal's spectrum, 2/N
+  double *nyq;             // [n_utt][nyq_slices][4]: partial sums of Y[N/2], Re/Im Y[N/2-1] (mean-free signal), 2/N
+  int nyq_slices;          // slices of 4096 samples per utterance slot
   double *quirk;           // [n_utt][nch][4] per-band constants of the mirror-store term (bandfilter.h)
   const double *win_tab;   // [hw][4] = sin/cos(pi d), sin/cos(pi WAVE d), d = 2/(2hw+1): refinement window steps
   Tables tab;

@@ -78,24 +78,28 @@ __global__ void hv_remove_mean(HarvestParams p) {
 
 // the utterance's two spectrum bins next to Nyquist and the per-band constants of the
 // reference's mirror-store term (bandfilter.h)
-__global__ void hv_nyquist_bins(HarvestParams p) {
+__global__ void hv_nyquist_bins(HarvestParams p) {          // partial sums per slice of kMeanSlice samples
   DYN_LDS(lds);
   double *scratch = reinterpret_cast<double *>(lds);
-  const int u = blockIdx.x;
+  const int slice = blockIdx.x, u = blockIdx.y;
   const double w = 2.0 / p.ref_fft[u];
   double s0, s1r, s1i;
-  nyquist_pair(p.y + (size_t)u * p.y_stride, p.y_len[u], w, scratch, &s0, &s1r, &s1i);
-  if (threadIdx.x == 0) { double *o = p.nyq + (size_t)u * 4; o[0] = s0; o[1] = s1r; o[2] = s1i; o[3] = w; }
+  nyquist_pair(p.y + (size_t)u * p.y_stride, p.y_len[u], w, scratch, &s0, &s1r, &s1i, slice * kMeanSlice,
+               (slice + 1) * kMeanSlice);
+  if (threadIdx.x == 0) { double *o = p.nyq + ((size_t)u * gridDim.x + slice) * 4; o[0] = s0; o[1] = s1r; o[2] = s1i; o[3] = w; }
 }
 __global__ void hv_band_quirk(HarvestParams p) {
   DYN_LDS(lds);
   double *scratch = reinterpret_cast<double *>(lds);
   const int band = blockIdx.x, u = blockIdx.y;
-  const double *ny = p.nyq + (size_t)u * 4;
+  const double *part = p.nyq + (size_t)u * p.nyq_slices * 4;
+  double y0 = 0.0, y1r = 0.0, y1i = 0.0;
+  for (int k = 0; k < p.nyq_slices; ++k) { y0 += part[4 * k]; y1r += part[4 * k + 1]; y1i += part[4 * k + 2]; }
+  const double w = part[3];
   double h0, h1r, h1i;
-  nyquist_pair(p.band_taps + p.band_off[band], 2 * p.band_half[band] + 1, ny[3], scratch, &h0, &h1r, &h1i);
+  nyquist_pair(p.band_taps + p.band_off[band], 2 * p.band_half[band] + 1, w, scratch, &h0, &h1r, &h1i);
   if (threadIdx.x == 0)
-    mirror_store_constants(ny[0], ny[1], ny[2], h0, h1r, h1i, ny[3], p.quirk + ((size_t)u * p.nch + band) * 4);
+    mirror_store_constants(y0, y1r, y1i, h0, h1r, h1i, w, p.quirk + ((size_t)u * p.nch + band) * 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -447,7 +451,7 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   const int slices = (max_y_len + kMeanSlice - 1) / kMeanSlice;
   WH_BLOCKS(hv_partial_sums, dim3(slices, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_remove_mean, dim3(slices, B), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(hv_nyquist_bins, dim3(B), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(hv_nyquist_bins, dim3(p.nyq_slices, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
   WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);

@@ -60,9 +60,13 @@ def measured_traffic(kernel, frames_per_launch):
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("frames_per_launch") != frames_per_launch or kernel not in t["kernels"]:
+        if t.get("frames_per_launch") != frames_per_launch:
             return None
-        k = t["kernels"][kernel]
+        # rocprofv3 prints template arguments ("d4c_groupdelay<4096>"), the library's labels do not
+        names = [n for n in t["kernels"] if n == kernel or n.startswith(kernel + "<")]
+        if not names:
+            return None
+        k = t["kernels"][names[0]]
         return int((2.0 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0)
     except (OSError, ValueError, KeyError):
         return None

@@ -15,7 +15,7 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     fs = int(rng.choice([16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000]))
-    dur = float(rng.uniform(0.25, 1.2))
+    dur = float(rng.uniform(0.03, 0.25)) if rng.random() < 0.2 else float(rng.uniform(0.25, 1.2))
     kind = rng.choice(['vowel', 'utt', 'noise', 'mix', 'gappy', 'quiet', 'dc', 'clip', 'impulses'])
     seed = int(rng.integers(1, 10**6))
     if kind == 'vowel': x = synth.vowel(fs, dur, seed=seed, base_f0=float(rng.uniform(75, 420))).numpy()
@@ -68,7 +68,19 @@ for case in range(n_cases):
     y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
     e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
     if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
+    # parameter modification as in test.cpp:221-240: shifted F0, other output length
+    f0m = f0_o * float(rng.choice([0.5, 0.8, 1.5, 2.0])); ylen = int(len(x) * float(rng.uniform(0.5, 1.0))) + 1   # beyond the parameters the reference extrapolates f0 and overruns its buffers
+    y_o, y = orc.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen), hip.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen)
+    e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
+    if e > 1e-7: msg.append(f'synthesis(modified) peak-rel={e:.1e}')
+    nd = int(rng.choice([1, 24, 60])); 
+    e = float(np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, nd) - orc.code_spectral_envelope(sp_o, fs, fft, nd))))
+    if e > 1e-9: msg.append(f'mcep abs={e:.1e}')
+    e = float(np.max(np.abs(hip.code_aperiodicity(ap_o, fs, fft) - orc.code_aperiodicity(ap_o, fs, fft))))
+    if e > 1e-9: msg.append(f'bap abs={e:.1e}')
     if msg:
         bad += 1
+        if os.path.isdir('gpurun_out'):       # keep the inputs of a diverging case for replay
+            np.savez(f'gpurun_out/fuzz_case_{case}.npz', x=x, fs=fs, hopt=repr(hopt), dopt=repr(dopt))
         print(f'case {case}: fs={fs} dur={dur:.2f} kind={kind} seed={seed}:', '; '.join(msg), flush=True)
 print(f'{n_cases} cases, {bad} with divergences, {time.time() - t0:.0f} s')

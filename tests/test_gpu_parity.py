@@ -372,3 +372,15 @@ def test_digital_silence_inside_a_signal(hip, oracle):
             tp_o, f0_o = oracle.harvest(x, fs, **opt)
             tp, f0 = hip.harvest(x, fs, **opt)
             assert_f0_close(f0, f0_o, rtol=1e-9, what=f"fs {fs} hole {hole}")
+
+
+def test_dio_leaves_f0_untouched_when_too_short(hip, oracle):
+    """FixF0Contour returns before writing when f0_length <= voice_range_minimum (dio.cpp:263-266):
+    the caller's buffer keeps whatever it held (found by tests/fuzz_parity.py on 40 ms inputs)"""
+    from world_amd import synth
+    x = synth.vowel(32000, 0.04, seed=564828, base_f0=180.0).numpy()
+    opt = dict(f0_floor=50.0, frame_period=10.0)
+    tp_o, f0_o = oracle.dio(x, 32000, **opt)
+    tp, f0 = hip.dio(x, 32000, **opt)
+    assert len(f0) <= 5 and np.array_equal(tp, tp_o)
+    assert np.array_equal(f0, f0_o) and not f0.any()          # numpy handed both zero-filled buffers

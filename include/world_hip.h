@@ -108,6 +108,35 @@ WORLD_HIP_API void Synthesis(const double *f0, int f0_length, const double *cons
                              const double *const *aperiodicity, int fft_size, double frame_period, int fs,
                              int y_length, double *y);
 
+/* ---- audio and parameter files: the reference's tools/ library ------------
+ * Same names, arguments and on-disk bytes as tools/audioio.h:25-47 and tools/parameterio.h:24-114,
+ * so examples/parameter_io/{f0,sp,ap}analysis.cpp, readandsynthesis.cpp and test/test.cpp link
+ * against this library ALONE.  Headers are parsed and written on the host; the per-sample
+ * PCM <-> double conversion of wavread()/wavwrite() runs on the GPU (bit-identical results).
+ * Failures print the reference's messages to stdout; there is no other error channel. */
+/* tools/audioio.h:25 (tools/audioio.cpp:84-130): 16-bit mono, q = int16(clamp(int(x*32767))); nbit is ignored */
+WORLD_HIP_API void wavwrite(const double *x, int x_length, int fs, int nbit, const char *filename);
+/* tools/audioio.h:35 (tools/audioio.cpp:132-173): samples in the file; 0 = cannot open, -1 = not accepted */
+WORLD_HIP_API int GetAudioLength(const char *filename);
+/* tools/audioio.h:47 (tools/audioio.cpp:175-252): mono PCM of 8..32 bits, x = q / 2^(nbit-1) */
+WORLD_HIP_API void wavread(const char *filename, int *fs, int *nbit, double *x);
+/* tools/parameterio.h:24 (tools/parameterio.cpp:58-88): "F0  " NOF FP + f64 values, or "%.5f %.5f\r\n" text */
+WORLD_HIP_API void WriteF0(const char *filename, int f0_length, double frame_period,
+                           const double *temporal_positions, const double *f0, int text_flag);
+/* tools/parameterio.h:39 (tools/parameterio.cpp:90-117): returns 1 on success; positions = i / 1000 * FP */
+WORLD_HIP_API int ReadF0(const char *filename, double *temporal_positions, double *f0);
+/* tools/parameterio.h:56 (tools/parameterio.cpp:119-143): "NOF ", "FP  ", "FFT ", "NOD ", "FS  "; 0 if absent */
+WORLD_HIP_API double GetHeaderInformation(const char *filename, const char *parameter);
+/* tools/parameterio.h:70,85 (tools/parameterio.cpp:145-191): "SPEC" NOF FP FFT NOD FS + rows of f64 */
+WORLD_HIP_API void WriteSpectralEnvelope(const char *filename, int fs, int f0_length, double frame_period,
+                                         int fft_size, int number_of_dimensions, const double *const *spectrogram);
+WORLD_HIP_API int ReadSpectralEnvelope(const char *filename, double **spectrogram);
+/* tools/parameterio.h:99,114 (tools/parameterio.cpp:193-243): "AP  ", same layout */
+WORLD_HIP_API void WriteAperiodicity(const char *filename, int fs, int f0_length, double frame_period,
+                                     int fft_size, int number_of_dimensions, const double *const *aperiodicity);
+WORLD_HIP_API int ReadAperiodicity(const char *filename, double **aperiodicity);
+
+
 /* ------------------------------------------------------------------------- */
 /* Part 2: batched device-resident API                                        */
 /* ------------------------------------------------------------------------- */
@@ -170,6 +199,19 @@ WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int
 /* 16-bit PCM (as stored in a WAV file) -> the doubles the reference's wavread() produces,
  * x = q / 32768 (tools/audioio.cpp:236-249), on the device: upload int16, not FP64. */
 WORLD_HIP_API int world_hip_pcm16_to_double(WorldHipContext *ctx, long long n, const short *d_pcm, double *d_x);
+
+/* The general form of the above for a WAV file's data bytes (nbit/8 = 1..4 bytes per sample, little
+ * endian, decoded exactly as wavread() does), its inverse for 16-bit output as wavwrite() quantises,
+ * and the host-side header parse a batch tool needs to find those bytes:
+ *   world_hip_wav_layout() returns 1 and fills fs / nbit / x_length / data_offset (bytes from the
+ *   start of the file), 0 if the file cannot be opened, -1 if wavread() would reject it. */
+WORLD_HIP_API int world_hip_pcm_to_double(WorldHipContext *ctx, long long n, int nbit, const void *d_pcm, double *d_x);
+WORLD_HIP_API int world_hip_double_to_pcm16(WorldHipContext *ctx, long long n, const double *d_x, short *d_pcm);
+WORLD_HIP_API int world_hip_wav_layout(const char *filename, int *fs, int *nbit, int *x_length,
+                                       long long *data_offset);
+/* Host-side writer for samples already quantised (e.g. by world_hip_double_to_pcm16 and one D2H of
+ * int16): wavwrite()'s 44-byte header + the samples.  Returns 1 on success, 0 if the file cannot be written. */
+WORLD_HIP_API int world_hip_wav_write_pcm16(const char *filename, int fs, long long n, const short *pcm);
 
 /* Coders on dense device rows (reference src/codec.cpp:217-324).  Rows are independent:
  *   spectrogram / aperiodicity  [rows][fft_size/2+1]

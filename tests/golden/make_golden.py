@@ -86,12 +86,82 @@ def synthesis_fixture(R):
     np.savez_compressed(os.path.join(OUT, "synthesis.npz"), **out)
 
 
+def _wav_bytes(fs, nbit, payload, claim=None, extra=b"", fmt_id=1, channels=1):
+    """A WAV file image assembled by hand (the reference only WRITES 16 bit)."""
+    import struct
+    qb = nbit // 8
+    head = b"RIFF" + struct.pack("<I", 36 + len(extra) + len(payload)) + b"WAVEfmt " + \
+        struct.pack("<IHHIIHH", 16, fmt_id, channels, fs, fs * qb, qb, nbit)
+    return head + extra + b"data" + struct.pack("<I", len(payload) if claim is None else claim) + payload
+
+
+def fileio_fixture():
+    """Audio / parameter files through the reference's own tools/ library,
+    oracle/_ref/libworld_tools_ref.so: what it decodes from hand-assembled WAV images and the
+    bytes it writes for given arrays."""
+    import tempfile
+    from world_amd.api import FileAPI
+    T = FileAPI(os.path.join(ROOT, "oracle", "_ref", "libworld_tools_ref.so"), hip_runtime=False)
+    rng = np.random.default_rng(20240607)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        def through_reference(name, image):
+            path = os.path.join(d, name + ".wav")
+            open(path, "wb").write(image)
+            out[name + "_bytes"] = np.frombuffer(image, dtype=np.uint8)
+            out[name + "_length"] = np.int64(T.audio_length(path))
+            r = T.wavread(path)
+            if r is not None:
+                out[name + "_x"], out[name + "_fs"], out[name + "_nbit"] = r[0], np.int64(r[1]), np.int64(r[2])
+        for nbit in (8, 16, 24, 32):
+            qb = nbit // 8
+            pcm = rng.integers(0, 256, size=(200, qb), dtype=np.uint8)
+            pcm[0] = 0; pcm[1] = 255; pcm[2] = [0] * (qb - 1) + [128]; pcm[3] = [255] * (qb - 1) + [127]
+            through_reference(f"wav{nbit}", _wav_bytes(22050, nbit, pcm.tobytes()))
+        pcm = rng.integers(0, 256, size=(120, 2), dtype=np.uint8)
+        through_reference("wavlist", _wav_bytes(16000, 16, pcm.tobytes(), extra=b"LIST\x07\x00\x00\x00dat" + b"xdada\x00d"))
+        through_reference("wavtrunc", _wav_bytes(8000, 24, pcm.tobytes()[:77], claim=120))
+        through_reference("bad_stereo", _wav_bytes(8000, 16, pcm.tobytes(), channels=2))
+        through_reference("bad_float", _wav_bytes(8000, 32, pcm.tobytes(), fmt_id=3))
+        through_reference("bad_nodata", _wav_bytes(8000, 16, b"")[:36] + b"junkjunkjunk")
+        through_reference("bad_riff", b"RIFX" + _wav_bytes(8000, 16, pcm.tobytes())[4:])
+
+        x = np.concatenate([rng.uniform(-1.2, 1.2, 300), [0.0, -0.0, 1.0, -1.0, 1.0000153, -1.0000306, 0.99998, 3e-5, -3e-5,
+                                                            1e5, -1e5, 7e4, -7e4, 1e300, -1e300, np.nan, np.inf, -np.inf]])
+        path = os.path.join(d, "w.wav")
+        T.wavwrite(path, x, 44100)
+        out["ww_x"], out["ww_bytes"] = x, np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+
+        nf = 7
+        tpos = np.arange(nf) * 0.005
+        f0 = np.array([0.0, 101.25, 99.999999, 440.0 / 3.0, 0.0, 71.5, 800.0])
+        for text in (0, 1):
+            T.write_f0(path, 5.0, tpos, f0, text=bool(text))
+            out[f"f0_file{text}"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        T.write_f0(path, 2.5, tpos, f0)
+        out["f0_tpos_2p5"] = T.read_f0(path)[0]
+        out["f0_tpos"], out["f0_values"] = tpos, f0
+        sp = rng.uniform(1e-9, 2.0, (nf, 9))
+        T.write_spectral_envelope(path, sp, 16000, 5.0, 16, 0)
+        out["sp"], out["sp_file"] = sp, np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        out["sp_header"] = np.array([T.header(path, k) for k in ("NOF ", "FP  ", "FFT ", "NOD ", "FS  ", "XYZ ")])
+        coded = rng.normal(size=(nf, 3))
+        T.write_aperiodicity(path, coded, 48000, 2.5, 2048, 3)
+        out["ap_coded"], out["ap_file"] = coded, np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        out["ap_read"] = T.read_aperiodicity(path)
+    np.savez_compressed(os.path.join(OUT, "fileio.npz"), **out)
+
+
 def main():
     build()
     R = RefOracle()
     if "--synthesis-only" in sys.argv:
         synthesis_fixture(R)
         print("synthesis.npz", os.path.getsize(os.path.join(OUT, "synthesis.npz")) // 1024, "KiB")
+        return
+    if "--fileio-only" in sys.argv:
+        fileio_fixture()
+        print("fileio.npz", os.path.getsize(os.path.join(OUT, "fileio.npz")) // 1024, "KiB")
         return
     if "--codec-only" in sys.argv:
         codec_fixture(R)
@@ -120,6 +190,7 @@ def main():
         interp_yi=np.array([-10, 5, 10, 15, 20, 39, 40, 70, 90.]))
     codec_fixture(R)
     synthesis_fixture(R)
+    fileio_fixture()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

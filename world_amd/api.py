@@ -77,6 +77,10 @@ def load_library(path=LIB_PATH):
     lib.world_hip_synthesis_batch.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, _ip, C.c_int, vp, vp, vp,
                                               _ip, C.c_int, vp]
     lib.world_hip_pcm16_to_double.argtypes = [vp, C.c_longlong, vp, vp]
+    lib.world_hip_pcm_to_double.argtypes = [vp, C.c_longlong, C.c_int, vp, vp]
+    lib.world_hip_double_to_pcm16.argtypes = [vp, C.c_longlong, vp, vp]
+    lib.world_hip_wav_layout.argtypes = [C.c_char_p, _ip, _ip, _ip, C.POINTER(C.c_longlong)]
+    lib.world_hip_wav_write_pcm16.argtypes = [C.c_char_p, C.c_int, C.c_longlong, vp]
     lib.world_hip_code_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.world_hip_decode_spectral_envelope.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.world_hip_code_aperiodicity.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -239,6 +243,85 @@ class HostAPI:
         return out
 
 
+class FileAPI:
+    """numpy binding of the reference's tools/ library (tools/audioio.h, tools/parameterio.h;
+    SURVEY.md 8f.2): WAV and F0 / SPEC / AP files.  Like HostAPI it works unchanged on
+    libworld_hip.so (default) and on a build of the reference's own tools."""
+
+    def __init__(self, path=LIB_PATH, hip_runtime=True):
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing (python -m world_amd.build); there is no fallback.")
+        if hip_runtime:
+            _hip_runtime_first()
+        self.lib = L = C.CDLL(path)
+        rows, s = C.POINTER(_dp), C.c_char_p
+        L.wavwrite.argtypes = [_dp, C.c_int, C.c_int, C.c_int, s]
+        L.GetAudioLength.argtypes = [s]
+        L.wavread.argtypes = [s, _ip, _ip, _dp]
+        L.WriteF0.argtypes = [s, C.c_int, C.c_double, _dp, _dp, C.c_int]
+        L.ReadF0.argtypes = [s, _dp, _dp]
+        L.GetHeaderInformation.argtypes = [s, s]
+        L.GetHeaderInformation.restype = C.c_double
+        for name in ("WriteSpectralEnvelope", "WriteAperiodicity"):
+            getattr(L, name).argtypes = [s, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, rows]
+        for name in ("ReadSpectralEnvelope", "ReadAperiodicity"):
+            getattr(L, name).argtypes = [s, rows]
+
+    @staticmethod
+    def _s(path):
+        return os.fsencode(path)
+
+    def audio_length(self, path):
+        return self.lib.GetAudioLength(self._s(path))
+
+    def wavread(self, path):
+        """-> (x, fs, nbit), or None where the reference prints an error and leaves x untouched."""
+        n = self.audio_length(path)
+        if n <= 0:
+            return None
+        x = np.zeros(n)
+        fs, nbit = C.c_int(0), C.c_int(0)
+        self.lib.wavread(self._s(path), C.byref(fs), C.byref(nbit), _p(x))
+        return x, fs.value, nbit.value
+
+    def wavwrite(self, path, x, fs, nbit=16):
+        x = _f64(x)
+        self.lib.wavwrite(_p(x), len(x), fs, nbit, self._s(path))
+
+    def write_f0(self, path, frame_period, tpos, f0, text=False):
+        tpos, f0 = _f64(tpos), _f64(f0)
+        self.lib.WriteF0(self._s(path), len(f0), frame_period, _p(tpos), _p(f0), 1 if text else 0)
+
+    def header(self, path, parameter):
+        return self.lib.GetHeaderInformation(self._s(path), parameter.encode())
+
+    def read_f0(self, path):
+        n = int(self.header(path, "NOF "))
+        tpos, f0 = np.zeros(n), np.zeros(n)
+        return (tpos, f0) if self.lib.ReadF0(self._s(path), _p(tpos), _p(f0)) == 1 else None
+
+    def _write_matrix(self, fn, path, m, fs, frame_period, fft_size, number_of_dimensions):
+        m = _f64(m)
+        fn(self._s(path), fs, m.shape[0], frame_period, fft_size, number_of_dimensions, _rows(m))
+
+    def _read_matrix(self, fn, path):
+        rows, fft, nod = (int(self.header(path, k)) for k in ("NOF ", "FFT ", "NOD "))
+        m = np.zeros((rows, nod if nod else fft // 2 + 1))
+        return m if fn(self._s(path), _rows(m)) == 1 else None
+
+    def write_spectral_envelope(self, path, sp, fs, frame_period, fft_size, number_of_dimensions=0):
+        self._write_matrix(self.lib.WriteSpectralEnvelope, path, sp, fs, frame_period, fft_size, number_of_dimensions)
+
+    def write_aperiodicity(self, path, ap, fs, frame_period, fft_size, number_of_dimensions=0):
+        self._write_matrix(self.lib.WriteAperiodicity, path, ap, fs, frame_period, fft_size, number_of_dimensions)
+
+    def read_spectral_envelope(self, path):
+        return self._read_matrix(self.lib.ReadSpectralEnvelope, path)
+
+    def read_aperiodicity(self, path):
+        return self._read_matrix(self.lib.ReadAperiodicity, path)
+
+
 class WorldHip:
     """Batched analysis on one GPU.  Tensors: x [B, L] float64 on the GPU."""
 
@@ -395,6 +478,51 @@ class WorldHip:
         self._check(self.lib.world_hip_pcm16_to_double(self._context(), pcm.numel(), pcm.data_ptr(), x.data_ptr()),
                     "pcm16_to_double")
         return x
+
+    def pcm_to_double(self, pcm_bytes, nbit):
+        """uint8 tensor holding a WAV file's sample bytes (nbit/8 per sample, little endian) ->
+        float64 samples exactly as wavread() decodes them, on the device"""
+        t = self.torch
+        assert pcm_bytes.dtype == t.uint8 and pcm_bytes.dim() == 1 and nbit // 8 >= 1
+        pcm_bytes = pcm_bytes.contiguous()
+        n = pcm_bytes.numel() // (nbit // 8)
+        x = t.empty(n, dtype=t.float64, device=pcm_bytes.device)
+        self._check(self.lib.world_hip_pcm_to_double(self._context(), n, nbit, pcm_bytes.data_ptr(), x.data_ptr()),
+                    "pcm_to_double")
+        return x
+
+    def double_to_pcm16(self, x):
+        """float64 samples -> the int16 values wavwrite() stores, on the device"""
+        t = self.torch
+        assert x.dtype == t.float64
+        x = x.contiguous()
+        q = t.empty(x.shape, dtype=t.int16, device=x.device)
+        self._check(self.lib.world_hip_double_to_pcm16(self._context(), x.numel(), x.data_ptr(), q.data_ptr()),
+                    "double_to_pcm16")
+        return q
+
+    def wav_layout(self, path):
+        """Host-side header parse: (fs, nbit, samples, byte offset of the samples); raises where wavread() refuses."""
+        fs, nbit, n, off = C.c_int(0), C.c_int(0), C.c_int(0), C.c_longlong(0)
+        rc = self.lib.world_hip_wav_layout(os.fsencode(path), C.byref(fs), C.byref(nbit), C.byref(n), C.byref(off))
+        if rc != 1:
+            raise OSError(f"{path}: " + ("cannot be opened" if rc == 0 else "not a mono PCM WAV file"))
+        return fs.value, nbit.value, n.value, off.value
+
+    def wavread(self, path):
+        """A WAV file -> (x on the device, fs): only the file's own bytes cross PCIe."""
+        fs, nbit, n, off = self.wav_layout(path)
+        raw = np.fromfile(path, dtype=np.uint8, offset=off, count=n * (nbit // 8))
+        if raw.size != n * (nbit // 8):
+            raise OSError(f"{path}: shorter than its header says")
+        return self.pcm_to_double(self.torch.from_numpy(raw).to(self.device), nbit), fs
+
+    def wavwrite(self, path, x, fs):
+        """float64 samples on the device -> a 16-bit WAV file as wavwrite() would store them
+        (quantised on the device; int16 crosses PCIe)."""
+        q = self.double_to_pcm16(x.reshape(-1)).cpu().numpy()
+        if self.lib.world_hip_wav_write_pcm16(os.fsencode(path), fs, q.size, q.ctypes.data) != 1:
+            raise OSError(f"{path}: cannot be written")
 
     # ---- coders (reference codec.h): dense [..., cols] tensors, leading dims are rows ----
     def _codec(self, fn, what, src, fs, fft_size, out_cols, *dims):

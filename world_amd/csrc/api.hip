@@ -8,7 +8,10 @@
 // drop-in host-pointer entry points, which must hand results back in caller memory.
 #include "../../include/world_hip.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstring>
 #include <cstdarg>
 #include <mutex>
 #include <stdexcept>
@@ -701,6 +704,9 @@ static int number_of_aperiodicities(int fs) {                          // codec.
 }
 
 void launch_pcm16_to_double(const short *d_pcm, double *d_x, long n, hipStream_t stream);   // pcm.hip
+void launch_pcm_bytes_to_double(const unsigned char *d_pcm, double *d_x, long n, int qb, double zero_line,
+                                hipStream_t stream);
+void launch_double_to_pcm16(const double *d_x, short *d_pcm, long n, hipStream_t stream);
 
 enum CodecOp { kCodeSp, kDecodeSp, kCodeAp, kDecodeAp };
 static void run_codec(WorldHipContext *c, CodecOp op, int rows, int fs, int fft_size, int ndim, const double *d_in,
@@ -1002,3 +1008,4 @@ int world_hip_decode_aperiodicity(WorldHipContext *c, int rows, int fs, int fft_
 }  // extern "C"
 
 #include "dropin.inc"
+#include "fileio.inc"

@@ -72,6 +72,36 @@ def measured_traffic(kernel, frames_per_launch):
         return None
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X FP64 vector: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+
+
+def measured_fp64(kernels, frames_per_launch):
+    """FP64 work per launch from the committed rocprofv3 PMC pass (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64:
+    wave-level instructions, 64 lanes each, an FMA counted as two operations) set against the live
+    per-launch durations: {kernel: (flop per launch, achieved TFLOP/s)} and the pipeline's flop per frame.
+    None when the profile lacks the counters or was taken on another workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get("frames_per_launch") != frames_per_launch:
+        return None
+    out, total = {}, 0.0
+    for name, c in t["kernels"].items():
+        if "SQ_INSTS_VALU_FMA_F64" not in c:
+            continue
+        flop = 64.0 * (c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
+                       2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
+        base = name.split("<")[0]
+        if base in kernels and flop > 0:
+            k = kernels[base]
+            out[base] = (flop, flop / (k["avg_ms"] * 1e-3) / 1e12)
+            total += flop * k["launches_per_step"]
+    return (out, total / frames_per_launch) if out else None
+
+
 def cpu_baseline(x_np, reps=1):
     """Time the CPU oracle (the unmodified reference when its in-place build travelled
     here, else this repo's C restatement) on the same utterance, one host core."""
@@ -229,6 +259,14 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, units),
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
                     "note": "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~6 MFLOP/frame vs 18.3 kB/frame"}
+        fp64 = measured_fp64(kernels, units)
+        if fp64 and dom in fp64[0]:
+            flop, tflops = fp64[0][dom]
+            roofline["fp64"] = {"flop_per_launch": flop, "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                                "pipeline_flop_per_frame": fp64[1],
+                                "pipeline_achieved": fp64[1] * value / world / 1e12,
+                                "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU_*_F64) over live durations"}
 
     # ---- coders behind the path: reported beside the metric, never part of `value` ----
     codec = None

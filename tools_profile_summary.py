@@ -42,7 +42,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         print(f"   {k:48s} n={n:<5d} {vals}")
     for k in acc:
         for c, v in acc[k].items():
-            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+            if c in ("FETCH_SIZE", "WRITE_SIZE") or c.endswith("_F64"):
                 traffic.setdefault(k, {})[c] = v[0] / max(v[1], 1)
-json.dump({"frames_per_launch": int(os.environ.get("PROFILE_FRAMES", "2001")), "unit": "KB per dispatch (rocprofv3)",
+json.dump({"frames_per_launch": int(os.environ.get("PROFILE_FRAMES", "2001")), "unit": "FETCH_SIZE / WRITE_SIZE: KB per dispatch; *_F64: wave-level instructions per dispatch (rocprofv3)",
            "kernels": traffic}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

@@ -84,7 +84,7 @@ struct WorldHipContext {
   double *d_dc_remover = nullptr; // GetDCRemover(fft_size) of the synthesiser
   int dc_remover_len = 0;
   void *codec_tables = nullptr;  // world_hip::CodecTableSet (cached interp1 / DCT tables of the coders)
-  double *d_noise = nullptr;     // noise[k] = k-th randn() after reseed (grow-only constant table)
+  uint32_t *d_noise = nullptr;   // randn_value(noise[k]) = k-th randn() after reseed (grow-only constant table)
   size_t noise_len = 0;
   // pinned ring of staging buffers for the small per-call host arrays
   char *stage[kStageRing] = {};
@@ -109,15 +109,15 @@ static size_t pad256(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
 // The randn() stream is a constant of the algorithm: make sure its first `draws`
 // values are resident (generated once per context by jump-ahead, extended on demand).
-static const double *ensure_noise(WorldHipContext *c, size_t draws) {
+static const uint32_t *ensure_noise(WorldHipContext *c, size_t draws) {
   if (draws > 0xFFFFFFF0ull) fail("utterance consumes more than 2^32 randn() draws");
   if (draws > c->noise_len) {
     size_t cap = draws + draws / 4;
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
     devrt::sync(c->stream);
-    double *fresh = static_cast<double *>(devrt::dmalloc(sizeof(double) * cap));
+    uint32_t *fresh = static_cast<uint32_t *>(devrt::dmalloc(sizeof(uint32_t) * cap));
     if (c->d_noise) {
-      devrt::d2d(fresh, c->d_noise, sizeof(double) * c->noise_len, c->stream);
+      devrt::d2d(fresh, c->d_noise, sizeof(uint32_t) * c->noise_len, c->stream);
       devrt::sync(c->stream);
       devrt::dfree(c->d_noise);
     }
@@ -903,7 +903,7 @@ int world_hip_sync(WorldHipContext *c) {
 }
 
 unsigned long long world_hip_workspace_bytes(WorldHipContext *c) {
-  return c ? c->arena.cap + sizeof(double) * c->noise_len : 0;
+  return c ? c->arena.cap + sizeof(uint32_t) * c->noise_len : 0;
 }
 
 // per-kernel HIP-event timing (used by bench.py for the roofline figure)

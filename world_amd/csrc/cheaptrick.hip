@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   DYN_LDS(lds);
   const int lgn = p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
-  const int u = blockIdx.y, f = blockIdx.x;
+  const int u = blockIdx.y, f = xcd_grouped(blockIdx.x, gridDim.x);
   if (f >= p.b.n_frames[u]) return;
   const bool trace_me = f == 1000; (void)trace_me;
   WH_STAMP(0, 0);
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[(size_t)u * p.b.f_stride + f];
   const double cf0 = ct_effective_f0(p.f0[(size_t)u * p.b.f_stride + f], p.f0_floor);
-  const double *noise = p.noise + p.offsets[(size_t)u * p.b.f_stride + f];
+  const uint32_t *noise = p.noise + p.offsets[(size_t)u * p.b.f_stride + f];
   const int tid = threadIdx.x, nt = blockDim.x;
 
   WH_STAMP(0, 1);
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
     wv[q] = 0.0; av[q] = 0.0; nv[q] = 0.0;
     if (i < wlen) {
       const double w = 0.5 * cospi(win_scale * (i - hw)) + 0.5;   // cos(pi * position * f0), cheaptrick.cpp:101-102
-      const double a = x[imin(x_len - 1, imax(0, origin + i - hw))] * w, n = noise[i] * kTiny;
+      const double a = x[imin(x_len - 1, imax(0, origin + i - hw))] * w, n = randn_value(noise[i]) * kTiny;
       wv[q] = w; av[q] = a; nv[q] = n;
       s_ww += w * w; s_a += a; s_n += n; s_w += w;
     }
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, 4) ct_frame(CtParams p) {
         double smoothed = (hi - lo) / width;
         // AddInfinitesimalNoise: the per-bin draws continue the frame's stream after the
         // window draws (cheaptrick.cpp:147-151); then the log of SmoothingWithRecovery (:39-42)
-        return log(smoothed + fabs(noise[wlen + i]) * kEps);
+        return log(smoothed + fabs(randn_value(noise[wlen + i])) * kEps);
       },
       [&](int i, double lg) { P[i] = lg; });
   }

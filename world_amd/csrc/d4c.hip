@@ -85,7 +85,7 @@ __global__ void d4c_prepare2(D4cParams p) {
 // r2c input.  The window shape is recomputed in the second pass (one cosine) rather
 // than stored: no LDS, no long-lived registers.  Returns 2*hw+1.
 __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, double f0, double pos,
-                                            int kind, double ratio, const double *noise,
+                                            int kind, double ratio, const uint32_t *noise,
                                             cplx *z, bool packed, double *scratch) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int hw = mround(ratio * fs / f0 / 2.0);
@@ -99,7 +99,7 @@ __device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, 
   for (int i = tid; i < wlen; i += nt) {
     const double w = d4c_window_at(i, hw, kind, scale);
     // noise[i]: the window's draws in sample order (d4c.cpp:67-69)
-    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + noise[i] * kSafeGuardD4C;
+    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + randn_value(noise[i]) * kSafeGuardD4C;
     if (packed) { cplx e; e.re = v; e.im = w; z[swz(i)] = e; }
     else rfft_in(z, i) = v;
     s1 += v; s2 += w;
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_gro
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[fi];
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
-  const double *noise = p.noise + p.offsets2[fi];
+  const uint32_t *noise = p.noise + p.offsets2[fi];
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
 
   // ---- GetStaticCentroid (d4c.cpp:126-143) ----------------------------------

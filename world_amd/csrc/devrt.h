@@ -178,6 +178,23 @@ __device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x / WAVE
 __device__ __forceinline__ int waves_per_block() { return (int)((blockDim.x + WAVE - 1) / WAVE); }
 __device__ __forceinline__ int wave_item_x() { return (int)(blockIdx.x * waves_per_block() + wave_in_block()); }
 
+// Frame kernels (one workgroup per analysis frame) read windows of x that overlap their neighbours' by
+// 80-90 %, but consecutive workgroups go to different XCDs (round-robin, b % 8) and so to different L2s:
+// every L2 ends up fetching all of x.  This bijection on [0, n) hands each XCD runs of kXcdRun consecutive
+// frames instead (run j of a group of 8 runs goes to XCD j), which keeps the overlap inside one L2 while
+// the runs stay short.  Only for kernels whose frames all cost the same (CheapTrick): workgroups are
+// dispatched in order, so where frames can exit early (D4C and StoneMask skip unvoiced frames) a run of
+// cheap frames on one XCD leaves it waiting behind the others' full queues -- measured +9 % on
+// d4c_groupdelay, which therefore keeps the plain order.  The b % 8 placement is a speed heuristic only
+// (MI355X_MICROARCH.md: the map is undefined); nothing depends on it.
+constexpr int kXcdRun = 16;
+__device__ __forceinline__ int xcd_grouped(int b, int n) {
+  constexpr int kGroup = 8 * kXcdRun;
+  if (b >= n / kGroup * kGroup) return b;          // the ragged tail keeps its order
+  const int r = b % kGroup;
+  return b - r + (r % 8) * kXcdRun + r / 8;
+}
+
 // make one wave's LDS writes visible to its other lanes (no-op for a 1-lane wave)
 __device__ __forceinline__ void wave_sync() {
 #ifndef WORLD_EMU

@@ -27,12 +27,17 @@ __device__ __forceinline__ uint32_t xs_step(Xs128 &s) {
   return s.w;
 }
 
-__device__ __forceinline__ double xs_randn(Xs128 &s) {   // randn(), :244-264
+// randn(), :244-264, in two halves: the integer the 12 steps add up to (< 12 * 2^28, fits 32 bits) ...
+__device__ __forceinline__ uint32_t xs_randn_word(Xs128 &s) {
   uint32_t acc = 0;
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc += xs_step(s) >> 4;
-  return acc / 268435456.0 - 6.0;
+  return acc;
 }
+// ... and its recentring, acc / 2^28 - 6: the scaling is exact, so the one fma rounds exactly as the
+// reference's divide-then-subtract does.
+__device__ __forceinline__ double randn_value(uint32_t word) { return fma(static_cast<double>(word), 0x1p-28, -6.0); }
+__device__ __forceinline__ double xs_randn(Xs128 &s) { return randn_value(xs_randn_word(s)); }
 
 // state <- M_level * state  (advance by 2^level randn() calls)
 __device__ __forceinline__ Xs128 xs_jump_level(const uint4 *jump, Xs128 s, int level) {
@@ -61,15 +66,17 @@ __device__ __forceinline__ Xs128 xs_jump(const uint4 *jump, Xs128 s, uint32_t ca
 // Whole-stream generation (rng_fill.hip): thread t produces draws
 // [begin + t*kFillRun, begin + (t+1)*kFillRun) of an utterance's stream with ONE
 // jump-ahead, so the jump cost is amortised over kFillRun draws and every draw of
-// the stream is produced exactly once, in parallel.  Raw N(0,1) values are
-// stored; consumers apply their own scale (1e-12, 1e-6, |.|*eps).
+// the stream is produced exactly once, in parallel.  The table holds the draws'
+// 32-bit integer sums (4 bytes per draw, not 8: it is streamed once per frame by
+// CheapTrick and D4C and is their largest input); consumers recentre with
+// randn_value() and apply their own scale (1e-12, 1e-6, |.|*eps).
 constexpr int kFillRun = 32;
 //
 // The stream is the same for every utterance and every call (the reference reseeds
 // at the top of CheapTrick() and D4C()), so the context keeps ONE table
 // noise[k] = k-th randn() in HBM and only ever extends it: [begin, end) below.
 struct RngFillArgs {
-  double *noise;            // noise[k] = draw number k of the stream
+  uint32_t *noise;          // randn_value(noise[k]) = draw number k of the stream
   size_t begin, end;        // positions to (re)generate
   const uint4 *jump;
 };

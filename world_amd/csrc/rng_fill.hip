@@ -1,5 +1,5 @@
 // rng_fill.hip -- the reference's randn() stream (src/matlabfunctions.cpp:237-264)
-// materialised in HBM by jump-ahead (see rng.h): noise[k] = k-th draw after reseed.
+// materialised in HBM by jump-ahead (see rng.h): randn_value(noise[k]) = k-th draw after reseed.
 #include "rng.h"
 
 namespace world_hip {
@@ -10,7 +10,7 @@ __global__ void rng_stream_fill(RngFillArgs a) {
   if (start >= a.end) return;
   Xs128 s = xs_jump(a.jump, xs_seed(), (uint32_t)start);
   const int n = a.end - start < (size_t)kFillRun ? (int)(a.end - start) : kFillRun;
-  for (int i = 0; i < n; ++i) a.noise[start + i] = xs_randn(s);
+  for (int i = 0; i < n; ++i) a.noise[start + i] = xs_randn_word(s);
 }
 
 void launch_rng_fill(const RngFillArgs &a, hipStream_t stream) {

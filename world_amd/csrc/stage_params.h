@@ -11,7 +11,7 @@ struct CtParams {
   const double *f0;      // [n_utt][f_stride]
   double *spectrogram;   // [n_utt][f_stride][fft/2+1]
   unsigned *offsets;     // [n_utt][f_stride] stream position of each frame's first draw
-  const double *noise;   // noise[k] = k-th randn() of the stream (context-wide table)
+  const uint32_t *noise; // randn_value(noise[k]) = k-th randn() of the stream (context-wide table)
   Tables tab;
   double q1;
   double f0_floor;       // GetF0FloorForCheapTrick()
@@ -30,7 +30,7 @@ struct D4cParams {
   unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
   unsigned *offsets2;     // [n_utt][f_stride]  position of the frame's 3 body windows within pass 2
   unsigned *draws1;       // [n_utt] total draws of pass 1 (pass 2 continues the stream there)
-  const double *noise;    // noise[k] = k-th randn() of the stream (context-wide table)
+  const uint32_t *noise;  // randn_value(noise[k]) = k-th randn() of the stream (context-wide table)
   const double *nuttall;  // [wl] NuttallWindow(wl), built on the host
   Tables tab;
   double threshold;

@@ -35,7 +35,7 @@ struct SynthParams {
   int pulse_cap;
   double *resp;             // [n_utt][pulse_cap][fft_size] impulse response of every pulse
   const double *dc_remover; // [fft_size] GetDCRemover(), host-built
-  const double *noise;      // noise[k] = k-th randn() after reseed
+  const uint32_t *noise;    // randn_value(noise[k]) = k-th randn() after reseed
   Tables tab;
 };
 

@@ -279,16 +279,16 @@ __global__ void __launch_bounds__(kSyThreads) sy_pulse(SynthParams p) {
   minimum_phase(Z, C, LG, lgn, tw);
   // GetNoiseSpectrum (:19-33): this pulse's draws, mean removed, zero padded; its spectrum is
   // multiplied into the minimum-phase spectrum as the merge step emits it
-  const double *noise = p.noise + (idx - pidx[0]);
+  const uint32_t *noise = p.noise + (idx - pidx[0]);
   double avg = 0.0;
-  for (int i = tid; i < noise_size; i += nt) avg += noise[i];
+  for (int i = tid; i < noise_size; i += nt) avg += randn_value(noise[i]);
   avg = block_sum(avg, scratch) / noise_size;
   block_rfft_from<3>(Z, lgn, tw,
     [&](int n) {
       cplx v;
       const int a = 2 * n, b = 2 * n + 1;
-      v.re = a < noise_size ? noise[a] - avg : 0.0;
-      v.im = b < noise_size ? noise[b] - avg : 0.0;
+      v.re = a < noise_size ? randn_value(noise[a]) - avg : 0.0;
+      v.im = b < noise_size ? randn_value(noise[b]) - avg : 0.0;
       return v;
     },
     [&](int k, double re, double im) {

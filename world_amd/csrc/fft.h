@@ -23,7 +23,9 @@ namespace world_hip {
 struct cplx { double re, im; };
 
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-  cplx r; r.re = a.re * b.re - a.im * b.im; r.im = a.re * b.im + a.im * b.re; return r;
+  // one product + one fused multiply-add per component (4 FP64 instructions instead of 6); the fused
+  // form rounds once less than the reference's FFT, whose results the path only ever has to meet to 1e-4
+  cplx r; r.re = fma(a.re, b.re, -(a.im * b.im)); r.im = fma(a.re, b.im, a.im * b.re); return r;
 }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { cplx r; r.re = a.re + b.re; r.im = a.im + b.im; return r; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { cplx r; r.re = a.re - b.re; r.im = a.im - b.im; return r; }

@@ -328,6 +328,28 @@ def main():
             synthesis["cpu_baseline"] = {"ms": (time.perf_counter() - t1) * 1e3, "cores": 1, "kind": orc.kind,
                                          "sample": "the same utterance, one call"}
 
+    # ---- the same job through the reference's host-pointer API (the drop-in boundary):
+    # x uploaded, results downloaded into row-pointer arrays, one synchronisation per stage.  PCIe-inclusive,
+    # reported beside the metric and never part of `value`.
+    host_to_host = None
+    if rank == 0 and not args.no_extras:
+        from world_amd.api import HostAPI
+        H = HostAPI()
+        x_host = xs[0].cpu().numpy()[:n]
+
+        def host_job():
+            tp, f0 = H.harvest(x_host, FS, frame_period=FRAME_PERIOD)
+            H.cheaptrick(x_host, FS, tp, f0, fft_size=FFT_SIZE)
+            H.d4c(x_host, FS, tp, f0, FFT_SIZE)
+            return len(f0)
+        host_job()
+        t1 = time.perf_counter()
+        frames_h = sum(host_job() for _ in range(5))
+        dt_h = time.perf_counter() - t1
+        host_to_host = {"workload": "Harvest() + CheapTrick() + D4C() on host pointers (libworld_hip.so drop-in symbols), "
+                                    "one utterance at a time, PCIe and per-stage synchronisation included",
+                        "ms_per_utterance": dt_h / 5 * 1e3, "frames_per_s": frames_h / dt_h}
+
     cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x_host = xs[0].cpu().numpy()
@@ -353,6 +375,7 @@ def main():
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
                 kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "single_job_latency_ms": lat, "codec": codec, "synthesis": synthesis,
+            "host_to_host": host_to_host,
             "workspace_bytes": sum(w.workspace_bytes() for w in whs),
         }
         print(json.dumps(out))

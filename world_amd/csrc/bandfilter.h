@@ -339,12 +339,12 @@ __device__ __forceinline__ void compact_event_segments(const double *seg_events,
 __device__ __forceinline__ double interval_loc(const double *e, int k, double fs) { return (e[k] + e[k + 1]) / 2.0 / fs; }
 __device__ __forceinline__ double interval_f0(const double *e, int k, double fs) { return fs / (e[k + 1] - e[k]); }
 
-// interp1 (matlabfunctions.cpp:136-176) of the n_int intervals of one family at time t:
-// the bin is clamp(#{locations <= t}, 1, n-1), so both ends extrapolate linearly.
-__device__ __forceinline__ double interp_intervals(const double *e, int n_int, double fs, double t) {
-  // count of locations <= t.  Crossings of a band-passed signal are nearly uniform in time, so a
-  // proportional guess lands within a few intervals of the answer: bracket it by doubling steps
-  // from the guess, then bisect the bracket (same result as bisecting [0, n_int), ~4 probes, not 10).
+// #{intervals whose location is <= t} of one family (the bin interp1 derives from it, matlabfunctions.cpp:
+// 136-176, is clamp(count, 1, n-1), so both ends extrapolate linearly).  Crossings of a band-passed signal
+// are nearly uniform in time, so a proportional guess lands within a few intervals of the answer: bracket
+// it by doubling steps from the guess, then bisect the bracket (same result as bisecting [0, n_int),
+// ~4 probes, not 10).
+__device__ __forceinline__ int intervals_at_or_before(const double *e, int n_int, double fs, double t) {
   int lo = 0, hi = n_int;
   if (n_int > 8) {
     const double first = interval_loc(e, 0, fs), last = interval_loc(e, n_int - 1, fs);
@@ -370,10 +370,51 @@ __device__ __forceinline__ double interp_intervals(const double *e, int n_int, d
     int mid = (lo + hi) >> 1;
     if (interval_loc(e, mid, fs) <= t) lo = mid + 1; else hi = mid;
   }
+  return lo;
+}
+
+// interp1 of the n_int interval F0s of one family at time t
+__device__ __forceinline__ double interp_intervals(const double *e, int n_int, double fs, double t) {
+  const int lo = intervals_at_or_before(e, n_int, fs, t);
   int k = lo < 1 ? 1 : (lo > n_int - 1 ? n_int - 1 : lo);
   double x0 = interval_loc(e, k - 1, fs), x1 = interval_loc(e, k, fs);
   double y0 = interval_f0(e, k - 1, fs), y1 = interval_f0(e, k, fs);
   double sl = (t - x0) / (x1 - x0);
+  return y0 + sl * (y1 - y0);
+}
+
+// The same for a workgroup that owns a run of consecutive frame times [t_first, t_last]: the counts at the
+// two ends (found once, by one thread per family and end) bound every frame's count, so the intervals any
+// of its frames can touch are one short contiguous range.  Their locations and F0s -- two FP64 divisions
+// each, which the per-thread search above redoes at every probe -- are computed once into LDS, and each
+// frame then bisects that range in LDS.  Same comparisons, same operands, same result.
+struct IntervalRange {       // per family, in LDS
+  int c_first, c_last;       // counts at t_first / t_last
+  int j_lo, m;               // staged intervals [j_lo, j_lo + m)
+};
+constexpr int kIntervalCap = 384;   // staged intervals per family (a 0.256 s run holds <= ~340 at 1.3 kHz): 24.6 KB, 6 workgroups per CU
+
+__device__ __forceinline__ void interval_range_ends(const double *e, int n_int, double fs, double t, bool last,
+                                                    IntervalRange *r) {
+  const int c = intervals_at_or_before(e, n_int, fs, t);
+  if (last) r->c_last = c; else r->c_first = c;
+}
+__device__ __forceinline__ void interval_range_close(int n_int, IntervalRange *r) {
+  const int k_first = r->c_first < 1 ? 1 : (r->c_first > n_int - 1 ? n_int - 1 : r->c_first);
+  const int k_last = r->c_last < 1 ? 1 : (r->c_last > n_int - 1 ? n_int - 1 : r->c_last);
+  r->j_lo = k_first - 1;
+  r->m = k_last - r->j_lo + 1;
+}
+__device__ __forceinline__ double interp_staged(const IntervalRange &r, const double *loc, const double *f0,
+                                                int n_int, double t) {
+  int lo = r.c_first, hi = r.c_last;               // count(t) lies between the run's ends
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (loc[mid - r.j_lo] <= t) lo = mid + 1; else hi = mid;
+  }
+  const int k = (lo < 1 ? 1 : (lo > n_int - 1 ? n_int - 1 : lo)) - r.j_lo;
+  const double x0 = loc[k - 1], x1 = loc[k], y0 = f0[k - 1], y1 = f0[k];
+  const double sl = (t - x0) / (x1 - x0);
   return y0 + sl * (y1 - y0);
 }
 

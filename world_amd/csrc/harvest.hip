@@ -133,31 +133,72 @@ __global__ void hv_compact_events(HarvestParams p) {
 
 // ---------------------------------------------------------------------------
 // interp1 of the interval F0s onto the 1 ms grid + gating (harvest.cpp:240-293);
-// one thread per (frame, band, utt).
-__global__ void hv_raw_candidates(HarvestParams p) {
-  const int frame = flat_thread_x(), band = blockIdx.y, u = blockIdx.z;
-  if (frame >= p.nfb[u]) return;
+// one workgroup per run of kRawFrames frames of one (band, utt), one thread per frame.
+constexpr int kRawFrames = 256;
+__device__ __forceinline__ double hv_gate(const HarvestParams &p, int band, double v0, double v1, double v2, double v3) {
+  double c = (v0 + v1 + v2 + v3) / 4.0;
+  const double fb = p.band_f0[band];
+  if (c > fb * 1.1 || c < fb * 0.9 || c > p.f0_ceil || c < p.f0_floor) c = 0.0;
+  return c;
+}
+__global__ void __launch_bounds__(kRawFrames) hv_raw_candidates(HarvestParams p) {
+  DYN_LDS(lds);
+  const int band = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+  const int f_begin = blockIdx.x * kRawFrames, f_end = imin(f_begin + kRawFrames, p.nfb[u]);
+  if (f_begin >= f_end) return;
   const int *cnt = p.ev_count + (u * p.nch + band) * 4;
   const double *ev = p.events + ((size_t)(u * p.nch + band) * 4) * p.ev_cap;
-  double out = 0.0;
+  double *out = p.raw + ((size_t)u * p.nch + band) * p.fb_stride;
   int n_int[4];
   bool ok = true;
   for (int fam = 0; fam < 4; ++fam) {
     n_int[fam] = cnt[fam] >= 2 ? cnt[fam] - 1 : 0;
     if (n_int[fam] - 2 <= 0) ok = false;                 // CheckEvent(n - 2), harvest.cpp:263-269
   }
-  if (ok) {
-    const double t = frame * 1 / 1000.0;                  // harvest.cpp:1175 (frame_period = 1)
-    double v0 = interp_intervals(ev, n_int[0], p.afs, t);
-    double v1 = interp_intervals(ev + p.ev_cap, n_int[1], p.afs, t);
-    double v2 = interp_intervals(ev + 2 * (size_t)p.ev_cap, n_int[2], p.afs, t);
-    double v3 = interp_intervals(ev + 3 * (size_t)p.ev_cap, n_int[3], p.afs, t);
-    double c = (v0 + v1 + v2 + v3) / 4.0;
-    const double fb = p.band_f0[band];
-    if (c > fb * 1.1 || c < fb * 0.9 || c > p.f0_ceil || c < p.f0_floor) c = 0.0;
-    out = c;
+  if (!ok) {
+    for (int f = f_begin + tid; f < f_end; f += nt) out[f] = 0.0;
+    return;
   }
-  p.raw[((size_t)u * p.nch + band) * p.fb_stride + frame] = out;
+  double *loc = reinterpret_cast<double *>(lds);          // [4][kIntervalCap]
+  double *fz = loc + 4 * kIntervalCap;                    // [4][kIntervalCap]
+  IntervalRange *range = reinterpret_cast<IntervalRange *>(fz + 4 * kIntervalCap);   // [4]
+  // frame f sits at t = f * 1 / 1000.0 (harvest.cpp:1175, frame_period = 1)
+  for (int job = tid; job < 8; job += nt) {
+    const int fam = job >> 1;
+    const bool last = job & 1;
+    interval_range_ends(ev + (size_t)fam * p.ev_cap, n_int[fam], p.afs, (last ? f_end - 1 : f_begin) * 1 / 1000.0, last,
+                        range + fam);
+  }
+  __syncthreads();
+  for (int fam = tid; fam < 4; fam += nt) interval_range_close(n_int[fam], range + fam);
+  __syncthreads();
+  const bool staged = range[0].m <= kIntervalCap && range[1].m <= kIntervalCap && range[2].m <= kIntervalCap &&
+                      range[3].m <= kIntervalCap;
+  if (!staged) {                                          // cannot happen at 1 ms frames; kept exact all the same
+    for (int f = f_begin + tid; f < f_end; f += nt) {
+      const double t = f * 1 / 1000.0;
+      out[f] = hv_gate(p, band, interp_intervals(ev, n_int[0], p.afs, t), interp_intervals(ev + p.ev_cap, n_int[1], p.afs, t),
+                       interp_intervals(ev + 2 * (size_t)p.ev_cap, n_int[2], p.afs, t),
+                       interp_intervals(ev + 3 * (size_t)p.ev_cap, n_int[3], p.afs, t));
+    }
+    return;
+  }
+  for (int fam = 0; fam < 4; ++fam) {
+    const double *e = ev + (size_t)fam * p.ev_cap + range[fam].j_lo;
+    for (int i = tid; i < range[fam].m; i += nt) {
+      loc[fam * kIntervalCap + i] = interval_loc(e, i, p.afs);
+      fz[fam * kIntervalCap + i] = interval_f0(e, i, p.afs);
+    }
+  }
+  __syncthreads();
+  for (int f = f_begin + tid; f < f_end; f += nt) {
+    const double t = f * 1 / 1000.0;
+    double v[4];
+#pragma unroll
+    for (int fam = 0; fam < 4; ++fam)
+      v[fam] = interp_staged(range[fam], loc + fam * kIntervalCap, fz + fam * kIntervalCap, n_int[fam], t);
+    out[f] = hv_gate(p, band, v[0], v[1], v[2], v[3]);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -455,7 +496,8 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
   WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);
-  WH_THREADS(hv_raw_candidates, max_fb, p.nch, B, stream, p);
+  WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawFrames - 1) / kRawFrames, p.nch, B), kRawFrames,
+            8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
   WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
   WH_BLOCKS(hv_prune, dim3((max_fb + kPruneFrames - 1) / kPruneFrames, B), 256,

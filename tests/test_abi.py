@@ -66,3 +66,18 @@ def test_missing_library_fails_loudly(tmp_path):
         load_library(str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         HostAPI(str(tmp_path / "nope.so"))
+
+
+def test_batch_tools_refuse_to_run_without_a_gpu(tmp_path):
+    """The command-line tools have no CPU path either: without a GPU they stop with an error
+    before touching any file (here: CPU-only container; skipped where a GPU is present)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "world_amd.tools", "analysis", "absent.wav", "--outdir", str(tmp_path / "o")],
+                       cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs a GPU" in r.stderr
+    assert not (tmp_path / "o").exists()

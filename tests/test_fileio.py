@@ -105,6 +105,15 @@ def check_audio_files(F, fx, tmp_path):
         assert np.array_equal(x, fx[name + "_x"]), name
     for name in BAD:
         assert F.wavread(put(tmp_path, name + ".wav", fx[name + "_bytes"])) is None
+    # a "data" tag far into the file (beyond the reader's first window), decoys before it
+    from oracle import fileformats as ff
+    rng = np.random.default_rng(3)
+    junk = bytes(rng.integers(0, 256, 150001, dtype=np.uint8)).replace(b"data", b"dat_") + b"dat"
+    image = bytes(fx["wav16_bytes"][:36]) + b"LIST" + len(junk).to_bytes(4, "little") + junk + bytes(fx["wav16_bytes"][36:])
+    q = put(tmp_path, "late.wav", image)
+    assert F.audio_length(q) == 200
+    x, fs, nbit = F.wavread(q)
+    assert np.array_equal(x, ff.wav_decode(image)[2]) and np.array_equal(x, fx["wav16_x"])
     p = os.path.join(str(tmp_path), "w.wav")
     F.wavwrite(p, fx["ww_x"], 44100)
     assert slurp(p) == bytes(fx["ww_bytes"])

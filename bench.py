@@ -264,7 +264,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, units),
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
-                    "note": "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~6 MFLOP/frame vs 18.3 kB/frame"}
+                    "note": "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~7 MFLOP/frame (measured, see fp64) vs 18.3 kB/frame"}
         fp64 = measured_fp64(kernels, units)
         if fp64 and dom in fp64[0]:
             flop, tflops = fp64[0][dom]

@@ -302,6 +302,35 @@ def test_randomised_sweep_vs_oracle(hip, oracle):
         assert np.max(np.abs(y - y_o)) <= 1e-6 * max(np.max(np.abs(y_o)), 1e-9)
 
 
+def test_stages_fed_with_arbitrary_f0_tracks(hip, oracle):
+    """A slice of tests/fuzz_given_f0.py: StoneMask, CheapTrick, D4C and Synthesis take F0 from the caller,
+    who may hand them anything -- values below the floors, up to 1 kHz, jumps, mostly zeros."""
+    from world_amd import synth
+    rng = np.random.default_rng(77)
+    for case, style in enumerate(["random", "steps", "low", "high", "sparse", "random", "steps", "low"]):
+        fs = int(rng.choice([16000, 22050, 32000, 44100, 48000]))
+        x = synth.utterance(int(rng.integers(1, 10**6)), fs, float(rng.uniform(0.2, 0.6))).numpy()
+        fp = float(rng.choice([2.5, 5.0, 10.0]))
+        nf = int(1000.0 * len(x) / fs / fp) + 1
+        tp = np.arange(nf) * fp / 1000.0
+        if style == "random": f0 = rng.uniform(30.0, 1000.0, nf)
+        elif style == "steps": f0 = np.repeat(rng.uniform(60.0, 600.0, nf // 7 + 1), 7)[:nf]
+        elif style == "low": f0 = rng.uniform(20.0, 90.0, nf)
+        elif style == "high": f0 = rng.uniform(500.0, 1000.0, nf)
+        else: f0 = np.where(rng.random(nf) < 0.15, rng.uniform(80.0, 400.0, nf), 0.0)
+        f0[rng.random(nf) < 0.2] = 0.0
+        what = f"case {case} ({style}, {fs} Hz, {fp} ms)"
+        assert_f0_close(hip.stonemask(x, fs, tp, f0), oracle.stonemask(x, fs, tp, f0), what=what + " stonemask")
+        fft = hip.cheaptrick_fft_size(fs)
+        sp_o = oracle.cheaptrick(x, fs, tp, f0, fft_size=fft)
+        assert max_rel(hip.cheaptrick(x, fs, tp, f0, fft_size=fft), sp_o) <= RTOL, what
+        ap_o = oracle.d4c(x, fs, tp, f0, fft)
+        assert max_rel(hip.d4c(x, fs, tp, f0, fft), ap_o) <= RTOL, what
+        y_o = oracle.synthesis(f0, sp_o, ap_o, fft, fp, fs, len(x))
+        y = hip.synthesis(f0, sp_o, ap_o, fft, fp, fs, len(x))
+        assert np.max(np.abs(y - y_o)) <= 1e-6 * max(np.max(np.abs(y_o)), 1e-9), what
+
+
 def test_fft_size_4096_paths(hip, oracle):
     """f0_floor 40 at 48 kHz makes CheapTrick pick fft_size 4096 (cheaptrick.cpp:191-194): the largest
     transforms CheapTrick, D4C's output rows, the coders and Synthesis handle"""

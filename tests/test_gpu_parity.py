@@ -413,3 +413,31 @@ def test_dio_leaves_f0_untouched_when_too_short(hip, oracle):
     tp, f0 = hip.dio(x, 32000, **opt)
     assert len(f0) <= 5 and np.array_equal(tp, tp_o)
     assert np.array_equal(f0, f0_o) and not f0.any()          # numpy handed both zero-filled buffers
+
+
+@pytest.mark.gpu
+def test_device_resident_c_api_from_plain_cpp(tmp_path):
+    """examples/batch_analysis.cpp drives Part 2 of include/world_hip.h with nothing but the HIP runtime
+    (no Python, no torch in that process): a ragged batch of two utterances.  Its per-utterance sums must
+    be those of the same analysis made through the Python binding on the same samples."""
+    import re
+    import subprocess
+    import torch
+    from world_amd.api import WorldHip
+    from world_amd.build import build_examples
+    exe = build_examples()
+    if exe is None:
+        pytest.skip("examples/batch_analysis.cpp not present")
+    dump = str(tmp_path / "x.f64")
+    r = subprocess.run([exe, dump], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = re.findall(r"utterance (\d) *: frames (\d+) voiced (\d+) sum_f0 (\S+) sum_log_sp (\S+) sum_ap (\S+)", r.stdout)
+    assert len(rows) == 2, r.stdout
+    x = torch.from_numpy(np.fromfile(dump, dtype=np.float64).reshape(2, 48000)).cuda()
+    tpos, f0, sp, ap, nf = WorldHip().analyze(x, 48000, x_len=np.array([48000, 31000], dtype=np.int32))
+    for u, (_, frames, voiced, s_f0, s_sp, s_ap) in enumerate(rows):
+        n = int(nf[u])
+        assert n == int(frames) and int((f0[u, :n] > 0).sum()) == int(voiced) and int(voiced) > 50
+        assert abs(float(f0[u, :n].sum()) - float(s_f0)) <= 1e-9 * float(s_f0)
+        assert abs(float(torch.log(sp[u, :n]).sum()) - float(s_sp)) <= 1e-9 * abs(float(s_sp))
+        assert abs(float(ap[u, :n].sum()) - float(s_ap)) <= 1e-9 * float(s_ap)

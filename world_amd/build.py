@@ -64,5 +64,22 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_examples():
+    """examples/batch_analysis.cpp: the device-resident C API from plain C++ (hipcc, host code only)."""
+    root = os.path.dirname(HERE)
+    src, exe = os.path.join(root, "examples", "batch_analysis.cpp"), os.path.join(root, "examples", "batch_analysis")
+    if not os.path.exists(src):
+        return None
+    newest = max(os.path.getmtime(src), os.path.getmtime(LIB), os.path.getmtime(os.path.join(root, "include", "world_hip.h")))
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
+        r = subprocess.run([hipcc(), "-O1", "-I", os.path.join(root, "include"), src, "-L", HERE, "-lworld_hip",
+                            "-Wl,-rpath,$ORIGIN/../world_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on the example:\n" + r.stdout + r.stderr)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--examples" in sys.argv:
+        print(build_examples())

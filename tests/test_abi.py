@@ -5,6 +5,7 @@ import os
 import re
 import shutil
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -81,3 +82,43 @@ def test_batch_tools_refuse_to_run_without_a_gpu(tmp_path):
                        cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs a GPU" in r.stderr
     assert not (tmp_path / "o").exists()
+
+
+def test_option_and_size_helpers_agree_with_the_reference_build(lib_path):
+    """The host-arithmetic helpers (frame counts, FFT sizes, floors, band counts, option defaults) of
+    libworld_hip.so against the same symbols of the unmodified reference built in place -- a sweep of
+    sampling rates, lengths and frame periods; exact equality (they size every caller-owned buffer)."""
+    from oracle.loader import ref_available
+    if not ref_available():
+        pytest.skip("oracle/_ref not built")
+    from world_amd.api import CheapTrickOption, D4COption, DioOption, HarvestOption
+    ours = ctypes.CDLL(lib_path)
+    ref = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                                   "libworld_ref.so"))
+    for L in (ours, ref):
+        L.GetSamplesForHarvest.argtypes = L.GetSamplesForDIO.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.GetFFTSizeForCheapTrick.argtypes = [ctypes.c_int, ctypes.POINTER(CheapTrickOption)]
+        L.GetF0FloorForCheapTrick.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.GetF0FloorForCheapTrick.restype = ctypes.c_double
+        L.InitializeCheapTrickOption.argtypes = [ctypes.c_int, ctypes.POINTER(CheapTrickOption)]
+        L.GetNumberOfAperiodicities.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(8)
+    rates = [8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 192000]
+    for _ in range(2000):
+        fs = int(rng.choice(rates)) if rng.random() < 0.8 else int(rng.integers(4000, 200000))
+        n = int(rng.integers(1, 2_000_000))
+        fp = float(rng.choice([1.0, 2.5, 5.0, 10.0, 12.5])) if rng.random() < 0.8 else float(rng.uniform(0.5, 20.0))
+        assert ours.GetSamplesForHarvest(fs, n, fp) == ref.GetSamplesForHarvest(fs, n, fp)
+        assert ours.GetSamplesForDIO(fs, n, fp) == ref.GetSamplesForDIO(fs, n, fp)
+        a, b = CheapTrickOption(), CheapTrickOption()
+        ours.InitializeCheapTrickOption(fs, ctypes.byref(a)); ref.InitializeCheapTrickOption(fs, ctypes.byref(b))
+        assert (a.q1, a.f0_floor, a.fft_size) == (b.q1, b.f0_floor, b.fft_size)
+        a.f0_floor = b.f0_floor = float(rng.uniform(20.0, 300.0))
+        size = ours.GetFFTSizeForCheapTrick(fs, ctypes.byref(a))
+        assert size == ref.GetFFTSizeForCheapTrick(fs, ctypes.byref(b))
+        assert ours.GetF0FloorForCheapTrick(fs, size) == ref.GetF0FloorForCheapTrick(fs, size)
+        assert ours.GetNumberOfAperiodicities(fs) == ref.GetNumberOfAperiodicities(fs)
+    for cls, init in ((DioOption, "InitializeDioOption"), (HarvestOption, "InitializeHarvestOption"), (D4COption, "InitializeD4COption")):
+        a, b = cls(), cls()
+        getattr(ours, init)(ctypes.byref(a)); getattr(ref, init)(ctypes.byref(b))
+        assert bytes(a) == bytes(b), init

@@ -278,3 +278,57 @@ def test_batch_tools_write_what_the_reference_programs_write(tmp_path):
     subprocess.run(tool + ["synthesis", "hip/a.f0", "coded/a.sp", "coded/a.ap", "-o", "coded/a.wav"], cwd=d, env=env,
                    check=True, timeout=600)
     assert F.audio_length(os.path.join(d, "coded", "a.wav")) == int(181 * 5.0 / 1000.0 * 16000)
+
+
+def test_randomised_files_against_the_reference_tools(tmp_path):
+    """Random parameter arrays and random WAV images (any of 8/16/24/32 bits, junk chunks of any size before
+    `data`, claimed lengths beyond the file's end) through the library's file functions (the PCM decode through
+    the host-emulated kernels) and through the unmodified reference tools: same bytes, same samples."""
+    from world_amd.api import FileAPI
+    lib = os.path.join(REF_DIR, "libworld_tools_ref.so")
+    if not os.path.exists(lib):
+        pytest.skip("oracle/_ref not built")
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.run(["make", "-s", "-C", emu_dir], check=True)
+    R, E, F = FileAPI(lib, hip_runtime=False), FileAPI(os.path.join(emu_dir, "libworld_emu.so"), hip_runtime=False), FileAPI()
+    rng = np.random.default_rng(99)
+    d = str(tmp_path)
+    for case in range(120):
+        nf, nb = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        f0 = rng.uniform(-5.0, 900.0, nf)
+        f0[rng.random(nf) < 0.1] = rng.choice([np.nan, np.inf, -np.inf, 0.0, -0.0])
+        tpos, fp = rng.uniform(0.0, 10.0, nf), float(rng.choice([1.0, 2.5, 5.0, 12.34]))
+        m = rng.normal(size=(nf, nb)) * 10.0 ** rng.integers(-300, 300)
+        fft, nod, fs = 2 * (nb - 1), int(rng.choice([0, nb])), int(rng.integers(1, 200000))
+        for L, tag in ((R, "r"), (F, "o")):
+            L.write_f0(f"{d}/{tag}.f0", fp, tpos, f0, text=bool(case % 2))
+            L.write_spectral_envelope(f"{d}/{tag}.sp", m, fs, fp, max(fft, 2), nod if fft >= 2 else nb)
+            L.write_aperiodicity(f"{d}/{tag}.ap", m, fs, fp, max(fft, 2), nod if fft >= 2 else nb)
+        for ext in ("f0", "sp", "ap"):
+            assert slurp(f"{d}/r.{ext}") == slurp(f"{d}/o.{ext}"), (case, ext)
+        if case % 2 == 0:
+            a, b = R.read_f0(f"{d}/r.f0"), F.read_f0(f"{d}/r.f0")
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True)
+        assert np.array_equal(R.read_spectral_envelope(f"{d}/r.sp"), F.read_spectral_envelope(f"{d}/r.sp"))
+        keys = ("NOF ", "FP  ", "FFT ", "NOD ", "FS  ")
+        assert [R.header(f"{d}/r.ap", k) for k in keys] == [F.header(f"{d}/r.ap", k) for k in keys]
+        # a WAV image
+        nbit = int(rng.choice([8, 16, 24, 32]))
+        qb, n = nbit // 8, int(rng.integers(0, 300))
+        payload = bytes(rng.integers(0, 256, n * qb, dtype=np.uint8))
+        junk = bytes(rng.integers(0, 256, int(rng.choice([0, 5, 26, 70000])), dtype=np.uint8)).replace(b"data", b"dat_")
+        extra = (b"LIST" + len(junk).to_bytes(4, "little") + junk) if junk else b""
+        claim = len(payload) + int(rng.choice([0, 0, qb, 7 * qb + 1]))
+        image = (b"RIFF" + (36 + len(extra) + len(payload)).to_bytes(4, "little") + b"WAVEfmt " + (16).to_bytes(4, "little") +
+                 (1).to_bytes(2, "little") + (1).to_bytes(2, "little") + fs.to_bytes(4, "little") + (fs * qb % 2**32).to_bytes(4, "little") +
+                 qb.to_bytes(2, "little") + nbit.to_bytes(2, "little") + extra + b"data" + claim.to_bytes(4, "little") + payload)
+        p = put(tmp_path, "c.wav", image)
+        want_n = R.audio_length(p)
+        assert F.audio_length(p) == want_n == E.audio_length(p), case
+        if want_n > 0 and len(payload) >= qb:       # (with no whole sample in the file the reference decodes stack garbage)
+            a, b = R.wavread(p), E.wavread(p)
+            assert a[1:] == b[1:] and np.array_equal(a[0], b[0]), (case, nbit, n, claim)
+        x = rng.uniform(-1.3, 1.3, int(rng.integers(0, 500)))
+        R.wavwrite(f"{d}/r.wav", x, fs % 2**31)
+        E.wavwrite(f"{d}/e.wav", x, fs % 2**31)
+        assert slurp(f"{d}/r.wav") == slurp(f"{d}/e.wav")

@@ -95,3 +95,42 @@ def test_emulated_silence_and_dc(emu, port_oracle):
     assert np.allclose(sp, sp_o, rtol=1e-7, atol=0)
     ap = emu.d4c(x, fs, tp, f0, fft)
     assert np.all(ap == 1.0 - 1e-12)
+
+
+def test_emulated_randomised_sweep(emu, port_oracle):
+    """A CPU-sized slice of the GPU sweeps: random rates, lengths, options and F0 tracks through every
+    stage of the host-emulated kernels against the oracle (which stage a case stresses is random too)."""
+    from world_amd import synth
+    from util import max_rel
+    rng = np.random.default_rng(4242)
+    for case in range(14):
+        fs = int(rng.choice([16000, 22050, 32000, 44100, 48000]))
+        x = synth.utterance(int(rng.integers(1, 10**6)), fs, float(rng.uniform(0.10, 0.22))).numpy()
+        x = np.round((x + rng.normal(size=len(x)) * float(rng.uniform(0.0, 0.02))) * 32768) / 32768
+        fp = float(rng.choice([2.5, 5.0, 10.0]))
+        what = f"case {case}: {fs} Hz, {len(x)} samples, {fp} ms"
+        opt = dict(f0_floor=float(rng.uniform(50, 90)), f0_ceil=float(rng.uniform(500, 900)), frame_period=fp)
+        tp_o, f0_o = port_oracle.harvest(x, fs, **opt)
+        tp, f0 = emu.harvest(x, fs, **opt)
+        assert np.array_equal(tp, tp_o) and np.array_equal(f0 > 0, f0_o > 0), what
+        assert max_rel(f0[f0_o > 0], f0_o[f0_o > 0]) <= 1e-7, what
+        dopt = dict(opt, speed=int(rng.integers(1, 7)), channels_in_octave=float(rng.choice([2.0, 3.0])),
+                    allowed_range=float(rng.uniform(0.05, 0.2)))
+        fd_o, fd = port_oracle.dio(x, fs, **dopt)[1], emu.dio(x, fs, **dopt)[1]
+        assert np.array_equal(fd > 0, fd_o > 0) and max_rel(fd[fd_o > 0], fd_o[fd_o > 0]) <= 1e-7, what + " dio"
+        # the F0-consuming stages on a track of the caller's making
+        f0_in = np.where(rng.random(len(tp)) < 0.25, 0.0, rng.uniform(30.0, 900.0, len(tp)))
+        sm_o, sm = port_oracle.stonemask(x, fs, tp, f0_in), emu.stonemask(x, fs, tp, f0_in)
+        assert np.array_equal(sm > 0, sm_o > 0) and max_rel(sm[sm_o > 0], sm_o[sm_o > 0]) <= 1e-7, what + " stonemask"
+        fft = emu.cheaptrick_fft_size(fs)
+        q1 = float(rng.uniform(-0.3, 0.0))
+        sp_o = port_oracle.cheaptrick(x, fs, tp, f0_in, q1=q1, fft_size=fft)
+        assert max_rel(emu.cheaptrick(x, fs, tp, f0_in, q1=q1, fft_size=fft), sp_o) <= 1e-6, what + " cheaptrick"
+        thr = float(rng.uniform(0.0, 0.95))
+        ap_o = port_oracle.d4c(x, fs, tp, f0_in, fft, threshold=thr)
+        assert max_rel(emu.d4c(x, fs, tp, f0_in, fft, threshold=thr), ap_o) <= 1e-6, what + " d4c"
+        y_o = port_oracle.synthesis(f0_in, sp_o, ap_o, fft, fp, fs, len(x))
+        y = emu.synthesis(f0_in, sp_o, ap_o, fft, fp, fs, len(x))
+        assert np.max(np.abs(y - y_o)) <= 1e-7 * max(np.max(np.abs(y_o)), 1e-9), what + " synthesis"
+        nd = int(rng.integers(10, 60))
+        assert np.max(np.abs(emu.code_spectral_envelope(sp_o, fs, fft, nd) - port_oracle.code_spectral_envelope(sp_o, fs, fft, nd))) <= 1e-7 * 30

@@ -871,10 +871,25 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
 // ---------------------------------------------------------------------------
 // error plumbing for the C ABI
 // ---------------------------------------------------------------------------
+// A context's allocations and launches belong to ITS device: a thread that drives several GPUs calls in
+// with whatever device it last selected, so select the context's for the duration of the call and put the
+// caller's back afterwards.
+struct DeviceScope {
+  int before, wanted;
+  explicit DeviceScope(int device) : before(devrt::current_device()), wanted(device) {
+    if (before != wanted) devrt::set_device(wanted);
+  }
+  ~DeviceScope() {
+    if (before != wanted) {
+      try { devrt::set_device(before); } catch (...) {}
+    }
+  }
+};
 template <class F> static int guarded(WorldHipContext *c, F f) {
   if (!c) { g_last_error = "null context"; return 2; }
   std::lock_guard<std::mutex> g(c->lock);
   try {
+    DeviceScope on_device(c->device);
     f();
     return 0;
   } catch (const std::exception &e) {
@@ -894,7 +909,7 @@ extern "C" {
 
 WorldHipContext *world_hip_create(int device, void *stream) {
   try {
-    devrt::set_device(device);
+    DeviceScope on_device(device);       // the caller's current device is left as it was
     WorldHipContext *c = new WorldHipContext;
     c->device = device;
     c->stream = static_cast<hipStream_t>(stream);

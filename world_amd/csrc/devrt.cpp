@@ -8,6 +8,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace devrt {
@@ -64,6 +65,11 @@ void dzero(void *dst, size_t n, hipStream_t s) {
   if (n) check(hipMemsetAsync(dst, 0, n, s), "hipMemsetAsync");
 }
 void sync(hipStream_t s) { Timed t_("api:stream_sync"); check(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+int current_device() {
+  int device = 0;
+  check(hipGetDevice(&device), "hipGetDevice");
+  return device;
+}
 void set_device(int device) {
   int count = 0;
   check(hipGetDeviceCount(&count), "hipGetDeviceCount");
@@ -87,10 +93,14 @@ void event_sync(void *ev) { Timed t_("api:event_sync"); check(hipEventSynchroniz
 
 
 void allow_large_lds(const void *kernel, size_t lds, const char *name) {
+  // the attribute belongs to the function ON THE CURRENT DEVICE: a process that drives several GPUs
+  // (one context each) must be granted it once per device
   static std::mutex lock;
-  static std::map<const void *, size_t> granted;
+  static std::map<std::pair<int, const void *>, size_t> granted;
+  int device = 0;
+  check(hipGetDevice(&device), "hipGetDevice");
   std::lock_guard<std::mutex> g(lock);
-  size_t &have = granted[kernel];
+  size_t &have = granted[std::make_pair(device, kernel)];
   if (lds <= have) return;
   Timed t_("api:func_set_attribute");
   check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);

@@ -68,6 +68,7 @@ static inline void d2d(void *dst, const void *src, size_t n, hipStream_t) { memc
 static inline void dzero(void *dst, size_t n, hipStream_t) { memset(dst, 0, n); }
 static inline void sync(hipStream_t) {}
 static inline void set_device(int) {}
+static inline int current_device() { return 0; }
 static inline void *hmalloc_pinned(size_t n) { return malloc(n); }
 static inline void hfree_pinned(void *p) { free(p); }
 static inline void *event_create() { return nullptr; }
@@ -106,6 +107,7 @@ void d2d(void *dst, const void *src, size_t n, hipStream_t s);
 void dzero(void *dst, size_t n, hipStream_t s);
 void sync(hipStream_t s);
 void set_device(int device);
+int current_device();
 void *hmalloc_pinned(size_t n);
 void hfree_pinned(void *p);
 void *event_create();

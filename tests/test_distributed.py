@@ -54,3 +54,50 @@ def test_two_rank_gather_roundtrip(tmp_path):
     port = 29500 + os.getpid() % 400
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}.npy") for r in range(world))
+
+
+def _fake_analyze(x, fs, x_len=None, frame_period=5.0, **_):
+    """stand-in for WorldHip.analyze with the same shapes: results that identify (utterance content, frame, bin)"""
+    from world_amd.api import frame_count
+    nf = [frame_count(fs, int(n), frame_period) for n in x_len]
+    F, hop, nb = max(nf), int(fs * frame_period / 1000.0), 5
+    f0 = torch.zeros((x.shape[0], F), dtype=torch.float64)
+    for u, n in enumerate(nf):
+        idx = torch.clamp(torch.arange(n) * hop, max=int(x_len[u]) - 1)
+        f0[u, :n] = x[u, idx]
+    sp = f0[:, :, None] + torch.arange(nb, dtype=torch.float64)
+    return None, f0, sp, -sp, torch.tensor(nf)
+
+
+def _sharded_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        lengths = [1600, 400, 2400, 801, 1203] if world == 2 else [700]      # world 3: two ranks own nothing
+        xs = [torch.rand(n, generator=g, dtype=torch.float64) + i for i, n in enumerate(lengths)]
+        f0, sp, ap, nf = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze)
+        for i, x in enumerate(xs):
+            _, f0_i, sp_i, ap_i, nf_i = _fake_analyze(x[None], 16000, x_len=[len(x)])
+            n = int(nf_i[0])
+            assert int(nf[i]) == n
+            assert torch.equal(f0[i, :n], f0_i[0]) and torch.equal(sp[i, :n], sp_i[0]) and torch.equal(ap[i, :n], ap_i[0])
+            assert torch.all(f0[i, n:] == 0)
+        np.save(os.path.join(tmp, f"sharded{world}_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_analyze_sharded_reassembles_every_utterance_on_every_rank(tmp_path, world):
+    port = 29900 + (os.getpid() + 7 * world) % 90
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"sharded{world}_{r}.npy") for r in range(world))
+
+
+def test_analyze_sharded_without_a_process_group():
+    xs = [torch.rand(900, dtype=torch.float64), torch.rand(300, dtype=torch.float64)]
+    f0, sp, ap, nf = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze)
+    assert f0.shape == (2, int(nf.max())) and sp.shape == (2, int(nf.max()), 5) and torch.equal(ap, -sp)

@@ -68,3 +68,66 @@ def assemble(gathered, parts, n_total):
         if idx:
             out[torch.tensor(idx, device=gathered.device)] = gathered[r, :len(idx)]
     return out
+
+
+_analyzers = {}
+
+
+def _default_analyzer():
+    """one WorldHip (library context + workspace) per device and process, created on first use"""
+    from .api import WorldHip
+    device = torch.cuda.current_device()
+    if device not in _analyzers:
+        _analyzers[device] = WorldHip(device=device)
+    return _analyzers[device]
+
+
+def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, **options):
+    """The whole multi-GPU recipe in one call (BASELINE configs[3]).
+
+    x_list: every utterance of the job as a 1-D float64 tensor -- the same list on every rank (only this
+    rank's share is uploaded and analysed).  analyze(x [b, L] on the device, fs, x_len=..., frame_period=...,
+    **options) -> (tpos, f0, sp, ap, n_frames) is WorldHip.analyze unless given.
+    Returns (f0 [n, F], sp [n, F, nb], ap [n, F, nb], n_frames [n]) for ALL utterances, in input order, on
+    every rank: utterances go to ranks longest-first (partition), each rank runs one batched analysis, and
+    one all-gather per array over equal-size padded shards reassembles the results.
+    """
+    from .api import frame_count
+    if analyze is None:
+        analyze = _default_analyzer().analyze
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    lengths = [int(x.numel()) for x in x_list]
+    n_frames = [frame_count(fs, n, frame_period) for n in lengths]
+    parts = partition(lengths, world)
+    mine, rows, F = parts[rank], max(len(p) for p in parts), max(n_frames)
+    device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    f0 = sp = ap = None
+    if mine:
+        xb = torch.zeros((len(mine), max(lengths[i] for i in mine)), dtype=torch.float64, device=device)
+        for row, i in enumerate(mine):
+            xb[row, :lengths[i]] = x_list[i].to(device)
+        _, f0, sp, ap, _ = analyze(xb, fs, x_len=[lengths[i] for i in mine], frame_period=frame_period, **options)
+
+    def shard(t, tail):
+        """this rank's [len(mine), F_local, ...] result as an equal-size [rows, F, ...] block"""
+        block = torch.zeros((rows, F) + tail, dtype=torch.float64, device=device)
+        if t is not None:
+            block[:t.shape[0], :t.shape[1]] = t
+        return block
+
+    if world > 1:                      # every rank must know the bin count, also one that owns no utterance
+        nb_t = torch.tensor([sp.shape[-1] if sp is not None else 0], device=device)
+        dist.all_reduce(nb_t, op=dist.ReduceOp.MAX, group=group)
+        nb = int(nb_t.item())
+    else:
+        nb = sp.shape[-1] if sp is not None else 0
+    blocks = [shard(f0, ()), shard(sp, (nb,)), shard(ap, (nb,))]
+    if world > 1:
+        gathered, works = all_gather_results(blocks, group=group, async_op=True)
+        wait_all(works)
+    else:
+        gathered = [b.unsqueeze(0) for b in blocks]
+    f0_all, sp_all, ap_all = (assemble(g, parts, len(x_list)) for g in gathered)
+    return f0_all, sp_all, ap_all, torch.tensor(n_frames, dtype=torch.int32)

@@ -441,3 +441,21 @@ def test_device_resident_c_api_from_plain_cpp(tmp_path):
         assert abs(float(f0[u, :n].sum()) - float(s_f0)) <= 1e-9 * float(s_f0)
         assert abs(float(torch.log(sp[u, :n]).sum()) - float(s_sp)) <= 1e-9 * abs(float(s_sp))
         assert abs(float(ap[u, :n].sum()) - float(s_ap)) <= 1e-9 * float(s_ap)
+
+
+@pytest.mark.gpu
+def test_analyze_sharded_on_one_gpu_equals_per_utterance_calls():
+    """world_amd.distributed.analyze_sharded without a process group (one rank owns everything): ragged
+    utterances in, every utterance's rows out, identical to analysing them one at a time."""
+    import torch
+    from world_amd import distributed as wd, synth
+    from world_amd.api import WorldHip
+    fs = 48000
+    xs = [synth.utterance(i, fs, d) for i, d in enumerate([0.5, 0.21, 0.37])]
+    f0, sp, ap, nf = wd.analyze_sharded(xs, fs)
+    wh = WorldHip()
+    for i, x in enumerate(xs):
+        _, f0_i, sp_i, ap_i, nf_i = wh.analyze(x[None].cuda().contiguous(), fs)
+        n = int(nf_i[0])
+        assert int(nf[i]) == n
+        assert torch.equal(f0[i, :n], f0_i[0, :n]) and torch.equal(sp[i, :n], sp_i[0, :n]) and torch.equal(ap[i, :n], ap_i[0, :n])

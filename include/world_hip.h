@@ -160,8 +160,14 @@ WORLD_HIP_API WorldHipContext *world_hip_create(int device, void *stream);
 WORLD_HIP_API void world_hip_destroy(WorldHipContext *ctx);
 WORLD_HIP_API const char *world_hip_last_error(void);
 WORLD_HIP_API int world_hip_sync(WorldHipContext *ctx);
-/* bytes of device workspace currently held by the context */
+/* bytes of device workspace currently held by the context (its arena) */
 WORLD_HIP_API unsigned long long world_hip_workspace_bytes(WorldHipContext *ctx);
+/* The reference's randn() stream (src/matlabfunctions.cpp:237-264) is a constant of the algorithm: one
+ * table per device, shared by every context of the process, checked in full against a sequential host
+ * statement of the generator whenever it is (re)built.  bytes() = what it holds (live + superseded
+ * generations); verify() reduces the live table again and compares (0 = intact; synchronises). */
+WORLD_HIP_API unsigned long long world_hip_noise_table_bytes(WorldHipContext *ctx);
+WORLD_HIP_API int world_hip_verify_tables(WorldHipContext *ctx);
 
 /* Per-kernel timing with HIP events on the launch stream (process-wide switch).
  * collect() waits for the recorded kernels and returns "kernel_name ms\n" lines. */

@@ -84,9 +84,6 @@ struct WorldHipContext {
   double *d_dc_remover = nullptr; // GetDCRemover(fft_size) of the synthesiser
   int dc_remover_len = 0;
   void *codec_tables = nullptr;  // world_hip::CodecTableSet (cached interp1 / DCT tables of the coders)
-  uint32_t *d_noise = nullptr;   // randn_value(noise[k]) = k-th randn() after reseed (grow-only constant table)
-  size_t noise_len = 0;
-  std::vector<uint4> jump_host;  // host copy of tab.jump: spot checks of the table after every extension
   // pinned ring of staging buffers for the small per-call host arrays
   char *stage[kStageRing] = {};
   void *stage_ev[kStageRing] = {};
@@ -108,78 +105,10 @@ static void ensure_arena(WorldHipContext *c, size_t bytes) {
 
 static size_t pad256(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
-// Host statement of rng.h (same generator, same jump tables), used to spot-check what the fill kernel wrote:
-// the table is a process-wide constant every D4C / CheapTrick / Synthesis result depends on, so a wrong entry
-// must stop the call instead of quietly shifting results by 1e-4.
-struct HostXs { uint32_t x, y, z, w; };
-static uint32_t host_xs_step(HostXs &s) {
-  const uint32_t t = s.x ^ (s.x << 11);
-  s.x = s.y; s.y = s.z; s.z = s.w;
-  s.w = (s.w ^ (s.w >> 19)) ^ (t ^ (t >> 8));
-  return s.w;
-}
-static HostXs host_xs_at(const std::vector<uint4> &jump, uint32_t calls) {   // state after `calls` randn() calls
-  HostXs s = {123456789u, 362436069u, 521288629u, 88675123u};
-  for (int level = 0; calls != 0; ++level, calls >>= 1) {
-    if (!(calls & 1u)) continue;
-    const uint4 *tab = jump.data() + (size_t)level * kJumpStride;
-    const uint32_t in[4] = {s.x, s.y, s.z, s.w};
-    HostXs r = {0, 0, 0, 0};
-    for (int wd = 0; wd < 4; ++wd)
-      for (int n = 0; n < 8; ++n) {
-        const uint4 e = tab[(wd * 8 + n) * 16 + ((in[wd] >> (4 * n)) & 15u)];
-        r.x ^= e.x; r.y ^= e.y; r.z ^= e.z; r.w ^= e.w;
-      }
-    s = r;
-  }
-  return s;
-}
-static void verify_noise(WorldHipContext *c, const uint32_t *d_table, size_t begin, size_t end) {
-  constexpr size_t kProbes = 64, kRun = 32;
-  if (end <= begin) return;
-  const size_t run = std::min(kRun, end - begin), span = end - begin - run;
-  std::vector<uint32_t> got(kProbes * run);
-  size_t at[kProbes];
-  for (size_t i = 0; i < kProbes; ++i) {
-    at[i] = begin + span * i / (kProbes - 1);
-    devrt::d2h(got.data() + i * run, d_table + at[i], sizeof(uint32_t) * run, c->stream);
-  }
-  devrt::sync(c->stream);
-  for (size_t i = 0; i < kProbes; ++i) {
-    HostXs s = host_xs_at(c->jump_host, static_cast<uint32_t>(at[i]));
-    for (size_t j = 0; j < run; ++j) {
-      uint32_t acc = 0;
-      for (int k = 0; k < 12; ++k) acc += host_xs_step(s) >> 4;
-      if (got[i * run + j] != acc)
-        fail("randn table verification failed at draw %zu (extension [%zu, %zu)): got %u, expected %u", at[i] + j, begin, end,
-             got[i * run + j], acc);
-    }
-  }
-}
-
-// The randn() stream is a constant of the algorithm: make sure its first `draws`
-// values are resident (generated once per context by jump-ahead, extended on demand).
+// The randn() stream is a constant of the algorithm: its first `draws` values live in the device's
+// shared, fully verified table (rng.h / rng_fill.hip), generated once per process and extended on demand.
 static const uint32_t *ensure_noise(WorldHipContext *c, size_t draws) {
-  if (draws > 0xFFFFFFF0ull) fail("utterance consumes more than 2^32 randn() draws");
-  if (draws > c->noise_len) {
-    size_t cap = draws + draws / 4;
-    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-    devrt::sync(c->stream);
-    uint32_t *fresh = static_cast<uint32_t *>(devrt::dmalloc(sizeof(uint32_t) * cap));
-    if (c->d_noise) {
-      devrt::d2d(fresh, c->d_noise, sizeof(uint32_t) * c->noise_len, c->stream);
-      devrt::sync(c->stream);
-      devrt::dfree(c->d_noise);
-    }
-    RngFillArgs fill = {fresh, c->noise_len, cap, c->tab.jump};
-    launch_rng_fill(fill, c->stream);
-    const size_t filled_from = c->noise_len;
-    c->d_noise = fresh;
-    c->noise_len = cap;
-    verify_noise(c, fresh, 0, filled_from);        // what the copy carried over
-    verify_noise(c, fresh, filled_from, cap);      // what the fill kernel wrote
-  }
-  return c->d_noise;
+  return noise_table_acquire(c->device, draws, c->tab.jump, c->stream);
 }
 
 // Small host arrays travel through pinned staging so the async copy never reads
@@ -924,7 +853,7 @@ WorldHipContext *world_hip_create(int device, void *stream) {
     devrt::sync(c->stream);
     c->tab.tw = d_tw;
     c->tab.jump = d_jump;
-    c->jump_host = std::move(jump);
+    noise_table_retain(device);
     c->dio_bands = new DioBands;
     c->codec_tables = new CodecTableSet;
     return c;
@@ -942,7 +871,7 @@ void world_hip_destroy(WorldHipContext *c) {
     devrt::dfree(const_cast<uint4 *>(c->tab.jump));
     if (c->arena.base) devrt::dfree(c->arena.base);
     if (c->d_nuttall) devrt::dfree(c->d_nuttall);
-    if (c->d_noise) devrt::dfree(c->d_noise);
+    noise_table_release(c->device);
     if (c->dio_bands) {
       DioBands *db = static_cast<DioBands *>(c->dio_bands);
       if (db->d_band_f0) {
@@ -972,7 +901,15 @@ int world_hip_sync(WorldHipContext *c) {
 }
 
 unsigned long long world_hip_workspace_bytes(WorldHipContext *c) {
-  return c ? c->arena.cap + sizeof(uint32_t) * c->noise_len : 0;
+  return c ? c->arena.cap : 0;
+}
+
+// the device's shared randn table (live + superseded generations), see rng.h
+unsigned long long world_hip_noise_table_bytes(WorldHipContext *c) { return c ? noise_table_bytes(c->device) : 0; }
+
+// re-reduce the live randn table on the device and compare it with the host's sums (diagnostic; synchronises)
+int world_hip_verify_tables(WorldHipContext *c) {
+  return guarded(c, [&] { noise_table_verify(c->device, c->stream); });
 }
 
 // per-kernel HIP-event timing (used by bench.py for the roofline figure)

@@ -64,22 +64,38 @@ __device__ __forceinline__ Xs128 xs_jump(const uint4 *jump, Xs128 s, uint32_t ca
 }
 
 // Whole-stream generation (rng_fill.hip): thread t produces draws
-// [begin + t*kFillRun, begin + (t+1)*kFillRun) of an utterance's stream with ONE
-// jump-ahead, so the jump cost is amortised over kFillRun draws and every draw of
-// the stream is produced exactly once, in parallel.  The table holds the draws'
-// 32-bit integer sums (4 bytes per draw, not 8: it is streamed once per frame by
-// CheapTrick and D4C and is their largest input); consumers recentre with
-// randn_value() and apply their own scale (1e-12, 1e-6, |.|*eps).
+// [begin + t*kFillRun, begin + (t+1)*kFillRun) of the stream with ONE jump-ahead, so the
+// jump cost is amortised over kFillRun draws and every draw of the stream is produced
+// exactly once, in parallel.  The table holds the draws' 32-bit integer sums (4 bytes per
+// draw, not 8: it is streamed once per frame by CheapTrick and D4C and is their largest
+// input); consumers recentre with randn_value() and apply their own scale (1e-12, 1e-6,
+// |.|*eps).
 constexpr int kFillRun = 32;
-//
-// The stream is the same for every utterance and every call (the reference reseeds
-// at the top of CheapTrick() and D4C()), so the context keeps ONE table
-// noise[k] = k-th randn() in HBM and only ever extends it: [begin, end) below.
 struct RngFillArgs {
   uint32_t *noise;          // randn_value(noise[k]) = draw number k of the stream
   size_t begin, end;        // positions to (re)generate
   const uint4 *jump;
 };
 void launch_rng_fill(const RngFillArgs &a, hipStream_t stream);
+
+// The stream is the same for every utterance, every call and every context (the reference
+// reseeds at the top of CheapTrick(), D4C() and Synthesis()), so a PROCESS keeps ONE table
+// noise[k] = k-th randn() per device, shared by all contexts of that device and only ever
+// replaced by a longer one.  Every table is checked IN FULL before it is published: the fill
+// kernel's output is reduced to one (sum, index-weighted sum) pair per kNoiseChunk draws on
+// the device and compared with the same pairs computed on the host by stepping the generator
+// sequentially from the seed (no jump tables involved) -- a wrong word anywhere stops the
+// call instead of shifting D4C / CheapTrick results by 1e-4.  Superseded tables stay
+// allocated until the device's last context is destroyed (other contexts' kernels may still
+// be reading them); with doubling growth they add up to less than the live one.
+constexpr size_t kNoiseChunk = (size_t)1 << 16;
+constexpr size_t kNoiseMaxDraws = 0xFFFFFFF0ull;   // stream positions are 32-bit (xs_jump)
+void noise_table_retain(int device);
+void noise_table_release(int device);              // last release frees the device's tables
+// first `draws` words resident, verified and visible to `stream`; throws std::runtime_error
+const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jump, hipStream_t stream);
+// re-reduce the live table on `stream` and compare with the host's sums (diagnostic; synchronises); throws on mismatch
+void noise_table_verify(int device, hipStream_t stream);
+size_t noise_table_bytes(int device);              // live + superseded tables
 
 }  // namespace world_hip

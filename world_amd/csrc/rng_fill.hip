@@ -1,6 +1,14 @@
 // rng_fill.hip -- the reference's randn() stream (src/matlabfunctions.cpp:237-264)
-// materialised in HBM by jump-ahead (see rng.h): randn_value(noise[k]) = k-th draw after reseed.
+// materialised in HBM by jump-ahead (see rng.h): randn_value(noise[k]) = k-th draw after
+// reseed; plus the per-device table that all contexts of a process share, verified in full
+// against a sequential host statement of the generator before anybody may read it.
 #include "rng.h"
+
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
 
 namespace world_hip {
 
@@ -20,6 +28,172 @@ void launch_rng_fill(const RngFillArgs &a, hipStream_t stream) {
   const size_t per_y = (size_t)1 << 20;
   const unsigned ny = (unsigned)((runs + per_y - 1) / per_y);
   WH_THREADS(rng_stream_fill, (long)(runs < per_y ? runs : per_y), ny, 1, stream, a);
+}
+
+// ---------------------------------------------------------------------------
+// Chunk sums: for chunk c (draws [c*kNoiseChunk, min(len, (c+1)*kNoiseChunk))):
+//   sums[2c] = sum w[i],  sums[2c+1] = sum w[i] * (i_local + 1)      (mod 2^64)
+// The weighted sum makes the pair sensitive to order and position, not just content.
+constexpr int kSumThreads = 256;
+__global__ void rng_chunk_sums(const uint32_t *noise, size_t len, unsigned long long *sums) {
+  DYN_LDS(lds);
+  unsigned long long *part = reinterpret_cast<unsigned long long *>(lds);   // [2][blockDim.x]
+  const size_t chunk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const size_t lo = chunk * kNoiseChunk;
+  if (lo >= len) return;
+  const size_t n = len - lo < kNoiseChunk ? len - lo : kNoiseChunk;
+  unsigned long long s1 = 0, s2 = 0;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const unsigned long long w = noise[lo + i];
+    s1 += w;
+    s2 += w * (unsigned long long)(i + 1);
+  }
+  part[threadIdx.x] = s1;
+  part[blockDim.x + threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t1 = 0, t2 = 0;
+    for (unsigned k = 0; k < blockDim.x; ++k) { t1 += part[k]; t2 += part[blockDim.x + k]; }
+    sums[2 * chunk] = t1;
+    sums[2 * chunk + 1] = t2;
+  }
+}
+
+namespace {
+
+struct HostGen {                                    // src/matlabfunctions.cpp:237-264, stepped one draw at a time
+  uint32_t x = 123456789u, y = 362436069u, z = 521288629u, w = 88675123u;
+  uint32_t word() {
+    uint32_t acc = 0;
+    for (int k = 0; k < 12; ++k) {
+      const uint32_t t = x ^ (x << 11);
+      x = y; y = z; z = w;
+      w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+      acc += w >> 4;
+    }
+    return acc;
+  }
+};
+
+struct DeviceNoise {
+  int refs = 0;
+  uint32_t *live = nullptr;
+  size_t len = 0;
+  std::vector<uint32_t *> superseded;
+  size_t superseded_bytes = 0;
+  // host statement: generator positioned at draw host_pos (always a whole number of chunks
+  // until the 32-bit limit is reached), and every chunk's sums up to there
+  HostGen gen;
+  size_t host_pos = 0;
+  std::vector<unsigned long long> host_sums;
+};
+
+std::mutex g_noise_lock;
+std::map<int, DeviceNoise> g_noise;
+
+void host_extend(DeviceNoise &d, size_t upto) {
+  while (d.host_pos < upto) {
+    const size_t n = upto - d.host_pos < kNoiseChunk ? upto - d.host_pos : kNoiseChunk;
+    unsigned long long s1 = 0, s2 = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const unsigned long long w = d.gen.word();
+      s1 += w;
+      s2 += w * (unsigned long long)(i + 1);
+    }
+    d.host_sums.push_back(s1);
+    d.host_sums.push_back(s2);
+    d.host_pos += n;
+  }
+}
+
+// reduce `table[0, len)` on the device and compare every chunk with the host's sums
+void check_table(DeviceNoise &d, const uint32_t *table, size_t len, hipStream_t stream, const char *when) {
+  const size_t chunks = (len + kNoiseChunk - 1) / kNoiseChunk;
+  unsigned long long *d_sums = static_cast<unsigned long long *>(devrt::dmalloc(sizeof(unsigned long long) * 2 * chunks));
+  std::vector<unsigned long long> got(2 * chunks);
+  try {
+    const unsigned gx = (unsigned)(chunks < 32768 ? chunks : 32768), gy = (unsigned)((chunks + gx - 1) / gx);
+    WH_BLOCKS(rng_chunk_sums, dim3(gx, gy), kSumThreads, 2 * kSumThreads * sizeof(unsigned long long), stream, table, len,
+              d_sums);
+    host_extend(d, len);                              // overlaps the kernels in flight
+    devrt::d2h(got.data(), d_sums, sizeof(unsigned long long) * 2 * chunks, stream);
+    devrt::sync(stream);
+  } catch (...) {
+    devrt::dfree(d_sums);
+    throw;
+  }
+  devrt::dfree(d_sums);
+  for (size_t c = 0; c < chunks; ++c)
+    if (got[2 * c] != d.host_sums[2 * c] || got[2 * c + 1] != d.host_sums[2 * c + 1]) {
+      char msg[256];
+      snprintf(msg, sizeof msg,
+               "randn table verification failed (%s): chunk %zu of %zu (draws %zu..) sums %llx/%llx, expected %llx/%llx", when, c,
+               chunks, c * kNoiseChunk, got[2 * c], got[2 * c + 1], d.host_sums[2 * c], d.host_sums[2 * c + 1]);
+      throw std::runtime_error(msg);
+    }
+}
+
+}  // namespace
+
+void noise_table_retain(int device) {
+  std::lock_guard<std::mutex> g(g_noise_lock);
+  g_noise[device].refs += 1;
+}
+
+void noise_table_release(int device) {
+  std::lock_guard<std::mutex> g(g_noise_lock);
+  auto it = g_noise.find(device);
+  if (it == g_noise.end()) return;
+  DeviceNoise &d = it->second;
+  if (--d.refs > 0) return;
+  // the device's last context is gone (it drained its stream before releasing): nobody reads these any more
+  if (d.live) devrt::dfree(d.live);
+  for (uint32_t *p : d.superseded) devrt::dfree(p);
+  g_noise.erase(it);
+}
+
+const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jump, hipStream_t stream) {
+  if (draws > kNoiseMaxDraws) throw std::runtime_error("utterance consumes more than 2^32 randn() draws");
+  std::lock_guard<std::mutex> g(g_noise_lock);
+  DeviceNoise &d = g_noise[device];
+  if (draws <= d.len) return d.live;
+  // grow: at least double, whole chunks (only the final 32-bit clamp leaves a partial chunk, and nothing grows past it)
+  size_t cap = draws > 2 * d.len ? draws : 2 * d.len;
+  if (cap < ((size_t)1 << 22)) cap = (size_t)1 << 22;
+  cap = (cap + kNoiseChunk - 1) / kNoiseChunk * kNoiseChunk;
+  if (cap > kNoiseMaxDraws) cap = kNoiseMaxDraws;
+  uint32_t *fresh = static_cast<uint32_t *>(devrt::dmalloc(sizeof(uint32_t) * cap));
+  try {
+    // every word comes from the fill kernel (nothing is copied over from the shorter table) ...
+    RngFillArgs fill = {fresh, 0, cap, d_jump};
+    launch_rng_fill(fill, stream);
+    // ... and every word is accounted for before the table is published
+    check_table(d, fresh, cap, stream, "new table");
+  } catch (...) {
+    devrt::sync(stream);
+    devrt::dfree(fresh);
+    throw;
+  }
+  if (d.live) {
+    d.superseded.push_back(d.live);
+    d.superseded_bytes += sizeof(uint32_t) * d.len;
+  }
+  d.live = fresh;
+  d.len = cap;
+  return d.live;
+}
+
+void noise_table_verify(int device, hipStream_t stream) {
+  std::lock_guard<std::mutex> g(g_noise_lock);
+  auto it = g_noise.find(device);
+  if (it == g_noise.end() || !it->second.live) return;
+  check_table(it->second, it->second.live, it->second.len, stream, "re-check of the live table");
+}
+
+size_t noise_table_bytes(int device) {
+  std::lock_guard<std::mutex> g(g_noise_lock);
+  auto it = g_noise.find(device);
+  return it == g_noise.end() ? 0 : sizeof(uint32_t) * it->second.len + it->second.superseded_bytes;
 }
 
 }  // namespace world_hip

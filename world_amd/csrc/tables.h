@@ -12,7 +12,7 @@ namespace world_hip {
 
 constexpr int kTwLog2 = 13;            // largest real FFT on the path: 8192 (StoneMask)
 constexpr int kTwN = 1 << kTwLog2;
-constexpr int kJumpLevels = 30;        // up to 2^30 randn() calls per utterance
+constexpr int kJumpLevels = 32;        // every 32-bit stream position (xs_jump takes a uint32_t)
 constexpr int kJumpStride = 32 * 16;   // uint4 entries per level
 
 struct Tables {

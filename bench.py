@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- analysis frames/sec of the MI355X WORLD analysis path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--seconds S]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One "step" = one pass of Harvest + CheapTrick + D4C (48 kHz, 5 ms hop, CheapTrick
-fft 2048, D4C internal fft 4096) over one batch of synthetic utterances already
-resident in HBM, results left in HBM.  The default workload is BASELINE.json
-configs[1]: ONE 48 kHz x 10 s utterance per GPU (2001 frames); `--batch B` runs B
-utterances per step (the per-GPU share of configs[3] is --batch 128 --seconds 5).
-With N > 1 ranks every rank analyses its own utterances (utterances are the
-independent unit; weak scaling) and the per-rank f0 / spectrogram /
-aperiodicity shards are reassembled on every rank with one RCCL all-gather per
-array (north_star), double-buffered so step k's gather overlaps step k+1's compute.
+N = 1 (the default, what the driver's BENCH run executes)
+    `value` = BASELINE.json configs[1]: one 48 kHz x 10 s utterance per step (2001 frames), Harvest + CheapTrick +
+    D4C, 5 ms hop, fft_size 2048, inputs and outputs resident in HBM, `--streams` (8) independent jobs in flight.
+    The timed region is `repeats` back-to-back blocks of K steps inside ONE barrier + synchronize bracket, with
+    `repeats` chosen so that the region lasts >= --min-wall seconds (K = 20 steps are 20 ms of GPU time: too short
+    for any sampler).  After the timed region the run checks itself (`parity_in_run`): every in-flight slot's
+    (f0, sp, ap) must be bit-identical to a serial single-context run, and that run must agree with the CPU
+    reference computed for `cpu_baseline` to the contract's 1e-4 -- otherwise the process exits non-zero.
+    Beside `value` the line carries `value_single_job` (1 / latency of a lone job) and a `configs` object with one
+    timed leg per remaining single-GPU BASELINE config: configs[2] (256 x 5 s, Harvest only), the per-GPU share of
+    configs[3] (128 x 5 s, full pipeline) and configs[4] (64 x 16 kHz x 5 s, DIO + StoneMask + CheapTrick + D4C),
+    each run for >= --min-wall seconds with its dominant kernel and HBM / FP64 roofline fractions.
 
-Rank 0 prints ONE JSON line: metric/value (whole-job frames/s), `roofline` for the
-kernel that dominates the step (HIP-event timing on the launch stream, taken in a
-separate profiled pass) and `cpu_baseline` (the CPU oracle on this box's host cores).
+N > 1 (the driver's SCALE run; one rank per GPU over RCCL)
+    BASELINE.json configs[3]: ONE job of 1024 x (48 kHz, 5 s) utterances per step, split 1024/N per rank by
+    world_amd.distributed.analyze_sharded (longest-first partition, batched analysis in sub-batches, one packed
+    [frames][2 + 2*1025] block per rank, ONE all-gather).  Total work is fixed: "scaling": "strong".  Compute and
+    exchange are timed separately on every rank (`phases`).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the kernel that dominates a configs[1] step (HIP-event timing on
+the launch stream, taken in a separate profiled pass); `cpu_baseline*` are the unmodified reference timed on this
+box's host cores (1 core at -O1 = the reference's own flags, 1 core at -O3, and every core).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -36,66 +46,81 @@ if ROOT not in sys.path:
 FS = 48000
 FRAME_PERIOD = 5.0
 FFT_SIZE = 2048
-# compulsory HBM bytes per output frame of the full pipeline at 48 kHz:
-# one hop of x read once (240 samples * 8 B) + tpos + f0 + two rows of 1025 doubles written once
-BYTES_PER_FRAME = 240 * 8 + 8 + 8 + 2 * 1025 * 8
+# compulsory HBM bytes per output frame (one hop of x read once, tpos + f0 + the rows written once)
+BYTES_PER_FRAME = 240 * 8 + 8 + 8 + 2 * 1025 * 8          # 48 kHz, full pipeline (configs 1, 3)
+BYTES_PER_FRAME_HARVEST = 240 * 8 + 16                     # 48 kHz, Harvest only (configs 2)
+BYTES_PER_FRAME_16K = 80 * 8 + 16 + 2 * 513 * 8            # 16 kHz, fft 1024 (configs 4)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+RTOL = 1e-4                     # north_star: F0 / envelope / aperiodicity within 1e-4 relative
 
 
-def cpu_baseline_all_cores(x_np):
-    """The reference is re-entrant (no globals), so the fairest whole-box CPU number is one
-    analysis per core: P worker PROCESSES (the reference allocates per candidate, threads would
-    fight over one heap) each analyse the utterance once, concurrently."""
-    from oracle.loader import best_oracle, parallel_analyses
-    cores = os.cpu_count() or 1
-    procs = max(1, min(cores, 64))
-    kind = best_oracle().kind
-    frames, dt = parallel_analyses(x_np, FS, FRAME_PERIOD, FFT_SIZE, procs)
-    return {"value": frames / dt, "unit": "frames/s", "cores": procs,
-            "kind": "reference" if kind == "reference" else "port",
-            "sample": f"{procs} concurrent analyses of the same {len(x_np) / FS:.1f} s utterance, one per process, "
-                      f"{dt:.1f} s wall (excluding worker start-up)", "host_cores_available": cores}
+# ---------------------------------------------------------------------------------------------------------
+# committed PMC evidence (profiles/pmc_traffic.json, written by tools/profile_summary.py on the GPU box)
+def csrc_hash():
+    """Hash of the kernel sources the library is built from: the PMC profile is stamped with it, and a line
+    whose sources differ from the profiled ones says so (`traffic_stale`) instead of silently replaying."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "world_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, written by tools_profile_summary.py).  FETCH_SIZE is
-    doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read);
-    WRITE_SIZE is used as reported (uncalibrated).  None when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("frames_per_launch") != frames_per_launch:
-            return None
-        # rocprofv3 prints template arguments ("d4c_groupdelay<4096>"), the library's labels do not
-        names = [n for n in t["kernels"] if n == kernel or n.startswith(kernel + "<")]
-        if not names:
-            return None
-        k = t["kernels"][names[0]]
-        return int((2.0 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0)
-    except (OSError, ValueError, KeyError):
-        return None
-
-
-FP64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X FP64 vector (SURVEY.md 8d): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
-
-
-def measured_fp64(kernels, frames_per_launch):
-    """FP64 work per launch from the committed rocprofv3 PMC pass (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64:
-    wave-level instructions, 64 lanes each, an FMA counted as two operations) set against the live
-    per-launch durations: {kernel: (flop per launch, achieved TFLOP/s)} and the pipeline's flop per frame.
-    None when the profile lacks the counters or was taken on another workload."""
+def _pmc(config="1"):
+    """{kernel: counters} of one profiled config, its frames per launch, and whether the stamp is stale."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return None
-    if t.get("frames_per_launch") != frames_per_launch:
+    stale = t.get("csrc_hash") != csrc_hash()
+    if "configs" in t:
+        c = t["configs"].get(str(config))
+        if not c:
+            return None
+        return c["kernels"], c.get("frames_per_launch"), stale
+    if str(config) != "1":
+        return None
+    return t.get("kernels", {}), t.get("frames_per_launch"), stale
+
+
+def measured_traffic(kernel, frames_per_launch, config="1"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes.  FETCH_SIZE is doubled per
+    MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); WRITE_SIZE is used as reported
+    (uncalibrated).  None when no profile of this workload exists."""
+    p = _pmc(config)
+    if not p or p[1] != frames_per_launch:
+        return None
+    # rocprofv3 prints template arguments ("d4c_groupdelay<4096>"), the library's labels do not
+    names = [n for n in p[0] if n == kernel or n.startswith(kernel + "<")]
+    if not names:
+        return None
+    k = p[0][names[0]]
+    if "FETCH_SIZE" not in k and "WRITE_SIZE" not in k:
+        return None
+    return int((2.0 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0)
+
+
+def traffic_stale(config="1"):
+    p = _pmc(config)
+    return None if not p else bool(p[2])
+
+
+def measured_fp64(kernels, frames_per_launch, config="1"):
+    """FP64 work per launch from the committed rocprofv3 PMC pass (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64:
+    wave-level instructions, 64 lanes each, an FMA counted as two operations) set against the live
+    per-launch durations: {kernel: (flop per launch, achieved TFLOP/s)} and the pipeline's flop per frame.
+    None when the profile lacks the counters or was taken on another workload."""
+    p = _pmc(config)
+    if not p or p[1] != frames_per_launch:
         return None
     out, total = {}, 0.0
-    for name, c in t["kernels"].items():
+    for name, c in p[0].items():
         if "SQ_INSTS_VALU_FMA_F64" not in c:
             continue
         flop = 64.0 * (c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
@@ -108,42 +133,68 @@ def measured_fp64(kernels, frames_per_launch):
     return (out, total / frames_per_launch) if out else None
 
 
-def cpu_baseline(x_np, reps=1):
-    """Time the CPU oracle (the unmodified reference when its in-place build travelled
-    here, else this repo's C restatement) on the same utterance, one host core."""
-    from oracle.loader import best_oracle
-    o = best_oracle()
+# ---------------------------------------------------------------------------------------------------------
+# CPU baselines: the unmodified reference (oracle/_ref, built in place by oracle/Makefile) on this box's cores
+def cpu_baseline(x_np, optimized=False, keep_outputs=False):
+    """One analysis of the same utterance on ONE host core; returns (record, outputs or None)."""
+    from oracle.loader import PortOracle, RefOracle, ref_available
+    o = RefOracle(optimized=optimized) if ref_available() else PortOracle()
     t0 = time.perf_counter()
-    frames = 0
-    for _ in range(reps):
-        tp, f0 = o.harvest(x_np, FS, frame_period=FRAME_PERIOD)
-        o.cheaptrick(x_np, FS, tp, f0, fft_size=FFT_SIZE)
-        o.d4c(x_np, FS, tp, f0, FFT_SIZE)
-        frames += len(f0)
+    tp, f0 = o.harvest(x_np, FS, frame_period=FRAME_PERIOD)
+    sp = o.cheaptrick(x_np, FS, tp, f0, fft_size=FFT_SIZE)
+    ap = o.d4c(x_np, FS, tp, f0, FFT_SIZE)
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1,
-            "kind": "reference" if o.kind == "reference" else "port",
-            "sample": f"{reps} x ({len(x_np) / FS:.1f} s of 48 kHz audio, Harvest+CheapTrick+D4C, {frames // reps} frames), "
-                      f"{getattr(o, 'flags', 'gcc -O2 restatement')}, {dt:.1f} s of CPU time",
-            "host_cores_available": os.cpu_count()}
+    rec = {"value": len(f0) / dt, "unit": "frames/s", "cores": 1,
+           "kind": "reference" if o.kind == "reference" else "port",
+           "sample": f"1 x ({len(x_np) / FS:.1f} s of 48 kHz audio, Harvest+CheapTrick+D4C, {len(f0)} frames), "
+                     f"{getattr(o, 'flags', 'gcc -O2 restatement')}, {dt:.1f} s of CPU time",
+           "host_cores_available": os.cpu_count()}
+    return rec, ((tp, f0, sp, ap) if keep_outputs else None)
 
 
+def cpu_baseline_all_cores(x_np, optimized=False):
+    """The reference is re-entrant (no globals), so the whole-box CPU number is one analysis per core:
+    P worker PROCESSES (the reference allocates per candidate, threads would fight over one heap), P = every
+    host core, each analysing the utterance once, all started at the same instant."""
+    from oracle.loader import parallel_analyses, ref_available
+    cores = os.cpu_count() or 1
+    procs = max(1, min(cores, int(os.environ.get("WORLD_BENCH_CPU_PROCS", cores))))
+    frames, dt, flags = parallel_analyses(x_np, FS, FRAME_PERIOD, FFT_SIZE, procs, optimized=optimized)
+    return {"value": frames / dt, "unit": "frames/s", "cores": procs,
+            "kind": "reference" if ref_available() else "port", "flags": flags,
+            "sample": f"{procs} concurrent analyses of the same {len(x_np) / FS:.1f} s utterance, one per process, "
+                      f"{dt:.1f} s wall (excluding worker start-up)", "host_cores_available": cores}
+
+
+def rel_err(a, b):
+    import numpy as np
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step")
-    ap.add_argument("--seconds", type=float, default=10.0, help="utterance length")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="N = 1: utterances per step of the headline leg")
+    ap.add_argument("--seconds", type=float, default=10.0, help="N = 1: utterance length of the headline leg")
+    ap.add_argument("--min-wall", type=float, default=2.0,
+                    help="every timed region repeats its K steps until it has lasted this many seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs[2] / [3]-share / [4] legs")
+    ap.add_argument("--only-config", type=int, default=0,
+                    help="N = 1: run ONLY the leg of this BASELINE config (2, 3 or 4) -- the profiling entry point")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
-    ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis legs reported beside the metric")
+    ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis / host-pointer legs")
+    ap.add_argument("--job-utterances", type=int, default=1024, help="N > 1: utterances of the configs[3] job")
+    ap.add_argument("--sub-batch", type=int, default=128, help="N > 1: utterances per batched call on a rank")
     ap.add_argument("--streams", type=int, default=8,
                     help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
                          "stream with its own workspace; 1 = strictly one after the other)")
     args = ap.parse_args()
-    args.no_gather_cfg = args.no_gather
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from world_amd import distributed as wd
@@ -163,16 +214,195 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(os.environ.get("WORLD_HIP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    dev = torch.device("cuda", local)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    dev = torch.device("cuda", local)
-    # synthetic utterances of this rank (distinct per rank and per slot), resident in HBM
+    def timed_region(step, finish, steps, est_ms_per_step):
+        """`repeats` blocks of `steps` steps inside one barrier + synchronize bracket; max over ranks"""
+        repeats = max(1, int(args.min_wall * 1e3 / max(est_ms_per_step * steps, 1e-3) + 0.999))
+        if world > 1:
+            r = torch.tensor([repeats], device=dev)
+            dist.all_reduce(r, op=dist.ReduceOp.MAX)
+            repeats = int(r.item())
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(repeats * steps):
+            step()
+        finish()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, repeats
+
+    def estimate(step, finish, n=3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        finish()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def kernel_profile(wh, run, reps=2):
+        prof = wh.profile(lambda: [run() for _ in range(reps)])
+        torch.cuda.synchronize()
+        return {k: {"launches_per_step": len(v) // reps, "ms_per_step": sum(v) / reps, "avg_ms": sum(v) / len(v)}
+                for k, v in prof.items()}
+
+    def roofline_of(kernels, frames, bytes_per_frame, config):
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        alg = bytes_per_frame * frames
+        ach = alg / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom, frames, config),
+             "traffic_stale": traffic_stale(config),
+             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernels[dom]["avg_ms"]}
+        fp = measured_fp64(kernels, frames, config)
+        if fp and dom in fp[0]:
+            flop, tflops = fp[0][dom]
+            r["fp64"] = {"flop_per_launch": flop, "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "pipeline_flop_per_frame": fp[1],
+                         "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU_*_F64) over live durations"}
+        return r
+
+    # =====================================================================================================
+    # N > 1: BASELINE configs[3], one job of --job-utterances utterances per step, sharded over the ranks
+    # =====================================================================================================
+    if world > 1:
+        n_job, sec = args.job_utterances, 5.0
+        n_samp = int(round(FS * sec))
+        lengths = [n_samp] * n_job
+        parts = wd.partition(lengths, world)
+        mine = parts[rank]
+        xs = {i: synth.utterance(i, FS, sec, device=dev) for i in mine}        # only this rank's share exists here
+        wh = WorldHip(device=local)
+        phases = {"compute_ms": 0.0, "exchange_ms": 0.0, "steps": 0}
+
+        def step():
+            out = wd.analyze_sharded(xs, FS, lengths=lengths, analyze=wh.analyze, packer=wh, sub_batch=args.sub_batch,
+                                     gather=not args.no_gather, timings=phases)
+            return out
+
+        for _ in range(max(1, args.warmup)):
+            step()
+        phases.update(compute_ms=0.0, exchange_ms=0.0, steps=0)
+        est = estimate(step, lambda: None, 1)
+        phases.update(compute_ms=0.0, exchange_ms=0.0, steps=0)
+        dt, repeats = timed_region(step, lambda: None, args.steps, est)
+        frames_per_step = sum(frame_count(FS, n, FRAME_PERIOD) for n in lengths)
+        nsteps = args.steps * repeats
+        ph = torch.tensor([phases["compute_ms"], phases["exchange_ms"]], dtype=torch.float64, device=dev) / max(1, phases["steps"])
+        ph_max = ph.clone()
+        dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
+        barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            nb = FFT_SIZE // 2 + 1
+            print(json.dumps({
+                "metric": "analysis frames/sec (Harvest+CheapTrick+D4C, 48 kHz, 5 ms hop)",
+                "value": frames_per_step * nsteps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "repeats": repeats, "warmup": args.warmup, "ms_per_step": dt / nsteps * 1e3, "timed_wall_s": dt,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"configs[3]: one job of {n_job} x (48 kHz, {sec:g} s) utterances per step, "
+                                       f"Harvest+CheapTrick+D4C, fft_size=2048, frame_period=5 ms, {n_job // world} utterances "
+                                       f"per GPU in sub-batches of {args.sub_batch}, inputs/outputs in HBM",
+                           "frames_per_step": frames_per_step, "utterances_per_gpu": len(mine),
+                           "parallelism": f"utterance-sharded x{world}" + (
+                               ", no collective" if args.no_gather else
+                               f", ONE RCCL all-gather of a packed [frames][{2 + 2 * nb}] f64 block per rank per step "
+                               f"({frames_per_step * (2 + 2 * nb) * 8 / 1e9:.1f} GB reassembled on every rank)")},
+                "phases": {"compute_ms_per_step_max_over_ranks": float(ph_max[0]), "exchange_ms_per_step_max_over_ranks": float(ph_max[1]),
+                           "note": "host wall clock around the analysis calls (synchronised) and around pack + all-gather"},
+                "roofline": None, "cpu_baseline": None}))
+        return
+
+    # =====================================================================================================
+    # N = 1
+    # =====================================================================================================
+    def run_leg(name, config, workload, make_x, fs, analyze, frames_of, bytes_per_frame, n_ctx=2):
+        """one timed leg: `n_ctx` contexts alternate (two batched jobs in flight), >= --min-wall seconds"""
+        x = make_x()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)]
+        whs = [WorldHip(device=local) for _ in range(n_ctx)]
+        counter = [0]
+        out = [None] * n_ctx
+
+        def step():
+            k = counter[0] % n_ctx
+            counter[0] += 1
+            with torch.cuda.stream(streams[k]):
+                out[k] = analyze(whs[k], x)
+
+        for _ in range(n_ctx + 1):
+            step()
+        est = estimate(step, lambda: None, 2)
+        dt, repeats = timed_region(step, lambda: None, args.steps, est)
+        frames = frames_of(out[0])
+        nsteps = args.steps * repeats
+
+        def lone():
+            with torch.cuda.stream(streams[0]):
+                analyze(whs[0], x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lone()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) * 1e3
+        kernels = kernel_profile(whs[0], lone)
+        leg = {"workload": workload, "value": frames * nsteps / dt, "unit": "frames/s", "frames_per_step": frames,
+               "steps": args.steps, "repeats": repeats, "ms_per_step": dt / nsteps * 1e3, "timed_wall_s": dt,
+               "jobs_in_flight": n_ctx, "single_step_latency_ms": lat,
+               "roofline": roofline_of(kernels, frames, bytes_per_frame, config),
+               "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
+                   kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])[:12]},
+               "workspace_bytes": sum(w.workspace_bytes() for w in whs)}
+        for w in whs:
+            w.close()
+        del x, out
+        torch.cuda.empty_cache()
+        return leg
+
+    def leg_config2():
+        B = 256
+        return run_leg("configs[2]", "2", f"configs[2]: batch of {B} x (48 kHz, 5 s) vowels / chirps, Harvest F0 only, one batched call per step",
+                       lambda: torch.stack([synth.utterance(i, FS, 5.0, device=dev) for i in range(B)]).contiguous(), FS,
+                       lambda wh, x: wh.harvest(x, FS, frame_period=FRAME_PERIOD), lambda o: int(o[2].sum()),
+                       BYTES_PER_FRAME_HARVEST)
+
+    def leg_config3():
+        B = 128
+        return run_leg("configs[3]-share", "3", f"configs[3] per-GPU share at 8 GPUs: batch of {B} x (48 kHz, 5 s), Harvest+CheapTrick+D4C, "
+                       "one batched call per stage per step",
+                       lambda: torch.stack([synth.utterance(i, FS, 5.0, device=dev) for i in range(B)]).contiguous(), FS,
+                       lambda wh, x: wh.analyze(x, FS, frame_period=FRAME_PERIOD), lambda o: int(o[4].sum()),
+                       BYTES_PER_FRAME)
+
+    def leg_config4():
+        B, fs = 64, 16000
+        return run_leg("configs[4]", "4", f"configs[4]: batch of {B} x (16 kHz, 5 s) vowels, Dio + StoneMask + CheapTrick(fft 1024, q1 -0.15) "
+                       "+ D4C(threshold 0.85), one batched call per stage per step",
+                       lambda: torch.stack([synth.vowel(fs, 5.0, seed=100 + i, base_f0=90.0 + (i % 32) * 8.0, device=dev)
+                                            for i in range(B)]).contiguous(), fs,
+                       lambda wh, x: wh.analyze(x, fs, f0_method="dio", frame_period=FRAME_PERIOD), lambda o: int(o[4].sum()),
+                       BYTES_PER_FRAME_16K)
+
+    if args.only_config:
+        leg = {2: leg_config2, 3: leg_config3, 4: leg_config4}[args.only_config]()
+        print(json.dumps(leg))
+        return
+
+    # ---- the headline leg: configs[1] ---------------------------------------------------------------------
     B = args.batch
-    xs = [synth.vowel(FS, args.seconds, seed=12345, device=dev) if (rank == 0 and i == 0)
-          else synth.utterance(rank * B + i, FS, args.seconds, device=dev) for i in range(B)]
+    xs = [synth.vowel(FS, args.seconds, seed=12345, device=dev) if i == 0
+          else synth.utterance(i, FS, args.seconds, device=dev) for i in range(B)]
     x = torch.stack(xs).contiguous()
     n = x.shape[1]
     nf = frame_count(FS, n, FRAME_PERIOD)
@@ -181,113 +411,78 @@ def main():
     # so one job's short serial kernels (contour logic, decimation) overlap another job's
     # wide ones.  Every job still does the full work; nothing is cached between steps.
     S = max(1, args.streams)
-    nbuf = max(S, 2 if world > 1 else 1)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nbuf)]
-    whs = [WorldHip(device=local) for _ in range(nbuf)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    whs = [WorldHip(device=local) for _ in range(S)]
     wh = whs[0]
-    sp_bufs = [torch.empty((B, nf, FFT_SIZE // 2 + 1), dtype=torch.float64, device=dev) for _ in range(nbuf)]
-    ap_bufs = [torch.empty_like(sp_bufs[0]) for _ in range(nbuf)]
-    pending = [None] * nbuf
+    sp_bufs = [torch.empty((B, nf, FFT_SIZE // 2 + 1), dtype=torch.float64, device=dev) for _ in range(S)]
+    ap_bufs = [torch.empty_like(sp_bufs[0]) for _ in range(S)]
+    last = [None] * S
     counter = [0]
-    # one-time initialisation of every slot (workspace allocation, constant tables): not a step
-    for k in range(nbuf):
-        with torch.cuda.stream(streams[k]):
-            whs[k].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k], ap_out=ap_bufs[k])
-    torch.cuda.synchronize()
 
     def step():
-        """analysis of this rank's utterances; at N > 1 followed by the asynchronous
-        all-gather of (f0, sp, ap) whose completion is awaited when the slot is reused"""
-        k = counter[0] % nbuf
+        k = counter[0] % S
         counter[0] += 1
         with torch.cuda.stream(streams[k]):
-            if pending[k] is not None:
-                wd.wait_all(pending[k][1])
-            tpos, f0, sp, ap, _ = whs[k].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k],
-                                                 ap_out=ap_bufs[k])
-            if world > 1 and not args.no_gather:
-                pending[k] = wd.all_gather_results([f0, sp, ap], async_op=True)
-        return tpos, f0, sp, ap
+            last[k] = whs[k].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k], ap_out=ap_bufs[k])
 
-    def drain():
-        for k in range(nbuf):
-            if pending[k] is not None:
-                with torch.cuda.stream(streams[k]):
-                    wd.wait_all(pending[k][1])
-                pending[k] = None
-
+    # one-time initialisation of every slot (workspace allocation, constant tables): not a step
+    for _ in range(S):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    drain()
+    est = estimate(step, lambda: None, max(3, S))
+    dt, repeats = timed_region(step, lambda: None, args.steps, est)
+    nsteps = args.steps * repeats
+    frames_per_step = nf * B
+    value = frames_per_step * nsteps / dt
+
+    # ---- the run checks itself: every slot of the timed mode against a serial single-context run ---------
     torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
+    sp_ser, ap_ser = torch.empty_like(sp_bufs[0]), torch.empty_like(sp_bufs[0])
+    ser = WorldHip(device=local)
+    tpos_ser, f0_ser, _, _, _ = ser.analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_ser, ap_out=ap_ser)
     torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    frames_per_step = nf * B * world
-    value = frames_per_step * args.steps / dt
+    slots_equal = all(last[k] is not None and torch.equal(last[k][0], tpos_ser) and torch.equal(last[k][1], f0_ser) and
+                      torch.equal(sp_bufs[k], sp_ser) and torch.equal(ap_bufs[k], ap_ser) for k in range(S))
+    tables_ok = ser.verify_tables()
+    ser.close()
+    parity = {"slots": S, "slots_bit_identical_to_serial_run": bool(slots_equal), "randn_table_intact": bool(tables_ok),
+              "frames": nf * B}
 
     # latency of ONE job with nothing else in flight (not the headline number)
-    lat = None
-    if rank == 0:
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        with torch.cuda.stream(streams[0]):
+            whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            with torch.cuda.stream(streams[0]):
-                whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
-            torch.cuda.synchronize()
-        lat = (time.perf_counter() - t1) / 3 * 1e3
+    lat = (time.perf_counter() - t1) / 5 * 1e3
 
-    # ---- roofline leg: per-kernel HIP-event timing of a few extra steps (rank 0) ----
-    roofline = None
-    kernels = {}
-    if rank == 0:
-        def lone():
-            with torch.cuda.stream(streams[0]):
-                whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
-        prof = wh.profile(lambda: [lone() for _ in range(3)])
-        torch.cuda.synchronize()
-        kernels = {k: {"launches_per_step": len(v) // 3, "ms_per_step": sum(v) / 3.0, "avg_ms": sum(v) / len(v)}
-                   for k, v in prof.items()}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        units = nf * B                              # frames one launch of the dominant kernel covers
-        alg_bytes = BYTES_PER_FRAME * units
-        achieved = alg_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, units),
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernels[dom]["avg_ms"],
-                    "note": "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~7 MFLOP/frame (measured, see fp64) vs 18.3 kB/frame"}
-        fp64 = measured_fp64(kernels, units)
-        if fp64 and dom in fp64[0]:
-            flop, tflops = fp64[0][dom]
-            roofline["fp64"] = {"flop_per_launch": flop, "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
-                                "pipeline_flop_per_frame": fp64[1],
-                                "pipeline_achieved": fp64[1] * value / world / 1e12,
-                                "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU_*_F64) over live durations"}
+    # ---- roofline leg: per-kernel HIP-event timing of a few extra steps ------------------------------------
+    def lone():
+        with torch.cuda.stream(streams[0]):
+            whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
+    kernels = kernel_profile(wh, lone, 3)
+    roofline = roofline_of(kernels, nf * B, BYTES_PER_FRAME, "1")
+    roofline["note"] = "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~7 MFLOP/frame (measured, see fp64) vs 18.3 kB/frame"
+    if "fp64" in roofline:
+        roofline["fp64"]["pipeline_achieved"] = roofline["fp64"]["pipeline_flop_per_frame"] * value / 1e12
 
     # ---- coders behind the path (SURVEY.md 8f.1): reported beside the metric, never part of `value` ----
-    codec = None
-    if rank == 0 and not args.no_extras:
-        sp, ap = sp_bufs[0], ap_bufs[0]
+    codec = synthesis = host_to_host = None
+    if not args.no_extras:
+        sp, apb = sp_bufs[0], ap_bufs[0]
         with torch.cuda.stream(streams[0]):
             for _ in range(2):
                 mcep = wh.code_spectral_envelope(sp, FS, FFT_SIZE, 60)
-                bap = wh.code_aperiodicity(ap, FS, FFT_SIZE)
+                bap = wh.code_aperiodicity(apb, FS, FFT_SIZE)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 20
             e0.record()
             for _ in range(reps):
                 mcep = wh.code_spectral_envelope(sp, FS, FFT_SIZE, 60)
-                bap = wh.code_aperiodicity(ap, FS, FFT_SIZE)
+                bap = wh.code_aperiodicity(apb, FS, FFT_SIZE)
             e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
@@ -297,22 +492,9 @@ def main():
                  "roofline": {"bound": "hbm", "achieved": cbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": cbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes": cbytes}}
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle.loader import best_oracle
-            orc = best_oracle()
-            sp_h, ap_h = sp[0].cpu().numpy(), ap[0].cpu().numpy()
-            t1 = time.perf_counter()
-            orc.code_spectral_envelope(sp_h, FS, FFT_SIZE, 60)
-            orc.code_aperiodicity(ap_h, FS, FFT_SIZE)
-            codec["cpu_baseline"] = {"value": nf / (time.perf_counter() - t1), "unit": "frames/s", "cores": 1,
-                                     "kind": orc.kind, "sample": f"the same {nf} frames, one call each"}
-
-    # ---- synthesis from the step's device-resident parameters: beside the metric ----
-    synthesis = None
-    if rank == 0 and not args.no_extras:
+        # synthesis from the step's device-resident parameters
         with torch.cuda.stream(streams[0]):
-            tpos1, f01, sp1, ap1, nf1 = whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0],
-                                                        ap_out=ap_bufs[0])
+            tpos1, f01, sp1, ap1, nf1 = whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
             y = wh.synthesis(f01, sp1, ap1, nf1, FFT_SIZE, FRAME_PERIOD, FS, n)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -325,20 +507,8 @@ def main():
                      "ms": ms, "x_realtime": B * args.seconds / (ms * 1e-3),
                      "note": "bound by the bit-faithful serial phase accumulation (one FP64 add per sample, "
                              "36-cycle dependent issue); utterances of a batch share that latency"}
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle.loader import best_oracle
-            orc = best_oracle()
-            f0_h, sp_h, ap_h = f01[0].cpu().numpy(), sp1[0].cpu().numpy(), ap1[0].cpu().numpy()
-            t1 = time.perf_counter()
-            orc.synthesis(f0_h, sp_h, ap_h, FFT_SIZE, FRAME_PERIOD, FS, n)
-            synthesis["cpu_baseline"] = {"ms": (time.perf_counter() - t1) * 1e3, "cores": 1, "kind": orc.kind,
-                                         "sample": "the same utterance, one call"}
-
-    # ---- the same job through the reference's host-pointer API (the drop-in boundary):
-    # x uploaded, results downloaded into row-pointer arrays, one synchronisation per stage.  PCIe-inclusive,
-    # reported beside the metric and never part of `value`.
-    host_to_host = None
-    if rank == 0 and not args.no_extras:
+        # the same job through the reference's host-pointer API (the drop-in boundary):
+        # PCIe-inclusive, reported beside the metric and never part of `value`
         from world_amd.api import HostAPI
         H = HostAPI()
         x_host = xs[0].cpu().numpy()[:n]
@@ -356,35 +526,67 @@ def main():
                                     "one utterance at a time, PCIe and per-stage synchronisation included",
                         "ms_per_utterance": dt_h / 5 * 1e3, "frames_per_s": frames_h / dt_h}
 
-    cpu = cpu_all = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        x_host = xs[0].cpu().numpy()
-        cpu = cpu_baseline(x_host)
-        cpu_all = cpu_baseline_all_cores(x_host)
+    workspace = sum(w.workspace_bytes() for w in whs)
+    table_bytes = wh.noise_table_bytes()
 
-    barrier()
-    if world > 1:
-        dist.destroy_process_group()
-    if rank == 0:
-        out = {
-            "metric": "analysis frames/sec (Harvest+CheapTrick+D4C, 48 kHz, 5 ms hop)",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {B} x (48 kHz, {args.seconds:g} s) utterance(s) per GPU, "
-                                   f"Harvest+CheapTrick+D4C, fft_size=2048, frame_period=5 ms, inputs/outputs in HBM",
-                       "frames_per_step": frames_per_step, "utterances_per_gpu": B, "jobs_in_flight": S,
-                       "parallelism": f"utterance-sharded x{world}" + (
-                           ", async RCCL all-gather of f0/sp/ap per step" if world > 1 and not args.no_gather_cfg
-                           else ", no collective")},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
-            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
-                kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-            "single_job_latency_ms": lat, "codec": codec, "synthesis": synthesis,
-            "host_to_host": host_to_host,
-            "workspace_bytes": sum(w.workspace_bytes() for w in whs),
-        }
-        print(json.dumps(out))
+    # ---- the other single-GPU BASELINE configs, each for >= --min-wall seconds -----------------------------
+    configs = None
+    if not args.no_configs:
+        f0_k, sp_k, ap_k = f0_ser[0].cpu().numpy(), sp_ser[0].cpu().numpy(), ap_ser[0].cpu().numpy()
+        tp_k = tpos_ser[0].cpu().numpy()
+        for w in whs:
+            w.close()
+        del sp_bufs, ap_bufs, last
+        torch.cuda.empty_cache()
+        configs = {"2": leg_config2(), "3_share": leg_config3(), "4": leg_config4()}
+    else:
+        f0_k, sp_k, ap_k = f0_ser[0].cpu().numpy(), sp_ser[0].cpu().numpy(), ap_ser[0].cpu().numpy()
+        tp_k = tpos_ser[0].cpu().numpy()
+
+    # ---- CPU reference on this box: the baseline AND the checker of the run's own outputs ------------------
+    cpu = cpu_o3 = cpu_all = cpu_all_o3 = None
+    if not args.no_cpu_baseline:
+        x_host = xs[0].cpu().numpy()
+        cpu, ref = cpu_baseline(x_host, optimized=False, keep_outputs=True)
+        tp_r, f0_r, sp_r, ap_r = ref
+        voiced = f0_r > 0
+        parity.update({
+            "checked_against": cpu["kind"] + " (" + cpu["sample"].split(", ")[-2] + ")",
+            "tpos_bit_exact": bool(np.array_equal(tp_k[:len(tp_r)], tp_r)),
+            "vuv_flips": int(np.sum((f0_k[:len(f0_r)] > 0) != voiced)),
+            "f0": rel_err(f0_k[:len(f0_r)][voiced], f0_r[voiced]),
+            "sp": rel_err(sp_k[:len(f0_r)], sp_r), "ap": rel_err(ap_k[:len(f0_r)], ap_r), "tolerance": RTOL})
+        cpu_o3, _ = cpu_baseline(x_host, optimized=True)
+        cpu_all = cpu_baseline_all_cores(x_host, optimized=False)
+        cpu_all_o3 = cpu_baseline_all_cores(x_host, optimized=True)
+    ok = parity["slots_bit_identical_to_serial_run"] and parity["randn_table_intact"]
+    if "f0" in parity:
+        ok = ok and parity["tpos_bit_exact"] and parity["vuv_flips"] == 0 and max(parity["f0"], parity["sp"], parity["ap"]) <= RTOL
+    parity["ok"] = bool(ok)
+
+    out = {
+        "metric": "analysis frames/sec (Harvest+CheapTrick+D4C, 48 kHz, 5 ms hop)",
+        "value": value, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "repeats": repeats, "warmup": args.warmup,
+        "ms_per_step": dt / nsteps * 1e3, "timed_wall_s": dt, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {B} x (48 kHz, {args.seconds:g} s) utterance(s) per step, "
+                               f"Harvest+CheapTrick+D4C, fft_size=2048, frame_period=5 ms, inputs/outputs in HBM, "
+                               f"{S} independent jobs in flight (one HIP stream + context each)",
+                   "frames_per_step": frames_per_step, "utterances_per_gpu": B, "jobs_in_flight": S,
+                   "parallelism": "single GPU, no collective"},
+        "value_single_job": frames_per_step / (lat * 1e-3), "single_job_latency_ms": lat,
+        "parity_in_run": parity,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_o3": cpu_o3,
+        "cpu_baseline_all_cores": cpu_all, "cpu_baseline_all_cores_o3": cpu_all_o3,
+        "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
+            kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+        "configs": configs, "codec": codec, "synthesis": synthesis, "host_to_host": host_to_host,
+        "workspace_bytes": workspace, "randn_table_bytes": table_bytes, "csrc_hash": csrc_hash(),
+    }
+    print(json.dumps(out))
+    if not ok:
+        sys.stderr.write("bench.py: parity_in_run failed: " + json.dumps(parity) + "\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -202,6 +202,40 @@ WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int
                                             const double *d_spectrogram, const double *d_aperiodicity,
                                             const int *y_length, int y_stride, double *d_y);
 
+/* The per-frame real FFT of the path in isolation (the reference's fft_plan_dft_r2c_1d / _c2r_1d +
+ * fft_execute, src/world/fft.h:22-44, as re-implemented in csrc/fft.h): `batch` transforms of 2^lg_n
+ * points (256 .. 8192), one workgroup each, straight from and to HBM -- the test and microbenchmark hook.
+ *   rfft : d_in [batch][N] -> d_spectrum [batch][N/2+1][2] (re, im), X[k] = sum x[n] e^{-2 pi i k n / N}
+ *   irfft: d_spectrum -> d_out [batch][N] = N * irfft (unscaled like the reference's c2r; Im of DC / Nyquist ignored)
+ * max_lr = 3 (radix-8 plan) or 4 (radix-16 plan); threads = workgroup size, 0 = one butterfly per thread. */
+WORLD_HIP_API int world_hip_probe_rfft(WorldHipContext *ctx, int lg_n, int max_lr, int threads, long long batch,
+                                       const double *d_in, double *d_spectrum);
+WORLD_HIP_API int world_hip_probe_irfft(WorldHipContext *ctx, int lg_n, int max_lr, int threads, long long batch,
+                                        const double *d_spectrum, double *d_out);
+
+/* Multi-GPU exchange (the reference has no counterpart).  Utterances are sharded over GPUs
+ * and analysed independently; a GPU's results are then packed into ONE contiguous block of records
+ *     row = [ tpos, f0, spectrogram[0 .. bins), aperiodicity[0 .. bins) ]      (2 + 2 bins doubles)
+ * holding the utterances' valid frames back to back, utterance u starting at record first_row + sum of
+ * n_frames[0 .. u).  pack / unpack convert between the batched arrays above and such a block (device side,
+ * on the context's stream, no synchronisation).
+ * world_hip_allgather_blocks is the exchange for ONE process that drives n_dev contexts (one per GPU, one
+ * stream each): afterwards d_dst[d] (on context d's device, room for sum(rows) records of `cols` doubles)
+ * holds d_src[0], d_src[1], ... back to back.  Every destination pulls its remote blocks with peer copies
+ * on its own stream, so all xGMI links of the mesh are busy at once; nothing waits on the host (the
+ * destination is valid, and the sources reusable, in the respective context's stream order).
+ * With one process PER GPU (torch.distributed / RCCL) the same blocks go through one all-gather:
+ * world_amd/distributed.py. */
+WORLD_HIP_API int world_hip_pack_results(WorldHipContext *ctx, int n_utt, const int *n_frames, int f_stride,
+                                         int bins, const double *d_tpos, const double *d_f0,
+                                         const double *d_spectrogram, const double *d_aperiodicity,
+                                         long long first_row, double *d_block);
+WORLD_HIP_API int world_hip_unpack_results(WorldHipContext *ctx, int n_utt, const int *n_frames, int f_stride,
+                                           int bins, const double *d_block, long long first_row, double *d_tpos,
+                                           double *d_f0, double *d_spectrogram, double *d_aperiodicity);
+WORLD_HIP_API int world_hip_allgather_blocks(int n_dev, WorldHipContext *const *ctxs, const double *const *d_src,
+                                             const long long *rows, int cols, double *const *d_dst);
+
 /* 16-bit PCM (as stored in a WAV file) -> the doubles the reference's wavread() produces,
  * x = q / 32768 (tools/audioio.cpp:236-249), on the device: upload int16, not FP64. */
 WORLD_HIP_API int world_hip_pcm16_to_double(WorldHipContext *ctx, long long n, const short *d_pcm, double *d_x);

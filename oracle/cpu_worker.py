@@ -1,6 +1,6 @@
 """One CPU analysis (Harvest + CheapTrick + D4C) by the oracle, timed -- a worker of
 oracle.loader.parallel_analyses (TEST / BENCH-BASELINE INFRASTRUCTURE, never the product).
-usage: cpu_worker.py x.npy fs frame_period fft_size start_at   -> prints "frames t_start t_end" """
+usage: cpu_worker.py x.npy fs frame_period fft_size start_at [library in oracle/_ref]   -> prints "frames t_start t_end" """
 import os
 import sys
 import time
@@ -12,7 +12,7 @@ import numpy as np  # noqa: E402
 def main():
     path, fs, frame_period, fft_size, start_at = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
     here = os.path.dirname(os.path.abspath(__file__))
-    ref = os.path.join(here, "_ref", "libworld_ref.so")
+    ref = os.path.join(here, "_ref", sys.argv[6] if len(sys.argv) > 6 else "libworld_ref.so")
     x = np.load(path)
     # bind through the generic C-ABI stub without importing torch-dependent code paths
     from world_amd.api import HostAPI

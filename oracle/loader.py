@@ -220,18 +220,22 @@ def best_oracle():
 
 
 # ---- whole-box CPU baseline: one analysis per worker process ---------------------------
-def parallel_analyses(x, fs, frame_period, fft_size, procs, timeout=300):
+def parallel_analyses(x, fs, frame_period, fft_size, procs, timeout=300, optimized=False):
     """Run `procs` full analyses concurrently, each in its own `python oracle/cpu_worker.py`
     process (no GPU runtime, own heap), all starting at the same wall-clock instant.
-    Returns (total frames, wall seconds from the common start to the last finish)."""
+    Returns (total frames, wall seconds from the common start to the last finish, build flags)."""
     import tempfile
     import time as _t
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "x.npy")
         np.save(path, np.ascontiguousarray(x, dtype=np.float64))
-        start_at = _t.time() + 3.0 + 0.04 * procs
+        start_at = _t.time() + 2.0 + 0.015 * procs
+        lib = "libworld_ref_o3.so" if optimized and _cpu_has("avx2") and _cpu_has("fma") else "libworld_ref.so"
+        flags = "-O3 -march=x86-64-v3" if lib.endswith("_o3.so") else "-O1 (reference makefile:6)"
+        if not os.path.exists(os.path.join(HERE, "_ref", lib)):
+            flags = "gcc -O2 restatement"
         cmd = [sys.executable, os.path.join(HERE, "cpu_worker.py"), path, str(fs), str(frame_period), str(fft_size),
-               repr(start_at)]
+               repr(start_at), lib]
         ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(procs)]
         frames, t_end = 0, start_at
         for p in ps:
@@ -239,4 +243,4 @@ def parallel_analyses(x, fs, frame_period, fft_size, procs, timeout=300):
             n, t0, t1 = out.split()[-3:]
             frames += int(n)
             t_end = max(t_end, float(t1))
-    return frames, t_end - start_at
+    return frames, t_end - start_at, flags

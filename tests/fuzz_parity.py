@@ -1,4 +1,5 @@
-"""Test infrastructure (run by hand: python tests/fuzz_parity.py <seed> <cases>): randomised parity sweep of the HIP path against the CPU oracle
+"""Test infrastructure (python tests/fuzz_parity.py <seed> <cases>; a slice runs in the -m gpu suite,
+tests/test_gpu_fullsize.py): randomised parity sweep of the HIP path against the CPU oracle
 (many seeds / sampling rates / signal kinds).  Prints every divergence above tolerance."""
 import os, sys, time
 import numpy as np
@@ -8,79 +9,87 @@ from oracle.loader import best_oracle
 from world_amd import synth
 from world_amd.api import HostAPI
 from util import max_rel
-hip, orc = HostAPI(), best_oracle()
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-bad = 0
-t0 = time.time()
-for case in range(n_cases):
-    fs = int(rng.choice([16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000]))
-    dur = float(rng.uniform(0.03, 0.25)) if rng.random() < 0.2 else float(rng.uniform(0.25, 1.2))
-    kind = rng.choice(['vowel', 'utt', 'noise', 'mix', 'gappy', 'quiet', 'dc', 'clip', 'impulses'])
-    seed = int(rng.integers(1, 10**6))
-    if kind == 'vowel': x = synth.vowel(fs, dur, seed=seed, base_f0=float(rng.uniform(75, 420))).numpy()
-    elif kind == 'utt': x = synth.utterance(seed, fs, dur).numpy()
-    elif kind == 'noise': x = np.round(rng.normal(size=int(fs * dur)) * 0.1 * 32768) / 32768
-    elif kind == 'impulses':
-        x = np.zeros(int(fs * dur)); x[::int(fs / float(rng.uniform(80, 300)))] = 0.5
-        x = np.round((x + rng.normal(size=len(x)) * 1e-3) * 32768) / 32768
-    else:
-        x = synth.vowel(fs, dur, seed=seed, base_f0=float(rng.uniform(90, 300))).numpy()
-        x = np.round((x + rng.normal(size=len(x)) * float(rng.uniform(0.001, 0.05))) * 32768) / 32768
-        if kind == 'gappy':
-            a, b = sorted(rng.integers(0, len(x), 2)); x[a:b] = 0.0          # exact digital silence inside
-        elif kind == 'quiet': x = np.round(x * 0.01 * 32768) / 32768
-        elif kind == 'dc': x = x * 0.5 + float(rng.uniform(-0.4, 0.4))
-        elif kind == 'clip': x = np.clip(x * float(rng.uniform(2, 10)), -1, 32767 / 32768)
-    x = np.clip(x, -1, 32767 / 32768)
-    msg = []
-    hopt = dict(f0_floor=float(rng.choice([40.0, 50.0, 71.0, 90.0])), f0_ceil=float(rng.choice([500.0, 800.0, 1200.0])),
-                frame_period=float(rng.choice([1.0, 2.5, 5.0, 10.0, 15.0])))
-    tp_o, f0_o = orc.harvest(x, fs, **hopt)
-    tp, f0 = hip.harvest(x, fs, **hopt)
-    if not np.array_equal(tp, tp_o): msg.append('tp')
-    flips = int(np.sum((f0 > 0) != (f0_o > 0)))
-    v = f0_o > 0
-    e = max_rel(f0[v & (f0 > 0)], f0_o[v & (f0 > 0)]) if v.any() else 0.0
-    if flips or e > 1e-6: msg.append(f'harvest flips={flips} rel={e:.1e}')
-    dopt = dict(f0_floor=float(rng.choice([50.0, 71.0])), f0_ceil=float(rng.choice([600.0, 800.0])),
-                channels_in_octave=float(rng.choice([2.0, 3.0])), frame_period=hopt['frame_period'],
-                speed=int(rng.choice([1, 2, 4, 11])), allowed_range=float(rng.choice([0.05, 0.1, 0.2])))
-    tpd_o, fd_o = orc.dio(x, fs, **dopt); tpd, fd = hip.dio(x, fs, **dopt)
-    flips = int(np.sum((fd > 0) != (fd_o > 0)))
-    # exact digital silence inside a signal: DIO then tracks zero crossings of the reference's own FFT
-    # rounding noise -- even the oracle restatement (same algorithm, another FFT) differs from the
-    # reference by up to 7e-5 there, so no implementation can be held to 1e-6 on those inputs
-    if kind != 'gappy' and (flips or max_rel(fd[fd_o > 0], fd_o[fd_o > 0]) > 1e-6): msg.append(f'dio flips={flips}')
-    sm_o, sm = orc.stonemask(x, fs, tpd_o, fd_o), hip.stonemask(x, fs, tpd_o, fd_o)
-    if np.sum((sm > 0) != (sm_o > 0)) or max_rel(sm[sm_o > 0], sm_o[sm_o > 0]) > 1e-6: msg.append('stonemask')
-    ct_floor = float(rng.choice([71.0, 71.0, 90.0, 60.0])); q1 = float(rng.choice([-0.15, -0.15, -0.09, 0.0]))
-    fft = hip.cheaptrick_fft_size(fs, ct_floor)
-    if fft > 4096: ct_floor = 71.0; fft = hip.cheaptrick_fft_size(fs, ct_floor)
-    sp_o = orc.cheaptrick(x, fs, tp_o, f0_o, q1=q1, f0_floor=ct_floor, fft_size=fft)
-    sp = hip.cheaptrick(x, fs, tp_o, f0_o, q1=q1, f0_floor=ct_floor, fft_size=fft)
-    e = max_rel(sp, sp_o)
-    if e > 1e-6: msg.append(f'cheaptrick rel={e:.1e}')
-    thr = float(rng.choice([0.85, 0.85, 0.5, 0.0]))
-    ap_o, ap = orc.d4c(x, fs, tp_o, f0_o, fft, threshold=thr), hip.d4c(x, fs, tp_o, f0_o, fft, threshold=thr)
-    e = max_rel(ap, ap_o)
-    if e > 1e-5: msg.append(f'd4c rel={e:.1e}')
-    y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
-    e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
-    if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
-    # parameter modification as in test.cpp:221-240: shifted F0, other output length
-    f0m = f0_o * float(rng.choice([0.5, 0.8, 1.5, 2.0])); ylen = int(len(x) * float(rng.uniform(0.5, 1.0))) + 1   # beyond the parameters the reference extrapolates f0 and overruns its buffers
-    y_o, y = orc.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen), hip.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen)
-    e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
-    if e > 1e-7: msg.append(f'synthesis(modified) peak-rel={e:.1e}')
-    nd = int(rng.choice([1, 24, 60])); 
-    e = float(np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, nd) - orc.code_spectral_envelope(sp_o, fs, fft, nd))))
-    if e > 1e-9: msg.append(f'mcep abs={e:.1e}')
-    e = float(np.max(np.abs(hip.code_aperiodicity(ap_o, fs, fft) - orc.code_aperiodicity(ap_o, fs, fft))))
-    if e > 1e-9: msg.append(f'bap abs={e:.1e}')
-    if msg:
-        bad += 1
-        if os.path.isdir('gpurun_out'):       # keep the inputs of a diverging case for replay
-            np.savez(f'gpurun_out/fuzz_case_{case}.npz', x=x, fs=fs, hopt=repr(hopt), dopt=repr(dopt))
-        print(f'case {case}: fs={fs} dur={dur:.2f} kind={kind} seed={seed}:', '; '.join(msg), flush=True)
-print(f'{n_cases} cases, {bad} with divergences, {time.time() - t0:.0f} s')
+
+
+def run(seed=0, n_cases=40, hip=None, orc=None, verbose=True):
+    hip, orc = hip or HostAPI(), orc or best_oracle()
+    rng = np.random.default_rng(seed)
+    bad = 0
+    failures = []
+    t0 = time.time()
+    for case in range(n_cases):
+        fs = int(rng.choice([16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000]))
+        dur = float(rng.uniform(0.03, 0.25)) if rng.random() < 0.2 else float(rng.uniform(0.25, 1.2))
+        kind = rng.choice(['vowel', 'utt', 'noise', 'mix', 'gappy', 'quiet', 'dc', 'clip', 'impulses'])
+        seed_c = int(rng.integers(1, 10**6))
+        if kind == 'vowel': x = synth.vowel(fs, dur, seed=seed_c, base_f0=float(rng.uniform(75, 420))).numpy()
+        elif kind == 'utt': x = synth.utterance(seed_c, fs, dur).numpy()
+        elif kind == 'noise': x = np.round(rng.normal(size=int(fs * dur)) * 0.1 * 32768) / 32768
+        elif kind == 'impulses':
+            x = np.zeros(int(fs * dur)); x[::int(fs / float(rng.uniform(80, 300)))] = 0.5
+            x = np.round((x + rng.normal(size=len(x)) * 1e-3) * 32768) / 32768
+        else:
+            x = synth.vowel(fs, dur, seed=seed_c, base_f0=float(rng.uniform(90, 300))).numpy()
+            x = np.round((x + rng.normal(size=len(x)) * float(rng.uniform(0.001, 0.05))) * 32768) / 32768
+            if kind == 'gappy':
+                a, b = sorted(rng.integers(0, len(x), 2)); x[a:b] = 0.0          # exact digital silence inside
+            elif kind == 'quiet': x = np.round(x * 0.01 * 32768) / 32768
+            elif kind == 'dc': x = x * 0.5 + float(rng.uniform(-0.4, 0.4))
+            elif kind == 'clip': x = np.clip(x * float(rng.uniform(2, 10)), -1, 32767 / 32768)
+        x = np.clip(x, -1, 32767 / 32768)
+        msg = []
+        hopt = dict(f0_floor=float(rng.choice([40.0, 50.0, 71.0, 90.0])), f0_ceil=float(rng.choice([500.0, 800.0, 1200.0])),
+                    frame_period=float(rng.choice([1.0, 2.5, 5.0, 10.0, 15.0])))
+        tp_o, f0_o = orc.harvest(x, fs, **hopt)
+        tp, f0 = hip.harvest(x, fs, **hopt)
+        if not np.array_equal(tp, tp_o): msg.append('tp')
+        flips = int(np.sum((f0 > 0) != (f0_o > 0)))
+        v = f0_o > 0
+        e = max_rel(f0[v & (f0 > 0)], f0_o[v & (f0 > 0)]) if v.any() else 0.0
+        if flips or e > 1e-6: msg.append(f'harvest flips={flips} rel={e:.1e}')
+        dopt = dict(f0_floor=float(rng.choice([50.0, 71.0])), f0_ceil=float(rng.choice([600.0, 800.0])),
+                    channels_in_octave=float(rng.choice([2.0, 3.0])), frame_period=hopt['frame_period'],
+                    speed=int(rng.choice([1, 2, 4, 11])), allowed_range=float(rng.choice([0.05, 0.1, 0.2])))
+        tpd_o, fd_o = orc.dio(x, fs, **dopt); tpd, fd = hip.dio(x, fs, **dopt)
+        flips = int(np.sum((fd > 0) != (fd_o > 0)))
+        # exact digital silence inside a signal: DIO then tracks zero crossings of the reference's own FFT
+        # rounding noise -- even the oracle restatement (same algorithm, another FFT) differs from the
+        # reference by up to 7e-5 there, so no implementation can be held to 1e-6 on those inputs
+        if kind != 'gappy' and (flips or max_rel(fd[fd_o > 0], fd_o[fd_o > 0]) > 1e-6): msg.append(f'dio flips={flips}')
+        sm_o, sm = orc.stonemask(x, fs, tpd_o, fd_o), hip.stonemask(x, fs, tpd_o, fd_o)
+        if np.sum((sm > 0) != (sm_o > 0)) or max_rel(sm[sm_o > 0], sm_o[sm_o > 0]) > 1e-6: msg.append('stonemask')
+        ct_floor = float(rng.choice([71.0, 71.0, 90.0, 60.0])); q1 = float(rng.choice([-0.15, -0.15, -0.09, 0.0]))
+        fft = hip.cheaptrick_fft_size(fs, ct_floor)
+        if fft > 4096: ct_floor = 71.0; fft = hip.cheaptrick_fft_size(fs, ct_floor)
+        sp_o = orc.cheaptrick(x, fs, tp_o, f0_o, q1=q1, f0_floor=ct_floor, fft_size=fft)
+        sp = hip.cheaptrick(x, fs, tp_o, f0_o, q1=q1, f0_floor=ct_floor, fft_size=fft)
+        e = max_rel(sp, sp_o)
+        if e > 1e-6: msg.append(f'cheaptrick rel={e:.1e}')
+        thr = float(rng.choice([0.85, 0.85, 0.5, 0.0]))
+        ap_o, ap = orc.d4c(x, fs, tp_o, f0_o, fft, threshold=thr), hip.d4c(x, fs, tp_o, f0_o, fft, threshold=thr)
+        e = max_rel(ap, ap_o)
+        if e > 1e-5: msg.append(f'd4c rel={e:.1e}')
+        y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
+        e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
+        if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
+        # parameter modification as in test.cpp:221-240: shifted F0, other output length
+        f0m = f0_o * float(rng.choice([0.5, 0.8, 1.5, 2.0])); ylen = int(len(x) * float(rng.uniform(0.5, 1.0))) + 1   # beyond the parameters the reference extrapolates f0 and overruns its buffers
+        y_o, y = orc.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen), hip.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen)
+        e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
+        if e > 1e-7: msg.append(f'synthesis(modified) peak-rel={e:.1e}')
+        nd = int(rng.choice([1, 24, 60])); 
+        e = float(np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, nd) - orc.code_spectral_envelope(sp_o, fs, fft, nd))))
+        if e > 1e-9: msg.append(f'mcep abs={e:.1e}')
+        e = float(np.max(np.abs(hip.code_aperiodicity(ap_o, fs, fft) - orc.code_aperiodicity(ap_o, fs, fft))))
+        if e > 1e-9: msg.append(f'bap abs={e:.1e}')
+        if msg:
+            bad += 1
+            if os.path.isdir('gpurun_out'):       # keep the inputs of a diverging case for replay
+                np.savez(f'gpurun_out/fuzz_case_{case}.npz', x=x, fs=fs, hopt=repr(hopt), dopt=repr(dopt))
+            if verbose: print(failures[-1], flush=True)
+    if verbose: print(f'{n_cases} cases, {bad} with divergences, {time.time() - t0:.0f} s')
+    return failures
+
+
+if __name__ == '__main__':
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40)

@@ -77,8 +77,11 @@ def _sharded_worker(rank, world, port, tmp):
         g = torch.Generator().manual_seed(5)
         lengths = [1600, 400, 2400, 801, 1203] if world == 2 else [700]      # world 3: two ranks own nothing
         xs = [torch.rand(n, generator=g, dtype=torch.float64) + i for i, n in enumerate(lengths)]
-        f0, sp, ap, nf = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze)
+        res = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze, bins=5, sub_batch=2)
+        f0, sp, ap, nf = res.dense()
         for i, x in enumerate(xs):
+            _, f0_v, sp_v, ap_v = res.utterance(i)            # views into the gathered block
+            assert torch.equal(f0_v, f0[i, :f0_v.shape[0]]) and torch.equal(sp_v, sp[i, :f0_v.shape[0]])
             _, f0_i, sp_i, ap_i, nf_i = _fake_analyze(x[None], 16000, x_len=[len(x)])
             n = int(nf_i[0])
             assert int(nf[i]) == n
@@ -99,5 +102,62 @@ def test_analyze_sharded_reassembles_every_utterance_on_every_rank(tmp_path, wor
 
 def test_analyze_sharded_without_a_process_group():
     xs = [torch.rand(900, dtype=torch.float64), torch.rand(300, dtype=torch.float64)]
-    f0, sp, ap, nf = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze)
+    f0, sp, ap, nf = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze, bins=5).dense()
+    assert len(wd.analyze_sharded([], 16000, analyze=_fake_analyze)) == 0
     assert f0.shape == (2, int(nf.max())) and sp.shape == (2, int(nf.max()), 5) and torch.equal(ap, -sp)
+
+
+# ---- the real analysis on 2 ranks: the kernel sources compiled for the host (tests/emu) ----------------
+def _emu_analyze(x, fs, x_len=None, frame_period=5.0, **_):
+    """WorldHip.analyze's contract on CPU tensors, computed by the emulated kernels (tests/emu/libworld_emu.so)
+    through the drop-in C ABI, one utterance at a time"""
+    import subprocess
+    from world_amd.api import HostAPI, cheaptrick_fft_size, frame_count
+    emu_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    subprocess.run(["make", "-s", "-f", os.path.join(emu_dir, "Makefile")], check=True)
+    H = HostAPI(os.path.join(emu_dir, "libworld_emu.so"))
+    fft = cheaptrick_fft_size(fs)
+    nf = [frame_count(fs, int(n), frame_period) for n in x_len]
+    B, F, nb = x.shape[0], max(nf), fft // 2 + 1
+    tpos, f0 = torch.zeros((B, F), dtype=torch.float64), torch.zeros((B, F), dtype=torch.float64)
+    sp, ap = torch.zeros((B, F, nb), dtype=torch.float64), torch.zeros((B, F, nb), dtype=torch.float64)
+    for u in range(B):
+        xu = x[u, :int(x_len[u])].numpy()
+        tp, f = H.harvest(xu, fs, frame_period=frame_period)
+        tpos[u, :nf[u]], f0[u, :nf[u]] = torch.from_numpy(tp), torch.from_numpy(f)
+        sp[u, :nf[u]] = torch.from_numpy(H.cheaptrick(xu, fs, tp, f, fft_size=fft))
+        ap[u, :nf[u]] = torch.from_numpy(H.d4c(xu, fs, tp, f, fft))
+    return tpos, f0, sp, ap, torch.tensor(nf)
+
+
+def _emu_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from world_amd import synth
+        fs = 16000
+        lengths = [4000, 2600, 3300]
+        parts = wd.partition(lengths, world)
+        # every rank materialises only its own share (dict form of x_list)
+        xs = {i: synth.utterance(i, fs, lengths[i] / fs) for i in parts[rank]}
+        res = wd.analyze_sharded(xs, fs, lengths=lengths, analyze=_emu_analyze, sub_batch=1)
+        for i, n in enumerate(lengths):                      # every utterance, on every rank, equals a lone analysis
+            tp_i, f0_i, sp_i, ap_i, nf_i = _emu_analyze(synth.utterance(i, fs, n / fs)[None], fs, x_len=[n])
+            tp, f0, sp, ap = res.utterance(i)
+            k = int(nf_i[0])
+            assert res.n_frames[i] == k and tp.shape[0] == k
+            assert torch.equal(tp, tp_i[0]) and torch.equal(f0, f0_i[0]) and torch.equal(sp, sp_i[0]) and torch.equal(ap, ap_i[0])
+        np.save(os.path.join(tmp, f"emu{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_run_the_real_analysis_and_exchange_packed_blocks(tmp_path):
+    """SURVEY.md 8e end to end on CPU: partition -> (emulated) Harvest + CheapTrick + D4C per rank -> one packed
+    block per rank -> one all-gather -> per-utterance views, bit-identical to analysing each utterance alone"""
+    world = 2
+    port = 29700 + os.getpid() % 200
+    mp.spawn(_emu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"emu{r}.npy") for r in range(world))

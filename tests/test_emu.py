@@ -134,3 +134,32 @@ def test_emulated_randomised_sweep(emu, port_oracle):
         assert np.max(np.abs(y - y_o)) <= 1e-7 * max(np.max(np.abs(y_o)), 1e-9), what + " synthesis"
         nd = int(rng.integers(10, 60))
         assert np.max(np.abs(emu.code_spectral_envelope(sp_o, fs, fft, nd) - port_oracle.code_spectral_envelope(sp_o, fs, fft, nd))) <= 1e-7 * 30
+
+
+def test_emulated_fft_matches_numpy():
+    """csrc/fft.h (plans, slot arithmetic, merge / pre-twiddle steps) through the probe entry points of the
+    host-compiled library: index logic only -- the GPU tests (tests/test_gpu_fft.py) cover the real kernels"""
+    import ctypes as C
+    subprocess.run(["make", "-s", "-f", os.path.join(EMU_DIR, "Makefile")], check=True)
+    L = C.CDLL(os.path.join(EMU_DIR, "libworld_emu.so"))
+    L.world_hip_create.restype = C.c_void_p
+    L.world_hip_create.argtypes = [C.c_int, C.c_void_p]
+    L.world_hip_destroy.argtypes = [C.c_void_p]
+    for f in (L.world_hip_probe_rfft, L.world_hip_probe_irfft):
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+    ctx = L.world_hip_create(0, None)
+    try:
+        rng = np.random.default_rng(3)
+        for lg in (8, 10, 11, 12, 13):
+            n = 1 << lg
+            for max_lr in (3, 4):
+                x = rng.standard_normal((3, n))
+                X = np.zeros((3, n // 2 + 1, 2))
+                assert L.world_hip_probe_rfft(ctx, lg, max_lr, 0, 3, x.ctypes.data, X.ctypes.data) == 0
+                ref = np.fft.rfft(x, axis=1)
+                assert np.abs(X[..., 0] + 1j * X[..., 1] - ref).max() < 1e-13 * np.abs(ref).max()
+                y = np.zeros((3, n))
+                assert L.world_hip_probe_irfft(ctx, lg, max_lr, 0, 3, X.ctypes.data, y.ctypes.data) == 0
+                assert np.abs(y / n - x).max() < 1e-13
+    finally:
+        L.world_hip_destroy(ctx)

@@ -452,10 +452,61 @@ def test_analyze_sharded_on_one_gpu_equals_per_utterance_calls():
     from world_amd.api import WorldHip
     fs = 48000
     xs = [synth.utterance(i, fs, d) for i, d in enumerate([0.5, 0.21, 0.37])]
-    f0, sp, ap, nf = wd.analyze_sharded(xs, fs)
+    res = wd.analyze_sharded(xs, fs, sub_batch=2)                 # two batched calls, one packed block
+    f0, sp, ap, nf = res.dense()
     wh = WorldHip()
     for i, x in enumerate(xs):
-        _, f0_i, sp_i, ap_i, nf_i = wh.analyze(x[None].cuda().contiguous(), fs)
+        tp_i, f0_i, sp_i, ap_i, nf_i = wh.analyze(x[None].cuda().contiguous(), fs)
         n = int(nf_i[0])
         assert int(nf[i]) == n
         assert torch.equal(f0[i, :n], f0_i[0, :n]) and torch.equal(sp[i, :n], sp_i[0, :n]) and torch.equal(ap[i, :n], ap_i[0, :n])
+        tp_v, f0_v, sp_v, ap_v = res.utterance(i)              # views into the block, no copy
+        assert torch.equal(tp_v, tp_i[0, :n]) and torch.equal(f0_v, f0_i[0, :n]) and torch.equal(sp_v, sp_i[0, :n]) and torch.equal(ap_v, ap_i[0, :n])
+
+
+@pytest.mark.gpu
+def test_pack_unpack_and_peer_allgather_from_the_c_abi():
+    """include/world_hip.h's exchange entries: pack -> world_hip_allgather_blocks (here: two contexts on two
+    streams of the one GPU, the peer copies degenerate to device-to-device copies) -> unpack gives back every
+    context's batched arrays on every context, bit for bit, with no host synchronisation in between."""
+    import ctypes as C
+    import torch
+    from world_amd import synth
+    from world_amd.api import WorldHip
+    fs = 16000
+    w = WorldHip()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    batches, blocks, rows = [], [], []
+    for k, s in enumerate(streams):
+        with torch.cuda.stream(s):
+            lens = [int(fs * d) for d in ([0.31, 0.5] if k == 0 else [0.42, 0.2, 0.27])]
+            x = torch.zeros((len(lens), max(lens)), dtype=torch.float64, device="cuda")
+            for u, n in enumerate(lens):
+                x[u, :n] = synth.utterance(10 * k + u, fs, n / fs).cuda()[:n]
+            tpos, f0, sp, ap, nf = w.analyze(x, fs, x_len=lens)
+            blk = torch.full((int(nf.sum()) + 3, 2 + 2 * sp.shape[-1]), -1.0, dtype=torch.float64, device="cuda")
+            w.pack_results(tpos, f0, sp, ap, nf, blk, first_row=3)          # records start at row 3
+            batches.append((tpos, f0, sp, ap, nf)); blocks.append(blk); rows.append(blk.shape[0])
+    ctxs = [w._ctxs[s.cuda_stream] for s in streams]
+    total = sum(rows)
+    dsts = [torch.zeros((total, blocks[0].shape[1]), dtype=torch.float64, device="cuda") for _ in streams]
+    vp = C.c_void_p
+    rc = w.lib.world_hip_allgather_blocks(2, (vp * 2)(*ctxs), (vp * 2)(*[b.data_ptr() for b in blocks]),
+                                          (C.c_longlong * 2)(*rows), blocks[0].shape[1], (vp * 2)(*[d.data_ptr() for d in dsts]))
+    assert rc == 0, w.lib.world_hip_last_error()
+    outs = []
+    for k, s in enumerate(streams):                                # unpack context 1-k's records on context k
+        with torch.cuda.stream(s):
+            other = 1 - k
+            first = 3 + (0 if other == 0 else rows[0])
+            outs.append(w.unpack_results(dsts[k], batches[other][4], first_row=first))
+    torch.cuda.synchronize()
+    assert torch.equal(dsts[0], dsts[1]) and torch.equal(dsts[0], torch.cat(blocks))
+    assert bool((blocks[0][:3] == -1.0).all())                     # rows before first_row untouched
+    for k in range(2):
+        tpos, f0, sp, ap, nf = batches[1 - k]
+        tp_u, f0_u, sp_u, ap_u = outs[k]
+        for u, n in enumerate(int(v) for v in nf):
+            assert torch.equal(tp_u[u, :n], tpos[u, :n]) and torch.equal(f0_u[u, :n], f0[u, :n])
+            assert torch.equal(sp_u[u, :n], sp[u, :n]) and torch.equal(ap_u[u, :n], ap[u, :n])
+    w.close()

@@ -65,6 +65,9 @@ def load_library(path=LIB_PATH):
     lib.world_hip_sync.argtypes = [vp]
     lib.world_hip_workspace_bytes.restype = C.c_ulonglong
     lib.world_hip_workspace_bytes.argtypes = [vp]
+    lib.world_hip_noise_table_bytes.restype = C.c_ulonglong
+    lib.world_hip_noise_table_bytes.argtypes = [vp]
+    lib.world_hip_verify_tables.argtypes = [vp]
     lib.world_hip_harvest_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(HarvestOption),
                                             C.c_int, vp, vp]
     lib.world_hip_dio_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(DioOption),
@@ -77,6 +80,12 @@ def load_library(path=LIB_PATH):
     lib.world_hip_synthesis_batch.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, _ip, C.c_int, vp, vp, vp,
                                               _ip, C.c_int, vp]
     lib.world_hip_pcm16_to_double.argtypes = [vp, C.c_longlong, vp, vp]
+    lib.world_hip_probe_rfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
+    lib.world_hip_probe_irfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
+    lib.world_hip_pack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, vp, vp, vp, C.c_longlong, vp]
+    lib.world_hip_unpack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, C.c_longlong, vp, vp, vp, vp]
+    lib.world_hip_allgather_blocks.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_longlong), C.c_int,
+                                               C.POINTER(vp)]
     lib.world_hip_pcm_to_double.argtypes = [vp, C.c_longlong, C.c_int, vp, vp]
     lib.world_hip_double_to_pcm16.argtypes = [vp, C.c_longlong, vp, vp]
     lib.world_hip_wav_layout.argtypes = [C.c_char_p, _ip, _ip, _ip, C.POINTER(C.c_longlong)]
@@ -332,25 +341,29 @@ class WorldHip:
             raise RuntimeError("WorldHip needs a GPU (torch.cuda.is_available() is False)")
         self.lib = load_library(lib_path)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        self.ctx = None
-        self._stream = None
+        self._ctxs = {}                  # stream handle -> library context
 
     def _context(self):
-        """One library context per torch stream in use (created lazily)."""
+        """One library context (workspace + stream binding) per torch stream in use, created lazily and kept:
+        code that alternates streams on one WorldHip keeps one context per stream."""
         s = self.torch.cuda.current_stream(self.device).cuda_stream
-        if self.ctx is None or s != self._stream:
-            if self.ctx is not None:
-                self.lib.world_hip_destroy(self.ctx)
-            self.ctx = self.lib.world_hip_create(self.device.index, C.c_void_p(s))
-            if not self.ctx:
+        ctx = self._ctxs.get(s)
+        if ctx is None:
+            ctx = self.lib.world_hip_create(self.device.index, C.c_void_p(s))
+            if not ctx:
                 raise RuntimeError("world_hip_create: " + self.lib.world_hip_last_error().decode())
-            self._stream = s
-        return self.ctx
+            self._ctxs[s] = ctx
+        return ctx
+
+    @property
+    def ctx(self):
+        """the context of torch's current stream (None before the first call on it)"""
+        return self._ctxs.get(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def close(self):
-        if self.ctx is not None:
-            self.lib.world_hip_destroy(self.ctx)
-            self.ctx = None
+        for ctx in self._ctxs.values():
+            self.lib.world_hip_destroy(ctx)
+        self._ctxs = {}
 
     def __del__(self):
         try:
@@ -365,6 +378,7 @@ class WorldHip:
     def _prep(self, x, x_len):
         t = self.torch
         assert x.dtype == t.float64 and x.is_cuda and x.dim() == 2 and x.is_contiguous()
+        assert x.device == self.device, f"x lives on {x.device}, this WorldHip on {self.device}"
         B, L = x.shape
         if x_len is None:
             x_len = [L] * B
@@ -387,7 +401,16 @@ class WorldHip:
         return out
 
     def workspace_bytes(self):
-        return int(self.lib.world_hip_workspace_bytes(self.ctx)) if self.ctx is not None else 0
+        """bytes of device workspace held by this object's contexts (their arenas)"""
+        return sum(int(self.lib.world_hip_workspace_bytes(c)) for c in self._ctxs.values())
+
+    def noise_table_bytes(self):
+        """bytes of the device's shared randn table (one per device and process)"""
+        return int(self.lib.world_hip_noise_table_bytes(self._context()))
+
+    def verify_tables(self):
+        """re-reduce the shared randn table on the device and compare with the host's sums; True = intact"""
+        return self.lib.world_hip_verify_tables(self._context()) == 0
 
     # ---- F0 ----
     def harvest(self, x, fs, x_len=None, f0_floor=71.0, f0_ceil=800.0, frame_period=5.0):
@@ -468,6 +491,60 @@ class WorldHip:
                                                        ap.data_ptr(), yl.ctypes.data_as(_ip), Y, y.data_ptr()),
                     "synthesis")
         return y
+
+    # ---- the per-frame FFT in isolation (include/world_hip.h: world_hip_probe_rfft) ----
+    def probe_rfft(self, x, max_lr=3, threads=0, out=None):
+        """x [batch, N] float64 -> [batch, N/2+1, 2] (re, im) by csrc/fft.h's block_rfft, one workgroup per row"""
+        t = self.torch
+        assert x.dtype == t.float64 and x.dim() == 2 and x.is_contiguous()
+        batch, N = x.shape
+        lg = N.bit_length() - 1
+        assert 1 << lg == N
+        out = out if out is not None else t.empty((batch, N // 2 + 1, 2), dtype=t.float64, device=x.device)
+        self._check(self.lib.world_hip_probe_rfft(self._context(), lg, max_lr, threads, batch, x.data_ptr(), out.data_ptr()),
+                    "probe_rfft")
+        return out
+
+    def probe_irfft(self, spec, max_lr=3, threads=0, out=None):
+        """spec [batch, N/2+1, 2] -> [batch, N] = N * irfft (the reference's unscaled c2r) by block_irfft"""
+        t = self.torch
+        assert spec.dtype == t.float64 and spec.dim() == 3 and spec.is_contiguous()
+        batch, N = spec.shape[0], 2 * (spec.shape[1] - 1)
+        lg = N.bit_length() - 1
+        assert 1 << lg == N
+        out = out if out is not None else t.empty((batch, N), dtype=t.float64, device=spec.device)
+        self._check(self.lib.world_hip_probe_irfft(self._context(), lg, max_lr, threads, batch, spec.data_ptr(), out.data_ptr()),
+                    "probe_irfft")
+        return out
+
+    # ---- multi-GPU exchange records (include/world_hip.h: world_hip_pack_results) ----
+    def pack_results(self, tpos, f0, sp, ap, n_frames, block, first_row=0):
+        """valid frames of a batched analysis -> records [tpos, f0, sp row, ap row] in block[first_row:] (device)"""
+        t = self.torch
+        B, F = f0.shape
+        nb = sp.shape[-1]
+        nf = np.ascontiguousarray(n_frames, dtype=np.int32)
+        assert block.dtype == t.float64 and block.is_contiguous() and block.shape[-1] == 2 + 2 * nb
+        assert first_row + int(nf.sum()) <= block.shape[0]
+        assert all(a.is_contiguous() and a.dtype == t.float64 for a in (tpos, f0, sp, ap))
+        self._check(self.lib.world_hip_pack_results(self._context(), B, nf.ctypes.data_as(_ip), F, nb, tpos.data_ptr(),
+                                                    f0.data_ptr(), sp.data_ptr(), ap.data_ptr(), first_row,
+                                                    block.data_ptr()), "pack_results")
+        return block
+
+    def unpack_results(self, block, n_frames, first_row=0):
+        """the inverse: (tpos [B, F], f0 [B, F], sp [B, F, nb], ap [B, F, nb]) padded to the longest utterance"""
+        t = self.torch
+        nf = np.ascontiguousarray(n_frames, dtype=np.int32)
+        B, F, nb = len(nf), int(nf.max()), (block.shape[-1] - 2) // 2
+        tpos = t.zeros((B, F), dtype=t.float64, device=block.device)
+        f0 = t.zeros_like(tpos)
+        sp = t.zeros((B, F, nb), dtype=t.float64, device=block.device)
+        ap = t.zeros_like(sp)
+        self._check(self.lib.world_hip_unpack_results(self._context(), B, nf.ctypes.data_as(_ip), F, nb, block.data_ptr(),
+                                                      first_row, tpos.data_ptr(), f0.data_ptr(), sp.data_ptr(),
+                                                      ap.data_ptr()), "unpack_results")
+        return tpos, f0, sp, ap
 
     def pcm16_to_double(self, pcm):
         """int16 samples (any shape) -> float64 / 32768, wavread()'s convention, on the device"""

@@ -23,6 +23,8 @@
 #include "codec.h"
 #include "decimate.h"
 #include "dio.h"
+#include "exchange.h"
+#include "fft_probe.h"
 #include "harvest.h"
 #include "stage_params.h"
 #include "synthesis.h"
@@ -89,6 +91,7 @@ struct WorldHipContext {
   void *stage_ev[kStageRing] = {};
   size_t stage_cap = 0, stage_used = 0;
   int stage_cur = 0;
+  void *xchg_ready = nullptr, *xchg_done = nullptr;   // events of world_hip_allgather_blocks
   std::mutex lock;               // one call at a time per context
 };
 
@@ -798,6 +801,37 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
 }
 
 // ---------------------------------------------------------------------------
+// Result packing for the multi-GPU exchange (exchange.hip)
+// ---------------------------------------------------------------------------
+static void run_pack(WorldHipContext *c, bool unpack, int n_utt, const int *n_frames, int f_stride, int nb,
+                     const double *d_tpos, const double *d_f0, const double *d_sp, const double *d_ap, long long first_row,
+                     double *d_block) {
+  if (n_utt <= 0) fail("n_utt must be positive");
+  if (!n_frames || !d_tpos || !d_f0 || !d_sp || !d_ap || !d_block) fail("null buffer");
+  if (nb < 1 || first_row < 0) fail("bad record shape");
+  std::vector<int> nf(n_frames, n_frames + n_utt), off(n_utt);
+  long long row = first_row;
+  int max_frames = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    if (nf[u] < 0 || nf[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
+    if (row + nf[u] > 0x7FFFFFFFll) fail("block exceeds 2^31 records");
+    off[u] = static_cast<int>(row);
+    row += nf[u];
+    max_frames = std::max(max_frames, nf[u]);
+  }
+  if (max_frames == 0) return;
+  ensure_arena(c, 2 * pad256(sizeof(int) * n_utt));
+  c->arena.reset();
+  CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
+  PackArgs a;
+  a.n_utt = n_utt; a.f_stride = f_stride; a.nb = nb;
+  a.n_frames = upload(c, nf);
+  a.row_offset = upload(c, off);
+  a.tpos = d_tpos; a.f0 = d_f0; a.sp = d_sp; a.ap = d_ap; a.block = d_block;
+  launch_pack_rows(a, max_frames, unpack, c->stream);
+}
+
+// ---------------------------------------------------------------------------
 // error plumbing for the C ABI
 // ---------------------------------------------------------------------------
 // A context's allocations and launches belong to ITS device: a thread that drives several GPUs calls in
@@ -889,6 +923,8 @@ void world_hip_destroy(WorldHipContext *c) {
     HarvestBands &hb = c->bands;
     if (hb.d_band_f0) { devrt::dfree(hb.d_band_f0); devrt::dfree(hb.d_taps); devrt::dfree(hb.d_half); devrt::dfree(hb.d_off); }
     if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
+    if (c->xchg_ready) devrt::event_destroy(c->xchg_ready);
+    if (c->xchg_done) devrt::event_destroy(c->xchg_done);
   } catch (...) {
   }
   delete c;
@@ -984,6 +1020,96 @@ int world_hip_synthesis_batch(WorldHipContext *c, int n_utt, int fs, double fram
     run_synthesis(c, n_utt, fs, frame_period, fft_size, n_frames, f_stride, d_f0, d_spectrogram, d_aperiodicity,
                   y_length, y_stride, d_y);
   });
+}
+
+// fft.h in isolation (fft_probe.hip): `batch` real transforms of 2^lg_n points, one workgroup each
+static void run_fft_probe(WorldHipContext *c, bool inverse, int lg_n, int max_lr, int threads, long long batch,
+                          const void *d_in, void *d_out) {
+  if (lg_n < 8 || lg_n > kTwLog2) fail("probe: 2^%d points unsupported (256 .. %d)", lg_n, kTwN);
+  if (max_lr != 3 && max_lr != 4) fail("probe: max_lr must be 3 (radix-8 plan) or 4 (radix-16 plan)");
+  if (threads == 0) threads = std::max(64, (1 << lg_n) >> (max_lr + 1));      // one butterfly per thread and stage
+  if (threads < 64 || threads > 1024 || threads % 64) fail("probe: bad workgroup size %d", threads);
+  if (batch < 0 || batch > 0x7FFFFFFFll) fail("probe: bad batch");
+  if (batch == 0) return;
+  if (!d_in || !d_out) fail("null buffer");
+  launch_fft_probe(inverse, lg_n, max_lr, threads, (long)batch, d_in, d_out, c->tab, c->stream);
+}
+int world_hip_probe_rfft(WorldHipContext *c, int lg_n, int max_lr, int threads, long long batch, const double *d_in,
+                         double *d_spectrum) {
+  return guarded(c, [&] { run_fft_probe(c, false, lg_n, max_lr, threads, batch, d_in, d_spectrum); });
+}
+int world_hip_probe_irfft(WorldHipContext *c, int lg_n, int max_lr, int threads, long long batch, const double *d_spectrum,
+                          double *d_out) {
+  return guarded(c, [&] { run_fft_probe(c, true, lg_n, max_lr, threads, batch, d_spectrum, d_out); });
+}
+
+int world_hip_pack_results(WorldHipContext *c, int n_utt, const int *n_frames, int f_stride, int bins,
+                           const double *d_tpos, const double *d_f0, const double *d_spectrogram,
+                           const double *d_aperiodicity, long long first_row, double *d_block) {
+  return guarded(c, [&] {
+    run_pack(c, false, n_utt, n_frames, f_stride, bins, d_tpos, d_f0, d_spectrogram, d_aperiodicity, first_row, d_block);
+  });
+}
+
+int world_hip_unpack_results(WorldHipContext *c, int n_utt, const int *n_frames, int f_stride, int bins,
+                             const double *d_block, long long first_row, double *d_tpos, double *d_f0,
+                             double *d_spectrogram, double *d_aperiodicity) {
+  return guarded(c, [&] {
+    run_pack(c, true, n_utt, n_frames, f_stride, bins, d_tpos, d_f0, d_spectrogram, d_aperiodicity, first_row,
+             const_cast<double *>(d_block));
+  });
+}
+
+// One process, n_dev contexts (normally one per GPU): every context's packed block to every context.
+// Fully stream-ordered: destination d waits (on its own stream) for source s's block to be complete, pulls it
+// with a peer copy, and source s's stream in turn waits until every destination has pulled -- so the caller may
+// reuse the source blocks in stream order without ever synchronising the host.
+int world_hip_allgather_blocks(int n_dev, WorldHipContext *const *ctxs, const double *const *d_src, const long long *rows,
+                               int cols, double *const *d_dst) {
+  try {
+    if (n_dev <= 0 || !ctxs || !d_src || !rows || !d_dst || cols <= 0) fail("bad arguments");
+    std::vector<long long> first(n_dev + 1, 0);
+    for (int d = 0; d < n_dev; ++d) {
+      if (!ctxs[d] || rows[d] < 0 || (rows[d] > 0 && !d_src[d]) || !d_dst[d]) fail("bad block %d", d);
+      for (int e = 0; e < d; ++e)
+        if (ctxs[e] == ctxs[d]) fail("context %d listed twice", d);
+      first[d + 1] = first[d] + rows[d];
+    }
+    std::vector<std::unique_lock<std::mutex>> locks;
+    {                                                       // a fixed global order keeps concurrent callers deadlock-free
+      std::vector<WorldHipContext *> order(ctxs, ctxs + n_dev);
+      std::sort(order.begin(), order.end());
+      for (WorldHipContext *c : order) locks.emplace_back(c->lock);
+    }
+    for (int s = 0; s < n_dev; ++s) {
+      WorldHipContext *c = ctxs[s];
+      DeviceScope on_device(c->device);
+      if (!c->xchg_ready) { c->xchg_ready = devrt::event_create(); c->xchg_done = devrt::event_create(); }
+      for (int d = 0; d < n_dev; ++d) devrt::enable_peer_access(c->device, ctxs[d]->device);
+      devrt::event_record(c->xchg_ready, c->stream);
+    }
+    for (int d = 0; d < n_dev; ++d) {
+      WorldHipContext *c = ctxs[d];
+      DeviceScope on_device(c->device);
+      // remote blocks first, starting with the neighbour: destinations then pull from different sources at any moment
+      for (int k = 1; k <= n_dev; ++k) {
+        const int s = (d + k) % n_dev;
+        if (s != d) devrt::stream_wait_event(c->stream, ctxs[s]->xchg_ready);
+        devrt::peer_copy(d_dst[d] + first[s] * cols, c->device, d_src[s], ctxs[s]->device,
+                         sizeof(double) * (size_t)rows[s] * cols, c->stream);
+      }
+      devrt::event_record(c->xchg_done, c->stream);
+    }
+    for (int s = 0; s < n_dev; ++s) {
+      DeviceScope on_device(ctxs[s]->device);
+      for (int d = 0; d < n_dev; ++d)
+        if (d != s) devrt::stream_wait_event(ctxs[s]->stream, ctxs[d]->xchg_done);
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return 1;
+  }
 }
 
 int world_hip_pcm16_to_double(WorldHipContext *c, long long n, const short *d_pcm, double *d_x) {

@@ -90,6 +90,24 @@ void *event_create() {
 void event_destroy(void *ev) { if (ev) check(hipEventDestroy(static_cast<hipEvent_t>(ev)), "hipEventDestroy"); }
 void event_record(void *ev, hipStream_t s) { Timed t_("api:event_record"); check(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord"); }
 void event_sync(void *ev) { Timed t_("api:event_sync"); check(hipEventSynchronize(static_cast<hipEvent_t>(ev)), "hipEventSynchronize"); }
+void stream_wait_event(hipStream_t s, void *ev) { check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev), 0), "hipStreamWaitEvent"); }
+void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_t n, hipStream_t s) {
+  if (!n) return;
+  if (dst_device == src_device) check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync D2D");
+  else check(hipMemcpyPeerAsync(dst, dst_device, src, src_device, n, s), "hipMemcpyPeerAsync");
+}
+void enable_peer_access(int device, int peer) {
+  if (device == peer) return;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can) return;
+  int before = 0;
+  check(hipGetDevice(&before), "hipGetDevice");
+  check(hipSetDevice(device), "hipSetDevice");
+  const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+  else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+  check(hipSetDevice(before), "hipSetDevice");
+}
 
 
 void allow_large_lds(const void *kernel, size_t lds, const char *name) {

@@ -75,6 +75,9 @@ static inline void *event_create() { return nullptr; }
 static inline void event_destroy(void *) {}
 static inline void event_record(void *, hipStream_t) {}
 static inline void event_sync(void *) {}
+static inline void stream_wait_event(hipStream_t, void *) {}
+static inline void peer_copy(void *dst, int, const void *src, int, size_t n, hipStream_t) { memcpy(dst, src, n); }
+static inline void enable_peer_access(int, int) {}
 void emu_run_begin(size_t lds_bytes);
 void emu_run_end();
 template <class K, class... A>
@@ -114,6 +117,10 @@ void *event_create();
 void event_destroy(void *ev);
 void event_record(void *ev, hipStream_t s);
 void event_sync(void *ev);
+void stream_wait_event(hipStream_t s, void *ev);
+// copy between devices (xGMI when peer access is enabled, staged otherwise); same device = plain D2D
+void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_t n, hipStream_t s);
+void enable_peer_access(int device, int peer);    // idempotent; a refusal is not an error (copies are then staged)
 // optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 void prof_begin(const char *name, hipStream_t s);
 void prof_end(hipStream_t s);

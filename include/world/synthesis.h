@@ -1,0 +1,8 @@
+/* world/synthesis.h -- drop-in for the reference header of the same name: a caller that says
+ * #include "world/synthesis.h" compiles against this repository's include/ directory unchanged.
+ * Declares Synthesis (reference src/world/synthesis.h:30);
+ * all declarations live in ../world_hip.h (Part 1), which cites the reference line of each. */
+#ifndef WORLD_HIP_FORWARD_SYNTHESIS_H_
+#define WORLD_HIP_FORWARD_SYNTHESIS_H_
+#include "../world_hip.h"
+#endif

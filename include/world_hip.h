@@ -89,7 +89,7 @@ WORLD_HIP_API void D4C(const double *x, int x_length, int fs, const double *temp
                        double **aperiodicity);
 WORLD_HIP_API void InitializeD4COption(D4COption *option);
 
-/* reference src/world/codec.h:33,47,60,74,88 (src/codec.cpp:212-324) -- SURVEY.md 8f.1.
+/* reference src/world/codec.h:23,38,53,69,86 (src/codec.cpp:212-324) -- SURVEY.md 8f.1.
  * All five public symbols of codec.o are defined so that the object is never pulled from
  * a reference archive linked behind this library. */
 WORLD_HIP_API int GetNumberOfAperiodicities(int fs);
@@ -196,7 +196,12 @@ WORLD_HIP_API int world_hip_d4c_batch(WorldHipContext *ctx, int n_utt, int fs, c
 /* Waveform synthesis from analysis parameters (reference src/synthesis.cpp:339-399):
  *   f0 [n_utt][f_stride], spectrogram / aperiodicity [n_utt][f_stride][fft_size/2+1] (device),
  *   n_frames, y_length [n_utt] (HOST), y [n_utt][y_stride] (device).  frame_period in ms.
- * Pulses beyond a mean rate of 1200 Hz over the longest utterance are dropped. */
+ * The pulse count is data dependent and only known on the device: the workspace holds a mean pulse rate of
+ * 1200 Hz over the longest utterance unless world_hip_set_synthesis_pulse_capacity() said otherwise (pulses
+ * per utterance; 0 = automatic).  A call that needs more does NOT fail silently: the device records the count,
+ * world_hip_sync() then fails with it in world_hip_last_error(), world_hip_synthesis_pulses_dropped() returns it
+ * (0 = every pulse was rendered; synchronises; clears the record) -- set the capacity and repeat the call.
+ * The drop-in Synthesis() does exactly that by itself. */
 WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int fs, double frame_period,
                                             int fft_size, const int *n_frames, int f_stride, const double *d_f0,
                                             const double *d_spectrogram, const double *d_aperiodicity,
@@ -235,6 +240,9 @@ WORLD_HIP_API int world_hip_unpack_results(WorldHipContext *ctx, int n_utt, cons
                                            double *d_f0, double *d_spectrogram, double *d_aperiodicity);
 WORLD_HIP_API int world_hip_allgather_blocks(int n_dev, WorldHipContext *const *ctxs, const double *const *d_src,
                                              const long long *rows, int cols, double *const *d_dst);
+
+WORLD_HIP_API int world_hip_set_synthesis_pulse_capacity(WorldHipContext *ctx, int pulses_per_utterance);
+WORLD_HIP_API int world_hip_synthesis_pulses_dropped(WorldHipContext *ctx, int *needed);
 
 /* 16-bit PCM (as stored in a WAV file) -> the doubles the reference's wavread() produces,
  * x = q / 32768 (tools/audioio.cpp:236-249), on the device: upload int16, not FP64. */

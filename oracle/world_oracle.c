@@ -9,8 +9,8 @@
  * Ooura FFT differs from it by O(1e-16) rounding only).
  *
  * Build: see oracle/Makefile (gcc -std=c99 -O2 -ffp-contract=off).
- * Pinned by: tests/test_oracle_vs_ref.py (against oracle/_ref) and
- * tests/test_oracle_golden.py (against tests/golden/ fixtures).
+ * Pinned by: tests/test_oracle.py (against the unmodified reference in oracle/_ref, against the
+ * tests/golden/ fixtures generated from it, and against SURVEY.md 8c's checksums).
  */
 #define _USE_MATH_DEFINES
 #define _DEFAULT_SOURCE

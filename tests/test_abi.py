@@ -122,3 +122,44 @@ def test_option_and_size_helpers_agree_with_the_reference_build(lib_path):
         a, b = cls(), cls()
         getattr(ours, init)(ctypes.byref(a)); getattr(ref, init)(ctypes.byref(b))
         assert bytes(a) == bytes(b), init
+
+
+def test_forwarding_headers_compile_like_the_reference_tree(tmp_path):
+    """include/world/*.h (and the tools/ headers): a caller written against the reference's header tree --
+    #include "world/dio.h" ... -- compiles against this repository's include/ alone, as C and as C++, and sees
+    every drop-in symbol with the reference's signature (reference src/world/*.h)"""
+    import subprocess
+    src = tmp_path / "caller.c"
+    src.write_text('''
+#include "world/dio.h"
+#include "world/harvest.h"
+#include "world/stonemask.h"
+#include "world/cheaptrick.h"
+#include "world/d4c.h"
+#include "world/codec.h"
+#include "world/synthesis.h"
+#include "world/macrodefinitions.h"
+#include "audioio.h"
+#include "parameterio.h"
+WORLD_BEGIN_C_DECLS
+int uses_everything(const double *x, int n, int fs, double *tp, double *f0, double **sp, double **ap, double *y);
+WORLD_END_C_DECLS
+int uses_everything(const double *x, int n, int fs, double *tp, double *f0, double **sp, double **ap, double *y) {
+  DioOption d; HarvestOption h; CheapTrickOption c; D4COption a;
+  InitializeDioOption(&d); InitializeHarvestOption(&h); InitializeCheapTrickOption(fs, &c); InitializeD4COption(&a);
+  int nf = GetSamplesForHarvest(fs, n, h.frame_period) + 0 * GetSamplesForDIO(fs, n, d.frame_period);
+  Harvest(x, n, fs, &h, tp, f0); Dio(x, n, fs, &d, tp, f0); StoneMask(x, n, fs, tp, f0, nf, f0);
+  c.fft_size = GetFFTSizeForCheapTrick(fs, &c); (void)GetF0FloorForCheapTrick(fs, c.fft_size);
+  CheapTrick(x, n, fs, tp, f0, nf, &c, sp); D4C(x, n, fs, tp, f0, nf, c.fft_size, &a, ap);
+  CodeAperiodicity((const double *const *)ap, nf, fs, c.fft_size, ap); DecodeAperiodicity((const double *const *)ap, nf, fs, c.fft_size, ap);
+  CodeSpectralEnvelope((const double *const *)sp, nf, fs, c.fft_size, 4, sp); DecodeSpectralEnvelope((const double *const *)sp, nf, fs, c.fft_size, 4, sp);
+  Synthesis(f0, nf, (const double *const *)sp, (const double *const *)ap, c.fft_size, h.frame_period, fs, n, y);
+  wavwrite(y, n, fs, 16, "o.wav"); (void)GetAudioLength("o.wav"); WriteF0("o.f0", nf, 5.0, tp, f0, 0);
+  return GetNumberOfAperiodicities(fs);
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        r = subprocess.run([cc, std, "-x", "c" if cc == "gcc" else "c++", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -1,4 +1,6 @@
 """Ablation timing on the GPU box (development aid): swap in alternative source files, rebuild, time, restore."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import json, subprocess, sys, shutil
 VARIANTS = {
   'base': {},
@@ -7,7 +9,7 @@ VARIANTS = {
 }
 KERNELS = ('d4c_groupdelay', 'd4c_band', 'd4c_lovetrain', 'ct_frame')
 def run(name):
-    out = subprocess.run([sys.executable, 'bench.py', '--steps', '30', '--warmup', '3', '--streams', '1', '--no-cpu-baseline'],
+    out = subprocess.run([sys.executable, 'bench.py', '--steps', '30', '--warmup', '3', '--streams', '1', '--no-cpu-baseline', '--no-extras', '--no-configs', '--min-wall', '0'],,
                          capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]
     d = json.loads(out)
     k = d['kernels_ms_per_step']

@@ -1,5 +1,7 @@
 """Development aid: BASELINE.json configs[4] -- 64 x (16 kHz, 5 s), Dio + StoneMask + CheapTrick(fft 1024) + D4C
 in one batched call per stage -- timed on the GPU with the per-kernel breakdown (not the headline metric)."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import json, sys, time
 import torch
 from world_amd import synth

@@ -5,6 +5,8 @@ import os
 import sys
 from collections import defaultdict
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 out = sys.argv[1]
 
 
@@ -44,5 +46,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for c, v in acc[k].items():
             if c in ("FETCH_SIZE", "WRITE_SIZE") or c.endswith("_F64"):
                 traffic.setdefault(k, {})[c] = v[0] / max(v[1], 1)
-json.dump({"frames_per_launch": int(os.environ.get("PROFILE_FRAMES", "2001")), "unit": "FETCH_SIZE / WRITE_SIZE: KB per dispatch; *_F64: wave-level instructions per dispatch (rocprofv3)",
+import bench
+json.dump({"csrc_hash": bench.csrc_hash(), "config": os.environ.get("PROFILE_CONFIG", "1"),
+           "frames_per_launch": int(os.environ.get("PROFILE_FRAMES", "2001")), "unit": "FETCH_SIZE / WRITE_SIZE: KB per dispatch; *_F64: wave-level instructions per dispatch (rocprofv3)",
            "kernels": traffic}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

@@ -1,5 +1,7 @@
 """Development aid: build with -DWH_TRACE, run one analysis, print the cycle stamps one
 workgroup of d4c_band / d4c_groupdelay recorded (deltas in shader-clock cycles)."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import ctypes as C
 import os
 import subprocess

@@ -80,6 +80,8 @@ def load_library(path=LIB_PATH):
     lib.world_hip_synthesis_batch.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, _ip, C.c_int, vp, vp, vp,
                                               _ip, C.c_int, vp]
     lib.world_hip_pcm16_to_double.argtypes = [vp, C.c_longlong, vp, vp]
+    lib.world_hip_set_synthesis_pulse_capacity.argtypes = [vp, C.c_int]
+    lib.world_hip_synthesis_pulses_dropped.argtypes = [vp, _ip]
     lib.world_hip_probe_rfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
     lib.world_hip_probe_irfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
     lib.world_hip_pack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, vp, vp, vp, C.c_longlong, vp]
@@ -545,6 +547,16 @@ class WorldHip:
                                                       first_row, tpos.data_ptr(), f0.data_ptr(), sp.data_ptr(),
                                                       ap.data_ptr()), "unpack_results")
         return tpos, f0, sp, ap
+
+    def synthesis_pulses_dropped(self):
+        """pulses per utterance the last synthesis calls had no room for (0 = all rendered); synchronises"""
+        need = C.c_int(0)
+        self._check(self.lib.world_hip_synthesis_pulses_dropped(self._context(), C.byref(need)), "synthesis_pulses_dropped")
+        return need.value
+
+    def set_synthesis_pulse_capacity(self, pulses_per_utterance):
+        self._check(self.lib.world_hip_set_synthesis_pulse_capacity(self._context(), int(pulses_per_utterance)),
+                    "set_synthesis_pulse_capacity")
 
     def pcm16_to_double(self, pcm):
         """int16 samples (any shape) -> float64 / 32768, wavread()'s convention, on the device"""

@@ -85,6 +85,8 @@ struct WorldHipContext {
   void *dio_bands = nullptr;     // world_hip::DioBands (cached DIO filter tables)
   double *d_dc_remover = nullptr; // GetDCRemover(fft_size) of the synthesiser
   int dc_remover_len = 0;
+  int *d_synth_need = nullptr;   // largest pulse count a synthesis call could not hold (0 = nothing was dropped)
+  int synth_pulse_cap = 0;       // caller's capacity per utterance (0 = automatic)
   void *codec_tables = nullptr;  // world_hip::CodecTableSet (cached interp1 / DCT tables of the coders)
   // pinned ring of staging buffers for the small per-call host arrays
   char *stage[kStageRing] = {};
@@ -573,6 +575,9 @@ static void run_stonemask(WorldHipContext *c, int n_utt, int fs, const double *d
   }
   StoneMaskParams p;
   p.win_cap = 2 * static_cast<int>(1.5 * fs / 40.0 + 1.0) + 4;       // longest window: f0 just above 40 Hz
+  if (stonemask_lds_bytes(p.win_cap) > 160 * 1024)
+    fail("StoneMask: fs=%d needs a %d-sample window (%zu bytes of LDS > 160 KiB); fs <= 180 kHz supported", fs, p.win_cap,
+         stonemask_lds_bytes(p.win_cap));
   ensure_arena(c, 2 * pad256(sizeof(int) * n_utt));
   c->arena.reset();
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
@@ -774,9 +779,16 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
   p.lowest_f0 = fs / fft_size + 1.0;                                   // integer division (synthesis.cpp:361)
   p.f0 = d_f0; p.sp = d_sp; p.ap = d_ap; p.f_stride = f_stride; p.y = d_y; p.y_stride = y_stride;
   p.nblk = (max_y + kSyTile - 1) / kSyTile;
-  // room for a mean pulse rate of 1200 Hz over the longest utterance (voiced pulses come at f0,
-  // unvoiced ones at 500 Hz); pulses beyond it are dropped and np is clamped
-  p.pulse_cap = static_cast<int>(static_cast<double>(max_y) * 1200.0 / fs) + 16;
+  // Room for a mean pulse rate of 1200 Hz over the longest utterance unless the caller said otherwise (voiced
+  // pulses come at f0, unvoiced ones at 500 Hz).  The pulse count is only known on the device; a call that
+  // needs more records the count (need), world_hip_sync / world_hip_synthesis_pulses_dropped report it, and the
+  // drop-in Synthesis() -- which waits for its result anyway -- repeats the call with the exact capacity.
+  p.pulse_cap = c->synth_pulse_cap > 0 ? c->synth_pulse_cap : static_cast<int>(static_cast<double>(max_y) * 1200.0 / fs) + 16;
+  if (!c->d_synth_need) {
+    c->d_synth_need = static_cast<int *>(devrt::dmalloc(sizeof(int)));
+    devrt::dzero(c->d_synth_need, sizeof(int), c->stream);
+  }
+  p.need = c->d_synth_need;
   const size_t B = n_utt;
   size_t need = 2 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * y_stride) + pad256(B * y_stride) +
                 pad256(sizeof(double) * B * p.nblk) + pad256(sizeof(int) * B * p.nblk) +
@@ -916,6 +928,7 @@ void world_hip_destroy(WorldHipContext *c) {
     }
     free_codec_tables(c);
     if (c->d_dc_remover) devrt::dfree(c->d_dc_remover);
+    if (c->d_synth_need) devrt::dfree(c->d_synth_need);
     for (int k = 0; k < kStageRing; ++k) {
       if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
       if (c->stage_ev[k]) devrt::event_destroy(c->stage_ev[k]);
@@ -932,8 +945,38 @@ void world_hip_destroy(WorldHipContext *c) {
 
 const char *world_hip_last_error(void) { return g_last_error.c_str(); }
 
+// pulses a synthesis call since the last check had no room for (0 = none); synchronises, clears the record
+static int synthesis_need(WorldHipContext *c) {
+  if (!c->d_synth_need) return 0;
+  int need = 0;
+  devrt::d2h(&need, c->d_synth_need, sizeof(int), c->stream);
+  devrt::sync(c->stream);
+  if (need > 0) devrt::dzero(c->d_synth_need, sizeof(int), c->stream);
+  return need;
+}
+
 int world_hip_sync(WorldHipContext *c) {
-  return guarded(c, [&] { devrt::sync(c->stream); });
+  return guarded(c, [&] {
+    devrt::sync(c->stream);
+    const int need = synthesis_need(c);
+    if (need > 0)
+      fail("Synthesis dropped pulses: an utterance has %d, more than the capacity in force; call "
+           "world_hip_set_synthesis_pulse_capacity(ctx, %d) and repeat the call", need, need);
+  });
+}
+
+int world_hip_set_synthesis_pulse_capacity(WorldHipContext *c, int pulses_per_utterance) {
+  return guarded(c, [&] {
+    if (pulses_per_utterance < 0) fail("negative capacity");
+    c->synth_pulse_cap = pulses_per_utterance;
+  });
+}
+
+int world_hip_synthesis_pulses_dropped(WorldHipContext *c, int *needed) {
+  return guarded(c, [&] {
+    const int need = synthesis_need(c);
+    if (needed) *needed = need;
+  });
 }
 
 unsigned long long world_hip_workspace_bytes(WorldHipContext *c) {

@@ -48,5 +48,6 @@ struct StoneMaskParams {
 
 void launch_dio(const DioParams &p, int max_x_len, int max_y_len, int max_frames, hipStream_t stream);
 void launch_stonemask(const StoneMaskParams &p, int max_frames, hipStream_t stream);
+size_t stonemask_lds_bytes(int win_cap);      // dynamic LDS of sm_frame for a longest window of win_cap samples
 
 }  // namespace world_hip

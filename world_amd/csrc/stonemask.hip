@@ -103,9 +103,12 @@ __global__ void __launch_bounds__(256) sm_frame(StoneMaskParams p) {
   if (tid == 0) p.refined[fi] = mean;
 }
 
+size_t stonemask_lds_bytes(int win_cap) {
+  return sizeof(double) * (size_t)win_cap + sizeof(int) * (size_t)(win_cap + (win_cap & 1)) + sizeof(double) * 64;
+}
+
 void launch_stonemask(const StoneMaskParams &p, int max_frames, hipStream_t stream) {
-  size_t lds = sizeof(double) * (size_t)p.win_cap + sizeof(int) * (size_t)(p.win_cap + (p.win_cap & 1)) +
-               sizeof(double) * 64;
+  const size_t lds = stonemask_lds_bytes(p.win_cap);
   // Workgroup size follows the transform: a radix-8 stage of an N-point real transform has N/16 butterflies,
   // and threads beyond that idle through every stage.  Up to 24 kHz the transforms are 512-1024 points
   // (64 threads: 0.54 ms for 64 x 1001 frames at 16 kHz, 128: 0.69, 256: 1.32); at 48 kHz they are 2048-4096.

@@ -33,6 +33,7 @@ struct SynthParams {
   double *pshift;           // [n_utt][pulse_cap] pulse_locations_time_shift
   int *np;                  // [n_utt] number_of_pulses (clamped to pulse_cap)
   int pulse_cap;
+  int *need;                // context-wide: largest pulse count that did NOT fit pulse_cap (0 = none dropped so far)
   double *resp;             // [n_utt][pulse_cap][fft_size] impulse response of every pulse
   const double *dc_remover; // [fft_size] GetDCRemover(), host-built
   const uint32_t *noise;    // randn_value(noise[k]) = k-th randn() after reseed

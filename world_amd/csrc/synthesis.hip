@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(kSyThreads) sy_compact(SynthParams p) {
     if (blk == p.nblk - 1) {                        // the last tile publishes the pulse count
       const int all = c0 + p.blk_cnt[(size_t)u * p.nblk + blk];
       p.np[u] = all < p.pulse_cap ? all : p.pulse_cap;
+      if (all > p.pulse_cap) atomicMax(p.need, all);  // the caller is told (world_hip_sync / the drop-in retries)
     }
   }
   __syncthreads();

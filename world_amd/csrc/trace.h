@@ -1,6 +1,6 @@
 // trace.h -- development aid, compiled out of the product.  With -DWH_TRACE a kernel can
 // stamp the shader clock at phase boundaries of ONE chosen workgroup (`trace_me`); the stamps
-// are read back through world_hip_trace_read_<unit>() (tools_trace.py prints the deltas).
+// are read back through world_hip_trace_read_<unit>() (tools/trace.py prints the deltas).
 // In-situ phase latencies are what rocprofv3's per-kernel totals cannot show.
 #pragma once
 #if defined(WH_TRACE) && !defined(WORLD_EMU)

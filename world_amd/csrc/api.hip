@@ -236,7 +236,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     c->nuttall_len = wl;
   }
   size_t fr = (size_t)n_utt * f_stride;
-  const int gd_stride = fft_d4c / 2 + 2;
+  const int gd_stride = static_cast<int>(d4c_frame_scratch_doubles(ilog2_exact(fft_d4c)));
   size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 4 * pad256(sizeof(int) * n_utt) +
                 pad256(sizeof(double) * fr * gd_stride) + pad256(sizeof(double) * fr * 16);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }

@@ -21,6 +21,7 @@ constexpr double kMaximumValue = 100000.0;
 __host__ __device__ __forceinline__ int mround(double x) {
   return x > 0 ? static_cast<int>(x + 0.5) : static_cast<int>(x - 0.5);
 }
+constexpr int const_log2(int n) { return n <= 1 ? 0 : 1 + const_log2(n / 2); }
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 

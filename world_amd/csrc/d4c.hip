@@ -11,15 +11,14 @@
 // per-frame draw counts (d4c_prepare1 / d4c_prepare2) and GF(2) jump-ahead.
 //
 //   d4c_lovetrain : 256-thread workgroup per frame, one r2c FFT, two band sums.
-//   d4c_groupdelay: 512-thread workgroup per selected frame, all in LDS:
-//                   2 centroid transforms (each = the reference's two r2c FFTs
-//                   packed into ONE complex FFT: z = w x + i (n+1) w x), 1 power
-//                   spectrum, 2 DC corrections, 3 rectangular smoothings
-//                   (block-parallel prefix sums) -> static group delay to HBM.
-//   d4c_band      : workgroup per (3 kHz band, selected frame): windowed slice ->
-//                   r2c FFT -> power -> radix select in registers replacing the
-//                   reference's std::sort (only the sum of the N/2-boundary
-//                   smallest powers is used) -> one coarse aperiodicity value.
+//   d4c_frame     : one workgroup per selected frame, N/16 threads, one N-point real
+//                   transform buffer in LDS, every spectrum in registers: 4 centroid
+//                   transforms, 1 power spectrum, 2 DC corrections, 3 rectangular
+//                   smoothings (block-parallel prefix sums) -> static group delay ->
+//                   per 3 kHz band: Nuttall-windowed slice -> r2c FFT -> power ->
+//                   radix select in registers replacing the reference's std::sort
+//                   (only the sum of the N/2-boundary smallest powers is used) -> one
+//                   coarse aperiodicity value.  Nothing but that value leaves the CU.
 //   d4c_finish    : the 3 kHz-grid interpolation, every row written once to HBM.
 #include "stage_params.h"
 #include "trace.h"
@@ -147,50 +146,6 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
 }
 
-// ---------------------------------------------------------------------------
-// LinearSmoothing (common.cpp:27-111) on an LDS spectrum of half+1 bins.
-// seg: LDS work area of >= half + 2*bnd + 1 doubles.  in == out allowed.
-__device__ __forceinline__ void d4c_smooth(const double *in, double width, int fs, int N, double *seg,
-                                           double *out, double *scratch) {
-  const int tid = threadIdx.x, nt = blockDim.x, half = N / 2;
-  const int bnd = static_cast<int>(width * N / fs) + 1;
-  const int seg_len = half + 2 * bnd + 1;
-  const double inv_n = 1.0 / N;
-  __syncthreads();
-  for (int i = tid; i < seg_len; i += nt) {
-    double m;
-    if (i < bnd) m = in[bnd - i];
-    else if (i < half + bnd) m = in[i - bnd];
-    else m = in[half - (i - (half + bnd))];
-    seg[i] = m * fs * inv_n;                           // == m * fs / N: N is a power of two
-  }
-  block_scan_incl_double(seg, seg_len, scratch);
-  const double origin_axis = -(bnd - 0.5) * fs / N;
-  const double inv_step = static_cast<double>(N) / fs, inv_width = 1.0 / width;
-  for (int i = tid; i <= half; i += nt) {
-    double fa = static_cast<double>(i) * inv_n * fs - width / 2.0;
-    double lo = interp_uniform_rcp(origin_axis, inv_step, seg, seg_len, fa);
-    fa += width;
-    double hi = interp_uniform_rcp(origin_axis, inv_step, seg, seg_len, fa);
-    out[i] = (hi - lo) * inv_width;
-  }
-  __syncthreads();
-}
-
-// DCCorrection (common.cpp:56-75) in place on an LDS spectrum; tmp >= 2 + f0*N/fs doubles.
-__device__ __forceinline__ void d4c_dc_correct(double *spec, double f0, int fs, int N, double *tmp) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int upper = 2 + static_cast<int>(f0 * N / fs);
-  const int nrep = upper - 1;
-  const double dx = -static_cast<double>(fs) / N;
-  __syncthreads();
-  for (int i = tid; i < nrep; i += nt)
-    tmp[i] = interp_uniform(f0, dx, spec, upper + 1, static_cast<double>(i) * fs / N);
-  __syncthreads();
-  for (int i = tid; i < nrep; i += nt) spec[i] = spec[i] + tmp[i];
-  __syncthreads();
-}
-
 // Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them: a radix
 // select on the IEEE bit patterns (monotone for non-negative doubles), 8 bits per pass,
 // histogram in LDS.  Keys stay in registers.  Digits start at the first bit in which any
@@ -305,14 +260,89 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 }
 
 // ---------------------------------------------------------------------------
-// Stage A of D4CGeneralBody: static group delay of one selected frame -> HBM.
-// (GetStaticCentroid, GetSmoothedPowerSpectrum, GetStaticGroupDelay: d4c.cpp:126-188)
-// Workgroup shape of d4c_groupdelay: 256 threads with radix-16 butterflies, or 512 threads with
-// radix-8 butterflies (every thread busy in every FFT stage, half the registers per thread).
-constexpr int kGdThreads = 512;
-constexpr bool kGdRadix8 = true;
-template <int NMAX>
-__global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_groupdelay(D4cParams p) {
+// D4CGeneralBody for one selected frame in ONE workgroup (d4c.cpp:90-225, 291-316):
+//   GetStaticCentroid -> GetSmoothedPowerSpectrum -> GetStaticGroupDelay -> GetCoarseAperiodicity.
+//
+// Shape: T = N/16 threads (N = fft_size_d4c: 256 threads at 48 kHz), one radix-8 butterfly per thread and
+// stage, and ONE real-transform buffer of N doubles in LDS (32 KB + twiddles: four workgroups per CU where
+// the round-1 kernel, which packed the centroid's two transforms into one complex transform of 64 KB and kept
+// two spectra beside it, had two).  Everything that is indexed by frequency bin lives in REGISTERS: the
+// transform's merge step hands thread t the same 2 ceil((N/4+1)/T) bins (conjugate pairs k = t + m T, N/2-k) after
+// every transform (rfft_merge_items), so centroid, power spectrum, their quotient, the smoothed versions and
+// the group delay are per-thread arrays, and LDS is only the exchange medium -- the smoothing's prefix-sum
+// array, the few bins DCCorrection mirrors, the 513-sample band slices.  The static group delay never goes
+// to HBM: the five band transforms of GetCoarseAperiodicity read their Nuttall-windowed slices from LDS
+// (a first stage that knows all but one input of every butterfly to be zero), and the power values feed the
+// radix select from registers.
+template <int NMAX, int T> struct D4cShape {
+#ifdef WORLD_EMU
+  static constexpr int kItems = NMAX / 4 + 1;          // one emulated thread owns every bin
+#else
+  static constexpr int kItems = (NMAX / 4 + 1 + T - 1) / T;
+#endif
+  static constexpr int kBins = 2 * kItems;
+};
+
+struct D4cWin {            // GetWindowedWaveform's parameters (d4c.cpp:52-84)
+  const double *x;
+  const uint32_t *noise;   // the window's draws in sample order (d4c.cpp:67-69)
+  int x_len, hw, wlen, origin, kind;
+  double scale;
+};
+__device__ __forceinline__ D4cWin d4c_win(const double *x, int x_len, int fs, double f0, double pos, int kind, double ratio,
+                                          const uint32_t *noise) {
+  D4cWin w;
+  w.x = x; w.x_len = x_len; w.noise = noise; w.kind = kind;
+  w.hw = mround(ratio * fs / f0 / 2.0);
+  w.wlen = 2 * w.hw + 1;
+  w.origin = mround(pos * fs + 0.001);
+  w.scale = 2.0 / ratio / fs * f0;
+  return w;
+}
+// The window of a thread's samples i0, i0 + step, i0 + 2 step, ... by rotation: cos(pi scale (i - hw)) advances by
+// a fixed angle per sample, so one sincospi pair per thread and pass replaces one cospi per sample (the window
+// evaluations were a fifth of the frame kernel's instructions).  At most N / T = 16 rotations on the GPU.
+struct D4cWinRot { double c, s, dc, ds; };
+__device__ __forceinline__ D4cWinRot d4c_win_rot(const D4cWin &w, int i0, int step) {
+  D4cWinRot r;
+  sincospi(w.scale * (i0 - w.hw), &r.s, &r.c);
+  sincospi(w.scale * step, &r.ds, &r.dc);
+  return r;
+}
+__device__ __forceinline__ double d4c_win_next(const D4cWin &w, D4cWinRot &r) {   // value at the current sample, then advance
+  const double c1 = r.c;
+  const double v = w.kind == kHanning ? 0.5 * c1 + 0.5 : 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
+  r.c = c1 * r.dc - r.s * r.ds;
+  r.s = r.s * r.dc + c1 * r.ds;
+  return v;
+}
+struct D4cSample { double v, w; };
+// sample i of the windowed, dithered waveform (d4c.cpp:61-69); rot must stand at sample i
+__device__ __forceinline__ D4cSample d4c_sample(const D4cWin &w, int i, D4cWinRot &rot) {
+  D4cSample s;
+  s.w = d4c_win_next(w, rot);
+  s.v = w.x[imin(w.x_len - 1, imax(0, w.origin + i - w.hw))] * s.w + randn_value(w.noise[i]) * kSafeGuardD4C;
+  return s;
+}
+// windowed, dithered samples into the real-transform input; returns the DC-balance coefficient
+// (sum of the waveform / sum of the window, d4c.cpp:71-80) which the callers apply
+__device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, cplx *Z, double *scratch) {
+  double s1 = 0.0, s2 = 0.0;
+  D4cWinRot rot = d4c_win_rot(w, threadIdx.x, blockDim.x);
+  block_map<4, D4cSample>(w.wlen, [&](int i) { return d4c_sample(w, i, rot); },
+                          [&](int i, D4cSample s) { rfft_in(Z, i) = s.v; s1 += s.v; s2 += s.w; });
+  block_sum2(s1, s2, scratch);
+  return s1 / s2;
+}
+
+// resident waves per SIMD the register allocation aims at (4 = four 256-thread workgroups per CU, 128 VGPRs;
+// 3 = 168 VGPRs: measured within 3 % of each other, profiles/r02)
+#ifndef D4C_MIN_WAVES
+#define D4C_MIN_WAVES 4
+#endif
+template <int NMAX, int T>
+__global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
+  constexpr int kItems = D4cShape<NMAX, T>::kItems, kBins = D4cShape<NMAX, T>::kBins;
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
@@ -322,25 +352,35 @@ __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_gro
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
   const bool trace_me = f == 1000; (void)trace_me;
   WH_STAMP(32, 0);
-  const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
-  // LDS: Z (N complex + 8) | scratch (64) | twiddles.  The packed centroid transform
-  // needs all of Z; afterwards Z is re-carved into the real-FFT / prefix-sum work area
-  // [0, N), B = [N, N+H+1) and A = [N+H+1, N+2H+2).  During the centroid phase A lives
-  // in registers (each thread always owns the same bins).
+  // On the GPU the transform length is the shape's (launch_d4c picks the instantiation), so the plan, every
+  // stage's radix and stride and the digit reversal of the merge steps are compile-time constants.
+#ifdef WORLD_EMU
+  const int lgn = p.lg_d4c;
+#else
+  constexpr int lgn = const_log2(NMAX);
+#endif
+  const int N = 1 << lgn, H = N / 2, q = H / 2, fs = p.b.fs;
+  // LDS: Z (N doubles: the transform, or whatever is exchanged between transforms) | scratch (64) | twiddles
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
-  double *B = Zr + N;
-  double *A = B + (H + 1);
-  double *scratch = Zr + 2 * N + 8;
-  const TwLds tw = stage_twiddles(scratch + 64, lgn, p.tab.tw);
+  double *scratch = Zr + N;
+  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
 #ifdef WORLD_EMU
-  constexpr int kBinsPerThread = NMAX / 2 + 1;          // one emulated thread owns every bin
+  const FftPlan plan = make_plan_max(lgn - 1, 3);
+  auto cfft = [&]() { block_cfft_dif<3>(Z, plan, tw); };
 #else
-  constexpr int kBinsPerThread = (NMAX / 2 + 1 + kGdThreads - 1) / kGdThreads;
+  constexpr FftPlan plan = make_plan_max(lgn - 1, 3);
+  auto cfft = [&]() __attribute__((always_inline)) { block_cfft_dif_static<lgn - 1, 3>(Z, tw); };
 #endif
-  double a_reg[kBinsPerThread];
-  const FftPlan plan_c = kGdRadix8 ? make_plan_r8(lgn) : make_plan(lgn);            // the packed centroid transform: 2^lgn complex points
-  const int top_bit = plan_c.rl(plan_c.ns - 1) - 1; // bit of a slot index that carries the top bit of its bin
+  // body(slot, k) for every bin this thread owns (rfft_merge_items: item m = bins tid + m T and H - that, natural
+  // order, so LDS traffic indexed by bin is conflict-free); `slot` is a compile-time constant after unrolling
+  auto for_bins = [&](auto body) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < kItems; ++m) {
+      const int it = tid + m * nt;
+      if (it <= q) { body(2 * m, it); if (it < q) body(2 * m + 1, H - it); }
+    }
+  };
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
   const int x_len = p.b.x_len[u];
@@ -348,155 +388,191 @@ __global__ void __launch_bounds__(kGdThreads, kGdThreads == 512 ? 4 : 1) d4c_gro
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   const uint32_t *noise = p.noise + p.offsets2[fi];
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
+  double *spill = p.gd + fi * p.gd_stride;              // kBins * T doubles of this frame's own scratch row
+  const double inv_n = 1.0 / N;
 
-  // ---- GetStaticCentroid (d4c.cpp:126-143) ----------------------------------
-  for (int c = 0; c < 2; ++c) {
-    const double cpos = c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
+  // DCCorrection (common.cpp:56-75) on register bins: the few low bins it mirrors go through LDS
+  auto dc_correct = [&](double (&S)[kBins]) __attribute__((always_inline)) {
+    const int upper = 2 + static_cast<int>(cf0 * N / fs), nrep = upper - 1;
+    const double dx = -static_cast<double>(fs) / N;
+    __syncthreads();
+    for_bins([&](int slot, int k) { if (k <= upper) Zr[k] = S[slot]; });
+    __syncthreads();
+    for_bins([&](int slot, int k) {
+      if (k < nrep) S[slot] = S[slot] + interp_uniform(cf0, dx, Zr, upper + 1, static_cast<double>(k) * fs / N);
+    });
+    __syncthreads();
+  };
+  // LinearSmoothing (common.cpp:27-111): register bins -> mirrored segment in LDS -> block prefix sum -> register bins
+  auto smooth = [&](const double (&in)[kBins], double width, double (&out)[kBins]) __attribute__((always_inline)) {
+    const int bnd = static_cast<int>(width * N / fs) + 1;
+    const int seg_len = H + 2 * bnd + 1;
+    __syncthreads();
+    for_bins([&](int slot, int k) {
+      const double v = in[slot] * fs * inv_n;            // == .. * fs / N: N is a power of two
+      Zr[k + bnd] = v;
+      if (k >= 1 && k <= bnd) Zr[bnd - k] = v;
+      if (k < H && k >= H - bnd) Zr[2 * H + bnd - k] = v;
+    });
+    block_scan_incl_double(Zr, seg_len, scratch);
+    const double origin_axis = -(bnd - 0.5) * fs / N;
+    const double inv_step = static_cast<double>(N) / fs, inv_width = 1.0 / width;
+    for_bins([&](int slot, int k) {
+      double fa = static_cast<double>(k) * inv_n * fs - width / 2.0;
+      const double lo = interp_uniform_rcp(origin_axis, inv_step, Zr, seg_len, fa);
+      fa += width;
+      const double hi = interp_uniform_rcp(origin_axis, inv_step, Zr, seg_len, fa);
+      out[slot] = (hi - lo) * inv_width;
+    });
+  };
+
+  // ---- GetStaticCentroid (d4c.cpp:90-143) -------------------------------------
+  // centroid = Re(X2 conj X1) with X1 = FFT(w x / |w x|), X2 = FFT((n+1) w x / |w x|): two real transforms
+  // through the one buffer, X1 waiting in registers; the normalisation is applied to the product.
+  // One position: returns its centroid in `out`.  The first position's result waits in the frame's scratch row
+  // (HBM, L2-resident) while X1 of the second occupies the registers; the second adds it back.
+  auto centroid = [&](int c, double (&out)[kBins]) __attribute__((always_inline)) {
+    const D4cWin w = d4c_win(x, x_len, fs, cf0, c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0, kBlackman, 4.0,
+                             noise + (size_t)c * wdraws);
     __syncthreads();
     WH_STAMP(32, 1 + 5 * c);
-    const int wlen = d4c_windowed(x, x_len, fs, cf0, cpos, kBlackman, 4.0, noise + (size_t)c * wdraws,
-                                  Z, true, scratch);
-    WH_STAMP(32, 2 + 5 * c);
+    const double coef = d4c_window_to_lds(w, Z, scratch);
     double pw = 0.0;
-    for (int i = tid; i < wlen; i += nt) { const double v = Z[swz(i)].re; pw += v * v; }
-    pw = block_sum(pw, scratch);
-    const double inv_nrm = 1.0 / sqrt(pw);
-    for (int i = tid; i < N; i += nt) {
-      cplx &e = Z[swz(i)];
-      double v = i < wlen ? e.re * inv_nrm : 0.0;
-      e.re = v;
-      e.im = v * (i + 1.0);                          // second transform's input (d4c.cpp:111-112)
-    }
-    WH_STAMP(32, 3 + 5 * c);
-    block_cfft_dif<kGdRadix8 ? 3 : 4>(Z, plan_c, tw);
-    WH_STAMP(32, 4 + 5 * c);
-    // Bins k <= H in an order that makes consecutive lanes read consecutive physical
-    // slots (conflict-free): bins below H are exactly the slots whose last-stage digit
-    // has its top bit clear.  Item `it` names the same bin in both centroid passes.
-#pragma unroll
-    for (int slot = 0; slot < kBinsPerThread; ++slot) {
-      const int it = tid + slot * nt;
-      if (it > H) break;
-      int k, phys;
-      if (it < H) {
-        const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
-        phys = swz(pos);
-        k = fft_bin_of_slot(plan_c, phys);
-      } else {
-        k = H;
-        phys = fft_slot(plan_c, H);
+    {
+      D4cWinRot rot = d4c_win_rot(w, tid, nt);
+      for (int i = tid; i < N; i += nt) {
+        double v = 0.0;
+        if (i < w.wlen) { v = rfft_in(Z, i) - d4c_win_next(w, rot) * coef; pw += v * v; }
+        rfft_in(Z, i) = v;
       }
-      cplx za = Z[phys], zb = Z[fft_slot(plan_c, (N - k) & (N - 1))];
-      double x1r = 0.5 * (za.re + zb.re), x1i = 0.5 * (za.im - zb.im);
-      double x2r = 0.5 * (za.im + zb.im), x2i = -0.5 * (za.re - zb.re);
-      if (k == 0 || k == H) { x1i = 0.0; x2i = 0.0; }
-      double cen = x2r * x1r + x1i * x2i;            // d4c.cpp:115-116
-      a_reg[slot] = c == 0 ? cen : a_reg[slot] + cen;
     }
+    const double inv_pw = 1.0 / block_sum(pw, scratch);    // 1 / |w x|^2 (d4c.cpp:104-107)
+    WH_STAMP(32, 2 + 5 * c);
+    double x1r[kBins], x1i[kBins];
+    cfft();
+    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
+      x1r[2 * m] = ar; x1i[2 * m] = ai; x1r[2 * m + 1] = br; x1i[2 * m + 1] = bi;
+    });
+    WH_STAMP(32, 3 + 5 * c);
+    // second input: (n + 1) times the same balanced waveform (d4c.cpp:111-112), recomputed from x
+    {
+      D4cWinRot rot = d4c_win_rot(w, tid, nt);
+      block_map<4, double>(w.wlen, [&](int i) { const D4cSample s = d4c_sample(w, i, rot); return (s.v - s.w * coef) * (i + 1.0); },
+                           [&](int i, double v) { rfft_in(Z, i) = v; });
+    }
+    for (int i = w.wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
+    cfft();
+    WH_STAMP(32, 4 + 5 * c);
+    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
+      out[2 * m] = (ar * x1r[2 * m] + x1i[2 * m] * ai) * inv_pw;                           // d4c.cpp:115-116
+      out[2 * m + 1] = (br * x1r[2 * m + 1] + x1i[2 * m + 1] * bi) * inv_pw;
+    });
     WH_STAMP(32, 5 + 5 * c);
-  }
-  __syncthreads();
+  };
+  double A[kBins];
+  {
+    double first[kBins];
+    centroid(0, first);
 #pragma unroll
-  for (int slot = 0; slot < kBinsPerThread; ++slot) {
-    const int it = tid + slot * nt;
-    if (it > H) break;
-    int k = H;
-    if (it < H) {
-      const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
-      k = fft_bin_of_slot(plan_c, swz(pos));
-    }
-    A[k] = a_reg[slot];
+    for (int e = 0; e < kBins; ++e) spill[(size_t)e * nt + tid] = first[e];
   }
-  WH_STAMP(32, 11);
-  d4c_dc_correct(A, cf0, fs, N, Zr);
+  centroid(1, A);
+#pragma unroll
+  for (int e = 0; e < kBins; ++e) A[e] = spill[(size_t)e * nt + tid] + A[e];
+  dc_correct(A);
   WH_STAMP(32, 12);
 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
+  double B[kBins];
   {
-    const int wlen = d4c_windowed(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws,
-                                  Z, false, scratch);
-    for (int i = wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
+    const D4cWin w = d4c_win(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws);
+    const double coef = d4c_window_to_lds(w, Z, scratch);
+    {
+      D4cWinRot rot = d4c_win_rot(w, tid, nt);
+      for (int i = tid; i < N; i += nt)
+        rfft_in(Z, i) = i < w.wlen ? rfft_in(Z, i) - d4c_win_next(w, rot) * coef : 0.0;
+    }
     WH_STAMP(32, 13);
-    block_rfft<kGdRadix8 ? 3 : 4>(Z, lgn, tw, [&](int k, double re, double im) { B[k] = re * re + im * im; });
+    cfft();
+    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
+      B[2 * m] = ar * ar + ai * ai; B[2 * m + 1] = br * br + bi * bi;
+    });
     WH_STAMP(32, 14);
   }
-  d4c_dc_correct(B, cf0, fs, N, Zr);
-  WH_STAMP(32, 15);
-  d4c_smooth(B, cf0, fs, N, Zr, B, scratch);
+  dc_correct(B);
+  smooth(B, cf0, B);
   WH_STAMP(32, 16);
 
   // ---- GetStaticGroupDelay (d4c.cpp:172-188) ----------------------------------
-  for (int i = tid; i <= H; i += nt) A[i] = A[i] / B[i];
-  WH_STAMP(32, 17);
-  d4c_smooth(A, cf0 / 2.0, fs, N, Zr, A, scratch);
-  WH_STAMP(32, 18);
-  d4c_smooth(A, cf0, fs, N, Zr, B, scratch);
-  WH_STAMP(32, 19);
-  double *gd = p.gd + fi * p.gd_stride;
-  for (int i = tid; i <= H; i += nt) gd[i] = A[i] - B[i];
-  WH_STAMP(32, 20);
-}
-
-// ---------------------------------------------------------------------------
-// Stage B: one workgroup per (band, selected frame).  GetCoarseAperiodicity
-// (d4c.cpp:194-225): Nuttall-windowed slice of the group delay -> r2c -> power ->
-// share of the N/2-boundary smallest bins.  The power values never touch LDS: the
-// transform's merge step hands bin tid + q*T to thread tid, which is exactly the key
-// layout of the radix select.
-template <int NMAX>
-__global__ void __launch_bounds__(256) d4c_band(D4cParams p) {
-  constexpr int kSelKeys = SelKeys<NMAX>::n;
-  DYN_LDS(lds);
-  const int band = blockIdx.x, f = blockIdx.y, u = blockIdx.z;
-  if (f >= p.b.n_frames[u]) return;
-  const size_t fi = (size_t)u * p.b.f_stride + f;
-  const double f0 = p.f0[fi];
-  if (f0 == 0 || p.ap0[fi] <= p.threshold) return;
-  const int tid = threadIdx.x;
-  const bool trace_me = band == 2 && f == 1000; (void)trace_me;
-  WH_STAMP(0, 0);
-  const int lgn = p.lg_d4c, N = 1 << lgn, H = N / 2, fs = p.b.fs;
-  cplx *Z = reinterpret_cast<cplx *>(lds);
-  double *Zr = reinterpret_cast<double *>(lds);
-  int *hist = reinterpret_cast<int *>(Zr + N);
-  double *scratch = reinterpret_cast<double *>(hist + kSelHists * 256);
-  // table for the inner N/2-point complex transform only (the merge step derives its odd twiddles)
-  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
-  WH_STAMP(0, 1);
-  const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
-  const int bnd = mround(N * 8.0 / p.wl);
-  const int hwl = p.wl / 2;
-  const int center = static_cast<int>(3000.0 * (band + 1) * N / fs);
-  const double *gd = p.gd + fi * p.gd_stride + (center - hwl);
-  const double *nut = p.nuttall;
-  const int wl = 2 * hwl + 1;
-  unsigned long long key[kSelKeys];
 #pragma unroll
-  for (int q = 0; q < kSelKeys; ++q) key[q] = ~0ull;
-  int filled = 0;
-  // the windowed slice is short (wl of N samples): the first FFT stage reads it straight from HBM
-  block_rfft_from(Z, lgn, tw,
-    [&](int n) {
-      cplx v; v.re = 0.0; v.im = 0.0;
-      const int i = 2 * n;
-      if (i < wl) v.re = gd[i] * nut[i];
-      if (i + 1 < wl) v.im = gd[i + 1] * nut[i + 1];
-      return v;
-    },
-    [&](int k, double re, double im) {
-      (void)k;
-      key[filled < kSelKeys ? filled : kSelKeys - 1] = (unsigned long long)__double_as_longlong(re * re + im * im);
-      ++filled;
+  for (int e = 0; e < kBins; ++e) A[e] = A[e] / B[e];
+  smooth(A, cf0 / 2.0, A);
+  smooth(A, cf0, B);
+  double G[kBins];
+#pragma unroll
+  for (int e = 0; e < kBins; ++e) G[e] = A[e] - B[e];
+  WH_STAMP(32, 19);
+
+  // ---- GetCoarseAperiodicity (d4c.cpp:194-225) per 3 kHz band ------------------
+  const int bnd = mround(N * 8.0 / p.wl);
+  const int hwl = p.wl / 2, wl = 2 * hwl + 1;
+  const int nz = hwl + 1;                               // packed complex input elements that are not zero
+  int mine = 0;
+  for_bins([&](int, int) { ++mine; });
+  int *hist = reinterpret_cast<int *>(Zr);
+  for (int band = 0; band < p.nap; ++band) {
+    const int lo_k = static_cast<int>(3000.0 * (band + 1) * N / fs) - hwl;
+    __syncthreads();                                    // the previous band's histograms are done
+    for_bins([&](int slot, int k) { const int i = k - lo_k; if (i >= 0 && i < wl) Zr[i] = G[slot] * p.nuttall[i]; });
+    __syncthreads();
+    // First DIF stage with every input beyond element nz known to be zero.  The slice sits in the buffer the
+    // stage writes, so a butterfly's inputs are fetched before anybody writes.
+    auto slice = [&](int n) { cplx v; v.re = Zr[2 * n]; v.im = 2 * n + 1 < wl ? Zr[2 * n + 1] : 0.0; return v; };
+#ifdef WORLD_EMU
+    {
+      cplx head[NMAX / 2];
+      for (int n = 0; n < nz; ++n) head[n] = slice(n);
+      block_cfft_dif_head<3>(Z, plan, tw, [&](int n) { return head[n]; }, nz);
+    }
+#else
+    {
+      constexpr int R = 8;
+      const int sh = plan.lg - 3, qq = 1 << sh;         // qq == T: one butterfly per thread (launch_d4c)
+      cplx a[R];
+      const bool single = tid + qq >= nz;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { cplx z0; z0.re = 0.0; z0.im = 0.0; a[r] = tid + r * qq < nz ? slice(tid + r * qq) : z0; }
+      __syncthreads();
+      if (single) {
+#pragma unroll
+        for (int r = 1; r < R; ++r) a[r] = a[0];         // DFT of a delta
+      } else {
+        dft_reg<true, 3>(a);
+      }
+      mul_powers<3>(a, twiddle(tw, tid, plan.lg, -1));
+      const int s0 = swz(tid);
+#pragma unroll
+      for (int k = 0; k < R; ++k) Z[s0 ^ swz(k << sh)] = a[k];
+      DifStages<lgn - 1, 3, lgn - 1 - 3>::run(Z, tw);
+      __syncthreads();
+    }
+#endif
+    unsigned long long key[kBins];
+#pragma unroll
+    for (int e = 0; e < kBins; ++e) key[e] = ~0ull;
+    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
+      key[2 * m] = (unsigned long long)__double_as_longlong(ar * ar + ai * ai);
+      if (paired) key[2 * m + 1] = (unsigned long long)__double_as_longlong(br * br + bi * bi);
     });
-  WH_STAMP(0, 2);
-  double part, tot;
-  block_smallest_sum(key, filled, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
-  WH_STAMP(0, 9);
-  if (tid == 0) {
-    double c = 10 * log10(part / tot);
-    c = c + (cf0 - 100) / 50.0;                       // d4c.cpp:314-316
-    p.coarse[fi * 16 + 1 + band] = c < 0.0 ? c : 0.0;
+    double part, tot;
+    block_smallest_sum(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
+    if (tid == 0) {
+      double c = 10 * log10(part / tot);
+      c = c + (cf0 - 100) / 50.0;                       // d4c.cpp:314-316
+      p.coarse[fi * 16 + 1 + band] = c < 0.0 ? c : 0.0;
+    }
   }
+  WH_STAMP(32, 20);
 }
 
 // ---------------------------------------------------------------------------
@@ -534,13 +610,21 @@ __global__ void d4c_finish(D4cParams p) {
 
 // ---------------------------------------------------------------------------
 size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 8 + 2); }
-size_t d4c_groupdelay_lds_bytes(int lg) {
+// Z (N doubles) | scratch (64) | quarter-wave table of the inner N/2-point complex transform
+size_t d4c_frame_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(2 * N + 8 + 64 + N / 4 + 2);
+  return sizeof(double) * (size_t)(N + 64 + N / 8 + 2);
 }
-size_t d4c_band_lds_bytes(int lg) {
-  int N = 1 << lg;
-  return sizeof(double) * (size_t)(N + kSelHists * 128 + 64 + N / 8 + 2);
+int d4c_frame_threads(int lg) { return (1 << lg) / 16; }   // one radix-8 butterfly per thread and stage
+// doubles of per-frame scratch (D4cParams::gd) the frame kernel needs: its register bins, one row per slot
+size_t d4c_frame_scratch_doubles(int lg) {
+#ifdef WORLD_EMU
+  (void)lg;
+  return D4cShape<8192, 1>::kBins;                       // the one emulated thread owns every slot of the largest shape
+#else
+  const int T = d4c_frame_threads(lg), N = 1 << lg;
+  return (size_t)2 * ((N / 4 + 1 + T - 1) / T) * T;
+#endif
 }
 
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz
@@ -555,18 +639,17 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   // band 0.97 -> 0.65
   WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), p.lg_love <= 11 ? 128 : 256, d4c_love_lds_bytes(p.lg_love), stream, p);
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
-  // per-thread register arrays are sized for the internal FFT: 4096 points up to 48 kHz, 8192 up to 96 kHz
-  if (p.lg_d4c <= 12) {
-    devrt::launch_blocks("d4c_groupdelay", d4c_groupdelay<4096>, dim3(max_frames, p.b.n_utt), p.lg_d4c <= 11 ? 256 : kGdThreads,
-                         d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
-    devrt::launch_blocks("d4c_band", d4c_band<4096>, dim3(p.nap, max_frames, p.b.n_utt), p.lg_d4c <= 11 ? 128 : 256,
-                         d4c_band_lds_bytes(p.lg_d4c), stream, p);
-  } else {
-    devrt::launch_blocks("d4c_groupdelay", d4c_groupdelay<8192>, dim3(max_frames, p.b.n_utt), kGdThreads,
-                         d4c_groupdelay_lds_bytes(p.lg_d4c), stream, p);
-    devrt::launch_blocks("d4c_band", d4c_band<8192>, dim3(p.nap, max_frames, p.b.n_utt), 256,
-                         d4c_band_lds_bytes(p.lg_d4c), stream, p);
-  }
+  // one radix-8 butterfly per thread: 128 / 256 / 512 threads for the 2048- / 4096- / 8192-point internal FFT
+  // (fs <= 24 kHz / <= 48 kHz / <= 96 kHz); the register arrays are sized per shape
+  const dim3 grid(max_frames, p.b.n_utt);
+  const size_t lds = d4c_frame_lds_bytes(p.lg_d4c);
+#ifdef WORLD_EMU
+  devrt::launch_blocks("d4c_frame", d4c_frame<8192, 1>, grid, 1, lds, stream, p);
+#else
+  if (p.lg_d4c == 11) devrt::launch_blocks("d4c_frame", d4c_frame<2048, 128>, grid, 128, lds, stream, p);
+  else if (p.lg_d4c == 12) devrt::launch_blocks("d4c_frame", d4c_frame<4096, 256>, grid, 256, lds, stream, p);
+  else devrt::launch_blocks("d4c_frame", d4c_frame<8192, 512>, grid, 512, lds, stream, p);
+#endif
   WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 0, stream, p);
 }
 

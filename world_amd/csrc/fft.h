@@ -80,7 +80,7 @@ __device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign
 struct FftPlan {
   int lg, ns;
   unsigned stages;                                   // log2(radix) of stage s in nibble s (no arrays: stays in registers)
-  __host__ __device__ __forceinline__ int rl(int s) const { return (int)((stages >> (4 * s)) & 15u); }
+  constexpr __host__ __device__ int rl(int s) const { return (int)((stages >> (4 * s)) & 15u); }
 };
 __host__ __device__ __forceinline__ FftPlan make_plan(int lg) {
   FftPlan p; p.lg = lg; p.ns = 0; p.stages = 0;
@@ -91,8 +91,8 @@ __host__ __device__ __forceinline__ FftPlan make_plan(int lg) {
 }
 // the same with smaller butterflies (max_lr = 3: radix 8): twice the butterflies per stage (every thread of a 256-thread
 // workgroup stays busy on a 2048-point transform) and half the registers, for one more LDS pass
-__host__ __device__ __forceinline__ FftPlan make_plan_max(int lg, int max_lr) {
-  FftPlan p; p.lg = lg; p.ns = 0; p.stages = 0;
+constexpr __host__ __device__ FftPlan make_plan_max(int lg, int max_lr) {
+  FftPlan p{lg, 0, 0u};
   int r = lg;
   while (r >= max_lr) { p.stages |= (unsigned)max_lr << (4 * p.ns++); r -= max_lr; }
   if (r) p.stages |= (unsigned)r << (4 * p.ns++);
@@ -103,6 +103,11 @@ __host__ __device__ __forceinline__ FftPlan make_plan_r8(int lg) { return make_p
 // butterfly->thread mapping below every ds_read_b128 of every stage of every plan
 // (256..4096 points) is conflict-free in the gfx950 bank model (MI355X_MICROARCH.md
 // section LDS; brute-forced in DESIGN.md), at zero cost in LDS capacity.
+// The swizzle is linear over GF(2) (shift, mask, xor), so for index fields that do not overlap
+//     swz(base | field) = swz(base) ^ swz(field):
+// a butterfly computes swz(base) once and reaches its R elements with one XOR each against constants that are
+// uniform over the workgroup (scalar registers) -- the address arithmetic was two thirds of the FFT kernels'
+// VALU instructions (profiles/r02, SQ_INSTS_VALU against the FP64 counters).
 __device__ __forceinline__ int swz(int i) { return i ^ ((i >> 4) & 15); }
 // slot that holds bin k after the forward (DIF) transform = slot the inverse (DIT)
 // transform expects bin k in: the digits of k, least significant first, select
@@ -211,17 +216,20 @@ template <int LR> __device__ __forceinline__ void mul_powers(cplx *a, cplx w1) {
 // one decimation-in-frequency stage: sub-transforms of length 2^lev split R ways
 template <int LR> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int lev, const TwLds &tw) {
   constexpr int R = 1 << LR;
-  const int q = 1 << (lev - LR), nbf = 1 << (lg - LR);
+  const int sh = lev - LR, q = 1 << sh, nbf = 1 << (lg - LR);
+  int c[R];                                          // swz(r q): uniform
+#pragma unroll
+  for (int r = 0; r < R; ++r) c[r] = swz(r << sh);
   for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
     const int j = b & (q - 1);
-    const int base = ((b >> (lev - LR)) << lev) + j;
+    const int s0 = swz(((b >> sh) << lev) + j);      // bits [sh, lev) of the base index are clear
     cplx a[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) a[r] = z[swz(base + r * q)];
+    for (int r = 0; r < R; ++r) a[r] = z[s0 ^ c[r]];
     dft_reg<true, LR>(a);
     if (q > 1) mul_powers<LR>(a, twiddle(tw, j, lev, -1));
 #pragma unroll
-    for (int k = 0; k < R; ++k) z[swz(base + k * q)] = a[k];
+    for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = a[k];
   }
 }
 // the first DIF stage with its inputs taken from src(n) (element n of the transform) instead of LDS:
@@ -229,15 +237,47 @@ template <int LR> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int
 template <int LR, class Src>
 __device__ __forceinline__ void dif_first_stage(cplx *z, int lg, const TwLds &tw, Src src) {
   constexpr int R = 1 << LR;
-  const int q = 1 << (lg - LR);
+  const int sh = lg - LR, q = 1 << sh;
+  int c[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) c[r] = swz(r << sh);
   for (int j = threadIdx.x; j < q; j += blockDim.x) {
     cplx a[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = src(j + r * q);
     dft_reg<true, LR>(a);
     if (q > 1) mul_powers<LR>(a, twiddle(tw, j, lg, -1));
+    const int s0 = swz(j);
 #pragma unroll
-    for (int k = 0; k < R; ++k) z[swz(j + k * q)] = a[k];
+    for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = a[k];
+  }
+}
+// The same stage for an input whose elements n >= nz are zero (a short window in a long transform): a
+// butterfly with a single non-zero input is the DFT of a delta -- every output equals that input, only the
+// twiddle powers remain -- and the zero elements are never asked for.  src(n) is called for n < nz only.
+template <int LR, class Src>
+__device__ __forceinline__ void dif_first_stage_head(cplx *z, int lg, const TwLds &tw, Src src, int nz) {
+  constexpr int R = 1 << LR;
+  const int sh = lg - LR, q = 1 << sh;
+  int c[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) c[r] = swz(r << sh);
+  for (int j = threadIdx.x; j < q; j += blockDim.x) {
+    cplx a[R];
+    if (j + q >= nz) {                               // only element j itself can be non-zero
+      cplx v; v.re = 0.0; v.im = 0.0;
+      if (j < nz) v = src(j);
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { cplx v; v.re = 0.0; v.im = 0.0; a[r] = j + r * q < nz ? src(j + r * q) : v; }
+      dft_reg<true, LR>(a);
+    }
+    if (q > 1) mul_powers<LR>(a, twiddle(tw, j, lg, -1));
+    const int s0 = swz(j);
+#pragma unroll
+    for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = a[k];
   }
 }
 
@@ -245,16 +285,19 @@ __device__ __forceinline__ void dif_first_stage(cplx *z, int lg, const TwLds &tw
 template <int LR> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
   constexpr int R = 1 << LR;
   const int q = 1 << done, L = done + LR, nbf = 1 << (lg - LR);
+  int c[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) c[r] = swz(r << done);
   for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
     const int j = b & (q - 1);
-    const int base = ((b >> done) << L) + j;
+    const int s0 = swz(((b >> done) << L) + j);      // bits [done, L) of the base index are clear
     cplx a[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) a[r] = z[swz(base + r * q)];
+    for (int r = 0; r < R; ++r) a[r] = z[s0 ^ c[r]];
     if (q > 1) mul_powers<LR>(a, twiddle(tw, j, L, +1));
     dft_reg<false, LR>(a);
 #pragma unroll
-    for (int k = 0; k < R; ++k) z[swz(base + k * q)] = a[k];
+    for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = a[k];
   }
 }
 
@@ -297,6 +340,48 @@ __device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, c
     }
     lev -= p.rl(s);
   }
+  __syncthreads();
+}
+
+// forward transform of a sequence whose elements n >= nz are zero, read from src(n) (dif_first_stage_head)
+template <int MAXLR = 4, class Src>
+__device__ __forceinline__ void block_cfft_dif_head(cplx *z, const FftPlan &p, const TwLds &tw, Src src, int nz) {
+  __syncthreads();                                   // earlier readers of z are done
+  switch (p.rl(0)) {
+    case 4: if (MAXLR >= 4) dif_first_stage_head<4>(z, p.lg, tw, src, nz); break;
+    case 3: if (MAXLR >= 3) dif_first_stage_head<3>(z, p.lg, tw, src, nz); break;
+    case 2: dif_first_stage_head<2>(z, p.lg, tw, src, nz); break;
+    default: dif_first_stage_head<1>(z, p.lg, tw, src, nz); break;
+  }
+  int lev = p.lg - p.rl(0);
+  for (int s = 1; s < p.ns; ++s) {
+    __syncthreads();
+    switch (p.rl(s)) {
+      case 4: if (MAXLR >= 4) dif_stage<4>(z, p.lg, lev, tw); break;
+      case 3: if (MAXLR >= 3) dif_stage<3>(z, p.lg, lev, tw); break;
+      case 2: dif_stage<2>(z, p.lg, lev, tw); break;
+      default: dif_stage<1>(z, p.lg, lev, tw); break;
+    }
+    lev -= p.rl(s);
+  }
+  __syncthreads();
+}
+
+// ---- the same with the transform length known at compile time ---------------------------------------
+// Kernels whose shape fixes the length (d4c_frame) instantiate the stages by recursion: no stage loop, no
+// radix switch, every stride a constant -- and a constexpr plan makes the digit reversals of the merge
+// steps (fft_slot / fft_bin_of_slot) straight-line bit arithmetic.
+template <int LG, int MAXLR, int LEV> struct DifStages {
+  static __device__ __forceinline__ void run(cplx *z, const TwLds &tw) {
+    constexpr int LR = LEV >= MAXLR ? MAXLR : LEV;
+    __syncthreads();
+    dif_stage<LR>(z, LG, LEV, tw);
+    if constexpr (LEV - LR > 0) DifStages<LG, MAXLR, LEV - LR>::run(z, tw);
+  }
+};
+template <int LG, int MAXLR>
+__device__ __forceinline__ void block_cfft_dif_static(cplx *z, const TwLds &tw) {
+  DifStages<LG, MAXLR, LG>::run(z, tw);
   __syncthreads();
 }
 
@@ -383,6 +468,44 @@ __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan
       emit(r.k, r.ar, r.ai);
       if (r.k != q) emit(h - r.k, r.br, r.bi);
     });
+  __syncthreads();
+}
+
+// The merge step for callers that keep their bins in REGISTERS.  A thread's items are it = tid + m T,
+// m = 0 .. KITEMS-1 (KITEMS >= ceil((N/4 + 1) / T)); the loop over m is unrolled, so `m` is a compile-time
+// constant inside emit and arrays indexed by it stay in registers.  Item it owns the conjugate pair of bins
+// (k, h-k) with k = it IN NATURAL ORDER -- it = 0: (DC, Nyquist); it = h/2: the single bin h/2 -- so
+// consecutive lanes own consecutive bins: whatever the caller later exchanges through LDS by bin index
+// (prefix-sum segments, spectrum slices) is conflict-free, at the price of digit-reversed (2..4-way
+// conflicting) reads of the transform here.  rfft_merge above makes the opposite choice.
+//   emit(m, k, Xre[k], Xim[k], paired, Xre[h-k], Xim[h-k])        paired = false only for it = h/2
+template <int KITEMS, class Emit>
+__device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit) {
+  const int lgh = lgn - 1, h = 1 << lgh, q = h >> 1;
+  const int tid = threadIdx.x, nt = blockDim.x;
+#pragma unroll
+  for (int m = 0; m < KITEMS; ++m) {
+    const int k = tid + m * nt;
+    if (k == 0) {
+      const cplx za = z[fft_slot(plan, 0)];
+      emit(m, 0, za.re + za.im, 0.0, true, za.re - za.im, 0.0);
+    } else if (k < q) {
+      const cplx za = z[fft_slot(plan, k)], zb = z[fft_slot(plan, h - k)];
+      cplx e, o;
+      e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
+      o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
+      const cplx ow = cmul(o, twiddle(tw, k, lgn, -1));
+      emit(m, k, e.re + ow.re, e.im + ow.im, true, e.re - ow.re, ow.im - e.im);
+    } else if (k == q) {
+      const cplx za = z[fft_slot(plan, q)];            // k = h/2: w = -i, X = conj(z)
+      emit(m, q, za.re, -za.im, false, 0.0, 0.0);
+    }
+#ifndef WORLD_EMU
+    // the callers live at the edge of their register budget: keep the scheduler from hoisting all items'
+    // LDS reads to the top (10 more registers per item in flight); two items overlap, not KITEMS
+    if (m & 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
   __syncthreads();
 }
 

@@ -24,7 +24,7 @@ struct D4cParams {
   const double *f0;       // [n_utt][f_stride]
   double *aperiodicity;   // [n_utt][f_stride][fft_out/2+1]
   double *ap0;            // [n_utt][f_stride]  LoveTrain result
-  double *gd;             // [n_utt][f_stride][gd_stride] static group delay of the selected frames
+  double *gd;             // [n_utt][f_stride][gd_stride] per-frame scratch row of d4c_frame (its register bins)
   int gd_stride;
   double *coarse;         // [n_utt][f_stride][16] coarse aperiodicity (dB) per band, slot 1 + band
   unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
@@ -45,5 +45,6 @@ void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream);
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
 size_t ct_max_draws_per_frame(int fft_size);
 size_t d4c_max_draws_per_frame(int fs);
+size_t d4c_frame_scratch_doubles(int lg_d4c);
 
 }  // namespace world_hip

@@ -212,11 +212,13 @@ WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int
  * points (256 .. 8192), one workgroup each, straight from and to HBM -- the test and microbenchmark hook.
  *   rfft : d_in [batch][N] -> d_spectrum [batch][N/2+1][2] (re, im), X[k] = sum x[n] e^{-2 pi i k n / N}
  *   irfft: d_spectrum -> d_out [batch][N] = N * irfft (unscaled like the reference's c2r; Im of DC / Nyquist ignored)
- * max_lr = 3 (radix-8 plan) or 4 (radix-16 plan); threads = workgroup size, 0 = one butterfly per thread. */
-WORLD_HIP_API int world_hip_probe_rfft(WorldHipContext *ctx, int lg_n, int max_lr, int threads, long long batch,
-                                       const double *d_in, double *d_spectrum);
-WORLD_HIP_API int world_hip_probe_irfft(WorldHipContext *ctx, int lg_n, int max_lr, int threads, long long batch,
-                                        const double *d_spectrum, double *d_out);
+ * max_lr = 3 (radix-8 plan) or 4 (radix-16 plan); threads = workgroup size, 0 = one butterfly per thread;
+ * static_plan != 0 selects the instantiation whose length is a compile-time constant (what the frame kernels
+ * run: radix-8 plan, 1024 / 2048 / 4096 points), 0 the one that takes it at run time. */
+WORLD_HIP_API int world_hip_probe_rfft(WorldHipContext *ctx, int lg_n, int max_lr, int threads, int static_plan,
+                                       long long batch, const double *d_in, double *d_spectrum);
+WORLD_HIP_API int world_hip_probe_irfft(WorldHipContext *ctx, int lg_n, int max_lr, int threads, int static_plan,
+                                        long long batch, const double *d_spectrum, double *d_out);
 
 /* Multi-GPU exchange (the reference has no counterpart).  Utterances are sharded over GPUs
  * and analysed independently; a GPU's results are then packed into ONE contiguous block of records

@@ -146,7 +146,7 @@ def test_emulated_fft_matches_numpy():
     L.world_hip_create.argtypes = [C.c_int, C.c_void_p]
     L.world_hip_destroy.argtypes = [C.c_void_p]
     for f in (L.world_hip_probe_rfft, L.world_hip_probe_irfft):
-        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
     ctx = L.world_hip_create(0, None)
     try:
         rng = np.random.default_rng(3)
@@ -155,11 +155,11 @@ def test_emulated_fft_matches_numpy():
             for max_lr in (3, 4):
                 x = rng.standard_normal((3, n))
                 X = np.zeros((3, n // 2 + 1, 2))
-                assert L.world_hip_probe_rfft(ctx, lg, max_lr, 0, 3, x.ctypes.data, X.ctypes.data) == 0
+                assert L.world_hip_probe_rfft(ctx, lg, max_lr, 0, 0, 3, x.ctypes.data, X.ctypes.data) == 0
                 ref = np.fft.rfft(x, axis=1)
                 assert np.abs(X[..., 0] + 1j * X[..., 1] - ref).max() < 1e-13 * np.abs(ref).max()
                 y = np.zeros((3, n))
-                assert L.world_hip_probe_irfft(ctx, lg, max_lr, 0, 3, X.ctypes.data, y.ctypes.data) == 0
+                assert L.world_hip_probe_irfft(ctx, lg, max_lr, 0, 0, 3, X.ctypes.data, y.ctypes.data) == 0
                 assert np.abs(y / n - x).max() < 1e-13
     finally:
         L.world_hip_destroy(ctx)

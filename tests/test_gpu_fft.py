@@ -57,6 +57,23 @@ def test_block_irfft_matches_numpy(wh, lg, max_lr):
         assert err < 2e-15 * lg, (lg, max_lr, threads, err)
 
 
+@pytest.mark.parametrize("lg", [10, 11, 12])
+def test_compile_time_plan_instantiations_match_numpy(wh, lg):
+    """the instantiations the frame kernels run (length a compile-time constant: static stages, constexpr digit
+    reversal) against numpy and, bit for bit, against the run-time-length instantiation of the same plan"""
+    import torch
+    n = 1 << lg
+    x = torch.from_numpy(_signals(29, n, 7 * lg)).cuda()
+    ref = np.fft.rfft(x.cpu().numpy(), axis=1)
+    got = wh.probe_rfft(x, max_lr=3, static_plan=True)
+    g = got.cpu().numpy()
+    assert (np.abs(g[..., 0] + 1j * g[..., 1] - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() < 2e-15 * lg
+    assert torch.equal(got, wh.probe_rfft(x, max_lr=3, static_plan=False))
+    back = wh.probe_irfft(got, max_lr=3, static_plan=True)
+    assert torch.equal(back, wh.probe_irfft(got, max_lr=3, static_plan=False))
+    assert float((back / n - x).abs().max()) < 1e-14 * lg
+
+
 def test_roundtrip_is_identity_at_path_sizes(wh):
     """c2r(r2c(x)) = N x: the pair the CheapTrick liftering runs (cheaptrick.cpp:22-57) loses nothing"""
     import torch

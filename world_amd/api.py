@@ -82,8 +82,8 @@ def load_library(path=LIB_PATH):
     lib.world_hip_pcm16_to_double.argtypes = [vp, C.c_longlong, vp, vp]
     lib.world_hip_set_synthesis_pulse_capacity.argtypes = [vp, C.c_int]
     lib.world_hip_synthesis_pulses_dropped.argtypes = [vp, _ip]
-    lib.world_hip_probe_rfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
-    lib.world_hip_probe_irfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
+    lib.world_hip_probe_rfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
+    lib.world_hip_probe_irfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
     lib.world_hip_pack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, vp, vp, vp, C.c_longlong, vp]
     lib.world_hip_unpack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, C.c_longlong, vp, vp, vp, vp]
     lib.world_hip_allgather_blocks.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_longlong), C.c_int,
@@ -495,7 +495,7 @@ class WorldHip:
         return y
 
     # ---- the per-frame FFT in isolation (include/world_hip.h: world_hip_probe_rfft) ----
-    def probe_rfft(self, x, max_lr=3, threads=0, out=None):
+    def probe_rfft(self, x, max_lr=3, threads=0, out=None, static_plan=False):
         """x [batch, N] float64 -> [batch, N/2+1, 2] (re, im) by csrc/fft.h's block_rfft, one workgroup per row"""
         t = self.torch
         assert x.dtype == t.float64 and x.dim() == 2 and x.is_contiguous()
@@ -503,11 +503,12 @@ class WorldHip:
         lg = N.bit_length() - 1
         assert 1 << lg == N
         out = out if out is not None else t.empty((batch, N // 2 + 1, 2), dtype=t.float64, device=x.device)
-        self._check(self.lib.world_hip_probe_rfft(self._context(), lg, max_lr, threads, batch, x.data_ptr(), out.data_ptr()),
+        self._check(self.lib.world_hip_probe_rfft(self._context(), lg, max_lr, threads, int(static_plan), batch, x.data_ptr(),
+                                                  out.data_ptr()),
                     "probe_rfft")
         return out
 
-    def probe_irfft(self, spec, max_lr=3, threads=0, out=None):
+    def probe_irfft(self, spec, max_lr=3, threads=0, out=None, static_plan=False):
         """spec [batch, N/2+1, 2] -> [batch, N] = N * irfft (the reference's unscaled c2r) by block_irfft"""
         t = self.torch
         assert spec.dtype == t.float64 and spec.dim() == 3 and spec.is_contiguous()
@@ -515,7 +516,8 @@ class WorldHip:
         lg = N.bit_length() - 1
         assert 1 << lg == N
         out = out if out is not None else t.empty((batch, N), dtype=t.float64, device=spec.device)
-        self._check(self.lib.world_hip_probe_irfft(self._context(), lg, max_lr, threads, batch, spec.data_ptr(), out.data_ptr()),
+        self._check(self.lib.world_hip_probe_irfft(self._context(), lg, max_lr, threads, int(static_plan), batch, spec.data_ptr(),
+                                                   out.data_ptr()),
                     "probe_irfft")
         return out
 

@@ -184,7 +184,9 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
     if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
     max_frames = std::max(max_frames, n_frames[u]);
   }
-  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 3 * pad256(sizeof(int) * n_utt);
+  const int seg_stride = ct_seg_stride(opt->fft_size);
+  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 3 * pad256(sizeof(int) * n_utt) +
+                pad256(sizeof(double) * (size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * seg_stride);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   CtParams p;
@@ -193,6 +195,8 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
   p.b.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
   p.tpos = d_tpos; p.f0 = d_f0; p.spectrogram = d_sp;
   p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
+  p.seg = c->arena.take<double>((size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * seg_stride);
+  p.seg_stride = seg_stride;
   p.noise = ensure_noise(c, (size_t)max_frames * ct_max_draws_per_frame(opt->fft_size));
   p.tab = c->tab;
   p.q1 = opt->q1;
@@ -1066,8 +1070,8 @@ int world_hip_synthesis_batch(WorldHipContext *c, int n_utt, int fs, double fram
 }
 
 // fft.h in isolation (fft_probe.hip): `batch` real transforms of 2^lg_n points, one workgroup each
-static void run_fft_probe(WorldHipContext *c, bool inverse, int lg_n, int max_lr, int threads, long long batch,
-                          const void *d_in, void *d_out) {
+static void run_fft_probe(WorldHipContext *c, bool inverse, int lg_n, int max_lr, int threads, int static_plan,
+                          long long batch, const void *d_in, void *d_out) {
   if (lg_n < 8 || lg_n > kTwLog2) fail("probe: 2^%d points unsupported (256 .. %d)", lg_n, kTwN);
   if (max_lr != 3 && max_lr != 4) fail("probe: max_lr must be 3 (radix-8 plan) or 4 (radix-16 plan)");
   if (threads == 0) threads = std::max(64, (1 << lg_n) >> (max_lr + 1));      // one butterfly per thread and stage
@@ -1075,15 +1079,16 @@ static void run_fft_probe(WorldHipContext *c, bool inverse, int lg_n, int max_lr
   if (batch < 0 || batch > 0x7FFFFFFFll) fail("probe: bad batch");
   if (batch == 0) return;
   if (!d_in || !d_out) fail("null buffer");
-  launch_fft_probe(inverse, lg_n, max_lr, threads, (long)batch, d_in, d_out, c->tab, c->stream);
+  if (static_plan && !fft_probe_has_static(lg_n, max_lr)) fail("probe: no compile-time plan for 2^%d points, max_lr %d", lg_n, max_lr);
+  launch_fft_probe(inverse, lg_n, max_lr, threads, static_plan != 0, (long)batch, d_in, d_out, c->tab, c->stream);
 }
-int world_hip_probe_rfft(WorldHipContext *c, int lg_n, int max_lr, int threads, long long batch, const double *d_in,
-                         double *d_spectrum) {
-  return guarded(c, [&] { run_fft_probe(c, false, lg_n, max_lr, threads, batch, d_in, d_spectrum); });
+int world_hip_probe_rfft(WorldHipContext *c, int lg_n, int max_lr, int threads, int static_plan, long long batch,
+                         const double *d_in, double *d_spectrum) {
+  return guarded(c, [&] { run_fft_probe(c, false, lg_n, max_lr, threads, static_plan, batch, d_in, d_spectrum); });
 }
-int world_hip_probe_irfft(WorldHipContext *c, int lg_n, int max_lr, int threads, long long batch, const double *d_spectrum,
-                          double *d_out) {
-  return guarded(c, [&] { run_fft_probe(c, true, lg_n, max_lr, threads, batch, d_spectrum, d_out); });
+int world_hip_probe_irfft(WorldHipContext *c, int lg_n, int max_lr, int threads, int static_plan, long long batch,
+                          const double *d_spectrum, double *d_out) {
+  return guarded(c, [&] { run_fft_probe(c, true, lg_n, max_lr, threads, static_plan, batch, d_spectrum, d_out); });
 }
 
 int world_hip_pack_results(WorldHipContext *c, int n_utt, const int *n_frames, int f_stride, int bins,

@@ -50,6 +50,7 @@ static inline unsigned __brev(unsigned v) {
   return r;
 }
 static inline double cospi(double x) { return cos(3.14159265358979323846 * x); }
+static inline double sinpi(double x) { return sin(3.14159265358979323846 * x); }
 static inline void sincospi(double x, double *s, double *c) {
   *s = sin(3.14159265358979323846 * x);
   *c = cos(3.14159265358979323846 * x);

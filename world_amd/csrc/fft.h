@@ -384,6 +384,28 @@ __device__ __forceinline__ void block_cfft_dif_static(cplx *z, const TwLds &tw) 
   DifStages<LG, MAXLR, LG>::run(z, tw);
   __syncthreads();
 }
+template <int LG, int MAXLR, class Src>
+__device__ __forceinline__ void block_cfft_dif_from_static(cplx *z, const TwLds &tw, Src src) {
+  constexpr int LR = LG >= MAXLR ? MAXLR : LG;
+  __syncthreads();                                   // earlier readers of z are done
+  dif_first_stage<LR>(z, LG, tw, src);
+  if constexpr (LG - LR > 0) DifStages<LG, MAXLR, LG - LR>::run(z, tw);
+  __syncthreads();
+}
+// inverse: the plan's stages in reverse order -- the remainder stage (if any) first, then the MAXLR ones
+template <int LG, int MAXLR, int DONE> struct DitStages {
+  static __device__ __forceinline__ void run(cplx *z, const TwLds &tw) {
+    constexpr int LR = (DONE == 0 && LG % MAXLR != 0) ? LG % MAXLR : MAXLR;
+    __syncthreads();
+    dit_stage<LR>(z, LG, DONE, tw);
+    if constexpr (DONE + LR < LG) DitStages<LG, MAXLR, DONE + LR>::run(z, tw);
+  }
+};
+template <int LG, int MAXLR>
+__device__ __forceinline__ void block_cfft_dit_static(cplx *z, const TwLds &tw) {
+  DitStages<LG, MAXLR, 0>::run(z, tw);
+  __syncthreads();
+}
 
 // ---- inverse (unscaled): bin k at slot fft_slot(plan, k) in -> element n at slot swz(n) out ----
 template <int MAXLR = 4>
@@ -415,18 +437,32 @@ __device__ __forceinline__ double &rfft_in(cplx *z, int n) {
 template <class Emit>
 __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit);
 
-template <int MAXLR = 4, class Emit>
+// LGN > 0: the transform length 2^LGN is a compile-time constant of the caller (static stages, constexpr plan);
+// LGN = 0: taken from `lgn` at run time.
+template <int MAXLR = 4, int LGN = 0, class Emit>
 __device__ __forceinline__ void block_rfft(cplx *z, int lgn, const TwLds &tw, Emit emit) {
-  const FftPlan plan = make_plan_max(lgn - 1, MAXLR);
-  block_cfft_dif<MAXLR>(z, plan, tw);
-  rfft_merge(z, lgn, plan, tw, emit);
+  if constexpr (LGN > 0) {
+    constexpr FftPlan plan = make_plan_max(LGN - 1, MAXLR);
+    block_cfft_dif_static<LGN - 1, MAXLR>(z, tw);
+    rfft_merge(z, LGN, plan, tw, emit);
+  } else {
+    const FftPlan plan = make_plan_max(lgn - 1, MAXLR);
+    block_cfft_dif<MAXLR>(z, plan, tw);
+    rfft_merge(z, lgn, plan, tw, emit);
+  }
 }
 // same transform with the packed input supplied by src(n) = (x[2n], x[2n+1]), n < N/2: z is pure workspace
-template <int MAXLR = 4, class Src, class Emit>
+template <int MAXLR = 4, int LGN = 0, class Src, class Emit>
 __device__ __forceinline__ void block_rfft_from(cplx *z, int lgn, const TwLds &tw, Src src, Emit emit) {
-  const FftPlan plan = make_plan_max(lgn - 1, MAXLR);
-  block_cfft_dif_from<MAXLR>(z, plan, tw, src);
-  rfft_merge(z, lgn, plan, tw, emit);
+  if constexpr (LGN > 0) {
+    constexpr FftPlan plan = make_plan_max(LGN - 1, MAXLR);
+    block_cfft_dif_from_static<LGN - 1, MAXLR>(z, tw, src);
+    rfft_merge(z, LGN, plan, tw, emit);
+  } else {
+    const FftPlan plan = make_plan_max(lgn - 1, MAXLR);
+    block_cfft_dif_from<MAXLR>(z, plan, tw, src);
+    rfft_merge(z, lgn, plan, tw, emit);
+  }
 }
 template <class Emit>
 __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit) {
@@ -512,10 +548,9 @@ __device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan
 // ---- real inverse transform (unscaled: N * irfft, like the reference's c2r) ----
 // spec(k) returns X[k] for k in [0, N/2] (the imaginary part of DC and Nyquist
 // is ignored, src/fft.cpp:28-29).  On return real output n is rfft_in(z, n).
-template <int MAXLR = 4, class Spec>
-__device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, Spec spec) {
+template <class Spec>
+__device__ __forceinline__ void irfft_pretwiddle(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Spec spec) {
   const int lgh = lgn - 1, h = 1 << lgh;
-  const FftPlan plan = make_plan_max(lgh, MAXLR);
   __syncthreads();
   // Pre-twiddle in conjugate pairs, walking physical slots like rfft_merge: with s = X[k] +
   // conj(X[h-k]), t = w_k (X[k] - conj(X[h-k])):  Z[k] = s + i t  and  Z[h-k] = conj(s - i t).
@@ -551,7 +586,18 @@ __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, S
       z[o.slot] = o.r;
       if (o.mslot >= 0) z[o.mslot] = o.rm;
     });
-  block_cfft_dit<MAXLR>(z, plan, tw);
+}
+template <int MAXLR = 4, int LGN = 0, class Spec>
+__device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, Spec spec) {
+  if constexpr (LGN > 0) {
+    constexpr FftPlan plan = make_plan_max(LGN - 1, MAXLR);
+    irfft_pretwiddle(z, LGN, plan, tw, spec);
+    block_cfft_dit_static<LGN - 1, MAXLR>(z, tw);
+  } else {
+    const FftPlan plan = make_plan_max(lgn - 1, MAXLR);
+    irfft_pretwiddle(z, lgn, plan, tw, spec);
+    block_cfft_dit<MAXLR>(z, plan, tw);
+  }
 }
 
 }  // namespace world_hip

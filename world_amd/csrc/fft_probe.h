@@ -4,6 +4,7 @@
 #include "tables.h"
 
 namespace world_hip {
-void launch_fft_probe(bool inverse, int lgn, int max_lr, int threads, long batch, const void *d_in, void *d_out,
-                      const Tables &tab, hipStream_t stream);
+bool fft_probe_has_static(int lgn, int max_lr);
+void launch_fft_probe(bool inverse, int lgn, int max_lr, int threads, bool static_plan, long batch, const void *d_in,
+                      void *d_out, const Tables &tab, hipStream_t stream);
 }

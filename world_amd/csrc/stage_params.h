@@ -11,6 +11,8 @@ struct CtParams {
   const double *f0;      // [n_utt][f_stride]
   double *spectrogram;   // [n_utt][f_stride][fft/2+1]
   unsigned *offsets;     // [n_utt][f_stride] stream position of each frame's first draw
+  double *seg;           // [n_utt][ceil(f_stride / WAVE)][seg_stride][WAVE] LinearSmoothing's mirrored segment / prefix sums
+  int seg_stride;
   const uint32_t *noise; // randn_value(noise[k]) = k-th randn() of the stream (context-wide table)
   Tables tab;
   double q1;
@@ -44,6 +46,7 @@ struct D4cParams {
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream);
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
 size_t ct_max_draws_per_frame(int fft_size);
+int ct_seg_stride(int fft_size);
 size_t d4c_max_draws_per_frame(int fs);
 size_t d4c_frame_scratch_doubles(int lg_d4c);
 

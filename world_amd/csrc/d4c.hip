@@ -176,10 +176,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     if (q < mine) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
   for (int i = tid; i < kSelHists * 256; i += nt) hist[i] = 0;
 #ifndef WORLD_EMU
-  for (int s = 32; s >= 1; s >>= 1) {
-    unsigned long long a = __shfl_xor(kmin, s, 64), b = __shfl_xor(kmax, s, 64);
-    kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
-  }
+  wave_minmax_u64(kmin, kmax);
   unsigned long long *ks = reinterpret_cast<unsigned long long *>(scratch);
   __syncthreads();
   if (lane == 0) { ks[wv] = kmin; ks[32 + wv] = kmax; }

@@ -99,6 +99,7 @@ void launch_blocks(const char * /*name*/, K kernel, dim3 grid, int /*threads*/, 
 #else
 // ------------------------------------------------------------------ gfx950
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #define WAVE 64
 #define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
 namespace devrt {
@@ -214,22 +215,113 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// ---- cross-lane moves without LDS ---------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 (two per double), an LDS-pipe round trip per level: ~700 cycles for a
+// 64-lane FP64 reduction, and the refinement / tracking kernels do hundreds of them per frame.  Within a row
+// of 16 lanes the same exchanges are DPP modifiers of a v_mov (quad permutes, mirrors, rotations: a few cycles);
+// the four row results are then read with v_readlane.  For a commutative reduction the mirrors pair the same
+// partial results as xor 4 / xor 8 would (the operands are uniform within the groups already reduced).
+#ifndef WORLD_EMU
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;           // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141, kDppMirror = 0x140;  // lane i <-> 7 - i within 8, i <-> 15 - i within 16
+constexpr int kDppRor8 = 0x128;                            // row_ror:8 == xor 8 within a row
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// sum over aligned groups of 8 / 16 lanes, every lane of the group gets it (bitwise what the xor butterfly gives)
+__device__ __forceinline__ double oct_sum(double v) {
+  v += dpp_f64<kDppXor1>(v); v += dpp_f64<kDppXor2>(v); v += dpp_f64<kDppHalfMirror>(v);
+  return v;
+}
+__device__ __forceinline__ double row_sum(double v) { v = oct_sum(v); v += dpp_f64<kDppMirror>(v); return v; }
+#endif
+
 // wave collectives (every lane gets the result)
 __device__ __forceinline__ double wave_sum(double v) {
 #ifndef WORLD_EMU
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v = row_sum(v);
+  v = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 #endif
   return v;
 }
 __device__ __forceinline__ int wave_sum_int(int v) {
 #ifndef WORLD_EMU
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += dpp_i32<kDppXor1>(v); v += dpp_i32<kDppXor2>(v); v += dpp_i32<kDppHalfMirror>(v); v += dpp_i32<kDppMirror>(v);
+  v = (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+      (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 #endif
   return v;
 }
 __device__ __forceinline__ int wave_max_int(int v) {
 #ifndef WORLD_EMU
-  for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+  int o;
+  o = dpp_i32<kDppXor1>(v); v = o > v ? o : v;
+  o = dpp_i32<kDppXor2>(v); v = o > v ? o : v;
+  o = dpp_i32<kDppHalfMirror>(v); v = o > v ? o : v;
+  o = dpp_i32<kDppMirror>(v); v = o > v ? o : v;
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
+            d = __builtin_amdgcn_readlane(v, 48);
+  const int ab = a > b ? a : b, cd = c > d ? c : d;
+  v = ab > cd ? ab : cd;
+#endif
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#ifndef WORLD_EMU
+  double o;
+  o = dpp_f64<kDppXor1>(v); v = o > v ? o : v;
+  o = dpp_f64<kDppXor2>(v); v = o > v ? o : v;
+  o = dpp_f64<kDppHalfMirror>(v); v = o > v ? o : v;
+  o = dpp_f64<kDppMirror>(v); v = o > v ? o : v;
+  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+  const double ab = a > b ? a : b, cd = c > d ? c : d;
+  v = ab > cd ? ab : cd;
+#endif
+  return v;
+}
+// min and max of one unsigned 64-bit key per lane (the radix select's key range)
+__device__ __forceinline__ void wave_minmax_u64(unsigned long long &lo, unsigned long long &hi) {
+#ifndef WORLD_EMU
+  auto mov = [](unsigned long long v, auto ctrl) {
+    const int l = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, decltype(ctrl)::value, 0xf, 0xf, true);
+    const int h = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), decltype(ctrl)::value, 0xf, 0xf, true);
+    return ((unsigned long long)(unsigned)h << 32) | (unsigned)l;
+  };
+  auto step = [&](auto ctrl) {
+    const unsigned long long a = mov(lo, ctrl), b = mov(hi, ctrl);
+    lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+  };
+  step(std::integral_constant<int, kDppXor1>{}); step(std::integral_constant<int, kDppXor2>{});
+  step(std::integral_constant<int, kDppHalfMirror>{}); step(std::integral_constant<int, kDppMirror>{});
+  auto rl = [](unsigned long long v, int lane) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  };
+  unsigned long long l = rl(lo, 0), h = rl(hi, 0);
+#pragma unroll
+  for (int r = 16; r < 64; r += 16) {
+    const unsigned long long a = rl(lo, r), b = rl(hi, r);
+    l = a < l ? a : l; h = b > h ? b : h;
+  }
+  lo = l; hi = h;
+#endif
+}
+__device__ __forceinline__ double wave_min(double v) {
+#ifndef WORLD_EMU
+  double o;
+  o = dpp_f64<kDppXor1>(v); v = o < v ? o : v;
+  o = dpp_f64<kDppXor2>(v); v = o < v ? o : v;
+  o = dpp_f64<kDppHalfMirror>(v); v = o < v ? o : v;
+  o = dpp_f64<kDppMirror>(v); v = o < v ? o : v;
+  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+  const double ab = a < b ? a : b, cd = c < d ? c : d;
+  v = ab < cd ? ab : cd;
 #endif
   return v;
 }

@@ -264,7 +264,9 @@ __global__ void hv_refine(HarvestParams p) {
   wave_sync();
   WH_ACC_END(0);
 
-  // Lane roles: harmonic h = lane % LH, sample phase g = lane / LH.  Slots are visited
+  // Lane roles: harmonic h = lane / G, sample phase g = lane % G -- the phases of a harmonic sit in eight
+  // neighbouring lanes, so the per-candidate reduction over phases is three DPP steps (oct_sum: no LDS), and
+  // the reduction over harmonics, which crosses rows of 16 lanes, is paid once per track in the deferred tail.  Slots are visited
   // track by track (j outer, the 7 neighbouring source frames m inner): consecutive
   // candidates then differ by a fraction of a Hz, so they usually share the window length
   // -- and with it the windowed samples and often the harmonic bin indices.  Whatever is
@@ -275,7 +277,7 @@ __global__ void hv_refine(HarvestParams p) {
   constexpr int G = WAVE / LH;                                    // sample phases
   constexpr int kIter = (6 + LH - 1) / LH;                        // harmonic groups per lane (1 on the GPU)
   constexpr int kM = (7 + G - 1) / G;                             // deferred slots per lane (1 on the GPU)
-  const int hl = lane % LH, g = lane / LH;
+  const int hl = lane / G, g = lane % G;
   int c_hw = -1, c_first = 0;                                      // window held in LDS
   int c_idx[kIter];
   double c_are[kIter], c_aim[kIter], c_dre[kIter], c_dim[kIter];   // reduced DFT sums of the previous candidate
@@ -369,10 +371,8 @@ __global__ void hv_refine(HarvestParams p) {
           dre = C * wl.x + D * wl.y; dim = D * wl.x - C * wl.y;
         }
 #ifndef WORLD_EMU
-        for (int s = LH; s < WAVE; s <<= 1) {
-          are += __shfl_xor(are, s, 64); aim += __shfl_xor(aim, s, 64);
-          dre += __shfl_xor(dre, s, 64); dim += __shfl_xor(dim, s, 64);
-        }
+        static_assert(G == 8, "oct_sum reduces over eight sample phases");
+        are = oct_sum(are); aim = oct_sum(aim); dre = oct_sum(dre); dim = oct_sum(dim);
 #endif
         c_idx[hi] = h < nh ? idx : -1;
         c_are[hi] = are; c_aim[hi] = aim; c_dre[hi] = dre; c_dim[hi] = dim;
@@ -409,7 +409,9 @@ __global__ void hv_refine(HarvestParams p) {
         }
       }
 #ifndef WORLD_EMU
-      for (int s = 1; s < LH; s <<= 1) {
+      // over the harmonics: lane bits 3..5 (xor 8 stays inside a DPP row, 16 and 32 cross rows)
+      num += dpp_f64<kDppRor8>(num); den += dpp_f64<kDppRor8>(den); sc += dpp_f64<kDppRor8>(sc);
+      for (int s = 2 * G; s < WAVE; s <<= 1) {
         num += __shfl_xor(num, s, 64); den += __shfl_xor(den, s, 64); sc += __shfl_xor(sc, s, 64);
       }
 #endif

@@ -80,25 +80,47 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
     if (a.force_ends && (i == 0 || i == nf - 1)) return false;
     return in[i] > 0;
   };
-  int n_start = 0, n_end = 0;
-  for (int base = 0; base < nf; base += blockDim.x) {
-    int f = base + threadIdx.x;
-    bool v = f < nf && voiced(f);
-    int is_start = v && !voiced(f - 1), is_end = v && !voiced(f + 1);
-    // starts in the low half-word, ends in the high one: one scan for both
-    int tot, off = block_excl_scan_int(is_start | (is_end << 16), &tot, scratch);
-    const int off_s = off & 0xFFFF, off_e = off >> 16;
-    if (is_start && n_start + off_s < p.sec_cap) st[n_start + off_s] = f;
-    if (is_end && n_end + off_e < p.sec_cap) ed[n_end + off_e] = f;
-    n_start += tot & 0xFFFF; n_end += tot >> 16;
+  // every thread owns a run of consecutive frames: ONE block scan for the whole utterance (a scan per 1024
+  // frames cost ten barrier rounds, 22 us per launch)
+  const int chunk = (nf + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int lo = (int)threadIdx.x * chunk, hi = imin(nf, lo + chunk);
+  int mine = 0;                                            // starts in the low half-word, ends in the high one
+  {
+    bool prev = voiced(lo - 1), cur = voiced(lo);
+    for (int f = lo; f < hi; ++f) {
+      const bool next = voiced(f + 1);
+      if (cur && !prev) mine += 1;
+      if (cur && !next) mine += 1 << 16;
+      prev = cur; cur = next;
+    }
+  }
+  int tot, at = block_excl_scan_int(mine, &tot, scratch);
+  const int n_start = tot & 0xFFFF;
+  {
+    int at_s = at & 0xFFFF, at_e = at >> 16;
+    bool prev = voiced(lo - 1), cur = voiced(lo);
+    for (int f = lo; f < hi; ++f) {
+      const bool next = voiced(f + 1);
+      if (cur && !prev) { if (at_s < p.sec_cap) st[at_s] = f; ++at_s; }
+      if (cur && !next) { if (at_e < p.sec_cap) ed[at_e] = f; ++at_e; }
+      prev = cur; cur = next;
+    }
   }
   __syncthreads();
   const int ns = imin(n_start, p.sec_cap);
   if (threadIdx.x == 0) {
     p.sec_n[u * 2] = ns;
     p.sec_n[u * 2 + 1] = 0;
-    int acc = 0;
-    for (int k = 0; k < ns; ++k) { off[k] = acc; acc += ed[k] - st[k] + 1 + a.extra; }
+  }
+  // offsets of the sections' private slices: exclusive scan of their lengths (a serial loop of one thread over
+  // global memory here cost ~1 us per section: 20 us per launch, three launches per job)
+  int running = 0;
+  for (int base = 0; base < ns; base += blockDim.x) {
+    const int k = base + threadIdx.x;
+    const int len = k < ns ? ed[k] - st[k] + 1 + a.extra : 0;
+    int tot, at = block_excl_scan_int(len, &tot, scratch);
+    if (k < ns) off[k] = running + at;
+    running += tot;
   }
 }
 
@@ -187,8 +209,7 @@ __global__ void hc_extend(HarvestParams p) {
         }
 #ifndef WORLD_EMU
         {
-          double dmin = best_d;
-          for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(dmin, m, 64); dmin = o < dmin ? o : dmin; }
+          const double dmin = wave_min(best_d);              // DPP + readlane: no LDS round trips on the frame-to-frame chain
           const int mine = best_d == dmin ? best_i : -1;        // several lanes tie only exceptionally
           const unsigned long long tied = __ballot(mine >= 0);
           int win = -1;
@@ -231,13 +252,12 @@ __device__ __forceinline__ double wave_best_score(double f0, const double *c, co
   double r = 0.0;                                        // SearchScore (:901-907)
   for (int i = lane_id(); i < nslot; i += WAVE)
     if (f0 == c[i] && r < s[i]) r = s[i];
-#ifndef WORLD_EMU
-  for (int m = 32; m >= 1; m >>= 1) { double o = __shfl_xor(r, m, 64); r = o > r ? o : r; }
-#endif
-  return r;
+  return wave_max(r);
 }
 
+constexpr int kMergeLdsSections = 512;   // section records a wavefront keeps in LDS (longer lists stay in HBM)
 __global__ void hc_merge(HarvestParams p) {
+  DYN_LDS(lds);
   const int u = wave_item_x();
   if (u >= p.b.n_utt) return;
   const int lane = lane_id(), nf = p.nfb[u], nslot = p.nc[u] * 7;
@@ -247,6 +267,22 @@ __global__ void hc_merge(HarvestParams p) {
   int *b_st = sec + 2 * p.sec_cap, *b_ed = sec + 3 * p.sec_cap;
   int *s_off = sec + 4 * p.sec_cap, *s_lo = sec + 5 * p.sec_cap;
   const double *sums = p.sec_sum + (size_t)u * p.sec_cap;
+  // The ordered part below is ONE lane walking the section records; from HBM every dependent access costs a
+  // microsecond (88 us for ~30 sections).  The records of a normal utterance fit LDS.
+  if (ns <= kMergeLdsSections) {
+    char *mine = lds + (size_t)wave_in_block() * kMergeLdsSections * (5 * sizeof(int) + sizeof(double));
+    double *l_sum = reinterpret_cast<double *>(mine);
+    int *l = reinterpret_cast<int *>(l_sum + kMergeLdsSections);
+    for (int k = lane; k < ns; k += WAVE) {
+      l_sum[k] = sums[k];
+      l[k] = 0; l[kMergeLdsSections + k] = b_st[k]; l[2 * kMergeLdsSections + k] = b_ed[k];
+      l[3 * kMergeLdsSections + k] = s_off[k]; l[4 * kMergeLdsSections + k] = s_lo[k];
+    }
+    order = l; b_st = l + kMergeLdsSections; b_ed = l + 2 * kMergeLdsSections;
+    s_off = l + 3 * kMergeLdsSections; s_lo = l + 4 * kMergeLdsSections;
+    sums = l_sum;
+    wave_sync();
+  }
   const double *ext = p.ext + (size_t)u * p.ext_cap;
   const double *step2 = hc_row(p.c2, p, u);
   double *out = hc_row(p.c3, p, u);
@@ -282,16 +318,34 @@ __global__ void hc_merge(HarvestParams p) {
   }
   wave_sync();
   kept = wave_bcast_int(kept, 0);
+  // out[f] = value(f) for f in [lo, hi]: eight loads in flight per lane (a plain loop has each iteration's load
+  // wait behind the previous store: one trip to HBM per 64 frames, 80 us for the 10 001 frames of a 10 s utterance)
+  auto fill = [&](int lo, int hi, auto value) __attribute__((always_inline)) {
+    constexpr int kB = 8;
+    for (int f0 = lo + lane; f0 <= hi; f0 += kB * WAVE) {
+      double v[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) v[q] = f0 + q * WAVE <= hi ? value(f0 + q * WAVE) : 0.0;
+#pragma unroll
+      for (int q = 0; q < kB; ++q) if (f0 + q * WAVE <= hi) out[f0 + q * WAVE] = v[q];
+    }
+  };
   if (kept == 0) {
-    for (int f = lane; f < nf; f += WAVE) out[f] = step2[f];
+    fill(0, nf - 1, [&](int f) { return step2[f]; });
     return;
   }
   // value of channel `ch` at frame f: its slice inside its extended run, zero elsewhere
   auto chan = [&](int ch, int f) {
     return (f >= b_st[ch] && f <= b_ed[ch]) ? ext[s_off[ch] + (f - s_lo[ch])] : 0.0;
   };
+  // the same for a whole range, the channel's record read once
+  auto fill_chan = [&](int lo, int hi, int ch) __attribute__((always_inline)) {
+    const int c_st = b_st[ch], c_ed = b_ed[ch];
+    const double *src = ext + s_off[ch] - s_lo[ch];
+    fill(lo, hi, [&](int f) { return (f >= c_st && f <= c_ed) ? src[f] : 0.0; });
+  };
   // MergeF0 (:937-963)
-  for (int f = lane; f < nf; f += WAVE) out[f] = chan(0, f);
+  fill_chan(0, nf - 1, 0);
   wave_sync();
   int cur_st = b_st[0], cur_ed = b_ed[0];                 // the reference's boundary_list[0], [1]
   for (int i = 1; i < kept; ++i) {
@@ -300,7 +354,7 @@ __global__ void hc_merge(HarvestParams p) {
     const int st2 = o == 0 ? cur_st : b_st[o];
     const int ed2 = o == 0 ? cur_ed : b_ed[o];
     if (st2 - cur_ed > 0) {
-      for (int f = st2 + lane; f <= ed2; f += WAVE) out[f] = chan(o, f);
+      fill_chan(st2, ed2, o);
       cur_st = st2; cur_ed = ed2;
     } else {
       // MergeF0Sub (:912-932)
@@ -311,8 +365,8 @@ __global__ void hc_merge(HarvestParams p) {
         s1 += wave_best_score(out[f], cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
         s2 += wave_best_score(chan(o, f), cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
       }
-      if (s1 > s2) { for (int f = ed1 + lane; f <= ed2; f += WAVE) out[f] = chan(o, f); }
-      else { for (int f = st2 + lane; f <= ed2; f += WAVE) out[f] = chan(o, f); }
+      if (s1 > s2) fill_chan(ed1, ed2, o);
+      else fill_chan(st2, ed2, o);
       cur_ed = ed2;
     }
     wave_sync();
@@ -421,7 +475,7 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
   WH_WAVES(hc_extend, p.sec_cap, B, 1, 0, stream, p);
-  WH_WAVES(hc_merge, B, 1, 1, 0, stream, p);
+  WH_WAVES(hc_merge, B, 1, 1, kMergeLdsSections * (5 * sizeof(int) + sizeof(double)), stream, p);
   devrt::d2d(p.c0, p.c3, row_bytes, stream);
   SecArgs a3 = {p.c3, 1, 0};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a3);

@@ -64,6 +64,8 @@ struct HarvestBands {            // cached per (fs, f0_floor, f0_ceil)
   int *d_half = nullptr, *d_off = nullptr;
   double *d_win_tab = nullptr;   // refinement-window angle steps per half length (hv_refine)
   int win_tab_len = 0;
+  double2 *d_spec = nullptr;     // [nch][kBandFftBins] spectra of the taps / kBandFft (FFT path of the filter bank)
+  int fft_seg = 0;               // outputs per block of that path (0: filters too long, direct FIR)
   std::vector<double> band_f0;
 };
 
@@ -309,6 +311,13 @@ static void prepare_bands(WorldHipContext *c, int fs, double f0_floor, double f0
   devrt::sync(c->stream);
   hb.fs = fs; hb.f0_floor = f0_floor; hb.f0_ceil = f0_ceil; hb.nch = nch; hb.max_half = max_half;
   hb.band_f0 = fb;
+  if (hb.d_spec) { devrt::dfree(hb.d_spec); hb.d_spec = nullptr; }
+  hb.fft_seg = getenv("WORLD_HIP_HARVEST_FIR") ? 0 : hv_fft_segment(max_half);
+  if (hb.fft_seg > 0) {
+    hb.d_spec = static_cast<double2 *>(devrt::dmalloc(sizeof(double2) * (size_t)nch * kBandFftBins));
+    launch_band_spectra(hb.d_taps, hb.d_off, hb.d_half, nch, hb.d_spec, c->tab, c->stream);
+    devrt::sync(c->stream);
+  }
   // GetMainWindow's angle step for every window half length hv_refine can meet (harvest.cpp:446-456):
   // cos/sin of pi*d and of pi*WAVE*d with d = 2/(2hw+1), so the kernel needs one sincospi per rebuild
   const int hw_max = static_cast<int>(1.5 * afs / f0_floor + 1.0) + 2;
@@ -364,7 +373,10 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.ext_cap = max_fb + 304 * p.sec_cap + 8;
   p.max_half = hb.max_half;
   p.tab = c->tab;
-  p.nseg = hv_segments(max_y);
+  p.fft_seg = hb.fft_seg;
+  p.fft_pre = hb.max_half - 1;
+  p.band_spec = hb.d_spec;
+  p.nseg = hv_segments(max_y, p.fft_seg);
 
   const size_t B = n_utt;
   const size_t cand_elems = B * p.fb_stride * p.maxc;
@@ -377,6 +389,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   need += pad256(sizeof(int) * B * p.nch * 4);
   need += pad256(sizeof(double) * B * p.nch * 4 * hv_segment_list_doubles(p.nseg));
   need += pad256(sizeof(int) * B * p.nch * 4 * p.nseg);
+  need += pad256(sizeof(double2) * B * p.nseg * kBandFftBins);
   need += pad256(sizeof(double) * B * p.nch * p.fb_stride);
   need += 4 * pad256(sizeof(double) * cand_elems);
   need += pad256(sizeof(int) * B);
@@ -404,6 +417,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.ev_count = c->arena.take<int>(B * p.nch * 4);
   p.seg_events = c->arena.take<double>(B * p.nch * 4 * hv_segment_list_doubles(p.nseg));
   p.seg_count = c->arena.take<int>(B * p.nch * 4 * p.nseg);
+  p.blk_spec = c->arena.take<double2>(B * p.nseg * kBandFftBins);
   p.raw = c->arena.take<double>(B * p.nch * p.fb_stride);
   p.cand_a = c->arena.take<double>(cand_elems); p.score_a = c->arena.take<double>(cand_elems);
   p.cand_b = c->arena.take<double>(cand_elems); p.score_b = c->arena.take<double>(cand_elems);
@@ -940,6 +954,7 @@ void world_hip_destroy(WorldHipContext *c) {
     HarvestBands &hb = c->bands;
     if (hb.d_band_f0) { devrt::dfree(hb.d_band_f0); devrt::dfree(hb.d_taps); devrt::dfree(hb.d_half); devrt::dfree(hb.d_off); }
     if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
+    if (hb.d_spec) devrt::dfree(hb.d_spec);
     if (c->xchg_ready) devrt::event_destroy(c->xchg_ready);
     if (c->xchg_done) devrt::event_destroy(c->xchg_done);
   } catch (...) {

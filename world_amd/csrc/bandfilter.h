@@ -212,6 +212,53 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
   fir_compute(job, taps, yt, s);
 }
 
+// The four zero-crossing families (falling, rising, peaks, dips: harvest.cpp:162-238, dio.cpp:357-435) of the `len`
+// filtered samples that start at time index t0; sample(k) = filtered[t0 + k] for k in [0, len + 2).  Every thread
+// inspects kOutPer consecutive samples (time order) and records the crossings of each family as a bit mask; ONE
+// block scan of the four packed counts gives the list positions; the sub-sample times (one FP64 division each)
+// are then evaluated only for the set bits and appended to the segment's lists.
+template <class Sample>
+__device__ __forceinline__ void tile_events(Sample sample, int t0, int len, int n, double *ev, size_t fam_stride,
+                                            int (&count)[4], double *scratch) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int sub = 0; sub < len; sub += nt * kOutPer) {
+    const int kbase = sub + tid * kOutPer;
+    double sv[kOutPer + 2];
+#pragma unroll
+    for (int q = 0; q < kOutPer + 2; ++q) sv[q] = kbase + q < len + 2 ? sample(kbase + q) : 0.0;
+    unsigned mask[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < kOutPer; ++q) {
+      const int i = t0 + kbase + q;
+      const bool live = kbase + q < len;
+      const double a = sv[q], b = sv[q + 1], c = sv[q + 2];
+      const double da = b - a, db = c - b;
+      const bool r01 = live && i <= n - 2, r23 = live && i <= n - 3;
+      if (r01 && 0.0 < a && b <= 0.0) mask[0] |= 1u << q;
+      if (r01 && a < 0.0 && 0.0 <= b) mask[1] |= 1u << q;
+      if (r23 && 0.0 < da && db <= 0.0) mask[2] |= 1u << q;
+      if (r23 && da < 0.0 && 0.0 <= db) mask[3] |= 1u << q;
+    }
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int fam = 0; fam < 4; ++fam) packed |= (unsigned long long)__builtin_popcount(mask[fam]) << (16 * fam);
+    unsigned long long total, off = block_excl_scan_u64(packed, &total, scratch);
+#pragma unroll
+    for (int fam = 0; fam < 4; ++fam) {
+      double *dst = ev + fam * fam_stride;
+      int at = count[fam] + (int)((off >> (16 * fam)) & 0xFFFF);
+      for (unsigned m = mask[fam]; m != 0; m &= m - 1) {
+        const int q = __builtin_ctz(m);
+        double a = sv[q], b = sv[q + 1];
+        if (fam >= 2) { const double c = sv[q + 2]; a = b - a; b = c - b; }
+        if (at < kSegCap) dst[at] = fine_edge(t0 + kbase + q + 1, a, b);
+        ++at;
+      }
+      count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
+    }
+  }
+}
+
 // Whole segment `seg` of one channel: filter tile by tile and append the crossing
 // times of the four families (falling, rising, peaks, dips) to the segment's lists.
 __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg) {
@@ -274,46 +321,7 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
     }
     WH_ACC_END(2);
     WH_ACC_BEGIN;
-    // events: every thread inspects kOutPer consecutive samples (time order) and records
-    // the crossings of each family as a bit mask; ONE block scan of the four packed counts
-    // gives the list positions; the sub-sample times (one FP64 division each) are then
-    // evaluated only for the set bits.
-    for (int sub = 0; sub < kTile; sub += nt * kOutPer) {
-      const int kbase = sub + tid * kOutPer;
-      double sv[kOutPer + 2];
-#pragma unroll
-      for (int q = 0; q < kOutPer + 2; ++q) sv[q] = kbase + q < kTile + 2 ? s[pad8(kbase + q)] : 0.0;
-      unsigned mask[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int q = 0; q < kOutPer; ++q) {
-        const int i = t0 + kbase + q;
-        const bool live = kbase + q < kTile;
-        const double a = sv[q], b = sv[q + 1], c = sv[q + 2];
-        const double da = b - a, db = c - b;
-        const bool r01 = live && i <= n - 2, r23 = live && i <= n - 3;
-        if (r01 && 0.0 < a && b <= 0.0) mask[0] |= 1u << q;
-        if (r01 && a < 0.0 && 0.0 <= b) mask[1] |= 1u << q;
-        if (r23 && 0.0 < da && db <= 0.0) mask[2] |= 1u << q;
-        if (r23 && da < 0.0 && 0.0 <= db) mask[3] |= 1u << q;
-      }
-      unsigned long long packed = 0;
-#pragma unroll
-      for (int fam = 0; fam < 4; ++fam) packed |= (unsigned long long)__builtin_popcount(mask[fam]) << (16 * fam);
-      unsigned long long total, off = block_excl_scan_u64(packed, &total, scratch);
-#pragma unroll
-      for (int fam = 0; fam < 4; ++fam) {
-        double *dst = ev + fam * fam_stride;
-        int at = count[fam] + (int)((off >> (16 * fam)) & 0xFFFF);
-        for (unsigned m = mask[fam]; m != 0; m &= m - 1) {
-          const int q = __builtin_ctz(m);
-          double a = sv[q], b = sv[q + 1];
-          if (fam >= 2) { const double c = sv[q + 2]; a = b - a; b = c - b; }
-          if (at < kSegCap) dst[at] = fine_edge(t0 + kbase + q + 1, a, b);
-          ++at;
-        }
-        count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
-      }
-    }
+    tile_events([&](int k) { return s[pad8(k)]; }, t0, kTile, n, ev, fam_stride, count, scratch);
     WH_ACC_END(3);
   }
   WH_ACC_SET(4, job.ntap);

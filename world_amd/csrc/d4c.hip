@@ -332,10 +332,11 @@ __device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, cplx *Z, do
   return s1 / s2;
 }
 
-// resident waves per SIMD the register allocation aims at (4 = four 256-thread workgroups per CU, 128 VGPRs;
-// 3 = 168 VGPRs: measured within 3 % of each other, profiles/r02)
+// Resident waves per SIMD the register allocation aims at.  4 (four 256-thread workgroups per CU, 128 VGPRs)
+// and 3 (168 VGPRs) run within 3 % of each other, but at 128 the compiler spills 216 bytes per lane and the
+// spill traffic (~200 MB per 2001 frames through L2) is most of what the kernel moves; at 168 it is 44 bytes.
 #ifndef D4C_MIN_WAVES
-#define D4C_MIN_WAVES 4
+#define D4C_MIN_WAVES 3
 #endif
 template <int NMAX, int T>
 __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {

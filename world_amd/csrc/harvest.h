@@ -27,6 +27,11 @@ struct HarvestParams {
   const int *band_half;    // [nch]  filter half length L
   const int *band_off;     // [nch]  offset of the band's taps in band_taps
   const double *band_taps; // Nuttall * cos band-pass FIRs (harvest.cpp:101-108), built on the host
+  // FFT path of the filter bank (harvest.hip: hv_block_spectra / hv_band_events_fft); fft_seg == 0: direct FIR
+  const double2 *band_spec;// [nch][kBandFftBins] spectrum of every band's taps / kBandFft, built once per band set
+  double2 *blk_spec;       // [n_utt][nseg][kBandFftBins] spectra of the signal's overlapping blocks (workspace)
+  int fft_seg;             // filtered samples one block yields: kBandFft - 2 max_half - 2
+  int fft_pre;             // samples a block starts before its first output: max_half - 1
   int max_half;            // max L
   const int *ref_fft;      // [n_utt] the reference's FFT length for this utterance (harvest.cpp:1164-1165)
   double *nyq;             // [n_utt][nyq_slices][4]: partial sums of Y[N/2], Re/Im Y[N/2-1] (mean-free signal), 2/N
@@ -58,7 +63,11 @@ struct HarvestParams {
   double *f0;              // [n_utt][f_stride]
 };
 
-int hv_segments(int max_y_len);
+constexpr int kBandFftLg = 12, kBandFft = 1 << kBandFftLg, kBandFftBins = kBandFft / 2 + 1;
+int hv_fft_segment(int max_half);          // outputs per block of the FFT path, 0 = filters too long for it
+void launch_band_spectra(const double *d_taps, const int *d_off, const int *d_half, int nch, double2 *d_spec,
+                         const Tables &tab, hipStream_t stream);
+int hv_segments(int max_y_len, int fft_seg);
 size_t hv_segment_list_doubles(int nseg);
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
                     hipStream_t stream);

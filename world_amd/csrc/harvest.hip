@@ -123,6 +123,112 @@ __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
   band_events_segment(job, seg);
 }
 
+// ---------------------------------------------------------------------------
+// The same filter bank by overlap-save (fast convolution) when the filters fit: the reference itself
+// filters through FFTs (harvest.cpp:99-148); the direct form above costs 2 (2L+1) flop per output, on
+// average ~350 for the 152 channels of the default range (L = 18 .. 246), a 4096-point block transform
+// ~40.  The signal is cut into blocks of kBandFft samples that start fft_pre samples before their
+// fft_seg outputs; a block's spectrum is formed ONCE (hv_block_spectra) and serves all channels; a
+// channel's spectrum (taps zero-padded, scaled by 1 / kBandFft) is formed once per band set
+// (hv_band_spectra, cached with the taps).  hv_band_events_fft = product of the two, one c2r transform
+// in LDS, and the zero-crossing detectors on the result: output i = t0 + k sits at sample
+// k + fft_pre + shift of the block, clear of the circular wrap for every channel.
+__global__ void __launch_bounds__(256) hv_band_spectra(const double *taps, const int *off, const int *half, double2 *spec,
+                                                       const double2 *tw_global) {
+  DYN_LDS(lds);
+  const int band = blockIdx.x, ntap = 2 * half[band] + 1;
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  const TwLds tw = stage_twiddles(reinterpret_cast<double *>(lds) + kBandFft, kBandFftLg - 1, tw_global);
+  const double *h = taps + off[band];
+  for (int i = threadIdx.x; i < kBandFft; i += blockDim.x) rfft_in(Z, i) = i < ntap ? h[i] : 0.0;
+  double2 *out = spec + (size_t)band * kBandFftBins;
+  block_rfft<3>(Z, kBandFftLg, tw, [&](int k, double re, double im) {
+    out[k] = make_double2(re * (1.0 / kBandFft), im * (1.0 / kBandFft));       // exact: a power of two
+  });
+}
+void launch_band_spectra(const double *d_taps, const int *d_off, const int *d_half, int nch, double2 *d_spec,
+                         const Tables &tab, hipStream_t stream) {
+  WH_BLOCKS(hv_band_spectra, dim3(nch), 256, sizeof(double) * (kBandFft + twiddle_lds_doubles(kBandFftLg - 1)), stream, d_taps,
+            d_off, d_half, d_spec, tab.tw);
+}
+int hv_fft_segment(int max_half) {
+  const int seg = (kBandFft - 2 * max_half - 2) & ~7;
+  return seg >= kBandFft / 2 ? seg : 0;          // below half a block per transform the direct form is kept
+}
+
+__global__ void __launch_bounds__(256) hv_block_spectra(HarvestParams p) {
+  DYN_LDS(lds);
+  const int blk = blockIdx.x, u = blockIdx.y, n = p.y_len[u];
+  const int m0 = blk * p.fft_seg - p.fft_pre;                 // signal index of the block's first sample
+  if (blk * p.fft_seg >= n) return;                           // no output of this utterance lies in the block
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  const TwLds tw = stage_twiddles(reinterpret_cast<double *>(lds) + kBandFft, kBandFftLg - 1, p.tab.tw);
+  const double *y = p.y + (size_t)u * p.y_stride;
+  for (int i = threadIdx.x; i < kBandFft; i += blockDim.x) {
+    const int idx = m0 + i;
+    rfft_in(Z, i) = (idx >= 0 && idx < n) ? y[idx] : 0.0;
+  }
+  double2 *out = p.blk_spec + ((size_t)u * p.nseg + blk) * kBandFftBins;
+#ifdef WORLD_EMU
+  block_rfft<3>(Z, kBandFftLg, tw, [&](int k, double re, double im) { out[k] = make_double2(re, im); });
+#else
+  block_rfft<3, kBandFftLg>(Z, kBandFftLg, tw, [&](int k, double re, double im) { out[k] = make_double2(re, im); });
+#endif
+}
+
+__global__ void __launch_bounds__(256, 4) hv_band_events_fft(HarvestParams p) {
+  DYN_LDS(lds);
+  const int seg = blockIdx.x, band = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+  const int n = p.y_len[u];
+  const size_t list = ((size_t)(u * p.nch + band) * 4);
+  int *cnt_out = p.seg_count + list * p.nseg + seg;
+  const int t0 = seg * p.fft_seg;
+  if (t0 >= n) {
+    if (tid == 0) for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = 0;
+    return;
+  }
+  const bool trace_me = blockIdx.x == 5 && blockIdx.y == 20; (void)trace_me;
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  double *scratch = reinterpret_cast<double *>(lds) + kBandFft;
+  const TwLds tw = stage_twiddles(scratch + 64, kBandFftLg - 1, p.tab.tw);
+  const double2 *X = p.blk_spec + ((size_t)u * p.nseg + seg) * kBandFftBins;
+  const double2 *H = p.band_spec + (size_t)band * kBandFftBins;
+  auto product = [&](int k) { const double2 x = X[k], h = H[k]; cplx a, b; a.re = x.x; a.im = x.y; b.re = h.x; b.im = h.y; return cmul(a, b); };
+#ifdef WORLD_EMU
+  block_irfft<3>(Z, kBandFftLg, tw, product);
+#else
+  block_irfft<3, kBandFftLg>(Z, kBandFftLg, tw, product);
+#endif
+  // filtered[t0 + k] = block sample k + fft_pre + shift, shift = L + 1 (delay compensation, harvest.cpp:140-142)
+  const int shift = p.band_half[band] + 1;
+  const int at0 = p.fft_pre + shift;
+  const int len = imin(p.fft_seg, n - t0);
+  {
+    // the reference's mirror-store term (bandfilter.h), a function of the undelayed index t0 + k + shift
+    const double *q = p.quirk + ((size_t)u * p.nch + band) * 4;
+    const double qc = q[0], qs = q[1], q0 = q[2], w = q[3];
+    const int n0 = t0 + tid + shift;
+    double sn, cs, sr, cr;
+    sincospi(n0 * w, &sn, &cs);
+    sincospi(nt * w, &sr, &cr);
+    const double sign = (n0 & 1) ? -1.0 : 1.0;
+    for (int k = tid, j = 0; k < len + 2; k += nt, ++j) {
+      const double flip = ((nt & 1) && (j & 1)) ? -sign : sign;     // (-1)^(n0 + j nt)
+      rfft_in(Z, k + at0) += flip * (qc * cs + qs * sn + q0);
+      const double c2 = cs * cr - sn * sr;
+      sn = sn * cr + cs * sr;
+      cs = c2;
+    }
+    __syncthreads();
+  }
+  double *ev = p.seg_events + (list * p.nseg + seg) * kSegCap;
+  const size_t fam_stride = (size_t)p.nseg * kSegCap;
+  int count[4] = {0, 0, 0, 0};
+  tile_events([&](int k) { return rfft_in(Z, k + at0); }, t0, len, n, ev, fam_stride, count, scratch);
+  if (tid == 0)
+    for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = imin(count[fam], kSegCap);
+}
+
 // concatenate the per-segment lists of one (family, band, utterance) in time order
 __global__ void hv_compact_events(HarvestParams p) {
   const int bf = blockIdx.x, u = blockIdx.y;        // bf = band * 4 + family
@@ -475,7 +581,7 @@ __global__ void hv_prune(HarvestParams p) {
 
 // ---------------------------------------------------------------------------
 size_t hv_band_lds_bytes(int max_half) { return band_lds_bytes(2 * max_half + 1); }
-int hv_segments(int max_y_len) { return band_segments(max_y_len); }
+int hv_segments(int max_y_len, int fft_seg) { return fft_seg > 0 ? (max_y_len + fft_seg - 1) / fft_seg : band_segments(max_y_len); }
 size_t hv_segment_list_doubles(int nseg) { return (size_t)nseg * kSegCap; }
 
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
@@ -496,7 +602,13 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   WH_BLOCKS(hv_remove_mean, dim3(slices, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_nyquist_bins, dim3(p.nyq_slices, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
+  if (p.fft_seg > 0) {
+    const size_t lds = sizeof(double) * (kBandFft + 64 + twiddle_lds_doubles(kBandFftLg - 1));
+    WH_BLOCKS(hv_block_spectra, dim3(p.nseg, B), 256, lds, stream, p);
+    WH_BLOCKS(hv_band_events_fft, dim3(p.nseg, p.nch, B), 256, lds, stream, p);
+  } else {
+    WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
+  }
   WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);
   WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawFrames - 1) / kRawFrames, p.nch, B), kRawFrames,
             8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);

@@ -43,6 +43,7 @@ typedef void *hipStream_t;
 #define hipSuccess 0
 #define WAVE 1
 #define DYN_LDS(name) char *name = emu_lds_base
+#define LDS_PTR(T) T *
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline unsigned __brev(unsigned v) {
   unsigned r = 0;
@@ -102,6 +103,9 @@ void launch_blocks(const char * /*name*/, K kernel, dim3 grid, int /*threads*/, 
 #include <type_traits>
 #define WAVE 64
 #define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// pointer into LDS with its address space in the type: accesses through it are ds_ instructions even where the
+// same code is also instantiated for global pointers (a generic pointer would make them flat_ accesses)
+#define LDS_PTR(T) __attribute__((address_space(3))) T *
 namespace devrt {
 void check(hipError_t e, const char *what);
 void *dmalloc(size_t bytes);

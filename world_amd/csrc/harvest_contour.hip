@@ -22,23 +22,45 @@ __device__ __forceinline__ double *hc_row(double *base, const HarvestParams &p, 
 }
 
 // ---- SearchF0Base + FixStep1 -------------------------------------------------
-__device__ __forceinline__ double hc_base_at(const HarvestParams &p, int u, int f, int nslot) {
+// SearchF0Base (:693-705): the candidate with the highest score, the FIRST one among equals.  One wavefront per
+// frame, lanes over the candidate slots (a thread per frame walking 42 slots of three frames was 33 us of pure
+// load latency on 157 wavefronts); the result goes to c0, FixStep1 then needs three neighbouring values of it.
+__global__ void hc_base(HarvestParams p) {
+  const int f = wave_item_x(), u = blockIdx.y;
+  if (f >= p.nfb[u]) return;
+  const int nslot = p.nc[u] * 7, lane = lane_id();
   const double *c = p.cand_a + ((size_t)u * p.fb_stride + f) * p.maxc;
   const double *s = p.score_a + ((size_t)u * p.fb_stride + f) * p.maxc;
   double best = 0.0, top = 0.0;
-  for (int j = 0; j < nslot; ++j)
-    if (s[j] > top) { best = c[j]; top = s[j]; }        // first maximum wins
-  return best;
+  int slot = 0x7FFFFFFF;                                   // lowest slot holding this lane's maximum
+  for (int j = lane; j < nslot; j += WAVE) {
+    const double sj = s[j];
+    if (sj > top) { best = c[j]; top = sj; slot = j; }
+  }
+  const double wtop = wave_max(top);
+  double v = 0.0;
+  if (wtop > 0.0) {
+    // among the lanes that hold the maximum the lowest slot wins (the serial loop keeps the first one it meets)
+    const int mine = top == wtop ? slot : 0x7FFFFFFF;
+    const int win = -wave_max_int(-mine);
+#ifndef WORLD_EMU
+    v = readlane_f64(best, __builtin_amdgcn_readfirstlane(win % WAVE));
+#else
+    (void)win;
+    v = best;
+#endif
+  }
+  if (lane == 0) hc_row(p.c0, p, u)[f] = v;
 }
 __global__ void hc_step1(HarvestParams p) {
   const int f = flat_thread_x(), u = blockIdx.y;
   if (f >= p.nfb[u]) return;
-  const int nslot = p.nc[u] * 7;
+  const double *base = hc_row(p.c0, p, u);
   double v = 0.0;
   if (f >= 2) {
-    double b0 = hc_base_at(p, u, f, nslot);
+    const double b0 = base[f];
     if (b0 != 0.0) {
-      double b1 = hc_base_at(p, u, f - 1, nslot), b2 = hc_base_at(p, u, f - 2, nslot);
+      const double b1 = base[f - 1], b2 = base[f - 2];
       double ref = b1 * 2 - b2;
       v = fabs((b0 - ref) / ref) > 0.008 && fabs((b0 - b1)) / b1 > 0.008 ? 0.0 : b0;
     }
@@ -148,8 +170,10 @@ constexpr int kMaxSlots = 256;       // candidate slots per frame handled by the
 constexpr int kExtReach = 100;       // frames a section may grow in each direction (:865)
 constexpr int kExtMargin = kExtReach + 1;
 
-__global__ void hc_extend(HarvestParams p) {
-  const int k = wave_item_x(), u = blockIdx.y;
+// One workgroup of two wavefronts per section: the forward and the backward extension do not depend on each
+// other (each starts from its end of the section and writes its own side of the slice), so they run side by side.
+__global__ void __launch_bounds__(2 * WAVE) hc_extend(HarvestParams p) {
+  const int k = blockIdx.x, u = blockIdx.y;
   if (k >= p.sec_n[u * 2]) return;
   const int nf = p.nfb[u], nslot = p.nc[u] * 7, lane = lane_id();
   int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
@@ -158,28 +182,38 @@ __global__ void hc_extend(HarvestParams p) {
   double *e = p.ext + (size_t)u * p.ext_cap + sec[4 * p.sec_cap + k];
   const double *in = hc_row(p.c2, p, u);
   const int len = ed - st + 1 + 2 * kExtMargin;
-  for (int i = lane; i < len; i += WAVE) {              // GetMultiChannelF0 (:767-778)
-    int f = lo + i;
-    e[i] = (f >= st && f <= ed) ? in[f] : 0.0;
+  {                                                      // GetMultiChannelF0 (:767-778), eight loads in flight per thread
+    constexpr int kB = 8;
+    const int nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < len; i0 += kB * nt) {
+      double v[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) { const int f = lo + i0 + q * nt; v[q] = (i0 + q * nt < len && f >= st && f <= ed) ? in[f] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) if (i0 + q * nt < len) e[i0 + q * nt] = v[q];
+    }
   }
-  wave_sync();
+  __syncthreads();
   const double *cands = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
-  int new_ed = ed, new_st = st;
-  for (int dir = 0; dir < 2; ++dir) {                   // forwards first, then backwards
+#ifdef WORLD_EMU
+  const int dir_begin = 0, dir_end = 2;                 // the one emulated thread walks both directions
+#else
+  const int dir_begin = wave_in_block(), dir_end = dir_begin + 1;
+#endif
+  for (int dir = dir_begin; dir < dir_end; ++dir) {     // 0: forwards from the section's end, 1: backwards from its start
     const int shift = dir == 0 ? 1 : -1;
     const int origin = dir == 0 ? ed : st;
     const int last = dir == 0 ? imin(nf - 2, ed + kExtReach) : imax(1, st - kExtReach);
     const int dist = last > origin ? last - origin : origin - last;
     double cur = e[origin - lo];
     int moved = origin, miss = 0;
-    // The frames to visit do not depend on the tracking result, so their candidate
-    // rows are fetched kAhead frames at a time (independent loads in flight) and the
-    // ordered part -- nearest candidate of the previous pick -- runs from registers.
+    // The frames to visit do not depend on the tracking result, so their candidate rows are fetched kAhead
+    // frames at a time, one batch ahead of the one being walked (double buffer in registers), and the ordered
+    // part -- nearest candidate of the previous pick -- runs from registers.
     constexpr int kAhead = 8;
     constexpr int kSlotsPerLane = (kMaxSlots + WAVE - 1) / WAVE;
     bool stop = false;
-    for (int i0 = 0; i0 <= dist && !stop; i0 += kAhead) {
-      double row[kAhead][kSlotsPerLane];
+    auto fetch = [&](double (&row)[kAhead][kSlotsPerLane], int i0) __attribute__((always_inline)) {
 #pragma unroll
       for (int a = 0; a < kAhead; ++a) {
         const int t = origin + shift * (i0 + a) + shift;
@@ -189,6 +223,8 @@ __global__ void hc_extend(HarvestParams p) {
           row[a][r] = (i0 + a <= dist && sl < nslot) ? cands[(size_t)t * p.maxc + sl] : 0.0;
         }
       }
+    };
+    auto walk = [&](const double (&row)[kAhead][kSlotsPerLane], int i0) __attribute__((always_inline)) {
 #pragma unroll
       for (int a = 0; a < kAhead; ++a) {
         if (i0 + a > dist || stop) break;
@@ -212,10 +248,11 @@ __global__ void hc_extend(HarvestParams p) {
           const double dmin = wave_min(best_d);              // DPP + readlane: no LDS round trips on the frame-to-frame chain
           const int mine = best_d == dmin ? best_i : -1;        // several lanes tie only exceptionally
           const unsigned long long tied = __ballot(mine >= 0);
+          // the winner is wave-uniform: v_readlane with a scalar lane index instead of LDS shuffles
           int win = -1;
           if (__popcll(tied) > 1) win = wave_max_int(mine);
-          else if (tied) win = __shfl(mine, __ffsll((long long)tied) - 1, 64);
-          best_v = __shfl(best_v, win < 0 ? 0 : win % WAVE, 64);   // that lane's local best IS slot `win`
+          else if (tied) win = __builtin_amdgcn_readlane(mine, __ffsll((long long)tied) - 1);
+          best_v = readlane_f64(best_v, __builtin_amdgcn_readfirstlane(win < 0 ? 0 : win % WAVE));   // that lane's local best IS slot `win`
           best_i = win;
           best_d = dmin;
         }
@@ -231,17 +268,32 @@ __global__ void hc_extend(HarvestParams p) {
         if (v == 0.0) { miss++; } else { cur = v; miss = 0; moved = t; }
         if (miss == 4) stop = true;
       }
+    };
+    double row_a[kAhead][kSlotsPerLane], row_b[kAhead][kSlotsPerLane];
+    fetch(row_a, 0);
+    for (int i0 = 0; i0 <= dist && !stop; i0 += 2 * kAhead) {
+      fetch(row_b, i0 + kAhead);
+      walk(row_a, i0);
+      if (stop || i0 + kAhead > dist) break;
+      fetch(row_a, i0 + 2 * kAhead);
+      walk(row_b, i0 + kAhead);
     }
-    if (dir == 0) new_ed = moved; else new_st = moved;
+    if (lane == 0) sec[(dir == 0 ? 3 : 2) * p.sec_cap + k] = moved;     // new end / new start
   }
-  wave_sync();
+  __syncthreads();
+  if (wave_in_block() != 0) return;
+  const int new_st = sec[2 * p.sec_cap + k], new_ed = sec[3 * p.sec_cap + k];
   // sum over [new_st, new_ed) for ExtendSub's running mean (:850)
   double s = 0.0;
-  for (int f = new_st + lane; f < new_ed; f += WAVE) s += e[f - lo];
+  for (int f0 = new_st + lane; f0 < new_ed; f0 += 8 * WAVE) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = f0 + q * WAVE < new_ed ? e[f0 + q * WAVE - lo] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
   s = wave_sum(s);
   if (lane == 0) {
-    sec[2 * p.sec_cap + k] = new_st;
-    sec[3 * p.sec_cap + k] = new_ed;
     sec[5 * p.sec_cap + k] = lo;
     p.sec_sum[(size_t)u * p.sec_cap + k] = s;
   }
@@ -267,109 +319,112 @@ __global__ void hc_merge(HarvestParams p) {
   int *b_st = sec + 2 * p.sec_cap, *b_ed = sec + 3 * p.sec_cap;
   int *s_off = sec + 4 * p.sec_cap, *s_lo = sec + 5 * p.sec_cap;
   const double *sums = p.sec_sum + (size_t)u * p.sec_cap;
-  // The ordered part below is ONE lane walking the section records; from HBM every dependent access costs a
-  // microsecond (88 us for ~30 sections).  The records of a normal utterance fit LDS.
+  // The ordered part is ONE lane walking the section records; from HBM every dependent access costs a
+  // microsecond (88 us for ~30 sections).  The records of a normal utterance fit LDS; the work is written once
+  // and instantiated for LDS pointers (ds_ accesses) and for the arrays in HBM.
+  auto work = [&](auto order, auto b_st, auto b_ed, auto s_off, auto s_lo, auto sums) __attribute__((always_inline)) {
+    const double *ext = p.ext + (size_t)u * p.ext_cap;
+    const double *step2 = hc_row(p.c2, p, u);
+    double *out = hc_row(p.c3, p, u);
+    const double *cands = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
+    const double *scores = p.score_a + (size_t)u * p.fb_stride * p.maxc;
+
+    // ExtendSub (:840-856): stable compaction of the sections longer than 2200/mean_f0;
+    // mean_f0 is deliberately NOT reset between sections.
+    int kept = 0;
+    if (lane == 0) {
+      double mean = 0.0;
+      for (int s = 0; s < ns; ++s) {
+        int st = b_st[s], ed = b_ed[s];
+        mean += sums[s];
+        mean /= ed - st;
+        if (2200.0 / mean < ed - st) {
+          int t;
+          t = b_st[kept]; b_st[kept] = b_st[s]; b_st[s] = t;
+          t = b_ed[kept]; b_ed[kept] = b_ed[s]; b_ed[s] = t;
+          t = s_off[kept]; s_off[kept] = s_off[s]; s_off[s] = t;
+          t = s_lo[kept]; s_lo[kept] = s_lo[s]; s_lo[s] = t;
+          kept++;
+        }
+      }
+      p.sec_n[u * 2 + 1] = kept;
+      // MakeSortedOrder (:883-896), quirks included
+      for (int i = 0; i < kept; ++i) order[i] = i;
+      for (int i = 1; i < kept; ++i)
+        for (int j = i - 1; j >= 0; --j) {
+          if (b_st[order[j]] > b_st[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+          else break;
+        }
+    }
+    wave_sync();
+    kept = wave_bcast_int(kept, 0);
+    // out[f] = value(f) for f in [lo, hi]: eight loads in flight per lane (a plain loop has each iteration's load
+    // wait behind the previous store: one trip to HBM per 64 frames, 80 us for the 10 001 frames of a 10 s utterance)
+    auto fill = [&](int lo, int hi, auto value) __attribute__((always_inline)) {
+      constexpr int kB = 8;
+      for (int f0 = lo + lane; f0 <= hi; f0 += kB * WAVE) {
+        double v[kB];
+  #pragma unroll
+        for (int q = 0; q < kB; ++q) v[q] = f0 + q * WAVE <= hi ? value(f0 + q * WAVE) : 0.0;
+  #pragma unroll
+        for (int q = 0; q < kB; ++q) if (f0 + q * WAVE <= hi) out[f0 + q * WAVE] = v[q];
+      }
+    };
+    if (kept == 0) {
+      fill(0, nf - 1, [&](int f) { return step2[f]; });
+      return;
+    }
+    // value of channel `ch` at frame f: its slice inside its extended run, zero elsewhere
+    auto chan = [&](int ch, int f) {
+      return (f >= b_st[ch] && f <= b_ed[ch]) ? ext[s_off[ch] + (f - s_lo[ch])] : 0.0;
+    };
+    // the same for a whole range, the channel's record read once
+    auto fill_chan = [&](int lo, int hi, int ch) __attribute__((always_inline)) {
+      const int c_st = b_st[ch], c_ed = b_ed[ch];
+      const double *src = ext + s_off[ch] - s_lo[ch];
+      fill(lo, hi, [&](int f) { return (f >= c_st && f <= c_ed) ? src[f] : 0.0; });
+    };
+    // MergeF0 (:937-963)
+    fill_chan(0, nf - 1, 0);
+    wave_sync();
+    int cur_st = b_st[0], cur_ed = b_ed[0];                 // the reference's boundary_list[0], [1]
+    for (int i = 1; i < kept; ++i) {
+      const int o = order[i];
+      // the reference reads boundary_list[o*2(+1)] AFTER possibly having overwritten entry 0
+      const int st2 = o == 0 ? cur_st : b_st[o];
+      const int ed2 = o == 0 ? cur_ed : b_ed[o];
+      if (st2 - cur_ed > 0) {
+        fill_chan(st2, ed2, o);
+        cur_st = st2; cur_ed = ed2;
+      } else {
+        // MergeF0Sub (:912-932)
+        const int st1 = cur_st, ed1 = cur_ed;
+        if (st1 <= st2 && ed1 >= ed2) { cur_ed = ed1; wave_sync(); continue; }
+        double s1 = 0.0, s2 = 0.0;
+        for (int f = st2; f <= ed1; ++f) {
+          s1 += wave_best_score(out[f], cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
+          s2 += wave_best_score(chan(o, f), cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
+        }
+        if (s1 > s2) fill_chan(ed1, ed2, o);
+        else fill_chan(st2, ed2, o);
+        cur_ed = ed2;
+      }
+      wave_sync();
+    }
+  };
   if (ns <= kMergeLdsSections) {
     char *mine = lds + (size_t)wave_in_block() * kMergeLdsSections * (5 * sizeof(int) + sizeof(double));
-    double *l_sum = reinterpret_cast<double *>(mine);
-    int *l = reinterpret_cast<int *>(l_sum + kMergeLdsSections);
+    LDS_PTR(double) l_sum = (LDS_PTR(double))reinterpret_cast<double *>(mine);
+    LDS_PTR(int) l = (LDS_PTR(int))reinterpret_cast<int *>(reinterpret_cast<double *>(mine) + kMergeLdsSections);
     for (int k = lane; k < ns; k += WAVE) {
       l_sum[k] = sums[k];
       l[k] = 0; l[kMergeLdsSections + k] = b_st[k]; l[2 * kMergeLdsSections + k] = b_ed[k];
       l[3 * kMergeLdsSections + k] = s_off[k]; l[4 * kMergeLdsSections + k] = s_lo[k];
     }
-    order = l; b_st = l + kMergeLdsSections; b_ed = l + 2 * kMergeLdsSections;
-    s_off = l + 3 * kMergeLdsSections; s_lo = l + 4 * kMergeLdsSections;
-    sums = l_sum;
     wave_sync();
-  }
-  const double *ext = p.ext + (size_t)u * p.ext_cap;
-  const double *step2 = hc_row(p.c2, p, u);
-  double *out = hc_row(p.c3, p, u);
-  const double *cands = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
-  const double *scores = p.score_a + (size_t)u * p.fb_stride * p.maxc;
-
-  // ExtendSub (:840-856): stable compaction of the sections longer than 2200/mean_f0;
-  // mean_f0 is deliberately NOT reset between sections.
-  int kept = 0;
-  if (lane == 0) {
-    double mean = 0.0;
-    for (int s = 0; s < ns; ++s) {
-      int st = b_st[s], ed = b_ed[s];
-      mean += sums[s];
-      mean /= ed - st;
-      if (2200.0 / mean < ed - st) {
-        int t;
-        t = b_st[kept]; b_st[kept] = b_st[s]; b_st[s] = t;
-        t = b_ed[kept]; b_ed[kept] = b_ed[s]; b_ed[s] = t;
-        t = s_off[kept]; s_off[kept] = s_off[s]; s_off[s] = t;
-        t = s_lo[kept]; s_lo[kept] = s_lo[s]; s_lo[s] = t;
-        kept++;
-      }
-    }
-    p.sec_n[u * 2 + 1] = kept;
-    // MakeSortedOrder (:883-896), quirks included
-    for (int i = 0; i < kept; ++i) order[i] = i;
-    for (int i = 1; i < kept; ++i)
-      for (int j = i - 1; j >= 0; --j) {
-        if (b_st[order[j]] > b_st[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
-        else break;
-      }
-  }
-  wave_sync();
-  kept = wave_bcast_int(kept, 0);
-  // out[f] = value(f) for f in [lo, hi]: eight loads in flight per lane (a plain loop has each iteration's load
-  // wait behind the previous store: one trip to HBM per 64 frames, 80 us for the 10 001 frames of a 10 s utterance)
-  auto fill = [&](int lo, int hi, auto value) __attribute__((always_inline)) {
-    constexpr int kB = 8;
-    for (int f0 = lo + lane; f0 <= hi; f0 += kB * WAVE) {
-      double v[kB];
-#pragma unroll
-      for (int q = 0; q < kB; ++q) v[q] = f0 + q * WAVE <= hi ? value(f0 + q * WAVE) : 0.0;
-#pragma unroll
-      for (int q = 0; q < kB; ++q) if (f0 + q * WAVE <= hi) out[f0 + q * WAVE] = v[q];
-    }
-  };
-  if (kept == 0) {
-    fill(0, nf - 1, [&](int f) { return step2[f]; });
-    return;
-  }
-  // value of channel `ch` at frame f: its slice inside its extended run, zero elsewhere
-  auto chan = [&](int ch, int f) {
-    return (f >= b_st[ch] && f <= b_ed[ch]) ? ext[s_off[ch] + (f - s_lo[ch])] : 0.0;
-  };
-  // the same for a whole range, the channel's record read once
-  auto fill_chan = [&](int lo, int hi, int ch) __attribute__((always_inline)) {
-    const int c_st = b_st[ch], c_ed = b_ed[ch];
-    const double *src = ext + s_off[ch] - s_lo[ch];
-    fill(lo, hi, [&](int f) { return (f >= c_st && f <= c_ed) ? src[f] : 0.0; });
-  };
-  // MergeF0 (:937-963)
-  fill_chan(0, nf - 1, 0);
-  wave_sync();
-  int cur_st = b_st[0], cur_ed = b_ed[0];                 // the reference's boundary_list[0], [1]
-  for (int i = 1; i < kept; ++i) {
-    const int o = order[i];
-    // the reference reads boundary_list[o*2(+1)] AFTER possibly having overwritten entry 0
-    const int st2 = o == 0 ? cur_st : b_st[o];
-    const int ed2 = o == 0 ? cur_ed : b_ed[o];
-    if (st2 - cur_ed > 0) {
-      fill_chan(st2, ed2, o);
-      cur_st = st2; cur_ed = ed2;
-    } else {
-      // MergeF0Sub (:912-932)
-      const int st1 = cur_st, ed1 = cur_ed;
-      if (st1 <= st2 && ed1 >= ed2) { cur_ed = ed1; wave_sync(); continue; }
-      double s1 = 0.0, s2 = 0.0;
-      for (int f = st2; f <= ed1; ++f) {
-        s1 += wave_best_score(out[f], cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
-        s2 += wave_best_score(chan(o, f), cands + (size_t)f * p.maxc, scores + (size_t)f * p.maxc, nslot);
-      }
-      if (s1 > s2) fill_chan(ed1, ed2, o);
-      else fill_chan(st2, ed2, o);
-      cur_ed = ed2;
-    }
-    wave_sync();
+    work(l, l + kMergeLdsSections, l + 2 * kMergeLdsSections, l + 3 * kMergeLdsSections, l + 4 * kMergeLdsSections, l_sum);
+  } else {
+    work(order, b_st, b_ed, s_off, s_lo, sums);
   }
 }
 
@@ -399,7 +454,9 @@ __global__ void hc_step4(HarvestParams p) {
 constexpr int kSmoothTail = 300;
 // One wavefront per voiced section; every lane filters one chunk of the section,
 // warmed up over the kSmoothTail samples before it (same convergence argument).
+constexpr int kSmoothLds = 3584;        // doubles of LDS per wavefront: sections up to 1642 frames filter out of LDS
 __global__ void hc_smooth(HarvestParams p) {
+  DYN_LDS(lds);
   const int k = wave_item_x(), u = blockIdx.y;
   if (k >= p.sec_n[u * 2]) return;
   const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
@@ -415,44 +472,64 @@ __global__ void hc_smooth(HarvestParams p) {
   const int j0 = lane_id() * chunk, j1 = imin(total, j0 + chunk);
   const double first = in[st], last = in[ed];
   constexpr int kBatch = 8;              // inputs fetched together ahead of the serial recurrence
-  // forward sweep: the section with its end values held on both sides
-  {
-    auto xin = [&](int j) { return j < 0 ? first : (j < len ? in[st + j] : last); };
-    int j = j0 - kSmoothTail;
-    double w0 = xin(j) * dc, w1 = w0;
-    for (; j < j1; j += kBatch) {
-      double v[kBatch];
+  // both sweeps, reading the section from xs[0 .. len) and keeping the forward sweep's output in ts[0 .. total)
+  auto sweeps = [&](auto xs, auto ts) __attribute__((always_inline)) {
+    // forward sweep: the section with its end values held on both sides
+    {
+      auto xin = [&](int j) { return j < 0 ? first : (j < len ? xs[j] : last); };
+      int j = j0 - kSmoothTail;
+      double w0 = xin(j) * dc, w1 = w0;
+      for (; j < j1; j += kBatch) {
+        double v[kBatch];
 #pragma unroll
-      for (int q = 0; q < kBatch; ++q) v[q] = j + q < j1 ? xin(j + q) : 0.0;
+        for (int q = 0; q < kBatch; ++q) v[q] = j + q < j1 ? xin(j + q) : 0.0;
 #pragma unroll
-      for (int q = 0; q < kBatch; ++q) {
-        if (j + q >= j1) break;
-        double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
-        double y = b0 * wt + b1 * w0 + b0 * w1;
-        w1 = w0; w0 = wt;
-        if (j + q >= j0) tmp[j + q] = y;
+        for (int q = 0; q < kBatch; ++q) {
+          if (j + q >= j1) break;
+          double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
+          double y = b0 * wt + b1 * w0 + b0 * w1;
+          w1 = w0; w0 = wt;
+          if (j + q >= j0) ts[j + q] = y;
+        }
       }
     }
-  }
-  wave_sync();
-  // backward sweep over the forward output (which has settled on `last` beyond the tail)
-  {
-    auto tin = [&](int j) { return j >= total ? last : tmp[j]; };
-    int j = j1 - 1 + kSmoothTail;
-    double w0 = tin(j) * dc, w1 = w0;
-    for (; j >= j0; j -= kBatch) {
-      double v[kBatch];
+    wave_sync();
+    // backward sweep over the forward output (which has settled on `last` beyond the tail)
+    {
+      auto tin = [&](int j) { return j >= total ? last : ts[j]; };
+      int j = j1 - 1 + kSmoothTail;
+      double w0 = tin(j) * dc, w1 = w0;
+      for (; j >= j0; j -= kBatch) {
+        double v[kBatch];
 #pragma unroll
-      for (int q = 0; q < kBatch; ++q) v[q] = j - q >= j0 ? tin(j - q) : 0.0;
+        for (int q = 0; q < kBatch; ++q) v[q] = j - q >= j0 ? tin(j - q) : 0.0;
 #pragma unroll
-      for (int q = 0; q < kBatch; ++q) {
-        if (j - q < j0) break;
-        double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
-        double y = b0 * wt + b1 * w0 + b0 * w1;
-        w1 = w0; w0 = wt;
-        if (j - q < j1 && j - q < len) out[st + j - q] = y;
+        for (int q = 0; q < kBatch; ++q) {
+          if (j - q < j0) break;
+          double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
+          double y = b0 * wt + b1 * w0 + b0 * w1;
+          w1 = w0; w0 = wt;
+          if (j - q < j1 && j - q < len) out[st + j - q] = y;
+        }
       }
     }
+  };
+  // Every batch of the recurrences waits for its inputs: out of HBM that is a microsecond per 8 steps (74 us for
+  // the sections of a 10 s utterance).  A section of ordinary length is staged in LDS once (input, then the forward
+  // sweep's output behind it) and filtered with LDS loads; longer ones keep working from HBM.
+  if (2 * len + kSmoothTail <= kSmoothLds) {
+    LDS_PTR(double) mine = (LDS_PTR(double))(reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * kSmoothLds);
+    for (int i0 = lane_id(); i0 < len; i0 += kBatch * WAVE) {     // kBatch loads in flight per lane
+      double v[kBatch];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) v[q] = i0 + q * WAVE < len ? in[st + i0 + q * WAVE] : 0.0;
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) if (i0 + q * WAVE < len) mine[i0 + q * WAVE] = v[q];
+    }
+    wave_sync();
+    sweeps(mine, mine + len);
+  } else {
+    sweeps(in + st, tmp);
   }
 }
 
@@ -470,11 +547,12 @@ __global__ void hc_output(HarvestParams p) {
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
   const size_t row_bytes = sizeof(double) * (size_t)B * p.fb_stride;
+  WH_WAVES(hc_base, max_fb, B, 1, 0, stream, p);
   WH_THREADS(hc_step1, max_fb, B, 1, stream, p);
   WH_THREADS(hc_step2, max_fb, B, 1, stream, p);
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
-  WH_WAVES(hc_extend, p.sec_cap, B, 1, 0, stream, p);
+  WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), 2 * WAVE, 0, stream, p);
   WH_WAVES(hc_merge, B, 1, 1, kMergeLdsSections * (5 * sizeof(int) + sizeof(double)), stream, p);
   devrt::d2d(p.c0, p.c3, row_bytes, stream);
   SecArgs a3 = {p.c3, 1, 0};
@@ -483,7 +561,7 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   SecArgs a4 = {p.c0, 0, kSmoothTail};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a4);
   devrt::dzero(p.basic_f0, row_bytes, stream);
-  WH_WAVES(hc_smooth, p.sec_cap, B, 1, 0, stream, p);
+  WH_WAVES(hc_smooth, p.sec_cap, B, 1, kSmoothLds * sizeof(double), stream, p);
   WH_THREADS(hc_output, max_frames, B, 1, stream, p);
 }
 

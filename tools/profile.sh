@@ -28,9 +28,10 @@ done
 tail -3 $OUT/trace.log
 PROFILE_FRAMES=$FRAMES PROFILE_CONFIG=$CFG python $ROOT/tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 head -40 $OUT/summary.txt
-# keep the evidence small: summaries + the stats CSVs only
+# keep the evidence small: the stats CSV and per-kernel averages of every PMC pass (a batch run has tens of
+# thousands of dispatch rows; gpurun merges at most 64 MiB back)
 mkdir -p $OUT/keep
 find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/keep/ \;
-for d in $OUT/pmc_*/; do n=$(basename $d); find $d -name "*counter_collection.csv" -exec cp {} $OUT/keep/$n.csv \; ; done
-rm -rf $OUT/trace $OUT/pmc_*/
+python $ROOT/tools/profile_aggregate.py $OUT
+rm -rf $OUT/trace $OUT/pmc_*/ $OUT/*.log
 du -sh $OUT

@@ -9,15 +9,8 @@ tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
 suffix = sys.argv[3] if len(sys.argv) > 3 else ""
 src, dst = f"gpurun_out/prof_{tag}", f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(src + "/keep/pmc_*.csv"):
-    acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("world_hip::", "").replace("void ", "")[:60]
-        a = acc[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
-    with open(os.path.join(dst, os.path.basename(f)[:-4] + suffix + "_by_kernel.csv"), "w") as o:
-        o.write("kernel,counter,dispatches,avg_per_dispatch\n")
-        for (k, c), (s, n) in sorted(acc.items()):
-            o.write(f'"{k}",{c},{n},{s / n:.6g}\n')
+for f in glob.glob(src + "/keep/pmc_*_by_kernel.csv"):
+    shutil.copy(f, os.path.join(dst, os.path.basename(f).replace("_by_kernel.csv", suffix + "_by_kernel.csv")))
 shutil.copy(src + "/keep/trace_kernel_stats.csv", dst + f"/kernel_stats{suffix}.csv")
 shutil.copy(src + "/summary.txt", dst + f"/rocprofv3_summary{suffix}.txt")
 new = json.load(open(src + "/pmc_traffic.json"))

@@ -362,7 +362,9 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   double *scratch = Zr + N;
-  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
+  // the quarter-wave table is staged two levels coarser than the merge steps ask for (fft.h: twiddle()): 2 KB
+  // instead of 8 keep the workgroup, parked centroid included, inside the 52 KB that three per CU allow
+  const TwLds tw = stage_twiddles(scratch + 64, lgn - 2, p.tab.tw);
 #ifdef WORLD_EMU
   const FftPlan plan = make_plan_max(lgn - 1, 3);
   auto cfft = [&]() { block_cfft_dif<3>(Z, plan, tw); };
@@ -386,7 +388,12 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   const uint32_t *noise = p.noise + p.offsets2[fi];
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
-  double *spill = p.gd + fi * p.gd_stride;              // kBins * T doubles of this frame's own scratch row
+  // The first position's centroid waits while X1 of the second occupies the registers: in LDS behind the
+  // twiddle table where the budget of three workgroups per CU allows (N <= 4096: 35 + 16 KB), else in the
+  // frame's scratch row in HBM (kBins * T doubles; it cost 68 MB of L2 traffic per 2001 frames).
+  constexpr bool kParkInLds = NMAX <= 4096;
+  double *park = scratch + 64 + twiddle_lds_doubles(lgn - 2);
+  double *spill = p.gd + fi * p.gd_stride;
   const double inv_n = 1.0 / N;
 
   // DCCorrection (common.cpp:56-75) on register bins: the few low bins it mirrors go through LDS
@@ -471,12 +478,20 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   {
     double first[kBins];
     centroid(0, first);
+    if (kParkInLds) {
+      for_bins([&](int slot, int k) { park[k] = first[slot]; });        // natural bin order: conflict-free
+    } else {
 #pragma unroll
-    for (int e = 0; e < kBins; ++e) spill[(size_t)e * nt + tid] = first[e];
+      for (int e = 0; e < kBins; ++e) spill[(size_t)e * nt + tid] = first[e];
+    }
   }
   centroid(1, A);
+  if (kParkInLds) {
+    for_bins([&](int slot, int k) { A[slot] = park[k] + A[slot]; });     // the thread reads back what it wrote
+  } else {
 #pragma unroll
-  for (int e = 0; e < kBins; ++e) A[e] = spill[(size_t)e * nt + tid] + A[e];
+    for (int e = 0; e < kBins; ++e) A[e] = spill[(size_t)e * nt + tid] + A[e];
+  }
   dc_correct(A);
   WH_STAMP(32, 12);
 
@@ -608,10 +623,11 @@ __global__ void d4c_finish(D4cParams p) {
 
 // ---------------------------------------------------------------------------
 size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 8 + 2); }
-// Z (N doubles) | scratch (64) | quarter-wave table of the inner N/2-point complex transform
+// Z (N doubles) | scratch (64) | quarter-wave table of an N/4-point transform (two levels coarser than the merge) | the parked
+// centroid of the first position (N/2 + 2; N <= 4096 only)
 size_t d4c_frame_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(N + 64 + N / 8 + 2);
+  return sizeof(double) * (size_t)(N + 64 + N / 16 + 2 + (N <= 4096 ? N / 2 + 2 : 0));
 }
 int d4c_frame_threads(int lg) { return (1 << lg) / 16; }   // one radix-8 butterfly per thread and stage
 // doubles of per-frame scratch (D4cParams::gd) the frame kernel needs: its register bins, one row per slot

@@ -36,6 +36,7 @@ __device__ __forceinline__ cplx cconj(cplx a) { a.im = -a.im; return a; }
 struct TwLds {
   const double *q; int lg;
   double fine_c, fine_s;     // cos/sin(2 pi / 2^(lg+1)): one level finer than the table (see twiddle())
+  double fine2_c, fine2_s;   // cos/sin(2 pi / 2^(lg+2)): two levels finer
 };
 
 // stage the table for transforms up to 2^lg points; call before the first transform
@@ -46,6 +47,8 @@ __device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2
   TwLds t; t.q = q; t.lg = lg;
   const double2 f = global_tw[lg + 1 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 1) : 0];
   t.fine_c = f.x; t.fine_s = f.y;
+  const double2 f2 = global_tw[lg + 2 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 2) : 0];
+  t.fine2_c = f2.x; t.fine2_s = f2.y;
   return t;
 }
 __host__ __device__ __forceinline__ size_t twiddle_lds_doubles(int lg) { return (size_t)(1 << (lg - 2)) + 2; }
@@ -64,11 +67,19 @@ __device__ __forceinline__ cplx twiddle_table(const TwLds &tw, int k, int lg, in
   cplx w; w.re = c; w.im = sign > 0 ? s : -s; return w;
 }
 // A real transform of 2^(tw.lg+1) points needs the table's resolution only for its inner complex
-// transform; its merge step asks for lg = tw.lg + 1 and gets w^k = W^(k>>1) * (k odd ? w^1 : 1).
+// transform; its merge step asks for lg = tw.lg + 1 and gets w^k = W^(k>>1) * (k odd ? w^1 : 1).  A kernel
+// short of LDS may stage a table two levels coarser than its finest request (lg = tw.lg + 2): the two low
+// bits of k then select 1, f, f^2 or f^3 with f = e^{2 pi i / 2^lg} (at most two extra products).
 __device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign) {
-  if (lg > tw.lg) {
+  if (lg == tw.lg + 1) {
     cplx a = twiddle_table(tw, k >> 1, tw.lg, sign);
     if (k & 1) { cplx f; f.re = tw.fine_c; f.im = sign > 0 ? tw.fine_s : -tw.fine_s; a = cmul(a, f); }
+    return a;
+  }
+  if (lg == tw.lg + 2) {
+    cplx a = twiddle_table(tw, k >> 2, tw.lg, sign);
+    if (k & 2) { cplx f; f.re = tw.fine_c; f.im = sign > 0 ? tw.fine_s : -tw.fine_s; a = cmul(a, f); }
+    if (k & 1) { cplx f; f.re = tw.fine2_c; f.im = sign > 0 ? tw.fine2_s : -tw.fine2_s; a = cmul(a, f); }
     return a;
   }
   return twiddle_table(tw, k, lg, sign);

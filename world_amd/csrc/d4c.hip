@@ -78,74 +78,6 @@ __global__ void d4c_prepare2(D4cParams p) {
   }
 }
 
-// Windowed, noise-dithered, DC-balanced segment (GetWindowedWaveform, d4c.cpp:52-84),
-// written straight into a transform's input: sample i goes to the real part of
-// complex element i (`packed`, the centroid transform) or to real element i of an
-// r2c input.  The window shape is recomputed in the second pass (one cosine) rather
-// than stored: no LDS, no long-lived registers.  Returns 2*hw+1.
-__device__ __forceinline__ int d4c_windowed(const double *x, int x_len, int fs, double f0, double pos,
-                                            int kind, double ratio, const uint32_t *noise,
-                                            cplx *z, bool packed, double *scratch) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int hw = mround(ratio * fs / f0 / 2.0);
-  const int wlen = 2 * hw + 1;
-  const int origin = mround(pos * fs + 0.001);
-  // Second pass needs each sample's window value again.  The packed layout has a free slot for
-  // it (the imaginary half, overwritten by the caller afterwards); the r2c layout has none, so
-  // the value is recomputed (one cospi, no division).
-  const double scale = 2.0 / ratio / fs * f0;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < wlen; i += nt) {
-    const double w = d4c_window_at(i, hw, kind, scale);
-    // noise[i]: the window's draws in sample order (d4c.cpp:67-69)
-    double v = x[imin(x_len - 1, imax(0, origin + i - hw))] * w + randn_value(noise[i]) * kSafeGuardD4C;
-    if (packed) { cplx e; e.re = v; e.im = w; z[swz(i)] = e; }
-    else rfft_in(z, i) = v;
-    s1 += v; s2 += w;
-  }
-  block_sum2(s1, s2, scratch);
-  const double coef = s1 / s2;
-  if (packed) {
-    for (int i = tid; i < wlen; i += nt) { cplx &e = z[swz(i)]; e.re -= e.im * coef; }
-  } else {
-    for (int i = tid; i < wlen; i += nt) rfft_in(z, i) -= d4c_window_at(i, hw, kind, scale) * coef;
-  }
-  __syncthreads();
-  return wlen;
-}
-
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
-  DYN_LDS(lds);
-  const int u = blockIdx.y, f = blockIdx.x;
-  if (f >= p.b.n_frames[u]) return;
-  const size_t fi = (size_t)u * p.b.f_stride + f;
-  const double f0 = p.f0[fi];
-  if (f0 == 0.0) { if (threadIdx.x == 0) p.ap0[fi] = 0.0; return; }   // d4c.cpp:274-277
-  const int lgn = p.lg_love, M = 1 << lgn, fs = p.b.fs;
-  cplx *Z = reinterpret_cast<cplx *>(lds);
-  double *Zr = reinterpret_cast<double *>(lds);
-  double *scratch = Zr + M;
-  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);    // inner complex transform's table
-  const double cf0 = f0 > 40.0 ? f0 : 40.0;
-  const int wlen = d4c_windowed(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi],
-                                kBlackman, 3.0, p.noise + p.offsets1[fi], Z, false, scratch);
-  for (int i = wlen + threadIdx.x; i < M; i += blockDim.x) rfft_in(Z, i) = 0.0;
-  const int b0 = static_cast<int>(ceil(100.0 * M / fs));
-  const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
-  const int b2 = static_cast<int>(ceil(7900.0 * M / fs));
-  double lo = 0.0, hi = 0.0;     // cumulative power (b0, b1] and (b0, b2]   (d4c.cpp:241-249)
-  block_rfft<3>(Z, lgn, tw, [&](int k, double re, double im) {
-    if (k > b0 && k <= b2) {
-      double pw = re * re + im * im;
-      hi += pw;
-      if (k <= b1) lo += pw;
-    }
-  });
-  block_sum2(lo, hi, scratch);
-  if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
-}
-
 // Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them: a radix
 // select on the IEEE bit patterns (monotone for non-negative doubles), 8 bits per pass,
 // histogram in LDS.  Keys stay in registers.  Digits start at the first bit in which any
@@ -330,6 +262,46 @@ __device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, cplx *Z, do
                           [&](int i, D4cSample s) { rfft_in(Z, i) = s.v; s1 += s.v; s2 += s.w; });
   block_sum2(s1, s2, scratch);
   return s1 / s2;
+}
+
+// ---------------------------------------------------------------------------
+// D4CLoveTrain (d4c.cpp:227-285): is the frame voiced enough to analyse?  LGN: log2 of the transform when the
+// instantiation fixes it (compile-time plan), 0 = p.lg_love.
+template <int LGN>
+__global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y, f = blockIdx.x;
+  if (f >= p.b.n_frames[u]) return;
+  const size_t fi = (size_t)u * p.b.f_stride + f;
+  const double f0 = p.f0[fi];
+  if (f0 == 0.0) { if (threadIdx.x == 0) p.ap0[fi] = 0.0; return; }   // d4c.cpp:274-277
+  const int lgn = LGN > 0 ? LGN : p.lg_love, M = 1 << lgn, fs = p.b.fs;
+  cplx *Z = reinterpret_cast<cplx *>(lds);
+  double *Zr = reinterpret_cast<double *>(lds);
+  double *scratch = Zr + M;
+  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);    // inner complex transform's table
+  const double cf0 = f0 > 40.0 ? f0 : 40.0;                            // d4c.cpp:263,279
+  const D4cWin w = d4c_win(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi], kBlackman, 3.0,
+                           p.noise + p.offsets1[fi]);
+  const double coef = d4c_window_to_lds(w, Z, scratch);
+  {
+    D4cWinRot rot = d4c_win_rot(w, threadIdx.x, blockDim.x);
+    for (int i = threadIdx.x; i < M; i += blockDim.x)
+      rfft_in(Z, i) = i < w.wlen ? rfft_in(Z, i) - d4c_win_next(w, rot) * coef : 0.0;
+  }
+  const int b0 = static_cast<int>(ceil(100.0 * M / fs));
+  const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
+  const int b2 = static_cast<int>(ceil(7900.0 * M / fs));
+  double lo = 0.0, hi = 0.0;     // cumulative power (b0, b1] and (b0, b2]   (d4c.cpp:241-249)
+  block_rfft<3, LGN>(Z, lgn, tw, [&](int k, double re, double im) {
+    if (k > b0 && k <= b2) {
+      double pw = re * re + im * im;
+      hi += pw;
+      if (k <= b1) lo += pw;
+    }
+  });
+  block_sum2(lo, hi, scratch);
+  if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
 }
 
 // Resident waves per SIMD the register allocation aims at.  4 (four 256-thread workgroups per CU, 128 VGPRs)
@@ -651,7 +623,17 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   // workgroup sizes follow the transform size (threads beyond N/16 idle through every radix-8 stage): for the
   // 2048-point internal FFT of fs <= 24 kHz, 64 x 1001 frames: lovetrain 0.53 -> 0.42 ms, groupdelay 3.77 -> 2.52,
   // band 0.97 -> 0.65
-  WH_BLOCKS(d4c_lovetrain, dim3(max_frames, p.b.n_utt), p.lg_love <= 11 ? 128 : 256, d4c_love_lds_bytes(p.lg_love), stream, p);
+  {
+    const dim3 love_grid(max_frames, p.b.n_utt);
+    const size_t love_lds = d4c_love_lds_bytes(p.lg_love);
+#ifdef WORLD_EMU
+    devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<0>, love_grid, 256, love_lds, stream, p);
+#else
+    if (p.lg_love == 11) devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<11>, love_grid, 128, love_lds, stream, p);
+    else if (p.lg_love == 12) devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<12>, love_grid, 256, love_lds, stream, p);
+    else devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<0>, love_grid, p.lg_love <= 11 ? 128 : 256, love_lds, stream, p);
+#endif
+  }
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
   // one radix-8 butterfly per thread: 128 / 256 / 512 threads for the 2048- / 4096- / 8192-point internal FFT
   // (fs <= 24 kHz / <= 48 kHz / <= 96 kHz); the register arrays are sized per shape

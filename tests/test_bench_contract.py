@@ -1,5 +1,6 @@
-"""bench.py's roofline bookkeeping (no GPU): the committed PMC profile must be found by the lookups the
-bench line uses, for every kernel that can come out as the dominant one."""
+"""bench.py's bookkeeping (no GPU): the committed PMC profile must be found by the lookups the bench line uses,
+for every kernel that can come out as the dominant one and for every BASELINE config that has a leg; the committed
+line carries the contract's fields; a profile taken on other kernel sources is reported as stale."""
 import json
 import os
 import sys
@@ -8,25 +9,64 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r02", "bench_n1.json")) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
 def test_committed_profile_feeds_the_bench_line():
     import bench
-    with open(os.path.join(ROOT, "profiles", "r01", "bench_n1.json")) as f:
-        line = json.load(f)
+    line = _line()
     frames = line["config"]["frames_per_step"]
     assert frames == 2001 and line["config"]["workload"].startswith("configs[1]")
     kernels = {k: {"avg_ms": v, "launches_per_step": 1, "ms_per_step": v} for k, v in line["kernels_ms_per_step"].items()}
-    for dominant in ("hv_refine", "d4c_groupdelay", "d4c_band", "hv_band_events", "ct_frame"):
+    for dominant in ("d4c_frame", "hv_refine", "hv_band_events_fft", "ct_envelope", "ct_spectrum"):
         traffic = bench.measured_traffic(dominant, frames)
         assert isinstance(traffic, int) and traffic > 1_000_000, dominant          # bytes per launch
         flops, per_frame = bench.measured_fp64(kernels, frames)
         assert dominant in flops and flops[dominant][0] > 1e8 and 0.5 < flops[dominant][1] < 78.6
-    assert 5e6 < per_frame < 1e7                                                    # ~7 MFLOP per output frame
+    assert 3e6 < per_frame < 1e7                                                    # ~5 MFLOP per output frame
     assert bench.measured_traffic("hv_refine", frames + 1) is None                  # another workload: no claim
-    # the committed line itself carries every field of the contract
+    # the legs of the other configs find their own counters
+    for config, key, dominant in (("2", "2", "hv_refine"), ("3", "3_share", "d4c_frame"), ("4", "4", "d4c_frame")):
+        n = line["configs"][key]["frames_per_step"]
+        assert isinstance(bench.measured_traffic(dominant, n, config), int), (config, dominant)
+
+
+def test_committed_line_carries_the_contract():
+    line = _line()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
-    assert line["dtype"] == "f64" and line["vs_baseline"] is None and line["roofline"]["traffic"] is not None
+    assert line["dtype"] == "f64" and line["vs_baseline"] is None
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-12
+    # round 2: the run checked itself, every single-GPU config has a leg, the timed regions are long enough to see
+    p = line["parity_in_run"]
+    assert p["ok"] and p["slots_bit_identical_to_serial_run"] and p["tpos_bit_exact"] and p["vuv_flips"] == 0
+    assert max(p["f0"], p["sp"], p["ap"]) <= 1e-4 and p["frames"] == 2001
+    assert line["timed_wall_s"] >= 2.0 and line["value_single_job"] > 0
+    for key in ("2", "3_share", "4"):
+        leg = line["configs"][key]
+        assert leg["timed_wall_s"] >= 2.0 and leg["value"] > 0 and leg["roofline"]["kernel"]
+    assert line["cpu_baseline"]["kind"] == "reference" and "-O1" in line["cpu_baseline"]["sample"]
+    assert "-O3" in line["cpu_baseline_o3"]["sample"] and line["cpu_baseline_all_cores"]["cores"] >= 1
+
+
+def test_a_profile_of_other_sources_is_reported_stale(tmp_path, monkeypatch):
+    import bench
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        t = json.load(f)
+    assert "csrc_hash" in t and set(t["configs"]) >= {"1", "2", "4"}
+    # same counters, another stamp
+    fake = tmp_path / "profiles"
+    fake.mkdir()
+    t["csrc_hash"] = "0" * 16
+    (fake / "pmc_traffic.json").write_text(json.dumps(t))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_hash", lambda: "f" * 16)
+    assert bench.traffic_stale("1") is True
+    t["csrc_hash"] = "f" * 16
+    (fake / "pmc_traffic.json").write_text(json.dumps(t))
+    assert bench.traffic_stale("1") is False and bench.traffic_stale("9") is None

@@ -154,9 +154,9 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     }
     // exactly one lane found the bin: two max-reductions broadcast (digit, below) and hsel
     {
-      const int got = wave_max_int(digit < 0 ? -1 : (digit << 12) | below);     // below <= 2049 < 2^12
+      const int got = wave_max_int(digit < 0 ? -1 : (digit << 13) | below);     // below <= 4097 < 2^13
       hsel = wave_max_int(hsel);
-      digit = got >> 12; below = got & 4095;
+      digit = got >> 13; below = got & 8191;
     }
     remaining -= below;
     bucket = hsel;

@@ -322,10 +322,11 @@ def main():
         wh = WorldHip(device=local)
         phases = {"compute_ms": 0.0, "exchange_ms": 0.0, "steps": 0}
 
+        last = [None]
+
         def step():
-            out = wd.analyze_sharded(xs, FS, lengths=lengths, analyze=wh.analyze, packer=wh, sub_batch=args.sub_batch,
-                                     gather=not args.no_gather, timings=phases)
-            return out
+            last[0] = wd.analyze_sharded(xs, FS, lengths=lengths, analyze=wh.analyze, packer=wh, sub_batch=args.sub_batch,
+                                         gather=not args.no_gather, timings=phases)
 
         for _ in range(max(1, args.warmup)):
             step()
@@ -338,6 +339,32 @@ def main():
         ph = torch.tensor([phases["compute_ms"], phases["exchange_ms"]], dtype=torch.float64, device=dev) / max(1, phases["steps"])
         ph_max = ph.clone()
         dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
+        # the run checks itself: utterances analysed on OTHER ranks, as this rank received them, against a lone
+        # analysis made here (bit-identical: batched == single, and the exchange must not touch a bit)
+        parity = None
+        if not args.no_gather:
+            res, checked, same = last[0], [], True
+            for i in sorted({(rank * 7 + 1) % n_job, n_job // 2, (n_job - 1 - rank) % n_job}):
+                tp1, f01, sp1, ap1, nf1 = wh.analyze(synth.utterance(i, FS, sec, device=dev).unsqueeze(0), FS)
+                tp, f0, sp, ap = res.utterance(i)
+                k = int(nf1[0])
+                same = same and tp.shape[0] == k and torch.equal(tp, tp1[0, :k]) and torch.equal(f0, f01[0, :k]) and \
+                    torch.equal(sp, sp1[0, :k]) and torch.equal(ap, ap1[0, :k])
+                checked.append(i)
+            ok = torch.tensor([1 if same else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            parity = {"utterances_checked_on_rank0": checked, "every_rank_bit_identical_to_lone_analysis": bool(ok.item()),
+                      "randn_table_intact": bool(wh.verify_tables())}
+        # roofline of the dominant kernel of ONE batched call of this rank's share (rank 0; HIP events per kernel)
+        roofline = None
+        if rank == 0 and mine:
+            idx = mine[:args.sub_batch]
+            xb = torch.stack([xs[i] for i in idx]).contiguous()
+            kernels = kernel_profile(wh, lambda: wh.analyze(xb, FS, frame_period=FRAME_PERIOD), 1)
+            roofline = roofline_of(kernels, frame_count(FS, n_samp, FRAME_PERIOD) * len(idx), BYTES_PER_FRAME,
+                                   "3" if len(idx) == 128 else "-")
+            roofline["scope"] = f"one batched analysis of {len(idx)} utterances on rank 0"
+            del xb
         barrier()
         dist.destroy_process_group()
         if rank == 0:
@@ -357,7 +384,10 @@ def main():
                                f"({frames_per_step * (2 + 2 * nb) * 8 / 1e9:.1f} GB reassembled on every rank)")},
                 "phases": {"compute_ms_per_step_max_over_ranks": float(ph_max[0]), "exchange_ms_per_step_max_over_ranks": float(ph_max[1]),
                            "note": "host wall clock around the analysis calls (synchronised) and around pack + all-gather"},
-                "roofline": None, "cpu_baseline": None}))
+                "parity_in_run": parity, "roofline": roofline, "cpu_baseline": None}))
+            if parity is not None and not (parity["every_rank_bit_identical_to_lone_analysis"] and parity["randn_table_intact"]):
+                sys.stderr.write("bench.py: parity_in_run failed: " + json.dumps(parity) + "\n")
+                sys.exit(1)
         return
 
     # =====================================================================================================

@@ -233,3 +233,23 @@ def test_sixty_second_utterance(wh, ref, pool):
     _check_full("60 s", (tpos[0].cpu().numpy(), f0[0].cpu().numpy(), sp[0].cpu().numpy(), ap[0].cpu().numpy()),
                 (tp_r, f0_r, jobs[0].result(), jobs[1].result()))
     wh.close()
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py --gpus 2 end to end (the SCALE run's code path): two ranks share this box's one GPU, the all-gather
+    goes through gloo with host staging (a functional check, never a number of record): partition, batched analysis
+    in sub-batches, pack, ONE all-gather, per-utterance views -- and the run's own check that utterances received
+    from the other rank are bit-identical to a lone analysis"""
+    env = dict(os.environ, WORLD_HIP_BENCH_BACKEND="gloo")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--job-utterances", "10", "--sub-batch", "3", "--min-wall", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["workload"].startswith("configs[3]")
+    assert line["config"]["frames_per_step"] == 10 * 1001 and line["value"] > 0
+    p = line["parity_in_run"]
+    assert p["every_rank_bit_identical_to_lone_analysis"] and p["randn_table_intact"], p
+    assert line["phases"]["compute_ms_per_step_max_over_ranks"] > 0 and line["roofline"]["kernel"]

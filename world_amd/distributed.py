@@ -36,7 +36,12 @@ def partition(lengths, world_size):
 def _gather_one(t, group, async_op):
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    if dist.get_backend(group) == "gloo":        # CPU tests
+    if dist.get_backend(group) == "gloo":        # CPU tests; device tensors are staged through the host (gloo has no
+        if t.is_cuda:                            # device all-gather): the functional check of bench.py --gpus N on a 1-GPU box
+            host = torch.empty((world,) + tuple(t.shape), dtype=t.dtype)
+            dist.all_gather(list(host.unbind(0)), t.contiguous().cpu(), group=group)
+            out.copy_(host)
+            return out, None
         chunks = list(out.unbind(0))
         work = dist.all_gather(chunks, t.contiguous(), group=group, async_op=async_op)
     else:

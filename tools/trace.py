@@ -13,7 +13,10 @@ import torch
 from world_amd import synth
 from world_amd.api import WorldHip
 wh = WorldHip()
-x = synth.vowel(48000, 10.0, seed=12345, device=torch.device("cuda", 0))[None]
+# seconds of signal (argv[1], default 10): at 5.1 s the traced frame 1000 falls into the launch's second round of
+# workgroups, which has about one workgroup per CU -- the phases' latencies without co-resident workgroups
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+x = synth.vowel(48000, seconds, seed=12345, device=torch.device("cuda", 0))[None]
 for _ in range(3):
     wh.analyze(x, 48000)
 torch.cuda.synchronize()

@@ -227,7 +227,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   if (fs < 15800) fail("D4C: fs=%d is below the 15.8 kHz the reference's LoveTrain band edges require", fs);
   const int nap = static_cast<int>(std::min(15000.0, fs / 2.0 - 3000.0) / 3000.0);
   const int wl = static_cast<int>(3000.0 * fft_d4c / fs) * 2 + 1;
-  if (nap < 1 || nap > 12) fail("D4C: unsupported number of aperiodicity bands %d", nap);
+  if (nap < 1 || nap > 6) fail("D4C: unsupported number of aperiodicity bands %d", nap);
   if (c->nuttall_len != wl) {                                         // NuttallWindow, common.cpp:113-121
     std::vector<double> w(wl);
     for (int i = 0; i < wl; ++i) {

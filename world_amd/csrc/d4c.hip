@@ -96,27 +96,54 @@ template <int NMAX> struct SelKeys {
 constexpr int kSelHists = 3;
 // key[q], q < mine: bit patterns of this thread's elements (n elements block-wide).
 // hist: kSelHists x 256 ints of LDS.
-template <int kSelKeys>
+template <int NT = 0, int kSelKeys>
 __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&key)[kSelKeys], int mine, int n, int m,
                                                    int *hist, double *scratch, double *partial, double *total,
                                                    bool trace_me = false) {
   (void)trace_me;
-  const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wv = wave_in_block(), nw = waves_per_block();
-  unsigned long long kmin = ~0ull, kmax = 0ull;
+  const int tid = wg_thread<NT>(), nt = wg_size<NT>(), lane = lane_id(), wv = wave_in_block(), nw = wg_waves<NT>();
+  // Range of the keys.  The keys are non-negative doubles, so their high words are non-negative ints and order
+  // like the keys: the range is taken on the high words (32-bit DPP reductions, a fifth of the 64-bit ones' cost)
+  // and only when every key shares its high word -- a constant spectrum -- on the full keys.
+  // The lower end need not be the smallest key.  The threshold is the (n-m+1)-th largest key, and each of the nt
+  // threads holds a key >= the smallest of the threads' maxima: with nt >= n-m+1 the threshold is >= that value,
+  // keys below it are below the threshold whatever their rank, and only the others (a few hundred of the 2049 of
+  // a band, where the first histogram's atomics used to pile 2560 keys on a few dozen bins) are histogrammed.
+  const bool lower_bound = nt >= n - m + 1;
+  int hmin = 0x7fffffff, hmax = 0;
 #pragma unroll
   for (int q = 0; q < kSelKeys; ++q)
-    if (q < mine) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
+    if (q < mine) { const int h = (int)(key[q] >> 32); hmin = h < hmin ? h : hmin; hmax = h > hmax ? h : hmax; }
   for (int i = tid; i < kSelHists * 256; i += nt) hist[i] = 0;
+  unsigned long long kmin, kmax;
 #ifndef WORLD_EMU
-  wave_minmax_u64(kmin, kmax);
-  unsigned long long *ks = reinterpret_cast<unsigned long long *>(scratch);
+  hmin = -wave_max_int(-(lower_bound ? hmax : hmin)); hmax = wave_max_int(hmax);
+  int *hs = reinterpret_cast<int *>(scratch);
   __syncthreads();
-  if (lane == 0) { ks[wv] = kmin; ks[32 + wv] = kmax; }
+  if (lane == 0) { hs[wv] = hmin; hs[32 + wv] = hmax; }
   __syncthreads();
-  for (int w = 0; w < nw; ++w) { kmin = ks[w] < kmin ? ks[w] : kmin; kmax = ks[32 + w] > kmax ? ks[32 + w] : kmax; }
+  for (int w = 0; w < nw; ++w) { hmin = hs[w] < hmin ? hs[w] : hmin; hmax = hs[32 + w] > hmax ? hs[32 + w] : hmax; }
 #else
   (void)lane; (void)wv; (void)nw;
+  if (lower_bound) hmin = hmax;
 #endif
+  if (hmin != hmax) {
+    // bits below the high word do not matter: the first differing bit is in the high word
+    kmin = (unsigned long long)(unsigned)hmin << 32; kmax = (unsigned long long)(unsigned)hmax << 32;
+  } else {
+    kmin = ~0ull; kmax = 0ull;
+#pragma unroll
+    for (int q = 0; q < kSelKeys; ++q)
+      if (q < mine) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
+#ifndef WORLD_EMU
+    wave_minmax_u64(kmin, kmax);
+    unsigned long long *ks = reinterpret_cast<unsigned long long *>(scratch);
+    __syncthreads();
+    if (lane == 0) { ks[wv] = kmin; ks[32 + wv] = kmax; }
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) { kmin = ks[w] < kmin ? ks[w] : kmin; kmax = ks[32 + w] > kmax ? ks[32 + w] : kmax; }
+#endif
+  }
   WH_STAMP(0, 3);
   const unsigned long long diff = kmin ^ kmax;
   int hi = diff ? 64 - __clzll((long long)diff) : 0;    // bits >= hi are common to every key
@@ -134,24 +161,38 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     }
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q) {
-      const bool in = q < mine && (it == 0 || (key[q] >> hi) == (prefix >> hi));
+      // first pass: everything from the floor's bin upwards (the floor rounded down to a bin boundary, so that a
+      // key is either counted here and in every later pass it qualifies for, or in none)
+      const bool in = q < mine && (it == 0 ? (key[q] >> shift) >= (kmin >> shift) : (key[q] >> hi) == (prefix >> hi));
       if (in) atomicAdd(&h[(int)((key[q] >> shift) & mask)], 1);
     }
     __syncthreads();
-    // every wave locates the digit redundantly: each lane sums its bins, a wave scan finds the rank
-    const int per_lane = 256 / WAVE;
-    int local = 0;
-    for (int j = 0; j < per_lane; ++j) local += h[lane_id() * per_lane + j];
-    int tot, before = wave_excl_scan_int(local, &tot);
+    // every wave locates the digit redundantly: each lane takes its four bins in one 16-byte read, a wave scan
+    // finds the lane holding the rank, that lane the bin
+    static_assert(256 / WAVE == 4 || WAVE == 1, "four bins per lane");
     int digit = -1, below = -1, hsel = -1;
+#ifndef WORLD_EMU
+    const int4 c4 = *reinterpret_cast<const int4 *>(h + 4 * lane);
+    const int local = (c4.x + c4.y) + (c4.z + c4.w);
+    int tot, before = wave_excl_scan_int(local, &tot);
+    if (it == 0) remaining -= n - tot;               // the keys below the floor rank below everything counted here
     if (before <= remaining && remaining < before + local) {
-      int acc = before;
-      for (int j = 0; j < per_lane; ++j) {
-        int c = h[lane_id() * per_lane + j];
-        if (remaining < acc + c) { digit = lane_id() * per_lane + j; below = acc; hsel = c; break; }
+      const int r = remaining - before, a1 = c4.x, a2 = a1 + c4.y, a3 = a2 + c4.z;
+      const int j = (r >= a1) + (r >= a2) + (r >= a3);
+      digit = 4 * lane + j;
+      below = before + (j == 0 ? 0 : j == 1 ? a1 : j == 2 ? a2 : a3);
+      hsel = j == 0 ? c4.x : j == 1 ? c4.y : j == 2 ? c4.z : c4.w;
+    }
+#else
+    {
+      int acc = 0;
+      for (int j = 0; j < 256; ++j) {
+        const int c = h[j];
+        if (remaining < acc + c) { digit = j; below = acc; hsel = c; break; }
         acc += c;
       }
     }
+#endif
     // exactly one lane found the bin: two max-reductions broadcast (digit, below) and hsel
     {
       const int got = wave_max_int(digit < 0 ? -1 : (digit << 13) | below);     // below <= 4097 < 2^13
@@ -182,7 +223,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
   }
   (void)n;
   WH_STAMP(0, 8);
-  block_sum3(s_lt, s_all, s_thr, scratch);
+  block_sum3<NT>(s_lt, s_all, s_thr, scratch);
   const double thr = hi > 0 ? s_thr : __longlong_as_double((long long)prefix);
   *partial = s_lt + (remaining + 1) * thr;
   *total = s_all;
@@ -255,12 +296,13 @@ __device__ __forceinline__ D4cSample d4c_sample(const D4cWin &w, int i, D4cWinRo
 }
 // windowed, dithered samples into the real-transform input; returns the DC-balance coefficient
 // (sum of the waveform / sum of the window, d4c.cpp:71-80) which the callers apply
+template <int NT = 0>
 __device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, cplx *Z, double *scratch) {
   double s1 = 0.0, s2 = 0.0;
-  D4cWinRot rot = d4c_win_rot(w, threadIdx.x, blockDim.x);
-  block_map<4, D4cSample>(w.wlen, [&](int i) { return d4c_sample(w, i, rot); },
-                          [&](int i, D4cSample s) { rfft_in(Z, i) = s.v; s1 += s.v; s2 += s.w; });
-  block_sum2(s1, s2, scratch);
+  D4cWinRot rot = d4c_win_rot(w, wg_thread<NT>(), wg_size<NT>());
+  block_map<4, D4cSample, NT>(w.wlen, [&](int i) { return d4c_sample(w, i, rot); },
+                              [&](int i, D4cSample s) { rfft_in(Z, i) = s.v; s1 += s.v; s2 += s.w; });
+  block_sum2<NT>(s1, s2, scratch);
   return s1 / s2;
 }
 
@@ -317,7 +359,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = wg_thread<T>();
+  constexpr int nt = T;                                                // launch_d4c launches exactly T threads
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
   const bool trace_me = f == 1000; (void)trace_me;
@@ -336,13 +379,13 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   double *scratch = Zr + N;
   // the quarter-wave table is staged two levels coarser than the merge steps ask for (fft.h: twiddle()): 2 KB
   // instead of 8 keep the workgroup, parked centroid included, inside the 52 KB that three per CU allow
-  const TwLds tw = stage_twiddles(scratch + 64, lgn - 2, p.tab.tw);
+  const TwLds tw = stage_twiddles<T>(scratch + 64, lgn - 2, p.tab.tw);
 #ifdef WORLD_EMU
   const FftPlan plan = make_plan_max(lgn - 1, 3);
   auto cfft = [&]() { block_cfft_dif<3>(Z, plan, tw); };
 #else
   constexpr FftPlan plan = make_plan_max(lgn - 1, 3);
-  auto cfft = [&]() __attribute__((always_inline)) { block_cfft_dif_static<lgn - 1, 3>(Z, tw); };
+  auto cfft = [&]() __attribute__((always_inline)) { block_cfft_dif_static<lgn - 1, 3, T>(Z, tw); };
 #endif
   // body(slot, k) for every bin this thread owns (rfft_merge_items: item m = bins tid + m T and H - that, natural
   // order, so LDS traffic indexed by bin is conflict-free); `slot` is a compile-time constant after unrolling
@@ -391,7 +434,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       if (k >= 1 && k <= bnd) Zr[bnd - k] = v;
       if (k < H && k >= H - bnd) Zr[2 * H + bnd - k] = v;
     });
-    block_scan_incl_double(Zr, seg_len, scratch);
+    block_scan_incl_double<T>(Zr, seg_len, scratch);
     const double origin_axis = -(bnd - 0.5) * fs / N;
     const double inv_step = static_cast<double>(N) / fs, inv_width = 1.0 / width;
     for_bins([&](int slot, int k) {
@@ -413,7 +456,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
                              noise + (size_t)c * wdraws);
     __syncthreads();
     WH_STAMP(32, 1 + 5 * c);
-    const double coef = d4c_window_to_lds(w, Z, scratch);
+    const double coef = d4c_window_to_lds<T>(w, Z, scratch);
     double pw = 0.0;
     {
       D4cWinRot rot = d4c_win_rot(w, tid, nt);
@@ -423,24 +466,24 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
         rfft_in(Z, i) = v;
       }
     }
-    const double inv_pw = 1.0 / block_sum(pw, scratch);    // 1 / |w x|^2 (d4c.cpp:104-107)
+    const double inv_pw = 1.0 / block_sum<T>(pw, scratch);    // 1 / |w x|^2 (d4c.cpp:104-107)
     WH_STAMP(32, 2 + 5 * c);
     double x1r[kBins], x1i[kBins];
     cfft();
-    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
+    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
       x1r[2 * m] = ar; x1i[2 * m] = ai; x1r[2 * m + 1] = br; x1i[2 * m + 1] = bi;
     });
     WH_STAMP(32, 3 + 5 * c);
     // second input: (n + 1) times the same balanced waveform (d4c.cpp:111-112), recomputed from x
     {
       D4cWinRot rot = d4c_win_rot(w, tid, nt);
-      block_map<4, double>(w.wlen, [&](int i) { const D4cSample s = d4c_sample(w, i, rot); return (s.v - s.w * coef) * (i + 1.0); },
+      block_map<4, double, T>(w.wlen, [&](int i) { const D4cSample s = d4c_sample(w, i, rot); return (s.v - s.w * coef) * (i + 1.0); },
                            [&](int i, double v) { rfft_in(Z, i) = v; });
     }
     for (int i = w.wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
     cfft();
     WH_STAMP(32, 4 + 5 * c);
-    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
+    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
       out[2 * m] = (ar * x1r[2 * m] + x1i[2 * m] * ai) * inv_pw;                           // d4c.cpp:115-116
       out[2 * m + 1] = (br * x1r[2 * m + 1] + x1i[2 * m + 1] * bi) * inv_pw;
     });
@@ -471,7 +514,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   double B[kBins];
   {
     const D4cWin w = d4c_win(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws);
-    const double coef = d4c_window_to_lds(w, Z, scratch);
+    const double coef = d4c_window_to_lds<T>(w, Z, scratch);
     {
       D4cWinRot rot = d4c_win_rot(w, tid, nt);
       for (int i = tid; i < N; i += nt)
@@ -479,7 +522,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     }
     WH_STAMP(32, 13);
     cfft();
-    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
+    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
       B[2 * m] = ar * ar + ai * ai; B[2 * m + 1] = br * br + bi * bi;
     });
     WH_STAMP(32, 14);
@@ -538,24 +581,22 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       const int s0 = swz(tid);
 #pragma unroll
       for (int k = 0; k < R; ++k) Z[s0 ^ swz(k << sh)] = a[k];
-      DifStages<lgn - 1, 3, lgn - 1 - 3>::run(Z, tw);
+      DifStages<lgn - 1, 3, lgn - 1 - 3, T>::run(Z, tw);
       __syncthreads();
     }
 #endif
     unsigned long long key[kBins];
 #pragma unroll
     for (int e = 0; e < kBins; ++e) key[e] = ~0ull;
-    rfft_merge_items<kItems>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
+    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
       key[2 * m] = (unsigned long long)__double_as_longlong(ar * ar + ai * ai);
       if (paired) key[2 * m + 1] = (unsigned long long)__double_as_longlong(br * br + bi * bi);
     });
     double part, tot;
-    block_smallest_sum(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
-    if (tid == 0) {
-      double c = 10 * log10(part / tot);
-      c = c + (cf0 - 100) / 50.0;                       // d4c.cpp:314-316
-      p.coarse[fi * 16 + 1 + band] = c < 0.0 ? c : 0.0;
-    }
+    block_smallest_sum<T>(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
+    // the band's two sums; d4c_finish turns them into dB (d4c.cpp:221-224, 314-316) -- a division and a log10 on
+    // one lane here would stand between this band's select and the next band's first barrier
+    if (tid == 0) { p.coarse[fi * 16 + 1 + band] = part; p.coarse[fi * 16 + 9 + band] = tot; }
   }
   WH_STAMP(32, 20);
 }
@@ -574,7 +615,17 @@ __global__ void d4c_finish(D4cParams p) {
     for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny;
     return;
   }
-  const double *coarse_in = p.coarse + fi * 16;
+  // the bands' coarse aperiodicity in dB from the sums d4c_frame left (d4c.cpp:221-224, 314-316), once per frame
+  DYN_LDS(lds);
+  double *coarse_db = reinterpret_cast<double *>(lds);                 // [1 + nap]
+  for (int b = tid; b < p.nap; b += nt) {
+    const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
+    double c = 10 * log10(p.coarse[fi * 16 + 1 + b] / p.coarse[fi * 16 + 9 + b]);
+    c = c + (cf0 - 100) / 50.0;
+    coarse_db[1 + b] = c < 0.0 ? c : 0.0;
+  }
+  __syncthreads();
+  const double *coarse_in = coarse_db;
   const int nk = p.nap + 2;
   for (int i = tid; i < nb_out; i += nt) {
     double xi = static_cast<double>(i) * fs / p.fft_out;
@@ -646,7 +697,7 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   else if (p.lg_d4c == 12) devrt::launch_blocks("d4c_frame", d4c_frame<4096, 256>, grid, 256, lds, stream, p);
   else devrt::launch_blocks("d4c_frame", d4c_frame<8192, 512>, grid, 512, lds, stream, p);
 #endif
-  WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 0, stream, p);
+  WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 8 * sizeof(double), stream, p);
 }
 
 }  // namespace world_hip

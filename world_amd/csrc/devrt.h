@@ -191,6 +191,20 @@ __device__ __forceinline__ int flat_thread_x() { return (int)(blockIdx.x * block
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x % WAVE); }
 __device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x / WAVE); }
 __device__ __forceinline__ int waves_per_block() { return (int)((blockDim.x + WAVE - 1) / WAVE); }
+// Workgroup size and thread index for code that may know the size at compile time (NT > 0: the launch uses exactly NT
+// threads; loops over `tid + m NT` then unroll with their bounds checks decided at compile time, and the stride
+// needs no register).  NT = 0: read from the launch.
+template <int NT> __device__ __forceinline__ int wg_size() {
+  if constexpr (NT > 0) return NT; else return (int)blockDim.x;
+}
+template <int NT> __device__ __forceinline__ int wg_thread() {
+  const int t = (int)threadIdx.x;
+#ifndef WORLD_EMU
+  if constexpr (NT > 0) __builtin_assume(t >= 0 && t < NT);
+#endif
+  return t;
+}
+template <int NT> __device__ __forceinline__ int wg_waves() { return (wg_size<NT>() + WAVE - 1) / WAVE; }
 __device__ __forceinline__ int wave_item_x() { return (int)(blockIdx.x * waves_per_block() + wave_in_block()); }
 
 // Frame kernels (one workgroup per analysis frame) read windows of x that overlap their neighbours' by
@@ -359,10 +373,10 @@ __device__ __forceinline__ int wave_bcast_int(int v, int src_lane) {
 
 // block collectives; `scratch` = LDS area of >= 64 doubles owned by the caller.
 // All threads must call; result returned to all; safe to call back to back.
-__device__ __forceinline__ double block_sum(double v, double *scratch) {
+template <int NT = 0> __device__ __forceinline__ double block_sum(double v, double *scratch) {
 #ifndef WORLD_EMU
   v = wave_sum(v);
-  int nw = waves_per_block();
+  int nw = wg_waves<NT>();
   if (nw == 1) return v;
   __syncthreads();  // previous users of scratch are done
   if (lane_id() == 0) scratch[wave_in_block()] = v;
@@ -375,10 +389,10 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
   return v;
 #endif
 }
-__device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch) {
+template <int NT = 0> __device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch) {
 #ifndef WORLD_EMU
   a = wave_sum(a); b = wave_sum(b);
-  int nw = waves_per_block();
+  int nw = wg_waves<NT>();
   if (nw == 1) return;
   __syncthreads();
   if (lane_id() == 0) { scratch[wave_in_block()] = a; scratch[32 + wave_in_block()] = b; }
@@ -390,10 +404,10 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch
   (void)scratch;
 #endif
 }
-__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *scratch) {
+template <int NT = 0> __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *scratch) {
 #ifndef WORLD_EMU
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
-  int nw = waves_per_block();
+  int nw = wg_waves<NT>();
   if (nw == 1) return;
   __syncthreads();
   if (lane_id() == 0) { scratch[wave_in_block()] = a; scratch[16 + wave_in_block()] = b; scratch[32 + wave_in_block()] = c; }
@@ -405,10 +419,10 @@ __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, doub
   (void)scratch;
 #endif
 }
-__device__ __forceinline__ void block_sum4(double &a, double &b, double &c, double &d, double *scratch) {
+template <int NT = 0> __device__ __forceinline__ void block_sum4(double &a, double &b, double &c, double &d, double *scratch) {
 #ifndef WORLD_EMU
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
-  int nw = waves_per_block();
+  int nw = wg_waves<NT>();
   if (nw == 1) return;
   __syncthreads();
   if (lane_id() == 0) {
@@ -429,9 +443,9 @@ __device__ __forceinline__ void block_sum4(double &a, double &b, double &c, doub
 // compiler must keep each store ahead of the next iteration's loads -- and a dependent FP64 op
 // costs 36 cycles on gfx950 (tools/microbench_fp64.hip), so with 2-4 waves per SIMD such loops
 // run at latency, not throughput.  K independent chains per thread close most of that gap.
-template <int K, class T, class Produce, class Consume>
+template <int K, class T, int NT = 0, class Produce, class Consume>
 __device__ __forceinline__ void block_map(int n, Produce produce, Consume consume) {
-  const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+  const int tid = wg_thread<NT>(), nt = wg_size<NT>();
   for (int base = tid; base < n; base += K * nt) {
     T v[K];
 #pragma unroll
@@ -493,8 +507,9 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
 // this is the plain serial left-to-right sum.)  NOT used where the reference's
 // serial rounding is part of the result (CheapTrick's smoothing keeps a serial
 // scan); used for D4C where the order is benign.
+template <int NT = 0>
 __device__ __forceinline__ void block_scan_incl_double(double *a, int n, double *scratch) {
-  int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+  int nt = wg_size<NT>(), tid = wg_thread<NT>();
   int chunk = (n + nt - 1) / nt;
   int lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
   __syncthreads();

@@ -40,9 +40,10 @@ struct TwLds {
 };
 
 // stage the table for transforms up to 2^lg points; call before the first transform
+template <int NT = 0>
 __device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2 *global_tw) {
   const int quarter = 1 << (lg - 2);
-  for (int i = threadIdx.x; i <= quarter; i += blockDim.x) q[i] = global_tw[(size_t)i << (kTwLog2 - lg)].x;
+  for (int i = wg_thread<NT>(); i <= quarter; i += wg_size<NT>()) q[i] = global_tw[(size_t)i << (kTwLog2 - lg)].x;
   __syncthreads();
   TwLds t; t.q = q; t.lg = lg;
   const double2 f = global_tw[lg + 1 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 1) : 0];
@@ -225,13 +226,13 @@ template <int LR> __device__ __forceinline__ void mul_powers(cplx *a, cplx w1) {
 }
 
 // one decimation-in-frequency stage: sub-transforms of length 2^lev split R ways
-template <int LR> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int lev, const TwLds &tw) {
+template <int LR, int NT = 0> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int lev, const TwLds &tw) {
   constexpr int R = 1 << LR;
   const int sh = lev - LR, q = 1 << sh, nbf = 1 << (lg - LR);
   int c[R];                                          // swz(r q): uniform
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = swz(r << sh);
-  for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
+  for (int b = wg_thread<NT>(); b < nbf; b += wg_size<NT>()) {
     const int j = b & (q - 1);
     const int s0 = swz(((b >> sh) << lev) + j);      // bits [sh, lev) of the base index are clear
     cplx a[R];
@@ -382,17 +383,17 @@ __device__ __forceinline__ void block_cfft_dif_head(cplx *z, const FftPlan &p, c
 // Kernels whose shape fixes the length (d4c_frame) instantiate the stages by recursion: no stage loop, no
 // radix switch, every stride a constant -- and a constexpr plan makes the digit reversals of the merge
 // steps (fft_slot / fft_bin_of_slot) straight-line bit arithmetic.
-template <int LG, int MAXLR, int LEV> struct DifStages {
+template <int LG, int MAXLR, int LEV, int NT = 0> struct DifStages {
   static __device__ __forceinline__ void run(cplx *z, const TwLds &tw) {
     constexpr int LR = LEV >= MAXLR ? MAXLR : LEV;
     __syncthreads();
-    dif_stage<LR>(z, LG, LEV, tw);
-    if constexpr (LEV - LR > 0) DifStages<LG, MAXLR, LEV - LR>::run(z, tw);
+    dif_stage<LR, NT>(z, LG, LEV, tw);
+    if constexpr (LEV - LR > 0) DifStages<LG, MAXLR, LEV - LR, NT>::run(z, tw);
   }
 };
-template <int LG, int MAXLR>
+template <int LG, int MAXLR, int NT = 0>
 __device__ __forceinline__ void block_cfft_dif_static(cplx *z, const TwLds &tw) {
-  DifStages<LG, MAXLR, LG>::run(z, tw);
+  DifStages<LG, MAXLR, LG, NT>::run(z, tw);
   __syncthreads();
 }
 template <int LG, int MAXLR, class Src>
@@ -526,10 +527,10 @@ __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan
 // (prefix-sum segments, spectrum slices) is conflict-free, at the price of digit-reversed (2..4-way
 // conflicting) reads of the transform here.  rfft_merge above makes the opposite choice.
 //   emit(m, k, Xre[k], Xim[k], paired, Xre[h-k], Xim[h-k])        paired = false only for it = h/2
-template <int KITEMS, class Emit>
+template <int KITEMS, int NT = 0, class Emit>
 __device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit) {
   const int lgh = lgn - 1, h = 1 << lgh, q = h >> 1;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = wg_thread<NT>(), nt = wg_size<NT>();
 #pragma unroll
   for (int m = 0; m < KITEMS; ++m) {
     const int k = tid + m * nt;

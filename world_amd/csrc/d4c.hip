@@ -296,10 +296,12 @@ __device__ __forceinline__ D4cSample d4c_sample(const D4cWin &w, int i, D4cWinRo
 }
 // windowed, dithered samples into the real-transform input; returns the DC-balance coefficient
 // (sum of the waveform / sum of the window, d4c.cpp:71-80) which the callers apply
+// rot0: d4c_win_rot(w, thread, workgroup size) -- the callers walk the same window two or three times and pay
+// its two sincospi once
 template <int NT = 0>
-__device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, cplx *Z, double *scratch) {
+__device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, const D4cWinRot &rot0, cplx *Z, double *scratch) {
   double s1 = 0.0, s2 = 0.0;
-  D4cWinRot rot = d4c_win_rot(w, wg_thread<NT>(), wg_size<NT>());
+  D4cWinRot rot = rot0;
   block_map<4, D4cSample, NT>(w.wlen, [&](int i) { return d4c_sample(w, i, rot); },
                               [&](int i, D4cSample s) { rfft_in(Z, i) = s.v; s1 += s.v; s2 += s.w; });
   block_sum2<NT>(s1, s2, scratch);
@@ -325,9 +327,10 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   const double cf0 = f0 > 40.0 ? f0 : 40.0;                            // d4c.cpp:263,279
   const D4cWin w = d4c_win(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi], kBlackman, 3.0,
                            p.noise + p.offsets1[fi]);
-  const double coef = d4c_window_to_lds(w, Z, scratch);
+  const D4cWinRot rot0 = d4c_win_rot(w, threadIdx.x, blockDim.x);
+  const double coef = d4c_window_to_lds(w, rot0, Z, scratch);
   {
-    D4cWinRot rot = d4c_win_rot(w, threadIdx.x, blockDim.x);
+    D4cWinRot rot = rot0;
     for (int i = threadIdx.x; i < M; i += blockDim.x)
       rfft_in(Z, i) = i < w.wlen ? rfft_in(Z, i) - d4c_win_next(w, rot) * coef : 0.0;
   }
@@ -456,10 +459,11 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
                              noise + (size_t)c * wdraws);
     __syncthreads();
     WH_STAMP(32, 1 + 5 * c);
-    const double coef = d4c_window_to_lds<T>(w, Z, scratch);
+    const D4cWinRot rot0 = d4c_win_rot(w, tid, nt);
+    const double coef = d4c_window_to_lds<T>(w, rot0, Z, scratch);
     double pw = 0.0;
     {
-      D4cWinRot rot = d4c_win_rot(w, tid, nt);
+      D4cWinRot rot = rot0;
       for (int i = tid; i < N; i += nt) {
         double v = 0.0;
         if (i < w.wlen) { v = rfft_in(Z, i) - d4c_win_next(w, rot) * coef; pw += v * v; }
@@ -476,7 +480,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     WH_STAMP(32, 3 + 5 * c);
     // second input: (n + 1) times the same balanced waveform (d4c.cpp:111-112), recomputed from x
     {
-      D4cWinRot rot = d4c_win_rot(w, tid, nt);
+      D4cWinRot rot = rot0;
       block_map<4, double, T>(w.wlen, [&](int i) { const D4cSample s = d4c_sample(w, i, rot); return (s.v - s.w * coef) * (i + 1.0); },
                            [&](int i, double v) { rfft_in(Z, i) = v; });
     }
@@ -514,9 +518,10 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   double B[kBins];
   {
     const D4cWin w = d4c_win(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws);
-    const double coef = d4c_window_to_lds<T>(w, Z, scratch);
+    const D4cWinRot rot0 = d4c_win_rot(w, tid, nt);
+    const double coef = d4c_window_to_lds<T>(w, rot0, Z, scratch);
     {
-      D4cWinRot rot = d4c_win_rot(w, tid, nt);
+      D4cWinRot rot = rot0;
       for (int i = tid; i < N; i += nt)
         rfft_in(Z, i) = i < w.wlen ? rfft_in(Z, i) - d4c_win_next(w, rot) * coef : 0.0;
     }

@@ -449,6 +449,11 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     });
   };
 
+  // The frame's three windows -- two Blackman for the centroid, one Hanning for the power spectrum -- share their
+  // length and their angle per sample (ratio 4, the same F0: d4c.cpp:97,101,155), so the cosine every one of them
+  // is built from starts and advances identically: one sincospi pair per frame.
+  const D4cWinRot rot0 = d4c_win_rot(d4c_win(x, x_len, fs, cf0, pos, kHanning, 4.0, noise), tid, nt);
+
   // ---- GetStaticCentroid (d4c.cpp:90-143) -------------------------------------
   // centroid = Re(X2 conj X1) with X1 = FFT(w x / |w x|), X2 = FFT((n+1) w x / |w x|): two real transforms
   // through the one buffer, X1 waiting in registers; the normalisation is applied to the product.
@@ -459,7 +464,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
                              noise + (size_t)c * wdraws);
     __syncthreads();
     WH_STAMP(32, 1 + 5 * c);
-    const D4cWinRot rot0 = d4c_win_rot(w, tid, nt);
     const double coef = d4c_window_to_lds<T>(w, rot0, Z, scratch);
     double pw = 0.0;
     {
@@ -518,7 +522,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   double B[kBins];
   {
     const D4cWin w = d4c_win(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws);
-    const D4cWinRot rot0 = d4c_win_rot(w, tid, nt);
     const double coef = d4c_window_to_lds<T>(w, rot0, Z, scratch);
     {
       D4cWinRot rot = rot0;

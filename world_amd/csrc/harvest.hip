@@ -457,6 +457,15 @@ __global__ void hv_refine(HarvestParams p) {
           const double c2 = 2.0 * st.x;
           double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
           int i = g;
+          // four samples per trip: the kernel is bound by instruction issue (four waves per SIMD cover the recurrence's
+          // latency), and index, compare and branch are a third of a two-sample trip
+          for (; i + 3 * G < blen; i += 4 * G) {
+            const cplx p0 = yw[i], p1 = yw[i + G], p2 = yw[i + 2 * G], p3 = yw[i + 3 * G];
+            const double sa = fma(c2, s1, p0.re) - s2, ta = fma(c2, t1, p0.im) - t2;
+            const double sb = fma(c2, sa, p1.re) - s1, tb = fma(c2, ta, p1.im) - t1;
+            s2 = fma(c2, sb, p2.re) - sa; t2 = fma(c2, tb, p2.im) - ta;
+            s1 = fma(c2, s2, p3.re) - sb; t1 = fma(c2, t2, p3.im) - tb;
+          }
           for (; i + G < blen; i += 2 * G) {
             const cplx p0 = yw[i], p1 = yw[i + G];
             const double a0 = p0.re, d0 = p0.im, a1 = p1.re, d1 = p1.im;

@@ -229,14 +229,20 @@ def parallel_analyses(x, fs, frame_period, fft_size, procs, timeout=300, optimiz
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "x.npy")
         np.save(path, np.ascontiguousarray(x, dtype=np.float64))
-        start_at = _t.time() + 2.0 + 0.015 * procs
         lib = "libworld_ref_o3.so" if optimized and _cpu_has("avx2") and _cpu_has("fma") else "libworld_ref.so"
         flags = "-O3 -march=x86-64-v3" if lib.endswith("_o3.so") else "-O1 (reference makefile:6)"
         if not os.path.exists(os.path.join(HERE, "_ref", lib)):
             flags = "gcc -O2 restatement"
         cmd = [sys.executable, os.path.join(HERE, "cpu_worker.py"), path, str(fs), str(frame_period), str(fft_size),
-               repr(start_at), lib]
-        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+               "-", lib]
+        ps = [subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+        for p in ps:                                   # every worker has its library and input loaded ...
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu_worker did not come up")
+        start_at = _t.time() + 0.25                    # ... before the common start is named
+        for p in ps:
+            p.stdin.write(repr(start_at) + "\n")
+            p.stdin.flush()
         frames, t_end = 0, start_at
         for p in ps:
             out, _ = p.communicate(timeout=timeout)

@@ -294,13 +294,13 @@ __device__ __forceinline__ void dif_first_stage_head(cplx *z, int lg, const TwLd
 }
 
 // one decimation-in-time stage: R finished sub-transforms of length 2^done are merged
-template <int LR> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
+template <int LR, int NT = 0> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
   constexpr int R = 1 << LR;
   const int q = 1 << done, L = done + LR, nbf = 1 << (lg - LR);
   int c[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = swz(r << done);
-  for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
+  for (int b = wg_thread<NT>(); b < nbf; b += wg_size<NT>()) {
     const int j = b & (q - 1);
     const int s0 = swz(((b >> done) << L) + j);      // bits [done, L) of the base index are clear
     cplx a[R];
@@ -405,17 +405,17 @@ __device__ __forceinline__ void block_cfft_dif_from_static(cplx *z, const TwLds 
   __syncthreads();
 }
 // inverse: the plan's stages in reverse order -- the remainder stage (if any) first, then the MAXLR ones
-template <int LG, int MAXLR, int DONE> struct DitStages {
+template <int LG, int MAXLR, int DONE, int NT = 0> struct DitStages {
   static __device__ __forceinline__ void run(cplx *z, const TwLds &tw) {
     constexpr int LR = (DONE == 0 && LG % MAXLR != 0) ? LG % MAXLR : MAXLR;
     __syncthreads();
-    dit_stage<LR>(z, LG, DONE, tw);
-    if constexpr (DONE + LR < LG) DitStages<LG, MAXLR, DONE + LR>::run(z, tw);
+    dit_stage<LR, NT>(z, LG, DONE, tw);
+    if constexpr (DONE + LR < LG) DitStages<LG, MAXLR, DONE + LR, NT>::run(z, tw);
   }
 };
-template <int LG, int MAXLR>
+template <int LG, int MAXLR, int NT = 0>
 __device__ __forceinline__ void block_cfft_dit_static(cplx *z, const TwLds &tw) {
-  DitStages<LG, MAXLR, 0>::run(z, tw);
+  DitStages<LG, MAXLR, 0, NT>::run(z, tw);
   __syncthreads();
 }
 
@@ -598,6 +598,40 @@ __device__ __forceinline__ void irfft_pretwiddle(cplx *z, int lgn, const FftPlan
       z[o.slot] = o.r;
       if (o.mslot >= 0) z[o.mslot] = o.rm;
     });
+}
+// The pre-twiddle for callers whose spectrum lives in GLOBAL memory: items in natural bin order (item it = tid + m T
+// owns bins it and h - it, like rfft_merge_items), so that a wavefront's spec(k) calls touch consecutive addresses.
+// irfft_pretwiddle above walks physical slots -- conflict-free LDS writes, but digit-reversed bins: from HBM/L2 every
+// lane of a load then sits in a cache line of its own (64 lines per instruction for 1 KB of data; the filter
+// bank's product step spent 23 of its 58 thousand cycles per workgroup there).  Same arithmetic, same values.
+template <int KITEMS, int NT = 0, class Spec>
+__device__ __forceinline__ void irfft_pretwiddle_items(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Spec spec) {
+  const int lgh = lgn - 1, h = 1 << lgh, q = h >> 1;
+  const int tid = wg_thread<NT>(), nt = wg_size<NT>();
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < KITEMS; ++m) {
+    const int k = tid + m * nt;
+    if (k == 0) {
+      const cplx x = spec(0), y = spec(h);
+      cplx r; r.re = x.re + y.re; r.im = x.re - y.re;        // imaginary parts of DC / Nyquist ignored
+      z[fft_slot(plan, 0)] = r;
+    } else if (k < q) {
+      cplx x = spec(k), y = spec(h - k);
+      y.im = -y.im;                                           // conj(X[h-k])
+      const cplx s = cadd(x, y), d = csub(x, y);
+      const cplx t = cmul(d, twiddle(tw, k, lgn, +1));
+      cplx r, rm;
+      r.re = s.re - t.im; r.im = s.im + t.re;
+      rm.re = s.re + t.im; rm.im = t.re - s.im;
+      z[fft_slot(plan, k)] = r;
+      z[fft_slot(plan, h - k)] = rm;
+    } else if (k == q) {
+      const cplx x = spec(q);                                 // k = h/2: w = +i
+      cplx r; r.re = 2.0 * x.re; r.im = -2.0 * x.im;
+      z[fft_slot(plan, q)] = r;
+    }
+  }
 }
 template <int MAXLR = 4, int LGN = 0, class Spec>
 __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, Spec spec) {

@@ -172,7 +172,16 @@ __global__ void __launch_bounds__(256) hv_block_spectra(HarvestParams p) {
 #ifdef WORLD_EMU
   block_rfft<3>(Z, kBandFftLg, tw, [&](int k, double re, double im) { out[k] = make_double2(re, im); });
 #else
-  block_rfft<3, kBandFftLg>(Z, kBandFftLg, tw, [&](int k, double re, double im) { out[k] = make_double2(re, im); });
+  {
+    // bins in natural order per wavefront: the spectrum goes to global memory (see irfft_pretwiddle_items)
+    constexpr FftPlan plan = make_plan_max(kBandFftLg - 1, 3);
+    block_cfft_dif_static<kBandFftLg - 1, 3, 256>(Z, tw);
+    rfft_merge_items<(kBandFft / 4 + 1 + 255) / 256, 256>(Z, kBandFftLg, plan, tw,
+      [&](int, int k, double ar, double ai, bool paired, double br, double bi) {
+        out[k] = make_double2(ar, ai);
+        if (paired) out[kBandFft / 2 - k] = make_double2(br, bi);
+      });
+  }
 #endif
 }
 
@@ -188,17 +197,25 @@ __global__ void __launch_bounds__(256, 4) hv_band_events_fft(HarvestParams p) {
     return;
   }
   const bool trace_me = blockIdx.x == 5 && blockIdx.y == 20; (void)trace_me;
+  WH_STAMP(24, 0);
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *scratch = reinterpret_cast<double *>(lds) + kBandFft;
   const TwLds tw = stage_twiddles(scratch + 64, kBandFftLg - 1, p.tab.tw);
+  WH_STAMP(24, 1);
   const double2 *X = p.blk_spec + ((size_t)u * p.nseg + seg) * kBandFftBins;
   const double2 *H = p.band_spec + (size_t)band * kBandFftBins;
   auto product = [&](int k) { const double2 x = X[k], h = H[k]; cplx a, b; a.re = x.x; a.im = x.y; b.re = h.x; b.im = h.y; return cmul(a, b); };
 #ifdef WORLD_EMU
   block_irfft<3>(Z, kBandFftLg, tw, product);
 #else
-  block_irfft<3, kBandFftLg>(Z, kBandFftLg, tw, product);
+  {
+    constexpr FftPlan plan = make_plan_max(kBandFftLg - 1, 3);
+    irfft_pretwiddle_items<(kBandFft / 4 + 1 + 255) / 256, 256>(Z, kBandFftLg, plan, tw, product);   // 256 threads: launch_harvest
+    WH_STAMP(24, 5);
+    block_cfft_dit_static<kBandFftLg - 1, 3, 256>(Z, tw);
+  }
 #endif
+  WH_STAMP(24, 2);
   // filtered[t0 + k] = block sample k + fft_pre + shift, shift = L + 1 (delay compensation, harvest.cpp:140-142)
   const int shift = p.band_half[band] + 1;
   const int at0 = p.fft_pre + shift;
@@ -221,10 +238,12 @@ __global__ void __launch_bounds__(256, 4) hv_band_events_fft(HarvestParams p) {
     }
     __syncthreads();
   }
+  WH_STAMP(24, 3);
   double *ev = p.seg_events + (list * p.nseg + seg) * kSegCap;
   const size_t fam_stride = (size_t)p.nseg * kSegCap;
   int count[4] = {0, 0, 0, 0};
   tile_events([&](int k) { return rfft_in(Z, k + at0); }, t0, len, n, ev, fam_stride, count, scratch);
+  WH_STAMP(24, 4);
   if (tid == 0)
     for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = imin(count[fam], kSegCap);
 }

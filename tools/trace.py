@@ -47,3 +47,5 @@ print("hv_band_events (workgroup seg 5, band 20): setup", t[0], "tile fetch/comm
 t = stamps("hv")[24:30]
 print("hv_band_events_fft (workgroup seg 5, band 20): twiddle table", t[1] - t[0], "spectrum product + pre-twiddle", t[5] - t[1],
       "c2r stages", t[2] - t[5], "mirror-store term", t[3] - t[2], "events", t[4] - t[3])
+t = stamps("hv")[32:35]
+print("   its events phase: sample reads + masks", t[0], "block scan", t[1], "edge times + stores", t[2])

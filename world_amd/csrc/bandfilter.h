@@ -219,9 +219,12 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
 // are then evaluated only for the set bits and appended to the segment's lists.
 template <class Sample>
 __device__ __forceinline__ void tile_events(Sample sample, int t0, int len, int n, double *ev, size_t fam_stride,
-                                            int (&count)[4], double *scratch) {
+                                            int (&count)[4], double *scratch, bool trace_me = false) {
   const int tid = threadIdx.x, nt = blockDim.x;
+  (void)trace_me;
+  WH_ACC_DECL;
   for (int sub = 0; sub < len; sub += nt * kOutPer) {
+    WH_ACC_BEGIN;
     const int kbase = sub + tid * kOutPer;
     double sv[kOutPer + 2];
 #pragma unroll
@@ -239,10 +242,14 @@ __device__ __forceinline__ void tile_events(Sample sample, int t0, int len, int 
       if (r23 && 0.0 < da && db <= 0.0) mask[2] |= 1u << q;
       if (r23 && da < 0.0 && 0.0 <= db) mask[3] |= 1u << q;
     }
+    WH_ACC_END(0);
+    WH_ACC_BEGIN;
     unsigned long long packed = 0;
 #pragma unroll
     for (int fam = 0; fam < 4; ++fam) packed |= (unsigned long long)__builtin_popcount(mask[fam]) << (16 * fam);
     unsigned long long total, off = block_excl_scan_u64(packed, &total, scratch);
+    WH_ACC_END(1);
+    WH_ACC_BEGIN;
 #pragma unroll
     for (int fam = 0; fam < 4; ++fam) {
       double *dst = ev + fam * fam_stride;
@@ -256,7 +263,9 @@ __device__ __forceinline__ void tile_events(Sample sample, int t0, int len, int 
       }
       count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
     }
+    WH_ACC_END(2);
   }
+  WH_ACC_FLUSH(32, tid == 0);
 }
 
 // Whole segment `seg` of one channel: filter tile by tile and append the crossing

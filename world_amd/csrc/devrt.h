@@ -343,11 +343,43 @@ __device__ __forceinline__ double wave_min(double v) {
 #endif
   return v;
 }
+// Inclusive add-scan over the wavefront by DPP (no LDS crossbar): Kogge-Stone inside each row of 16 lanes (row_shr
+// 1, 2, 4, 8; lanes shifted in from outside the row read 0), then row_bcast:15 hands every odd row the total of the
+// row before it and row_bcast:31 hands rows 2 and 3 the total of rows 0-1.  Six dependent VALU steps where the
+// ds_bpermute version paid six LDS round trips.
+__device__ __forceinline__ int wave_incl_scan_int(int v) {
+#ifndef WORLD_EMU
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+#endif
+  return v;
+}
+// the same for doubles (+0.0 shifted in where a lane has no source)
+#ifndef WORLD_EMU
+template <int CTRL, int ROWS, bool ZERO> __device__ __forceinline__ double dpp_f64_rows(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, ZERO),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, ZERO));
+}
+#endif
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+#ifndef WORLD_EMU
+  v += dpp_f64_rows<0x111, 0xf, true>(v);
+  v += dpp_f64_rows<0x112, 0xf, true>(v);
+  v += dpp_f64_rows<0x114, 0xf, true>(v);
+  v += dpp_f64_rows<0x118, 0xf, true>(v);
+  v += dpp_f64_rows<0x142, 0xa, false>(v);
+  v += dpp_f64_rows<0x143, 0xc, false>(v);
+#endif
+  return v;
+}
 __device__ __forceinline__ int wave_excl_scan_int(int v, int *total) {
 #ifndef WORLD_EMU
-  int lane = lane_id(), inc = v;
-  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-  *total = __shfl(inc, 63, 64);
+  const int inc = wave_incl_scan_int(v);
+  *total = __builtin_amdgcn_readlane(inc, 63);
   return inc - v;
 #else
   *total = v;
@@ -480,10 +512,12 @@ __device__ __forceinline__ int block_excl_scan_int(int v, int *total, double *sc
 __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *total,
                                                                   double *scratch) {
 #ifndef WORLD_EMU
+  // the four 16-bit fields never carry into each other, so the halves scan independently
   const int lane = lane_id();
-  unsigned long long inc = v;
-  for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-  const unsigned long long wt = __shfl(inc, 63, 64);
+  const unsigned lo = (unsigned)wave_incl_scan_int((int)(unsigned)v), hi = (unsigned)wave_incl_scan_int((int)(unsigned)(v >> 32));
+  const unsigned long long inc = ((unsigned long long)hi << 32) | lo;
+  const unsigned long long wt = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 63) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
   const int nw = waves_per_block();
   if (nw == 1) { *total = wt; return inc - v; }
   unsigned long long *us = reinterpret_cast<unsigned long long *>(scratch);
@@ -524,9 +558,8 @@ __device__ __forceinline__ void block_scan_incl_double(double *a, int n, double 
 #pragma unroll
     for (int q = 1; q < kRegChunk; ++q) v[q] += v[q - 1];
     const double s = v[kRegChunk - 1];
-    double inc = s;
     const int lane = lane_id(), w = wave_in_block();
-    for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    const double inc = wave_incl_scan_f64(s);
     __syncthreads();
     if (lane == 63) scratch[w] = inc;
     __syncthreads();
@@ -543,9 +576,8 @@ __device__ __forceinline__ void block_scan_incl_double(double *a, int n, double 
   for (int i = lo; i < hi; ++i) { s += a[i]; a[i] = s; }
 #ifndef WORLD_EMU
   // exclusive scan of chunk totals in thread order
-  double inc = s;
   int lane = lane_id();
-  for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+  const double inc = wave_incl_scan_f64(s);
   int nw = waves_per_block(), w = wave_in_block();
   __syncthreads();
   if (lane == 63) scratch[w] = inc;

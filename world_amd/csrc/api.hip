@@ -906,7 +906,7 @@ WorldHipContext *world_hip_create(int device, void *stream) {
     WorldHipContext *c = new WorldHipContext;
     c->device = device;
     c->stream = static_cast<hipStream_t>(stream);
-    std::vector<double2> tw(kTwN);
+    std::vector<double2> tw(kTwAlloc);
     build_twiddles(tw.data());
     std::vector<uint4> jump((size_t)kJumpLevels * kJumpStride);
     build_jump_tables(jump.data());

@@ -217,21 +217,22 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
 // inspects kOutPer consecutive samples (time order) and records the crossings of each family as a bit mask; ONE
 // block scan of the four packed counts gives the list positions; the sub-sample times (one FP64 division each)
 // are then evaluated only for the set bits and appended to the segment's lists.
-template <class Sample>
+// PER: consecutive samples a thread inspects per pass (the FFT path covers its whole block in one pass of 16)
+template <int PER = kOutPer, class Sample>
 __device__ __forceinline__ void tile_events(Sample sample, int t0, int len, int n, double *ev, size_t fam_stride,
                                             int (&count)[4], double *scratch, bool trace_me = false) {
   const int tid = threadIdx.x, nt = blockDim.x;
   (void)trace_me;
   WH_ACC_DECL;
-  for (int sub = 0; sub < len; sub += nt * kOutPer) {
+  for (int sub = 0; sub < len; sub += nt * PER) {
     WH_ACC_BEGIN;
-    const int kbase = sub + tid * kOutPer;
-    double sv[kOutPer + 2];
+    const int kbase = sub + tid * PER;
+    double sv[PER + 2];
 #pragma unroll
-    for (int q = 0; q < kOutPer + 2; ++q) sv[q] = kbase + q < len + 2 ? sample(kbase + q) : 0.0;
+    for (int q = 0; q < PER + 2; ++q) sv[q] = kbase + q < len + 2 ? sample(kbase + q) : 0.0;
     unsigned mask[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int q = 0; q < kOutPer; ++q) {
+    for (int q = 0; q < PER; ++q) {
       const int i = t0 + kbase + q;
       const bool live = kbase + q < len;
       const double a = sv[q], b = sv[q + 1], c = sv[q + 2];

@@ -43,7 +43,8 @@ struct TwLds {
 template <int NT = 0>
 __device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2 *global_tw) {
   const int quarter = 1 << (lg - 2);
-  for (int i = wg_thread<NT>(); i <= quarter; i += wg_size<NT>()) q[i] = global_tw[(size_t)i << (kTwLog2 - lg)].x;
+  const double *dense = reinterpret_cast<const double *>(global_tw + kTwN) + quarter_table_offset(lg);   // tables.h
+  for (int i = wg_thread<NT>(); i <= quarter; i += wg_size<NT>()) q[i] = dense[i];
   __syncthreads();
   TwLds t; t.q = q; t.lg = lg;
   const double2 f = global_tw[lg + 1 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 1) : 0];

@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, 4) hv_band_events_fft(HarvestParams p) {
   double *ev = p.seg_events + (list * p.nseg + seg) * kSegCap;
   const size_t fam_stride = (size_t)p.nseg * kSegCap;
   int count[4] = {0, 0, 0, 0};
-  tile_events([&](int k) { return rfft_in(Z, k + at0); }, t0, len, n, ev, fam_stride, count, scratch, trace_me);
+  tile_events<16>([&](int k) { return rfft_in(Z, k + at0); }, t0, len, n, ev, fam_stride, count, scratch, trace_me);
   WH_STAMP(24, 4);
   if (tid == 0)
     for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = imin(count[fam], kSegCap);

@@ -16,6 +16,11 @@ void build_twiddles(double2 *out) {
   out[kTwN / 4] = make_double2(0.0, 1.0);
   out[kTwN / 2] = make_double2(-1.0, 0.0);
   out[3 * kTwN / 4] = make_double2(0.0, -1.0);
+  // dense quarter-wave tables, one per transform size, copied from the entries above (bitwise the same values)
+  double *q = reinterpret_cast<double *>(out + kTwN);
+  for (int lg = 2; lg <= kTwLog2; ++lg)
+    for (int r = 0; r <= (1 << (lg - 2)); ++r) q[quarter_table_offset(lg) + r] = out[(size_t)r << (kTwLog2 - lg)].x;
+  if (kQuarterDoubles & 1) q[kQuarterDoubles] = 0.0;
 }
 
 namespace {

@@ -648,7 +648,7 @@ __global__ void d4c_finish(D4cParams p) {
     double x1 = k <= p.nap ? k * 3000.0 : fs / 2.0;
     double s = (xi - x0) / (x1 - x0);
     double y = cval(k - 1) + s * (cval(k) - cval(k - 1));
-    row[i] = pow(10.0, y / 20.0);
+    row[i] = exp10(y / 20.0);                           // the reference: pow(10.0, y / 20.0) -- same value to an ulp or two, a third of the instructions
   }
 }
 

@@ -391,6 +391,51 @@ __device__ __forceinline__ int intervals_at_or_before(const double *e, int n_int
   return lo;
 }
 
+// The same count found by 32 lanes together (every lane of the group passes the same arguments and gets the result):
+// the serial search above is a chain of ~9 dependent probes of global memory, and a workgroup of hv_raw_candidates
+// did nothing else while its eight end-point searches ran -- most of the kernel's time.  Here a round is ONE probe
+// per lane: 32 consecutive intervals around the proportional guess (which brackets the answer for a band-passed
+// signal), else 32 strided probes that narrow the range 32-fold.  The predicate is monotone in the index, so the
+// number of lanes that see loc <= t is the position of the last such interval.  Two or three rounds.
+// `group`: which 32-lane half of its wavefront the caller is (0 / 1); `sub`: lane within the group.
+__device__ __forceinline__ int intervals_at_or_before_group(const double *e, int n_int, double fs, double t, int group, int sub) {
+#ifdef WORLD_EMU
+  (void)group; (void)sub;
+  return intervals_at_or_before(e, n_int, fs, t);
+#else
+  if (n_int <= 0) return 0;
+  const double first = interval_loc(e, 0, fs), last = interval_loc(e, n_int - 1, fs);
+  if (!(first <= t)) return 0;
+  if (last <= t) return n_int;
+  // invariant: loc(lo) <= t < loc(hi); the answer is (last index with loc <= t) + 1, in (lo, hi]
+  int lo = 0, hi = n_int - 1;
+  auto ones_at = [&](int idx, bool valid) {
+    const bool pred = valid && interval_loc(e, idx, fs) <= t;
+    return __popc((unsigned)(__ballot(pred) >> (32 * group)));
+  };
+  if (hi - lo > 32) {
+    const double r = (t - first) / (last - first) * (n_int - 1);
+    const int g = r < 0.0 ? 0 : (r > n_int - 1.0 ? n_int - 1 : static_cast<int>(r));
+    int base = g - 15;
+    base = base < lo + 1 ? lo + 1 : base;
+    base = base > hi - 32 ? hi - 32 : base;                 // window [base, base + 31] inside (lo, hi)
+    const int ones = ones_at(base + sub, true);
+    if (ones == 0) hi = base;
+    else if (ones == 32) lo = base + 31;
+    else return base + ones;
+  }
+  while (hi - lo > 32) {
+    const int stride = (hi - lo + 31) / 32;                  // probes lo + stride, lo + 2 stride, ... below hi
+    const int idx = lo + (sub + 1) * stride;
+    const int ones = ones_at(idx, idx < hi);
+    const int nlo = lo + ones * stride, nhi = lo + (ones + 1) * stride;
+    lo = nlo;
+    hi = nhi < hi ? nhi : hi;
+  }
+  return lo + 1 + ones_at(lo + 1 + sub, lo + 1 + sub < hi);   // the <= 31 indices strictly between
+#endif
+}
+
 // interp1 of the n_int interval F0s of one family at time t
 __device__ __forceinline__ double interp_intervals(const double *e, int n_int, double fs, double t) {
   const int lo = intervals_at_or_before(e, n_int, fs, t);

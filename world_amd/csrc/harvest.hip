@@ -288,12 +288,24 @@ __global__ void __launch_bounds__(kRawFrames) hv_raw_candidates(HarvestParams p)
   double *fz = loc + 4 * kIntervalCap;                    // [4][kIntervalCap]
   IntervalRange *range = reinterpret_cast<IntervalRange *>(fz + 4 * kIntervalCap);   // [4]
   // frame f sits at t = f * 1 / 1000.0 (harvest.cpp:1175, frame_period = 1)
+#ifdef WORLD_EMU
   for (int job = tid; job < 8; job += nt) {
     const int fam = job >> 1;
     const bool last = job & 1;
     interval_range_ends(ev + (size_t)fam * p.ev_cap, n_int[fam], p.afs, (last ? f_end - 1 : f_begin) * 1 / 1000.0, last,
                         range + fam);
   }
+#else
+  {
+    // the eight end-point counts, one per group of 32 lanes (kRawFrames = 8 groups), each found by its lanes together
+    static_assert(kRawFrames == 8 * 32, "one 32-lane group per (family, end)");
+    const int job = tid >> 5, fam = job >> 1, sub = tid & 31;
+    const bool last = job & 1;
+    const int c = intervals_at_or_before_group(ev + (size_t)fam * p.ev_cap, n_int[fam], p.afs,
+                                               (last ? f_end - 1 : f_begin) * 1 / 1000.0, (tid >> 5) & 1, sub);
+    if (sub == 0) { if (last) range[fam].c_last = c; else range[fam].c_first = c; }
+  }
+#endif
   __syncthreads();
   for (int fam = tid; fam < 4; fam += nt) interval_range_close(n_int[fam], range + fam);
   __syncthreads();
@@ -308,9 +320,14 @@ __global__ void __launch_bounds__(kRawFrames) hv_raw_candidates(HarvestParams p)
     }
     return;
   }
-  for (int fam = 0; fam < 4; ++fam) {
-    const double *e = ev + (size_t)fam * p.ev_cap + range[fam].j_lo;
-    for (int i = tid; i < range[fam].m; i += nt) {
+  {
+    // the four families' intervals as ONE list of jobs: their loads are in flight together (four loops, one per
+    // family, were four dependent trips to global memory)
+    const int m0 = range[0].m, m1 = m0 + range[1].m, m2 = m1 + range[2].m, m3 = m2 + range[3].m;
+    for (int job = tid; job < m3; job += nt) {
+      const int fam = (job >= m0) + (job >= m1) + (job >= m2);
+      const int i = job - (fam == 0 ? 0 : fam == 1 ? m0 : fam == 2 ? m1 : m2);
+      const double *e = ev + (size_t)fam * p.ev_cap + range[fam].j_lo;
       loc[fam * kIntervalCap + i] = interval_loc(e, i, p.afs);
       fz[fam * kIntervalCap + i] = interval_f0(e, i, p.afs);
     }

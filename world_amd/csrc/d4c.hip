@@ -28,15 +28,6 @@ namespace world_hip {
 
 constexpr int kHanning = 1, kBlackman = 2;
 
-// window value of sample i; scale = 2 / ratio / fs * f0, so that scale * (i - hw) is
-// position * f0 of d4c.cpp:36,41 (the two divisions hoisted out of the per-sample loop)
-__device__ __forceinline__ double d4c_window_at(int i, int hw, int kind, double scale) {
-  const double c1 = cospi(scale * (i - hw));                        // cos(pi * position * f0)
-  if (kind == kHanning) return 0.5 * c1 + 0.5;
-  return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);             // cos(2a) = 2 cos^2(a) - 1
-}
-
-
 // ---------------------------------------------------------------------------
 __global__ void d4c_prepare1(D4cParams p) {
   DYN_LDS(lds);

@@ -376,7 +376,7 @@ __global__ void hv_detect(HarvestParams p) {
 // OverlapF0Candidates + RefineF0Candidates (harvest.cpp:417-631), one wavefront
 // per (frame, utt).  Slot s = j + nc*m takes candidate j of frame-m (m = 1..3) or
 // frame+(m-3) (m = 4..6); each non-zero slot is refined by instantaneous frequency.
-__device__ __forceinline__ int floor_log2_int(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
+__device__ __forceinline__ int floor_log2_int(int v) { return 31 - __builtin_clz((unsigned)v); }   // v >= 1
 
 __global__ void hv_refine(HarvestParams p) {
   DYN_LDS(lds);

@@ -425,22 +425,49 @@ __global__ void hv_refine(HarvestParams p) {
   double c_are[kIter], c_aim[kIter], c_dre[kIter], c_dim[kIter];   // reduced DFT sums of the previous candidate
   for (int q = 0; q < kIter; ++q) c_idx[q] = -1;
 
+  // What a slot's candidate fixes before any sample is touched (GetRefinedF0, harvest.cpp:589-617)
+  struct Cand { double f0c, bins; int hw, first, lgN, nh; };
+  auto cand_of = [&](int j, int m) {
+    Cand c;
+    const int sf = m == 0 ? frame : (m <= 3 ? frame - m : frame + (m - 3));
+    c.f0c = (m < 7 && sf >= 0 && sf < nfb) ? src[(size_t)sf * p.maxc + j] : 0.0;
+    const double f = c.f0c > 0.0 ? c.f0c : 1.0;                   // the values of an empty slot are never used
+    c.hw = static_cast<int>(1.5 * fs / f + 1.0);
+    c.lgN = 2 + floor_log2_int(2 * c.hw + 1);                     // fft_size = 2^(2+floor(log2(2hw+1)))
+    const double base0 = static_cast<double>(-c.hw) * inv_fs;    // first = round(..) + 0.001 margin absorbs the ulp
+    c.first = mround((pos + base0) * fs + 0.001);                 // GetBaseIndex, harvest.cpp:434-441
+    c.nh = imin(static_cast<int>(fs / 2.0 / f), 6);
+    c.bins = f * (1 << c.lgN) / fs;                               // bin of harmonic h: round(bins * (h + 1)), FixF0 :515
+    return c;
+  };
+
   for (int j = 0; j < nc; ++j) {
     double k_are[kM][kIter], k_aim[kM][kIter], k_dre[kM][kIter], k_dim[kM][kIter], k_f0[kM];
     int k_idx[kM][kIter], k_lgn[kM];
     for (int q = 0; q < kM; ++q) k_f0[q] = 0.0;
+#ifndef WORLD_EMU
+    // The seven slots of the track are set up side by side, slot m on lane m -- one load of the seven source
+    // frames, the divisions and roundings once per track -- and handed to the wavefront as scalars (v_readlane):
+    // done per slot by all 64 lanes they were a sixth of the kernel's instructions and seven dependent loads.
+    const Cand mine = cand_of(j, lane < 7 ? lane : 7);
+#endif
     for (int m = 0; m < 7; ++m) {
-      const int sf = m == 0 ? frame : (m <= 3 ? frame - m : frame + (m - 3));
-      const double f0c = (sf >= 0 && sf < nfb) ? src[(size_t)sf * p.maxc + j] : 0.0;
+#ifndef WORLD_EMU
+      const double f0c = readlane_f64(mine.f0c, m);
       if (!(f0c > 0.0)) continue;
-      // GetRefinedF0, harvest.cpp:589-617
-      const int hw = static_cast<int>(1.5 * fs / f0c + 1.0);
+      const double bins = readlane_f64(mine.bins, m);
+      const int hw = __builtin_amdgcn_readlane(mine.hw, m), lgN = __builtin_amdgcn_readlane(mine.lgN, m);
+      const int first = __builtin_amdgcn_readlane(mine.first, m), nh = __builtin_amdgcn_readlane(mine.nh, m);
+#else
+      const Cand cm = cand_of(j, m);
+      const double f0c = cm.f0c;
+      if (!(f0c > 0.0)) continue;
+      const double bins = cm.bins;
+      const int hw = cm.hw, lgN = cm.lgN, first = cm.first, nh = cm.nh;
+#endif
       const int blen = 2 * hw + 1;
       const double wlen_t = (2.0 * hw + 1.0) * inv_fs;
-      const int lgN = 2 + floor_log2_int(blen);                  // fft_size = 2^(2+floor(log2(2hw+1)))
       const int N = 1 << lgN;
-      const double base0 = static_cast<double>(-hw) * inv_fs;   // first = round(..) + 0.001 margin absorbs the ulp
-      const int first = mround((pos + base0) * fs + 0.001);      // GetBaseIndex, harvest.cpp:434-441
       const bool same_window = hw == c_hw && first == c_first;
       if (!same_window) {
         WH_ACC_BEGIN;
@@ -478,12 +505,11 @@ __global__ void hv_refine(HarvestParams p) {
         WH_ACC_END(1);
       }
       // 6-bin DFTs of both windowed signals, one Goertzel recurrence per (harmonic, phase)
-      const int nh = imin(static_cast<int>(fs / 2.0 / f0c), 6);
       WH_ACC_BEGIN;
       for (int hi = 0; hi < kIter; ++hi) {
         const int h = hi * LH + hl;
         double are = 0, aim = 0, dre = 0, dim = 0;
-        const int idx = h < nh ? mround(f0c * N / fs * (h + 1)) : 0;     // FixF0, harvest.cpp:515
+        const int idx = h < nh ? mround(bins * (h + 1)) : 0;             // FixF0, harvest.cpp:515: f0c * N / fs * (h + 1)
         const bool reuse = same_window && h < nh && idx == c_idx[hi];
         if (reuse) {
           if (g == 0) { are = c_are[hi]; aim = c_aim[hi]; dre = c_dre[hi]; dim = c_dim[hi]; }

@@ -531,7 +531,10 @@ def main():
             whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
     kernels = kernel_profile(wh, lone, 3)
     roofline = roofline_of(kernels, nf * B, BYTES_PER_FRAME, "1")
-    roofline["note"] = "FP64-ALU/LDS-bound pipeline (SURVEY.md 8d): ~7 MFLOP/frame (measured, see fp64) vs 18.3 kB/frame"
+    roofline["note"] = ("FP64 / latency-bound pipeline (SURVEY.md 8d): see fp64.pipeline_flop_per_frame (measured) against 18.3 kB of "
+                        "compulsory traffic per frame. frac is not comparable with round 1's 0.0203: that was quoted on "
+                        "d4c_groupdelay (0.212 ms), one of the two kernels (d4c_band: 0.186 ms) that d4c_frame replaces -- on "
+                        "their sum the same formula gave 0.0115 (DESIGN.md section 4)")
     if "fp64" in roofline:
         roofline["fp64"]["pipeline_achieved"] = roofline["fp64"]["pipeline_flop_per_frame"] * value / 1e12
 

@@ -535,9 +535,17 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   for (int e = 0; e < kBins; ++e) A[e] = A[e] / B[e];
   smooth(A, cf0 / 2.0, A);
   smooth(A, cf0, B);
-  double G[kBins];
+  // The group delay goes where the first centroid was parked (natural bin order, N/2 + 1 doubles), when that is LDS:
+  // the band transforms below read their slices from there -- no staging pass, two barriers fewer per band, and
+  // 2 kItems doubles fewer in registers through the kernel's hottest loop.  The 8192-point shape has no such room
+  // and keeps it in registers.
+  double G[kParkInLds ? 1 : kBins];
+  if constexpr (kParkInLds) {
+    for_bins([&](int slot, int k) { park[k] = A[slot] - B[slot]; });
+  } else {
 #pragma unroll
-  for (int e = 0; e < kBins; ++e) G[e] = A[e] - B[e];
+    for (int e = 0; e < kBins; ++e) G[e] = A[e] - B[e];
+  }
   WH_STAMP(32, 19);
 
   // ---- GetCoarseAperiodicity (d4c.cpp:194-225) per 3 kHz band ------------------
@@ -549,12 +557,25 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   int *hist = reinterpret_cast<int *>(Zr);
   for (int band = 0; band < p.nap; ++band) {
     const int lo_k = static_cast<int>(3000.0 * (band + 1) * N / fs) - hwl;
-    __syncthreads();                                    // the previous band's histograms are done
-    for_bins([&](int slot, int k) { const int i = k - lo_k; if (i >= 0 && i < wl) Zr[i] = G[slot] * p.nuttall[i]; });
-    __syncthreads();
-    // First DIF stage with every input beyond element nz known to be zero.  The slice sits in the buffer the
-    // stage writes, so a butterfly's inputs are fetched before anybody writes.
-    auto slice = [&](int n) { cplx v; v.re = Zr[2 * n]; v.im = 2 * n + 1 < wl ? Zr[2 * n + 1] : 0.0; return v; };
+    __syncthreads();                                    // the previous band's histograms are done (first band: park is written)
+    if constexpr (!kParkInLds) {
+      for_bins([&](int slot, int k) { const int i = k - lo_k; if (i >= 0 && i < wl) Zr[i] = G[slot] * p.nuttall[i]; });
+      __syncthreads();
+    }
+    // First DIF stage with every input beyond element nz known to be zero.  A slice staged in Z sits in the buffer
+    // the stage writes, so a butterfly's inputs are fetched before anybody writes.
+    auto slice = [&](int n) {
+      cplx v;
+      if constexpr (kParkInLds) {
+        const double *g = park + lo_k + 2 * n;
+        v.re = g[0] * p.nuttall[2 * n];
+        v.im = 2 * n + 1 < wl ? g[1] * p.nuttall[2 * n + 1] : 0.0;
+      } else {
+        v.re = Zr[2 * n];
+        v.im = 2 * n + 1 < wl ? Zr[2 * n + 1] : 0.0;
+      }
+      return v;
+    };
 #ifdef WORLD_EMU
     {
       cplx head[NMAX / 2];
@@ -569,7 +590,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       const bool single = tid + qq >= nz;
 #pragma unroll
       for (int r = 0; r < R; ++r) { cplx z0; z0.re = 0.0; z0.im = 0.0; a[r] = tid + r * qq < nz ? slice(tid + r * qq) : z0; }
-      __syncthreads();
+      if constexpr (!kParkInLds) __syncthreads();
       if (single) {
 #pragma unroll
         for (int r = 1; r < R; ++r) a[r] = a[0];         // DFT of a delta

@@ -517,13 +517,16 @@ def main():
               "frames": nf * B}
 
     # latency of ONE job with nothing else in flight (not the headline number)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
+    def lone_job():
         with torch.cuda.stream(streams[0]):
             whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
         torch.cuda.synchronize()
-    lat = (time.perf_counter() - t1) / 5 * 1e3
+    for _ in range(3):                                   # the parity leg above ran other contexts: settle first
+        lone_job()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        lone_job()
+    lat = (time.perf_counter() - t1) / 20 * 1e3
 
     # ---- roofline leg: per-kernel HIP-event timing of a few extra steps ------------------------------------
     def lone():

@@ -5,7 +5,7 @@
 
 N = 1 (the default, what the driver's BENCH run executes)
     `value` = BASELINE.json configs[1]: one 48 kHz x 10 s utterance per step (2001 frames), Harvest + CheapTrick +
-    D4C, 5 ms hop, fft_size 2048, inputs and outputs resident in HBM, `--streams` (8) independent jobs in flight.
+    D4C, 5 ms hop, fft_size 2048, inputs and outputs resident in HBM, `--streams` (12) independent jobs in flight.
     The timed region is `repeats` back-to-back blocks of K steps inside ONE barrier + synchronize bracket, with
     `repeats` chosen so that the region lasts >= --min-wall seconds (K = 20 steps are 20 ms of GPU time: too short
     for any sampler).  After the timed region the run checks itself (`parity_in_run`): every in-flight slot's
@@ -35,8 +35,9 @@ import time
 
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with
 # more independent jobs in flight than queues, jobs that share a queue run one after the other.  Must be set
-# before the runtime initialises (measured on configs[1]: 8 jobs on 16 queues 0.925 ms per job, 6 jobs on the
-# default 4 queues 0.98 ms, 8 jobs on 4 queues 1.05 ms).
+# before the runtime initialises (measured on configs[1] in round 1: 8 jobs on 16 queues 0.925 ms per job, 6 jobs on
+# the default 4 queues 0.98 ms, 8 jobs on 4 queues 1.05 ms; with round 2's kernels, frames/s at 16 queues: 6 jobs
+# 2.77 M, 8: 3.08 M, 10: 3.04 M, 12: 3.19 M, 14: 3.16 M, 16: 3.07 M -- the default).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -225,7 +226,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis / host-pointer legs")
     ap.add_argument("--job-utterances", type=int, default=1024, help="N > 1: utterances of the configs[3] job")
     ap.add_argument("--sub-batch", type=int, default=128, help="N > 1: utterances per batched call on a rank")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=12,
                     help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
                          "stream with its own workspace; 1 = strictly one after the other)")
     args = ap.parse_args()

@@ -242,9 +242,8 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     c->nuttall_len = wl;
   }
   size_t fr = (size_t)n_utt * f_stride;
-  const int gd_stride = static_cast<int>(d4c_frame_scratch_doubles(ilog2_exact(fft_d4c)));
   size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 4 * pad256(sizeof(int) * n_utt) +
-                pad256(sizeof(double) * fr * gd_stride) + pad256(sizeof(double) * fr * 16);
+                pad256(sizeof(double) * fr * 16);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   D4cParams p;
@@ -256,8 +255,6 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.offsets1 = c->arena.take<unsigned>(fr);
   p.offsets2 = c->arena.take<unsigned>(fr);
   p.draws1 = c->arena.take<unsigned>(n_utt);
-  p.gd = c->arena.take<double>(fr * gd_stride);
-  p.gd_stride = gd_stride;
   p.coarse = c->arena.take<double>(fr * 16);
   p.noise = ensure_noise(c, (size_t)max_frames * d4c_max_draws_per_frame(fs));
   p.nuttall = c->d_nuttall;

@@ -31,8 +31,9 @@ __device__ __forceinline__ double interp_uniform(double x0, double dx, const dou
   double p = (xi - x0) / dx;
   int b = static_cast<int>(p);
   double frac = p - b;
-  double dy = b < n - 1 ? y[b + 1] - y[b] : 0.0;
-  return y[b] + dy * frac;
+  // the slope beyond y[n-1] is 0: the clamped neighbour gives that without a divergent branch (b <= n - 1 for every caller)
+  const double y0 = y[b], y1 = y[b + 1 < n ? b + 1 : n - 1];
+  return y0 + (y1 - y0) * frac;
 }
 
 // Same, with the caller's 1/dx: one FP64 division per query is the dominant cost of the
@@ -43,8 +44,8 @@ __device__ __forceinline__ double interp_uniform_rcp(double x0, double inv_dx, c
   double p = (xi - x0) * inv_dx;
   int b = static_cast<int>(p);
   double frac = p - b;
-  double dy = b < n - 1 ? y[b + 1] - y[b] : 0.0;
-  return y[b] + dy * frac;
+  const double y0 = y[b], y1 = y[b + 1 < n ? b + 1 : n - 1];
+  return y0 + (y1 - y0) * frac;
 }
 
 // NuttallWindow(), src/common.cpp:113-121

@@ -225,16 +225,27 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 //   GetStaticCentroid -> GetSmoothedPowerSpectrum -> GetStaticGroupDelay -> GetCoarseAperiodicity.
 //
 // Shape: T = N/16 threads (N = fft_size_d4c: 256 threads at 48 kHz), one radix-8 butterfly per thread and
-// stage, and ONE real-transform buffer of N doubles in LDS (32 KB + twiddles: four workgroups per CU where
-// the round-1 kernel, which packed the centroid's two transforms into one complex transform of 64 KB and kept
-// two spectra beside it, had two).  Everything that is indexed by frequency bin lives in REGISTERS: the
-// transform's merge step hands thread t the same 2 ceil((N/4+1)/T) bins (conjugate pairs k = t + m T, N/2-k) after
-// every transform (rfft_merge_items), so centroid, power spectrum, their quotient, the smoothed versions and
-// the group delay are per-thread arrays, and LDS is only the exchange medium -- the smoothing's prefix-sum
-// array, the few bins DCCorrection mirrors, the 513-sample band slices.  The static group delay never goes
-// to HBM: the five band transforms of GetCoarseAperiodicity read their Nuttall-windowed slices from LDS
-// (a first stage that knows all but one input of every butterfly to be zero), and the power values feed the
-// radix select from registers.
+// stage, and ONE transform buffer of N doubles in LDS.  Everything that is indexed by frequency bin lives in
+// REGISTERS, LDS is only the exchange medium -- the smoothing's prefix-sum array, the few bins DCCorrection
+// mirrors, the 513-sample band slices.
+//
+// The centroid of one window position is Re(X2 conj X1) with X1 = FFT(u), X2 = FFT((n+1) u), u the balanced
+// windowed waveform.  Both spectra come out of ONE N-point complex transform of z[n] = u[n] (1 + i (n+1)):
+// with P = Z[k], Q = Z[N-k],  X1 = (P + conj Q)/2,  X2 = (P - conj Q)/(2i)  and the product collapses to
+//     Re(X2 conj X1) = (Im P Re Q + Im Q Re P) / 2 = Im(P Q) / 2.
+// The N-point transform runs as the two N/2-point halves of a radix-2 DIF split -- even bins from
+// e[n] = z[n] + z[n+N/2], odd bins from o[n] = (z[n] - z[n+N/2]) W_N^n -- through the one N/2-point complex
+// buffer, and bins k and N-k have the same parity, so each half yields its centroid values on its own:
+// nothing waits in registers across a transform (the previous version held X1, 40 VGPRs, through the second
+// transform and spilled), there is no twiddled merge step, and the window's samples are evaluated ONCE: a
+// thread keeps its <= 8 samples below N/2 in registers between the balance pass and the two input passes
+// (windows longer than N/2 -- F0 below 94 Hz at 48 kHz -- re-evaluate their upper samples, the rare case).
+// Thread t ends up owning the bin pairs (2 (t + m T), 2 (t + m T) + 1): "pair ownership".  The power spectrum
+// still comes from a real transform whose merge step hands out conjugate pairs (t + m T, N/2 - that): "natural
+// ownership"; LinearSmoothing goes through LDS by bin index anyway, so it converts between the two for free.
+// The static group delay never goes to HBM: the band transforms of GetCoarseAperiodicity read their
+// Nuttall-windowed slices from LDS (a first stage that knows all but one input of every butterfly to be zero),
+// and the power values feed the radix select from registers.
 template <int NMAX, int T> struct D4cShape {
 #ifdef WORLD_EMU
   static constexpr int kItems = NMAX / 4 + 1;          // one emulated thread owns every bin
@@ -242,6 +253,7 @@ template <int NMAX, int T> struct D4cShape {
   static constexpr int kItems = (NMAX / 4 + 1 + T - 1) / T;
 #endif
   static constexpr int kBins = 2 * kItems;
+  static constexpr int kLo = NMAX / 2 / T;             // window samples below N/2 per thread (8 on the GPU)
 };
 
 struct D4cWin {            // GetWindowedWaveform's parameters (d4c.cpp:52-84)
@@ -287,8 +299,7 @@ __device__ __forceinline__ D4cSample d4c_sample(const D4cWin &w, int i, D4cWinRo
 }
 // windowed, dithered samples into the real-transform input; returns the DC-balance coefficient
 // (sum of the waveform / sum of the window, d4c.cpp:71-80) which the callers apply
-// rot0: d4c_win_rot(w, thread, workgroup size) -- the callers walk the same window two or three times and pay
-// its two sincospi once
+// rot0: d4c_win_rot(w, thread, workgroup size)
 template <int NT = 0>
 __device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, const D4cWinRot &rot0, cplx *Z, double *scratch) {
   double s1 = 0.0, s2 = 0.0;
@@ -340,20 +351,35 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
 }
 
-// Resident waves per SIMD the register allocation aims at.  4 (four 256-thread workgroups per CU, 128 VGPRs)
-// and 3 (168 VGPRs) run within 3 % of each other, but at 128 the compiler spills 216 bytes per lane and the
-// spill traffic (~200 MB per 2001 frames through L2) is most of what the kernel moves; at 168 it is 44 bytes.
+// Resident waves per SIMD the register allocation aims at: 3 (three 256-thread workgroups per CU, 168 VGPRs;
+// LDS allows no more).
 #ifndef D4C_MIN_WAVES
 #define D4C_MIN_WAVES 3
 #endif
+// The kernel lives at its register cap: a scheduling fence after every item of a per-bin loop keeps the compiler from
+// putting all items' LDS reads in flight at once (it did, and spilled 170 dwords in the smoothing loops alone).
+#if !defined(WORLD_EMU) && defined(D4C_FENCES)
+#define D4C_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define D4C_SCHED_FENCE() do { } while (0)
+#endif
+#ifndef D4C_TW_LEVEL
+#define D4C_TW_LEVEL 2      // the twiddle table in LDS is this many levels coarser than the N-point merge asks for
+#endif
+#ifndef WORLD_EMU
+#define D4C_FRESH_TID() do { asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0 && tid < T); } while (0)
+#else
+#define D4C_FRESH_TID() do { } while (0)
+#endif
 template <int NMAX, int T>
 __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
-  constexpr int kItems = D4cShape<NMAX, T>::kItems, kBins = D4cShape<NMAX, T>::kBins;
+  constexpr int kItems = D4cShape<NMAX, T>::kItems, kBins = D4cShape<NMAX, T>::kBins, kLo = D4cShape<NMAX, T>::kLo;
+  constexpr bool kRot = T * 16 == NMAX;                                // twiddles by constant rotation (fft.h)
   DYN_LDS(lds);
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
-  const int tid = wg_thread<T>();
+  int tid = wg_thread<T>();
   constexpr int nt = T;                                                // launch_d4c launches exactly T threads
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
@@ -367,13 +393,11 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   constexpr int lgn = const_log2(NMAX);
 #endif
   const int N = 1 << lgn, H = N / 2, q = H / 2, fs = p.b.fs;
-  // LDS: Z (N doubles: the transform, or whatever is exchanged between transforms) | scratch (64) | twiddles
+  // LDS: Z (N doubles: the transform, or whatever is exchanged between transforms) | scratch (64) | twiddles | group delay
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   double *scratch = Zr + N;
-  // the quarter-wave table is staged two levels coarser than the merge steps ask for (fft.h: twiddle()): 2 KB
-  // instead of 8 keep the workgroup, parked centroid included, inside the 52 KB that three per CU allow
-  const TwLds tw = stage_twiddles<T>(scratch + 64, lgn - 2, p.tab.tw);
+  const TwLds tw = stage_twiddles<T>(scratch + 64, lgn - D4C_TW_LEVEL, p.tab.tw);
 #ifdef WORLD_EMU
   const FftPlan plan = make_plan_max(lgn - 1, 3);
   auto cfft = [&]() { block_cfft_dif<3>(Z, plan, tw); };
@@ -381,13 +405,25 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   constexpr FftPlan plan = make_plan_max(lgn - 1, 3);
   auto cfft = [&]() __attribute__((always_inline)) { block_cfft_dif_static<lgn - 1, 3, T>(Z, tw); };
 #endif
-  // body(slot, k) for every bin this thread owns (rfft_merge_items: item m = bins tid + m T and H - that, natural
-  // order, so LDS traffic indexed by bin is conflict-free); `slot` is a compile-time constant after unrolling
-  auto for_bins = [&](auto body) __attribute__((always_inline)) {
+  const cplx wb = twiddle(tw, tid, lgn, -1);                           // e^{-2 pi i tid / N}: every other twiddle of the
+                                                                       // thread is this one times a constant
+  // body(slot, k) for every bin this thread owns; `slot` is a compile-time constant after unrolling.
+  // natural ownership (rfft_merge_items): item m = bins tid + m T and H - that
+  auto for_nat = [&](auto body) __attribute__((always_inline)) {
 #pragma unroll
     for (int m = 0; m < kItems; ++m) {
       const int it = tid + m * nt;
       if (it <= q) { body(2 * m, it); if (it < q) body(2 * m + 1, H - it); }
+      D4C_SCHED_FENCE();
+    }
+  };
+  // pair ownership (the centroid's even / odd halves): item m = bins 2 (tid + m T) and the next one
+  auto for_pair = [&](auto body) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < kItems; ++m) {
+      const int it = tid + m * nt;
+      if (it <= q) { body(2 * m, 2 * it); if (it < q) body(2 * m + 1, 2 * it + 1); }
+      D4C_SCHED_FENCE();
     }
   };
 
@@ -397,32 +433,29 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   const uint32_t *noise = p.noise + p.offsets2[fi];
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
-  // The first position's centroid waits while X1 of the second occupies the registers: in LDS behind the
-  // twiddle table where the budget of three workgroups per CU allows (N <= 4096: 35 + 16 KB), else in the
-  // frame's scratch row in HBM (kBins * T doubles; it cost 68 MB of L2 traffic per 2001 frames).
-  constexpr bool kParkInLds = NMAX <= 4096;
-  double *park = scratch + 64 + twiddle_lds_doubles(lgn - 2);
-  double *spill = p.gd + fi * p.gd_stride;
+  constexpr bool kParkInLds = true;                                    // centroid sum, then the group delay: N/2 + 1 doubles behind the twiddle table
+  double *park = scratch + 64 + twiddle_lds_doubles(lgn - D4C_TW_LEVEL);
   const double inv_n = 1.0 / N;
 
   // DCCorrection (common.cpp:56-75) on register bins: the few low bins it mirrors go through LDS
-  auto dc_correct = [&](double (&S)[kBins]) __attribute__((always_inline)) {
+  auto dc_correct = [&](double (&S)[kBins], auto for_own) __attribute__((always_inline)) {
     const int upper = 2 + static_cast<int>(cf0 * N / fs), nrep = upper - 1;
     const double dx = -static_cast<double>(fs) / N;
     __syncthreads();
-    for_bins([&](int slot, int k) { if (k <= upper) Zr[k] = S[slot]; });
+    for_own([&](int slot, int k) { if (k <= upper) Zr[k] = S[slot]; });
     __syncthreads();
-    for_bins([&](int slot, int k) {
+    for_own([&](int slot, int k) {
       if (k < nrep) S[slot] = S[slot] + interp_uniform(cf0, dx, Zr, upper + 1, static_cast<double>(k) * fs / N);
     });
     __syncthreads();
   };
-  // LinearSmoothing (common.cpp:27-111): register bins -> mirrored segment in LDS -> block prefix sum -> register bins
-  auto smooth = [&](const double (&in)[kBins], double width, double (&out)[kBins]) __attribute__((always_inline)) {
+  // LinearSmoothing (common.cpp:27-111): register bins -> mirrored segment in LDS -> block prefix sum -> register bins;
+  // the input and the output may be owned differently
+  auto smooth = [&](const double (&in)[kBins], auto for_in, double width, double (&out)[kBins], auto for_out) __attribute__((always_inline)) {
     const int bnd = static_cast<int>(width * N / fs) + 1;
     const int seg_len = H + 2 * bnd + 1;
     __syncthreads();
-    for_bins([&](int slot, int k) {
+    for_in([&](int slot, int k) {
       const double v = in[slot] * fs * inv_n;            // == .. * fs / N: N is a power of two
       Zr[k + bnd] = v;
       if (k >= 1 && k <= bnd) Zr[bnd - k] = v;
@@ -431,7 +464,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     block_scan_incl_double<T>(Zr, seg_len, scratch);
     const double origin_axis = -(bnd - 0.5) * fs / N;
     const double inv_step = static_cast<double>(N) / fs, inv_width = 1.0 / width;
-    for_bins([&](int slot, int k) {
+    for_out([&](int slot, int k) {
       double fa = static_cast<double>(k) * inv_n * fs - width / 2.0;
       const double lo = interp_uniform_rcp(origin_axis, inv_step, Zr, seg_len, fa);
       fa += width;
@@ -445,121 +478,180 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   // is built from starts and advances identically: one sincospi pair per frame.
   const D4cWinRot rot0 = d4c_win_rot(d4c_win(x, x_len, fs, cf0, pos, kHanning, 4.0, noise), tid, nt);
 
-  // ---- GetStaticCentroid (d4c.cpp:90-143) -------------------------------------
-  // centroid = Re(X2 conj X1) with X1 = FFT(w x / |w x|), X2 = FFT((n+1) w x / |w x|): two real transforms
-  // through the one buffer, X1 waiting in registers; the normalisation is applied to the product.
-  // One position: returns its centroid in `out`.  The first position's result waits in the frame's scratch row
-  // (HBM, L2-resident) while X1 of the second occupies the registers; the second adds it back.
-  auto centroid = [&](int c, double (&out)[kBins]) __attribute__((always_inline)) {
-    const D4cWin w = d4c_win(x, x_len, fs, cf0, c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0, kBlackman, 4.0,
-                             noise + (size_t)c * wdraws);
-    __syncthreads();
-    WH_STAMP(32, 1 + 5 * c);
-    const double coef = d4c_window_to_lds<T>(w, rot0, Z, scratch);
-    double pw = 0.0;
-    {
-      D4cWinRot rot = rot0;
-      for (int i = tid; i < N; i += nt) {
-        double v = 0.0;
-        if (i < w.wlen) { v = rfft_in(Z, i) - d4c_win_next(w, rot) * coef; pw += v * v; }
-        rfft_in(Z, i) = v;
+  // One window (d4c.cpp:52-84): the thread's samples below N/2 -- i = tid + j T, j < kLo -- balanced and in registers
+  // (0 beyond the window); returns the balance coefficient.  Samples at and above N/2 exist only for windows longer
+  // than N/2; they are walked again by whoever needs them (for_hi), so the common case pays for nothing.
+  auto for_hi = [&](const D4cWin &w, double coef, auto body) __attribute__((always_inline)) {
+    if (w.wlen > H) {
+      D4cWinRot rot = rot0;                                            // H / T steps on: sample H + tid
+#pragma unroll 1
+      for (int i = tid; i < H; i += nt) d4c_win_next(w, rot);
+      for (int i = H + tid; i < w.wlen; i += nt) {
+        const D4cSample s = d4c_sample(w, i, rot);
+        body(i, s.v - s.w * coef);
       }
     }
-    const double inv_pw = 1.0 / block_sum<T>(pw, scratch);    // 1 / |w x|^2 (d4c.cpp:104-107)
-    WH_STAMP(32, 2 + 5 * c);
-    double x1r[kBins], x1i[kBins];
-    cfft();
-    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
-      x1r[2 * m] = ar; x1i[2 * m] = ai; x1r[2 * m + 1] = br; x1i[2 * m + 1] = bi;
-    });
-    WH_STAMP(32, 3 + 5 * c);
-    // second input: (n + 1) times the same balanced waveform (d4c.cpp:111-112), recomputed from x
-    {
-      D4cWinRot rot = rot0;
-      block_map<4, double, T>(w.wlen, [&](int i) { const D4cSample s = d4c_sample(w, i, rot); return (s.v - s.w * coef) * (i + 1.0); },
-                           [&](int i, double v) { rfft_in(Z, i) = v; });
-    }
-    for (int i = w.wlen + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
-    cfft();
-    WH_STAMP(32, 4 + 5 * c);
-    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
-      out[2 * m] = (ar * x1r[2 * m] + x1i[2 * m] * ai) * inv_pw;                           // d4c.cpp:115-116
-      out[2 * m + 1] = (br * x1r[2 * m + 1] + x1i[2 * m + 1] * bi) * inv_pw;
-    });
-    WH_STAMP(32, 5 + 5 * c);
   };
-  double A[kBins];
-  {
-    double first[kBins];
-    centroid(0, first);
-    if (kParkInLds) {
-      for_bins([&](int slot, int k) { park[k] = first[slot]; });        // natural bin order: conflict-free
-    } else {
+  auto balanced = [&](const D4cWin &w, double (&ulo)[kLo]) __attribute__((always_inline)) {
+    double wlo[kLo];
+    double s1 = 0.0, s2 = 0.0;
+    D4cWinRot rot = rot0;
 #pragma unroll
-      for (int e = 0; e < kBins; ++e) spill[(size_t)e * nt + tid] = first[e];
+    for (int j = 0; j < kLo; ++j) {
+      const int i = tid + j * nt;
+      ulo[j] = 0.0; wlo[j] = 0.0;
+      if (i < w.wlen && i < H) {
+        const D4cSample s = d4c_sample(w, i, rot);
+        ulo[j] = s.v; wlo[j] = s.w; s1 += s.v; s2 += s.w;
+      }
     }
-  }
-  centroid(1, A);
-  if (kParkInLds) {
-    for_bins([&](int slot, int k) { A[slot] = park[k] + A[slot]; });     // the thread reads back what it wrote
-  } else {
+    // a window longer than N/2 has used all kLo steps: rot stands at sample H + tid
+    for (int i = H + tid; i < w.wlen; i += nt) { const D4cSample s = d4c_sample(w, i, rot); s1 += s.v; s2 += s.w; }
+    block_sum2<T>(s1, s2, scratch);
+    const double coef = s1 / s2;
 #pragma unroll
-    for (int e = 0; e < kBins; ++e) A[e] = spill[(size_t)e * nt + tid] + A[e];
+    for (int j = 0; j < kLo; ++j) ulo[j] = ulo[j] - wlo[j] * coef;     // 0 - 0 * coef beyond the window
+    return coef;
+  };
+
+  // ---- GetStaticCentroid (d4c.cpp:90-143) -------------------------------------
+  // The centroid of the two positions is summed in LDS (`park`, natural bin order: a thread only ever touches its
+  // own pairs): nothing but the window's samples waits in registers through the transforms.
+#pragma unroll 1
+  for (int c = 0; c < 2; ++c) {
+    const D4cWin w = d4c_win(x, x_len, fs, cf0, c == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0, kBlackman, 4.0,
+                             noise + (size_t)c * wdraws);
+    D4C_FRESH_TID();
+    double ulo[kLo];
+    const double coef = balanced(w, ulo);
+    WH_STAMP(32, 1 + 4 * c);
+    // even half: e[n] = z[n] + z[n + H], z[n] = u[n] (1 + i (n + 1)); the previous readers of Z are behind a barrier
+    double pw = 0.0;
+#pragma unroll
+    for (int j = 0; j < kLo; ++j) {
+      const int n = tid + j * nt;
+      if (n < H) {
+        cplx e; e.re = ulo[j]; e.im = ulo[j] * (n + 1.0);
+        Z[swz(n)] = e;
+        pw += ulo[j] * ulo[j];
+      }
+    }
+    for_hi(w, coef, [&](int i, double uh) {
+      cplx &e = Z[swz(i - H)];                                         // this thread's own slot
+      e.re += uh; e.im += uh * (i + 1.0);
+      pw += uh * uh;
+    });
+    const double half_inv_pw = 0.5 / block_sum<T>(pw, scratch);       // 1 / |w x|^2 (d4c.cpp:104-107), and the 1/2 of Im(P Q)/2
+    cfft();
+#pragma unroll
+    for (int m = 0; m < kItems; ++m) {
+      const int it = tid + m * nt;
+      if (it <= q) {
+        const cplx P = Z[fft_slot(plan, it)], Q = Z[fft_slot(plan, (H - it) & (H - 1))];
+        const double v = (P.im * Q.re + Q.im * P.re) * half_inv_pw;    // d4c.cpp:115-116 at bin 2 it
+        park[2 * it] = c == 0 ? v : park[2 * it] + v;
+      }
+    }
+    WH_STAMP(32, 2 + 4 * c);
+    __syncthreads();
+    D4C_FRESH_TID();
+    // odd half: o[n] = (z[n] - z[n + H]) W_N^n
+#pragma unroll
+    for (int j = 0; j < kLo; ++j) {
+      const int n = tid + j * nt;
+      if (n < H) {
+        cplx zl; zl.re = ulo[j]; zl.im = ulo[j] * (n + 1.0);
+        const cplx wn = kRot ? mul_w16_fwd(wb, j) : twiddle(tw, n, lgn, -1);
+        Z[swz(n)] = cmul(zl, wn);
+      }
+    }
+    for_hi(w, coef, [&](int i, double uh) {
+      cplx zh; zh.re = uh; zh.im = uh * (i + 1.0);
+      const cplx d = cmul(zh, twiddle(tw, i - H, lgn, -1));
+      cplx &o = Z[swz(i - H)];
+      o.re -= d.re; o.im -= d.im;
+    });
+    WH_STAMP(32, 3 + 4 * c);
+    cfft();
+#pragma unroll
+    for (int m = 0; m < kItems; ++m) {
+      const int it = tid + m * nt;
+      if (it < q) {
+        const cplx P = Z[fft_slot(plan, it)], Q = Z[fft_slot(plan, H - 1 - it)];
+        const double v = (P.im * Q.re + Q.im * P.re) * half_inv_pw;    // bin 2 it + 1
+        park[2 * it + 1] = c == 0 ? v : park[2 * it + 1] + v;
+      }
+    }
+    WH_STAMP(32, 4 + 4 * c);
+    __syncthreads();
   }
-  dc_correct(A);
-  WH_STAMP(32, 12);
+  WH_STAMP(32, 9);
+  D4C_FRESH_TID();
 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
   double B[kBins];
   {
     const D4cWin w = d4c_win(x, x_len, fs, cf0, pos, kHanning, 4.0, noise + (size_t)2 * wdraws);
-    const double coef = d4c_window_to_lds<T>(w, rot0, Z, scratch);
-    {
-      D4cWinRot rot = rot0;
-      for (int i = tid; i < N; i += nt)
-        rfft_in(Z, i) = i < w.wlen ? rfft_in(Z, i) - d4c_win_next(w, rot) * coef : 0.0;
+    double ulo[kLo];
+    const double coef = balanced(w, ulo);
+#pragma unroll
+    for (int j = 0; j < kLo; ++j) {
+      const int n = tid + j * nt;
+      if (n < H) rfft_in(Z, n) = ulo[j];
     }
-    WH_STAMP(32, 13);
+    for (int i = H + tid; i < N; i += nt) rfft_in(Z, i) = 0.0;
+    for_hi(w, coef, [&](int i, double uh) { rfft_in(Z, i) = uh; });    // the thread's own slots
+    WH_STAMP(32, 10);
     cfft();
-    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool, double br, double bi) {
-      B[2 * m] = ar * ar + ai * ai; B[2 * m + 1] = br * br + bi * bi;
+    double Bn[kBins];
+    rfft_merge_items_rot<kItems, T>(Z, lgn, plan, tw, wb, [&](int m, int, double ar, double ai, bool, double br, double bi) {
+      Bn[2 * m] = ar * ar + ai * ai; Bn[2 * m + 1] = br * br + bi * bi;
     });
-    WH_STAMP(32, 14);
+    WH_STAMP(32, 11);
+    D4C_FRESH_TID();
+    dc_correct(Bn, for_nat);
+    smooth(Bn, for_nat, cf0, B, for_pair);
   }
-  dc_correct(B);
-  smooth(B, cf0, B);
-  WH_STAMP(32, 16);
+  WH_STAMP(32, 12);
 
   // ---- GetStaticGroupDelay (d4c.cpp:172-188) ----------------------------------
+  double A[kBins];
+  for_pair([&](int slot, int k) { A[slot] = park[k]; });               // the centroid: the thread's own pairs
+  dc_correct(A, for_pair);                                             // d4c.cpp:141-142
+  D4C_FRESH_TID();
 #pragma unroll
   for (int e = 0; e < kBins; ++e) A[e] = A[e] / B[e];
-  smooth(A, cf0 / 2.0, A);
-  smooth(A, cf0, B);
-  // The group delay goes where the first centroid was parked (natural bin order, N/2 + 1 doubles), when that is LDS:
-  // the band transforms below read their slices from there -- no staging pass, two barriers fewer per band, and
-  // 2 kItems doubles fewer in registers through the kernel's hottest loop.  The 8192-point shape has no such room
-  // and keeps it in registers.
+  D4C_FRESH_TID();
+  smooth(A, for_pair, cf0 / 2.0, A, for_pair);
+  D4C_FRESH_TID();
+  smooth(A, for_pair, cf0, B, for_pair);
+  // The group delay waits in LDS behind the twiddle table (natural bin order, N/2 + 1 doubles) where three workgroups
+  // per CU leave room: the band transforms below read their slices from there -- no staging pass, two barriers fewer
+  // per band.  The 8192-point shape has no such room and keeps it in registers.
   double G[kParkInLds ? 1 : kBins];
   if constexpr (kParkInLds) {
-    for_bins([&](int slot, int k) { park[k] = A[slot] - B[slot]; });
+    for_pair([&](int slot, int k) { park[k] = A[slot] - B[slot]; });
   } else {
 #pragma unroll
     for (int e = 0; e < kBins; ++e) G[e] = A[e] - B[e];
   }
-  WH_STAMP(32, 19);
+  WH_STAMP(32, 13);
 
   // ---- GetCoarseAperiodicity (d4c.cpp:194-225) per 3 kHz band ------------------
   const int bnd = mround(N * 8.0 / p.wl);
   const int hwl = p.wl / 2, wl = 2 * hwl + 1;
   const int nz = hwl + 1;                               // packed complex input elements that are not zero
   int mine = 0;
-  for_bins([&](int, int) { ++mine; });
+  for_nat([&](int, int) { ++mine; });
   int *hist = reinterpret_cast<int *>(Zr);
+  // the Nuttall taps of the thread's own slice element: the same for every band
+  const double nut0 = 2 * tid < wl ? p.nuttall[2 * tid] : 0.0, nut1 = 2 * tid + 1 < wl ? p.nuttall[2 * tid + 1] : 0.0;
   for (int band = 0; band < p.nap; ++band) {
     const int lo_k = static_cast<int>(3000.0 * (band + 1) * N / fs) - hwl;
+    D4C_FRESH_TID();
     __syncthreads();                                    // the previous band's histograms are done (first band: park is written)
     if constexpr (!kParkInLds) {
-      for_bins([&](int slot, int k) { const int i = k - lo_k; if (i >= 0 && i < wl) Zr[i] = G[slot] * p.nuttall[i]; });
+      for_pair([&](int slot, int k) { const int i = k - lo_k; if (i >= 0 && i < wl) Zr[i] = G[slot] * p.nuttall[i]; });
       __syncthreads();
     }
     // First DIF stage with every input beyond element nz known to be zero.  A slice staged in Z sits in the buffer
@@ -568,8 +660,13 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       cplx v;
       if constexpr (kParkInLds) {
         const double *g = park + lo_k + 2 * n;
-        v.re = g[0] * p.nuttall[2 * n];
-        v.im = 2 * n + 1 < wl ? g[1] * p.nuttall[2 * n + 1] : 0.0;
+        if (n == tid) {
+          v.re = g[0] * nut0;
+          v.im = 2 * n + 1 < wl ? g[1] * nut1 : 0.0;
+        } else {
+          v.re = g[0] * p.nuttall[2 * n];
+          v.im = 2 * n + 1 < wl ? g[1] * p.nuttall[2 * n + 1] : 0.0;
+        }
       } else {
         v.re = Zr[2 * n];
         v.im = 2 * n + 1 < wl ? Zr[2 * n + 1] : 0.0;
@@ -608,7 +705,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     unsigned long long key[kBins];
 #pragma unroll
     for (int e = 0; e < kBins; ++e) key[e] = ~0ull;
-    rfft_merge_items<kItems, T>(Z, lgn, plan, tw, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
+    rfft_merge_items_rot<kItems, T>(Z, lgn, plan, tw, wb, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
       key[2 * m] = (unsigned long long)__double_as_longlong(ar * ar + ai * ai);
       if (paired) key[2 * m + 1] = (unsigned long long)__double_as_longlong(br * br + bi * bi);
     });
@@ -618,7 +715,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     // one lane here would stand between this band's select and the next band's first barrier
     if (tid == 0) { p.coarse[fi * 16 + 1 + band] = part; p.coarse[fi * 16 + 9 + band] = tot; }
   }
-  WH_STAMP(32, 20);
+  WH_STAMP(32, 14);
 }
 
 // ---------------------------------------------------------------------------
@@ -666,24 +763,12 @@ __global__ void d4c_finish(D4cParams p) {
 
 // ---------------------------------------------------------------------------
 size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 8 + 2); }
-// Z (N doubles) | scratch (64) | quarter-wave table of an N/4-point transform (two levels coarser than the merge) | the parked
-// centroid of the first position (N/2 + 2; N <= 4096 only)
+// Z (N doubles) | scratch (64) | quarter-wave table of the N/2-point complex transform | the group delay (N/2 + 2; N <= 4096 only)
 size_t d4c_frame_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(N + 64 + N / 16 + 2 + (N <= 4096 ? N / 2 + 2 : 0));
+  return sizeof(double) * (size_t)(N + 64 + twiddle_lds_doubles(lg - D4C_TW_LEVEL) + N / 2 + 2);
 }
 int d4c_frame_threads(int lg) { return (1 << lg) / 16; }   // one radix-8 butterfly per thread and stage
-// doubles of per-frame scratch (D4cParams::gd) the frame kernel needs: its register bins, one row per slot
-size_t d4c_frame_scratch_doubles(int lg) {
-#ifdef WORLD_EMU
-  (void)lg;
-  return D4cShape<8192, 1>::kBins;                       // the one emulated thread owns every slot of the largest shape
-#else
-  const int T = d4c_frame_threads(lg), N = 1 << lg;
-  return (size_t)2 * ((N / 4 + 1 + T - 1) / T) * T;
-#endif
-}
-
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz
 size_t d4c_max_draws_per_frame(int fs) {
   return (size_t)(2 * mround(3.0 * fs / 40.0 / 2.0) + 1) + 3 * (size_t)(2 * mround(4.0 * fs / kFloorF0D4C / 2.0) + 1);

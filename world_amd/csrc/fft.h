@@ -528,8 +528,30 @@ __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan
 // (prefix-sum segments, spectrum slices) is conflict-free, at the price of digit-reversed (2..4-way
 // conflicting) reads of the transform here.  rfft_merge above makes the opposite choice.
 //   emit(m, k, Xre[k], Xim[k], paired, Xre[h-k], Xim[h-k])        paired = false only for it = h/2
-template <int KITEMS, int NT = 0, class Emit>
-__device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit) {
+// a * W16^m, m known after unrolling (folds to one of the mul_w16 cases)
+__device__ __forceinline__ cplx mul_w16_fwd(cplx a, int m) {
+  switch (m & 15) {
+    case 0: return a;
+    case 1: return mul_w16<true, 1>(a);
+    case 2: return mul_w16<true, 2>(a);
+    case 3: return mul_w16<true, 3>(a);
+    case 4: return mul_w16<true, 4>(a);
+    case 5: return mul_w16<true, 5>(a);
+    case 6: return mul_w16<true, 6>(a);
+    case 7: return mul_w16<true, 7>(a);
+    case 8: return mul_w16<true, 8>(a);
+    case 9: return mul_w16<true, 9>(a);
+    case 10: return mul_w16<true, 10>(a);
+    case 11: return mul_w16<true, 11>(a);
+    case 12: return mul_w16<true, 12>(a);
+    case 13: return mul_w16<true, 13>(a);
+    case 14: return mul_w16<true, 14>(a);
+    default: return mul_w16<true, 15>(a);
+  }
+}
+// wk(m, k): the merge twiddle e^{-2 pi i k / N} of item m
+template <int KITEMS, int NT, class Wk, class Emit>
+__device__ __forceinline__ void rfft_merge_items_w(cplx *z, int lgn, const FftPlan &plan, Wk wk, Emit emit) {
   const int lgh = lgn - 1, h = 1 << lgh, q = h >> 1;
   const int tid = wg_thread<NT>(), nt = wg_size<NT>();
 #pragma unroll
@@ -543,7 +565,7 @@ __device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan
       cplx e, o;
       e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
       o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
-      const cplx ow = cmul(o, twiddle(tw, k, lgn, -1));
+      const cplx ow = cmul(o, wk(m, k));
       emit(m, k, e.re + ow.re, e.im + ow.im, true, e.re - ow.re, ow.im - e.im);
     } else if (k == q) {
       const cplx za = z[fft_slot(plan, q)];            // k = h/2: w = -i, X = conj(z)
@@ -556,6 +578,21 @@ __device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan
 #endif
   }
   __syncthreads();
+}
+template <int KITEMS, int NT = 0, class Emit>
+__device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, Emit emit) {
+  rfft_merge_items_w<KITEMS, NT>(z, lgn, plan, [&](int, int k) { return twiddle(tw, k, lgn, -1); }, emit);
+}
+// The same for a workgroup of exactly NT = N / 16 threads that keeps wbase = e^{-2 pi i tid / N} in registers: item m's
+// twiddle is wbase * W16^m -- a constant rotation (at most 4 FP64 operations, none for m = 0 and 4) instead of a table
+// lookup with its quadrant selects and the fine-level products (a third of a merge's instructions).  Other
+// workgroup sizes (the one-thread host emulation) take the table.
+template <int KITEMS, int NT, class Emit>
+__device__ __forceinline__ void rfft_merge_items_rot(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, cplx wbase, Emit emit) {
+  rfft_merge_items_w<KITEMS, NT>(z, lgn, plan, [&](int m, int k) {
+    if (NT * 16 == (1 << lgn)) return mul_w16_fwd(wbase, m);
+    return twiddle(tw, k, lgn, -1);
+  }, emit);
 }
 
 // ---- real inverse transform (unscaled: N * irfft, like the reference's c2r) ----

@@ -26,8 +26,6 @@ struct D4cParams {
   const double *f0;       // [n_utt][f_stride]
   double *aperiodicity;   // [n_utt][f_stride][fft_out/2+1]
   double *ap0;            // [n_utt][f_stride]  LoveTrain result
-  double *gd;             // [n_utt][f_stride][gd_stride] per-frame scratch row of d4c_frame (its register bins)
-  int gd_stride;
   double *coarse;         // [n_utt][f_stride][16] coarse aperiodicity (dB) per band, slot 1 + band
   unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
   unsigned *offsets2;     // [n_utt][f_stride]  position of the frame's 3 body windows within pass 2
@@ -48,6 +46,5 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
 size_t ct_max_draws_per_frame(int fft_size);
 int ct_seg_stride(int fft_size);
 size_t d4c_max_draws_per_frame(int fs);
-size_t d4c_frame_scratch_doubles(int lg_d4c);
 
 }  // namespace world_hip

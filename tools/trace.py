@@ -28,7 +28,7 @@ def stamps(unit):
     return list(buf)
 
 
-for unit, name, base, n in (("d4c", "d4c_frame select (last band)", 0, 10), ("d4c", "d4c_frame", 32, 15), ("ct", "ct_frame", 0, 11)):
+for unit, name, base, n in (("d4c", "d4c_frame select (last band)", 0, 10), ("d4c", "d4c_frame", 32, 20), ("ct", "ct_frame", 0, 11)):
     t = stamps(unit)[base:base + n]
     print(name, "total", t[-1] - t[0], "cycles")
     prev = t[0]

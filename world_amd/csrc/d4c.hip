@@ -366,6 +366,16 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
 #ifndef D4C_TW_LEVEL
 #define D4C_TW_LEVEL 2      // the twiddle table in LDS is this many levels coarser than the N-point merge asks for
 #endif
+// A per-bin loop ends with the one conditional item of thread 0 (bin N/2): the compiler's sinking pass then moves the
+// arithmetic of the unconditional items below that branch, next to their first use, while the LDS loads that feed it
+// stay put -- dozens of loaded values wait in registers and spill.  A value passed through keep() is "used" where
+// it is computed, so its arithmetic stays in front of the branch.
+__device__ __forceinline__ double keep(double v) {
+#ifndef WORLD_EMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 #ifndef WORLD_EMU
 #define D4C_FRESH_TID() do { asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0 && tid < T); } while (0)
 #else
@@ -445,7 +455,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     for_own([&](int slot, int k) { if (k <= upper) Zr[k] = S[slot]; });
     __syncthreads();
     for_own([&](int slot, int k) {
-      if (k < nrep) S[slot] = S[slot] + interp_uniform(cf0, dx, Zr, upper + 1, static_cast<double>(k) * fs / N);
+      if (k < nrep) S[slot] = keep(S[slot] + interp_uniform(cf0, dx, Zr, upper + 1, static_cast<double>(k) * fs / N));
     });
     __syncthreads();
   };
@@ -469,7 +479,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       const double lo = interp_uniform_rcp(origin_axis, inv_step, Zr, seg_len, fa);
       fa += width;
       const double hi = interp_uniform_rcp(origin_axis, inv_step, Zr, seg_len, fa);
-      out[slot] = (hi - lo) * inv_width;
+      out[slot] = keep((hi - lo) * inv_width);
     });
   };
 
@@ -605,7 +615,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     cfft();
     double Bn[kBins];
     rfft_merge_items_rot<kItems, T>(Z, lgn, plan, tw, wb, [&](int m, int, double ar, double ai, bool, double br, double bi) {
-      Bn[2 * m] = ar * ar + ai * ai; Bn[2 * m + 1] = br * br + bi * bi;
+      Bn[2 * m] = keep(ar * ar + ai * ai); Bn[2 * m + 1] = keep(br * br + bi * bi);
     });
     WH_STAMP(32, 11);
     D4C_FRESH_TID();
@@ -616,13 +626,15 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
 
   // ---- GetStaticGroupDelay (d4c.cpp:172-188) ----------------------------------
   double A[kBins];
-  for_pair([&](int slot, int k) { A[slot] = park[k]; });               // the centroid: the thread's own pairs
+  for_pair([&](int slot, int k) { A[slot] = keep(park[k]); });         // the centroid: the thread's own pairs
   dc_correct(A, for_pair);                                             // d4c.cpp:141-142
+  WH_STAMP(32, 13);
   D4C_FRESH_TID();
 #pragma unroll
   for (int e = 0; e < kBins; ++e) A[e] = A[e] / B[e];
   D4C_FRESH_TID();
   smooth(A, for_pair, cf0 / 2.0, A, for_pair);
+  WH_STAMP(32, 14);
   D4C_FRESH_TID();
   smooth(A, for_pair, cf0, B, for_pair);
   // The group delay waits in LDS behind the twiddle table (natural bin order, N/2 + 1 doubles) where three workgroups
@@ -635,7 +647,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
 #pragma unroll
     for (int e = 0; e < kBins; ++e) G[e] = A[e] - B[e];
   }
-  WH_STAMP(32, 13);
+  WH_STAMP(32, 15);
 
   // ---- GetCoarseAperiodicity (d4c.cpp:194-225) per 3 kHz band ------------------
   const int bnd = mround(N * 8.0 / p.wl);
@@ -702,6 +714,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       __syncthreads();
     }
 #endif
+    if (band == 0) WH_STAMP(32, 16);
     unsigned long long key[kBins];
 #pragma unroll
     for (int e = 0; e < kBins; ++e) key[e] = ~0ull;
@@ -709,13 +722,15 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       key[2 * m] = (unsigned long long)__double_as_longlong(ar * ar + ai * ai);
       if (paired) key[2 * m + 1] = (unsigned long long)__double_as_longlong(br * br + bi * bi);
     });
+    if (band == 0) WH_STAMP(32, 17);
     double part, tot;
     block_smallest_sum<T>(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
     // the band's two sums; d4c_finish turns them into dB (d4c.cpp:221-224, 314-316) -- a division and a log10 on
     // one lane here would stand between this band's select and the next band's first barrier
     if (tid == 0) { p.coarse[fi * 16 + 1 + band] = part; p.coarse[fi * 16 + 9 + band] = tot; }
+    if (band == 0) WH_STAMP(32, 18);
   }
-  WH_STAMP(32, 14);
+  WH_STAMP(32, 19);
 }
 
 // ---------------------------------------------------------------------------

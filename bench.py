@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs[2] / [3]-share / [4] legs")
     ap.add_argument("--only-config", type=int, default=0,
                     help="N = 1: run ONLY the leg of this BASELINE config (2, 3 or 4) -- the profiling entry point")
+    ap.add_argument("--contexts", type=int, default=2,
+                    help="N = 1: batched jobs in flight in the configs[2] / [3] / [4] legs (1 = per-kernel durations free of queueing: profiles)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
     ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis / host-pointer legs")
     ap.add_argument("--job-utterances", type=int, default=1024, help="N > 1: utterances of the configs[3] job")
@@ -394,8 +396,9 @@ def main():
     # =====================================================================================================
     # N = 1
     # =====================================================================================================
-    def run_leg(name, config, workload, make_x, fs, analyze, frames_of, bytes_per_frame, n_ctx=2):
+    def run_leg(name, config, workload, make_x, fs, analyze, frames_of, bytes_per_frame, n_ctx=None):
         """one timed leg: `n_ctx` contexts alternate (two batched jobs in flight), >= --min-wall seconds"""
+        n_ctx = n_ctx or max(1, args.contexts)
         x = make_x()
         streams = [torch.cuda.Stream(device=dev) for _ in range(n_ctx)]
         whs = [WorldHip(device=local) for _ in range(n_ctx)]

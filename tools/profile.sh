@@ -16,7 +16,7 @@ if [ "$CFG" = "1" ]; then
   CMD="python $ROOT/bench.py --steps 5 --warmup 2 --streams 1 --min-wall 0 --no-cpu-baseline --no-extras --no-configs"
   FRAMES=2001
 else
-  CMD="python $ROOT/bench.py --only-config $CFG --steps 2 --min-wall 0"
+  CMD="python $ROOT/bench.py --only-config $CFG --steps 2 --min-wall 0 --contexts ${CTX:-1}"
   case $CFG in 2) FRAMES=256256;; 3) FRAMES=128128;; 4) FRAMES=64064;; esac
 fi
 echo "$CMD" > $OUT/command.txt

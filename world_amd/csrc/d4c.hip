@@ -109,11 +109,11 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
   unsigned long long kmin, kmax;
 #ifndef WORLD_EMU
   hmin = -wave_max_int(-(lower_bound ? hmax : hmin)); hmax = wave_max_int(hmax);
-  int *hs = reinterpret_cast<int *>(scratch);
-  __syncthreads();
-  if (lane == 0) { hs[wv] = hmin; hs[32 + wv] = hmax; }
-  __syncthreads();
-  for (int w = 0; w < nw; ++w) { hmin = hs[w] < hmin ? hs[w] : hmin; hmax = hs[32 + w] > hmax ? hs[32 + w] : hmax; }
+  // its own scratch area (doubles 48..63): whoever read it last (this function, one band ago) is behind several barriers
+  int *hs = reinterpret_cast<int *>(scratch + 48);
+  if (lane == 0) { hs[wv] = hmin; hs[16 + wv] = hmax; }
+  __syncthreads();                                   // also: the histograms are zero before anybody counts
+  for (int w = 0; w < nw; ++w) { hmin = hs[w] < hmin ? hs[w] : hmin; hmax = hs[16 + w] > hmax ? hs[16 + w] : hmax; }
 #else
   (void)lane; (void)wv; (void)nw;
   if (lower_bound) hmin = hmax;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
   }
   (void)n;
   WH_STAMP(0, 8);
-  block_sum3<NT>(s_lt, s_all, s_thr, scratch);
+  block_sum3<NT, false>(s_lt, s_all, s_thr, scratch);     // doubles 0..35: last read before this band's passes
   const double thr = hi > 0 ? s_thr : __longlong_as_double((long long)prefix);
   *partial = s_lt + (remaining + 1) * thr;
   *total = s_all;
@@ -450,12 +450,12 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   // DCCorrection (common.cpp:56-75) on register bins: the few low bins it mirrors go through LDS
   auto dc_correct = [&](double (&S)[kBins], auto for_own) __attribute__((always_inline)) {
     const int upper = 2 + static_cast<int>(cf0 * N / fs), nrep = upper - 1;
-    const double dx = -static_cast<double>(fs) / N;
+    const double inv_dx = -static_cast<double>(N) / fs;
     __syncthreads();
     for_own([&](int slot, int k) { if (k <= upper) Zr[k] = S[slot]; });
     __syncthreads();
     for_own([&](int slot, int k) {
-      if (k < nrep) S[slot] = keep(S[slot] + interp_uniform(cf0, dx, Zr, upper + 1, static_cast<double>(k) * fs / N));
+      if (k < nrep) S[slot] = keep(S[slot] + interp_uniform_rcp(cf0, inv_dx, Zr, upper + 1, static_cast<double>(k) * fs * inv_n));
     });
     __syncthreads();
   };
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     }
     // a window longer than N/2 has used all kLo steps: rot stands at sample H + tid
     for (int i = H + tid; i < w.wlen; i += nt) { const D4cSample s = d4c_sample(w, i, rot); s1 += s.v; s2 += s.w; }
-    block_sum2<T>(s1, s2, scratch);
+    block_sum2<T, false>(s1, s2, scratch);               // doubles 0..35; the last collective used another area
     const double coef = s1 / s2;
 #pragma unroll
     for (int j = 0; j < kLo; ++j) ulo[j] = ulo[j] - wlo[j] * coef;     // 0 - 0 * coef beyond the window
@@ -551,8 +551,14 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       e.re += uh; e.im += uh * (i + 1.0);
       pw += uh * uh;
     });
-    const double half_inv_pw = 0.5 / block_sum<T>(pw, scratch);       // 1 / |w x|^2 (d4c.cpp:104-107), and the 1/2 of Im(P Q)/2
+    // |w x|^2 (d4c.cpp:104-107) is needed after the transform only: the waves' partial sums cross in scratch (doubles
+    // 40..47) behind the transform's own barriers
+    pw = wave_sum(pw);
+    if (lane_id() == 0) scratch[40 + wave_in_block()] = pw;
     cfft();
+    pw = 0.0;
+    for (int wv = 0; wv < wg_waves<T>(); ++wv) pw += scratch[40 + wv];
+    const double half_inv_pw = 0.5 / pw;                               // and the 1/2 of Im(P Q)/2
 #pragma unroll
     for (int m = 0; m < kItems; ++m) {
       const int it = tid + m * nt;
@@ -631,7 +637,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   WH_STAMP(32, 13);
   D4C_FRESH_TID();
 #pragma unroll
-  for (int e = 0; e < kBins; ++e) A[e] = A[e] / B[e];
+  for (int e = 0; e < kBins; ++e) A[e] = fast_div(A[e], B[e]);        // the smoothed power spectrum is positive and normal
   D4C_FRESH_TID();
   smooth(A, for_pair, cf0 / 2.0, A, for_pair);
   WH_STAMP(32, 14);

@@ -405,12 +405,14 @@ __device__ __forceinline__ int wave_bcast_int(int v, int src_lane) {
 
 // block collectives; `scratch` = LDS area of >= 64 doubles owned by the caller.
 // All threads must call; result returned to all; safe to call back to back.
-template <int NT = 0> __device__ __forceinline__ double block_sum(double v, double *scratch) {
+// PRE = false: the caller guarantees that nobody is still reading this scratch area (e.g. the previous collective used
+// another area and had its own barrier): one barrier instead of two.
+template <int NT = 0, bool PRE = true> __device__ __forceinline__ double block_sum(double v, double *scratch) {
 #ifndef WORLD_EMU
   v = wave_sum(v);
   int nw = wg_waves<NT>();
   if (nw == 1) return v;
-  __syncthreads();  // previous users of scratch are done
+  if (PRE) __syncthreads();  // previous users of scratch are done
   if (lane_id() == 0) scratch[wave_in_block()] = v;
   __syncthreads();
   double t = 0.0;
@@ -421,12 +423,12 @@ template <int NT = 0> __device__ __forceinline__ double block_sum(double v, doub
   return v;
 #endif
 }
-template <int NT = 0> __device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch) {
+template <int NT = 0, bool PRE = true> __device__ __forceinline__ void block_sum2(double &a, double &b, double *scratch) {
 #ifndef WORLD_EMU
   a = wave_sum(a); b = wave_sum(b);
   int nw = wg_waves<NT>();
   if (nw == 1) return;
-  __syncthreads();
+  if (PRE) __syncthreads();
   if (lane_id() == 0) { scratch[wave_in_block()] = a; scratch[32 + wave_in_block()] = b; }
   __syncthreads();
   double ta = 0.0, tb = 0.0;
@@ -436,12 +438,12 @@ template <int NT = 0> __device__ __forceinline__ void block_sum2(double &a, doub
   (void)scratch;
 #endif
 }
-template <int NT = 0> __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *scratch) {
+template <int NT = 0, bool PRE = true> __device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *scratch) {
 #ifndef WORLD_EMU
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
   int nw = wg_waves<NT>();
   if (nw == 1) return;
-  __syncthreads();
+  if (PRE) __syncthreads();
   if (lane_id() == 0) { scratch[wave_in_block()] = a; scratch[16 + wave_in_block()] = b; scratch[32 + wave_in_block()] = c; }
   __syncthreads();
   double ta = 0.0, tb = 0.0, tc = 0.0;

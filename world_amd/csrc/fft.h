@@ -227,13 +227,30 @@ template <int LR> __device__ __forceinline__ void mul_powers(cplx *a, cplx w1) {
 }
 
 // one decimation-in-frequency stage: sub-transforms of length 2^lev split R ways
-template <int LR, int NT = 0> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int lev, const TwLds &tw) {
+// Butterfly -> thread maps.  Plain: b = tid, tid + T, ...  Wave-region (WR = log2 of the butterflies a thread owns):
+// the 64 2^WR butterflies of wavefront w are the CONSECUTIVE ones [64 2^WR w, 64 2^WR (w + 1)), so a stage whose
+// butterflies span <= 64 elements keeps every wavefront inside one contiguous slice of the transform -- the same
+// slice in every such stage, which therefore need no workgroup barrier between them (DifStages / DitStages).
+template <int NT, int WR> struct BflyMap {
+  static __device__ __forceinline__ int first() {
+    const int t = wg_thread<NT>();
+    if constexpr (WR >= 0) return ((t >> 6) << (6 + WR)) + (t & 63);
+    else return t;
+  }
+  static __device__ __forceinline__ int step() { if constexpr (WR >= 0) return 64; else return wg_size<NT>(); }
+  static __device__ __forceinline__ int count(int nbf) {       // butterflies of this thread (plain: loop bound on b)
+    (void)nbf;
+    if constexpr (WR >= 0) return 1 << WR; else return 0;
+  }
+};
+template <int LR, int NT = 0, int WR = -1> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int lev, const TwLds &tw) {
   constexpr int R = 1 << LR;
   const int sh = lev - LR, q = 1 << sh, nbf = 1 << (lg - LR);
   int c[R];                                          // swz(r q): uniform
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = swz(r << sh);
-  for (int b = wg_thread<NT>(); b < nbf; b += wg_size<NT>()) {
+  const int b_end = WR >= 0 ? BflyMap<NT, WR>::first() + (64 << (WR >= 0 ? WR : 0)) : nbf;
+  for (int b = BflyMap<NT, WR>::first(); b < b_end; b += BflyMap<NT, WR>::step()) {
     const int j = b & (q - 1);
     const int s0 = swz(((b >> sh) << lev) + j);      // bits [sh, lev) of the base index are clear
     cplx a[R];
@@ -295,13 +312,14 @@ __device__ __forceinline__ void dif_first_stage_head(cplx *z, int lg, const TwLd
 }
 
 // one decimation-in-time stage: R finished sub-transforms of length 2^done are merged
-template <int LR, int NT = 0> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
+template <int LR, int NT = 0, int WR = -1> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
   constexpr int R = 1 << LR;
   const int q = 1 << done, L = done + LR, nbf = 1 << (lg - LR);
   int c[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = swz(r << done);
-  for (int b = wg_thread<NT>(); b < nbf; b += wg_size<NT>()) {
+  const int b_end = WR >= 0 ? BflyMap<NT, WR>::first() + (64 << (WR >= 0 ? WR : 0)) : nbf;
+  for (int b = BflyMap<NT, WR>::first(); b < b_end; b += BflyMap<NT, WR>::step()) {
     const int j = b & (q - 1);
     const int s0 = swz(((b >> done) << L) + j);      // bits [done, L) of the base index are clear
     cplx a[R];
@@ -384,11 +402,26 @@ __device__ __forceinline__ void block_cfft_dif_head(cplx *z, const FftPlan &p, c
 // Kernels whose shape fixes the length (d4c_frame) instantiate the stages by recursion: no stage loop, no
 // radix switch, every stride a constant -- and a constexpr plan makes the digit reversals of the merge
 // steps (fft_slot / fft_bin_of_slot) straight-line bit arithmetic.
+// One radix-2^MAXLR butterfly per thread (NT = 2^(LG - MAXLR), whole wavefronts): a stage whose sub-transforms are <= 64
+// 2^MAXLR elements long then keeps wavefront w inside elements [64 2^MAXLR w, 64 2^MAXLR (w + 1)) -- the slice its own
+// lanes wrote in the stage before, if that one was of the same kind -- and the workgroup barrier between the two becomes
+// a wave-level fence.  The remainder stage (smaller radix, several butterflies per thread) uses the wave-region map.
+// A 2048-point complex transform on 256 threads: 5 barriers -> 2 + the closing one.
+template <int LG, int MAXLR, int NT> struct FftWaveLocal {
+  static constexpr bool one_per_thread = NT >= 64 && NT % 64 == 0 && LG > MAXLR && (1 << (LG - MAXLR)) == NT;
+  // DIF stage at level LEV (sub-transform length 2^LEV): the stage before it had butterflies spanning 2^LEV elements
+  static constexpr bool dif_local(int lev) { return one_per_thread && lev <= 6; }
+  // DIT stage that merges sub-transforms of length 2^DONE: its own butterflies span 2^DONE * R elements
+  static constexpr bool dit_local(int done, int lr) { return one_per_thread && done > 0 && done + lr <= 6 + MAXLR; }
+};
 template <int LG, int MAXLR, int LEV, int NT = 0> struct DifStages {
   static __device__ __forceinline__ void run(cplx *z, const TwLds &tw) {
     constexpr int LR = LEV >= MAXLR ? MAXLR : LEV;
-    __syncthreads();
-    dif_stage<LR, NT>(z, LG, LEV, tw);
+    constexpr bool local = FftWaveLocal<LG, MAXLR, NT>::dif_local(LEV);
+    if constexpr (local) wave_sync(); else __syncthreads();
+    // the remainder stage of a one-butterfly-per-thread plan owns 2^(MAXLR - LR) butterflies per thread: wave regions
+    if constexpr (FftWaveLocal<LG, MAXLR, NT>::one_per_thread && LR < MAXLR) dif_stage<LR, NT, MAXLR - LR>(z, LG, LEV, tw);
+    else dif_stage<LR, NT>(z, LG, LEV, tw);
     if constexpr (LEV - LR > 0) DifStages<LG, MAXLR, LEV - LR, NT>::run(z, tw);
   }
 };
@@ -409,8 +442,10 @@ __device__ __forceinline__ void block_cfft_dif_from_static(cplx *z, const TwLds 
 template <int LG, int MAXLR, int DONE, int NT = 0> struct DitStages {
   static __device__ __forceinline__ void run(cplx *z, const TwLds &tw) {
     constexpr int LR = (DONE == 0 && LG % MAXLR != 0) ? LG % MAXLR : MAXLR;
-    __syncthreads();
-    dit_stage<LR, NT>(z, LG, DONE, tw);
+    constexpr bool local = FftWaveLocal<LG, MAXLR, NT>::dit_local(DONE, LR);
+    if constexpr (local) wave_sync(); else __syncthreads();
+    if constexpr (FftWaveLocal<LG, MAXLR, NT>::one_per_thread && LR < MAXLR) dit_stage<LR, NT, MAXLR - LR>(z, LG, DONE, tw);
+    else dit_stage<LR, NT>(z, LG, DONE, tw);
     if constexpr (DONE + LR < LG) DitStages<LG, MAXLR, DONE + LR, NT>::run(z, tw);
   }
 };

@@ -44,8 +44,8 @@ print("hv_refine (one wave, frame 5000): cache fill", t[0], "window rebuilds", t
 t = stamps("hv")[16:24]
 print("hv_band_events (workgroup seg 5, band 20): setup", t[0], "tile fetch/commit", t[1], "FIR", t[2], "events", t[3], "taps", t[4])
 
-t = stamps("hv")[24:30]
-print("hv_band_events_fft (workgroup seg 5, band 20): twiddle table", t[1] - t[0], "spectrum product + pre-twiddle", t[5] - t[1],
-      "c2r stages", t[2] - t[5], "mirror-store term", t[3] - t[2], "events", t[4] - t[3])
+t = stamps("hv")[24:31]
+print("hv_band_events_fft (band 20, chunk 0, first block): twiddle table", t[1] - t[0], "H to registers", t[2] - t[1],
+      "X * H + pre-twiddle", t[3] - t[2], "c2r stages", t[4] - t[3], "mirror-store term", t[5] - t[4], "events", t[6] - t[5])
 t = stamps("hv")[32:35]
 print("   its events phase: sample reads + masks", t[0], "block scan", t[1], "edge times + stores", t[2])

@@ -373,7 +373,21 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.fft_seg = hb.fft_seg;
   p.fft_pre = hb.max_half - 1;
   p.band_spec = hb.d_spec;
-  p.nseg = hv_segments(max_y, p.fft_seg);
+  if (p.fft_seg > 0) {
+    // FFT path: a workgroup filters `chunk_blocks` consecutive blocks of one (band, utterance) and appends their events to one
+    // list.  Batches get one chunk per utterance (the final lists, no compaction pass); a lone utterance is cut into
+    // enough chunks to fill the chip (~2048 workgroups).
+    p.nblk = (max_y + p.fft_seg - 1) / p.fft_seg;
+    const int want = std::max(1, std::min(p.nblk, (2048 + p.nch * n_utt - 1) / (p.nch * n_utt)));
+    p.chunk_blocks = (p.nblk + want - 1) / want;
+    p.nseg = (p.nblk + p.chunk_blocks - 1) / p.chunk_blocks;
+    p.seg_cap = p.nseg == 1 ? p.ev_cap : std::min(p.ev_cap, p.chunk_blocks * p.fft_seg / 2 + 2);
+  } else {
+    p.nblk = 0; p.chunk_blocks = 0;
+    p.nseg = band_segments(max_y);
+    p.seg_cap = kSegCap;
+  }
+  const bool direct_lists = p.fft_seg > 0 && p.nseg == 1;     // the filter bank writes the final event lists itself
 
   const size_t B = n_utt;
   const size_t cand_elems = B * p.fb_stride * p.maxc;
@@ -384,9 +398,11 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   need += pad256(sizeof(double) * B * p.y_stride);
   need += pad256(sizeof(double) * B * p.nch * 4 * p.ev_cap);
   need += pad256(sizeof(int) * B * p.nch * 4);
-  need += pad256(sizeof(double) * B * p.nch * 4 * hv_segment_list_doubles(p.nseg));
-  need += pad256(sizeof(int) * B * p.nch * 4 * p.nseg);
-  need += pad256(sizeof(double2) * B * p.nseg * kBandFftBins);
+  if (!direct_lists) {
+    need += pad256(sizeof(double) * B * p.nch * 4 * p.nseg * p.seg_cap);
+    need += pad256(sizeof(int) * B * p.nch * 4 * p.nseg);
+  }
+  need += pad256(sizeof(double2) * B * p.nblk * kBandFftBins);
   need += pad256(sizeof(double) * B * p.nch * p.fb_stride);
   need += 4 * pad256(sizeof(double) * cand_elems);
   need += pad256(sizeof(int) * B);
@@ -412,9 +428,13 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.y = c->arena.take<double>(B * p.y_stride);
   p.events = c->arena.take<double>(B * p.nch * 4 * p.ev_cap);
   p.ev_count = c->arena.take<int>(B * p.nch * 4);
-  p.seg_events = c->arena.take<double>(B * p.nch * 4 * hv_segment_list_doubles(p.nseg));
-  p.seg_count = c->arena.take<int>(B * p.nch * 4 * p.nseg);
-  p.blk_spec = c->arena.take<double2>(B * p.nseg * kBandFftBins);
+  if (direct_lists) {
+    p.seg_events = p.events; p.seg_count = p.ev_count;
+  } else {
+    p.seg_events = c->arena.take<double>(B * p.nch * 4 * p.nseg * p.seg_cap);
+    p.seg_count = c->arena.take<int>(B * p.nch * 4 * p.nseg);
+  }
+  p.blk_spec = c->arena.take<double2>(B * p.nblk * kBandFftBins);
   p.raw = c->arena.take<double>(B * p.nch * p.fb_stride);
   p.cand_a = c->arena.take<double>(cand_elems); p.score_a = c->arena.take<double>(cand_elems);
   p.cand_b = c->arena.take<double>(cand_elems); p.score_b = c->arena.take<double>(cand_elems);

@@ -212,58 +212,76 @@ __device__ __forceinline__ void fir_tile(const BandJob &job, const double *taps,
   fir_compute(job, taps, yt, s);
 }
 
+// sub-sample crossing time with a reciprocal-based quotient (common.h: fast_div): the exact quotient is not part of
+// the contract -- an ulp of prev / (cur - prev) moves a crossing by 1e-16 samples -- and its ~25-instruction dependent
+// chain per event was half of the event phase.  Denominators outside the normal range take the exact division.
+__device__ __forceinline__ double fine_edge_fast(int e, double prev, double cur) {
+  const double den = cur - prev;
+  const double qt = fabs(den) > 1e-290 ? fast_div(prev, den) : prev / den;
+  return e - qt;
+}
+
 // The four zero-crossing families (falling, rising, peaks, dips: harvest.cpp:162-238, dio.cpp:357-435) of the `len`
 // filtered samples that start at time index t0; sample(k) = filtered[t0 + k] for k in [0, len + 2).  Every thread
-// inspects kOutPer consecutive samples (time order) and records the crossings of each family as a bit mask; ONE
-// block scan of the four packed counts gives the list positions; the sub-sample times (one FP64 division each)
-// are then evaluated only for the set bits and appended to the segment's lists.
-// PER: consecutive samples a thread inspects per pass (the FFT path covers its whole block in one pass of 16)
-template <int PER = kOutPer, class Sample>
+// inspects PER consecutive samples (time order) and records the crossings of each family as a bit mask; ONE
+// block scan of the four packed counts gives the list positions; the sub-sample times are then evaluated only for
+// the set bits -- the four families side by side, so that four independent quotient chains are in flight -- and
+// appended to the lists (capacity `cap` each; ev + fam * fam_stride is family fam's list, count[] its fill).
+// PER: consecutive samples a thread inspects per pass (the FFT path covers its whole block in one pass of 16).
+// PRE = false: the caller has a barrier between this call and whoever used `scratch` last.
+template <int PER = kOutPer, bool PRE = true, class Sample>
 __device__ __forceinline__ void tile_events(Sample sample, int t0, int len, int n, double *ev, size_t fam_stride,
-                                            int (&count)[4], double *scratch, bool trace_me = false) {
+                                            int (&count)[4], int cap, double *scratch, bool trace_me = false) {
   const int tid = threadIdx.x, nt = blockDim.x;
   (void)trace_me;
   WH_ACC_DECL;
   for (int sub = 0; sub < len; sub += nt * PER) {
     WH_ACC_BEGIN;
     const int kbase = sub + tid * PER;
-    double sv[PER + 2];
-#pragma unroll
-    for (int q = 0; q < PER + 2; ++q) sv[q] = kbase + q < len + 2 ? sample(kbase + q) : 0.0;
     unsigned mask[4] = {0u, 0u, 0u, 0u};
+    {
+      double a = kbase < len + 2 ? sample(kbase) : 0.0, b = kbase + 1 < len + 2 ? sample(kbase + 1) : 0.0;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int i = t0 + kbase + q;
-      const bool live = kbase + q < len;
-      const double a = sv[q], b = sv[q + 1], c = sv[q + 2];
-      const double da = b - a, db = c - b;
-      const bool r01 = live && i <= n - 2, r23 = live && i <= n - 3;
-      if (r01 && 0.0 < a && b <= 0.0) mask[0] |= 1u << q;
-      if (r01 && a < 0.0 && 0.0 <= b) mask[1] |= 1u << q;
-      if (r23 && 0.0 < da && db <= 0.0) mask[2] |= 1u << q;
-      if (r23 && da < 0.0 && 0.0 <= db) mask[3] |= 1u << q;
+      for (int q = 0; q < PER; ++q) {
+        const double c = kbase + q + 2 < len + 2 ? sample(kbase + q + 2) : 0.0;
+        const int i = t0 + kbase + q;
+        const bool live = kbase + q < len;
+        const double da = b - a, db = c - b;
+        const bool r01 = live && i <= n - 2, r23 = live && i <= n - 3;
+        if (r01 && 0.0 < a && b <= 0.0) mask[0] |= 1u << q;
+        if (r01 && a < 0.0 && 0.0 <= b) mask[1] |= 1u << q;
+        if (r23 && 0.0 < da && db <= 0.0) mask[2] |= 1u << q;
+        if (r23 && da < 0.0 && 0.0 <= db) mask[3] |= 1u << q;
+        a = b; b = c;
+      }
     }
     WH_ACC_END(0);
     WH_ACC_BEGIN;
     unsigned long long packed = 0;
 #pragma unroll
     for (int fam = 0; fam < 4; ++fam) packed |= (unsigned long long)__builtin_popcount(mask[fam]) << (16 * fam);
-    unsigned long long total, off = block_excl_scan_u64(packed, &total, scratch);
+    unsigned long long total, off = block_excl_scan_u64<PRE>(packed, &total, scratch);
     WH_ACC_END(1);
     WH_ACC_BEGIN;
+    int at[4];
 #pragma unroll
-    for (int fam = 0; fam < 4; ++fam) {
-      double *dst = ev + fam * fam_stride;
-      int at = count[fam] + (int)((off >> (16 * fam)) & 0xFFFF);
-      for (unsigned m = mask[fam]; m != 0; m &= m - 1) {
-        const int q = __builtin_ctz(m);
-        double a = sv[q], b = sv[q + 1];
-        if (fam >= 2) { const double c = sv[q + 2]; a = b - a; b = c - b; }
-        if (at < kSegCap) dst[at] = fine_edge(t0 + kbase + q + 1, a, b);
-        ++at;
+    for (int fam = 0; fam < 4; ++fam) at[fam] = count[fam] + (int)((off >> (16 * fam)) & 0xFFFF);
+    // the samples of a crossing come from LDS again (a register array indexed by the bit position would live in scratch)
+    while ((mask[0] | mask[1] | mask[2] | mask[3]) != 0u) {
+#pragma unroll
+      for (int fam = 0; fam < 4; ++fam) {
+        if (mask[fam] != 0u) {
+          const int q = __builtin_ctz(mask[fam]);
+          mask[fam] &= mask[fam] - 1;
+          double a = sample(kbase + q), b = sample(kbase + q + 1);
+          if (fam >= 2) { const double c = sample(kbase + q + 2); a = b - a; b = c - b; }
+          if (at[fam] < cap) ev[fam * fam_stride + at[fam]] = fine_edge_fast(t0 + kbase + q + 1, a, b);
+          ++at[fam];
+        }
       }
-      count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
     }
+#pragma unroll
+    for (int fam = 0; fam < 4; ++fam) count[fam] += (int)((total >> (16 * fam)) & 0xFFFF);
     WH_ACC_END(2);
   }
   WH_ACC_FLUSH(32, tid == 0);
@@ -331,7 +349,7 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
     }
     WH_ACC_END(2);
     WH_ACC_BEGIN;
-    tile_events([&](int k) { return s[pad8(k)]; }, t0, kTile, n, ev, fam_stride, count, scratch);
+    tile_events([&](int k) { return s[pad8(k)]; }, t0, kTile, n, ev, fam_stride, count, kSegCap, scratch);
     WH_ACC_END(3);
   }
   WH_ACC_SET(4, job.ntap);
@@ -341,13 +359,13 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
 }
 
 // concatenate the segment lists of one (channel, family) in time order
-__device__ __forceinline__ void compact_event_segments(const double *seg_events, const int *seg_count, int nseg,
+__device__ __forceinline__ void compact_event_segments(const double *seg_events, const int *seg_count, int nseg, int seg_cap,
                                                        double *events, int ev_cap, int *ev_count) {
   int base = 0;
   for (int sgm = 0; sgm < nseg; ++sgm) {
     const int c = seg_count[sgm];
     for (int i = threadIdx.x; i < c; i += blockDim.x)
-      if (base + i < ev_cap) events[base + i] = seg_events[(size_t)sgm * kSegCap + i];
+      if (base + i < ev_cap) events[base + i] = seg_events[(size_t)sgm * seg_cap + i];
     base += c;
   }
   if (threadIdx.x == 0) *ev_count = imin(base, ev_cap);

@@ -511,6 +511,7 @@ __device__ __forceinline__ int block_excl_scan_int(int v, int *total, double *sc
 }
 
 // exclusive scan of one 64-bit value per thread (four 16-bit counters packed together)
+template <bool PRE = true>
 __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *total,
                                                                   double *scratch) {
 #ifndef WORLD_EMU
@@ -523,7 +524,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
   const int nw = waves_per_block();
   if (nw == 1) { *total = wt; return inc - v; }
   unsigned long long *us = reinterpret_cast<unsigned long long *>(scratch);
-  __syncthreads();
+  if (PRE) __syncthreads();
   if (lane == 0) us[wave_in_block()] = wt;
   __syncthreads();
   unsigned long long base = 0, tot = 0;

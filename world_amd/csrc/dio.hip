@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(kBpThreads) dio_band_events(DioParams p) {
 __global__ void dio_compact_events(DioParams p) {
   const int bf = blockIdx.x, u = blockIdx.y;
   const size_t list = (size_t)u * p.nb * 4 + bf;
-  compact_event_segments(p.seg_events + list * p.nseg * kSegCap, p.seg_count + list * p.nseg, p.nseg,
+  compact_event_segments(p.seg_events + list * p.nseg * kSegCap, p.seg_count + list * p.nseg, p.nseg, kSegCap,
                          p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list);
 }
 

@@ -312,7 +312,11 @@ __device__ __forceinline__ void dif_first_stage_head(cplx *z, int lg, const TwLd
 }
 
 // one decimation-in-time stage: R finished sub-transforms of length 2^done are merged
-template <int LR, int NT = 0, int WR = -1> __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw) {
+// epi(n, v): what is stored for output element n (the plain transform stores v); a caller's last stage can fold an
+// element-wise pass over the result into the transform's own stores
+struct FftNoEpilogue { __device__ __forceinline__ cplx operator()(int, cplx v) const { return v; } };
+template <int LR, int NT = 0, int WR = -1, class Epi = FftNoEpilogue>
+__device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds &tw, Epi epi = Epi()) {
   constexpr int R = 1 << LR;
   const int q = 1 << done, L = done + LR, nbf = 1 << (lg - LR);
   int c[R];
@@ -321,14 +325,15 @@ template <int LR, int NT = 0, int WR = -1> __device__ __forceinline__ void dit_s
   const int b_end = WR >= 0 ? BflyMap<NT, WR>::first() + (64 << (WR >= 0 ? WR : 0)) : nbf;
   for (int b = BflyMap<NT, WR>::first(); b < b_end; b += BflyMap<NT, WR>::step()) {
     const int j = b & (q - 1);
-    const int s0 = swz(((b >> done) << L) + j);      // bits [done, L) of the base index are clear
+    const int base = ((b >> done) << L) + j;         // bits [done, L) of the base index are clear
+    const int s0 = swz(base);
     cplx a[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = z[s0 ^ c[r]];
     if (q > 1) mul_powers<LR>(a, twiddle(tw, j, L, +1));
     dft_reg<false, LR>(a);
 #pragma unroll
-    for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = a[k];
+    for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = epi(base + (k << done), a[k]);
   }
 }
 
@@ -440,18 +445,24 @@ __device__ __forceinline__ void block_cfft_dif_from_static(cplx *z, const TwLds 
 }
 // inverse: the plan's stages in reverse order -- the remainder stage (if any) first, then the MAXLR ones
 template <int LG, int MAXLR, int DONE, int NT = 0> struct DitStages {
-  static __device__ __forceinline__ void run(cplx *z, const TwLds &tw) {
+  template <class Epi> static __device__ __forceinline__ void run(cplx *z, const TwLds &tw, Epi epi) {
     constexpr int LR = (DONE == 0 && LG % MAXLR != 0) ? LG % MAXLR : MAXLR;
     constexpr bool local = FftWaveLocal<LG, MAXLR, NT>::dit_local(DONE, LR);
+    constexpr bool last = DONE + LR >= LG;
     if constexpr (local) wave_sync(); else __syncthreads();
-    if constexpr (FftWaveLocal<LG, MAXLR, NT>::one_per_thread && LR < MAXLR) dit_stage<LR, NT, MAXLR - LR>(z, LG, DONE, tw);
-    else dit_stage<LR, NT>(z, LG, DONE, tw);
-    if constexpr (DONE + LR < LG) DitStages<LG, MAXLR, DONE + LR, NT>::run(z, tw);
+    if constexpr (last) {                              // the epilogue belongs to the stage that produces the result
+      if constexpr (FftWaveLocal<LG, MAXLR, NT>::one_per_thread && LR < MAXLR) dit_stage<LR, NT, MAXLR - LR, Epi>(z, LG, DONE, tw, epi);
+      else dit_stage<LR, NT, -1, Epi>(z, LG, DONE, tw, epi);
+    } else {
+      if constexpr (FftWaveLocal<LG, MAXLR, NT>::one_per_thread && LR < MAXLR) dit_stage<LR, NT, MAXLR - LR>(z, LG, DONE, tw);
+      else dit_stage<LR, NT>(z, LG, DONE, tw);
+      DitStages<LG, MAXLR, DONE + LR, NT>::run(z, tw, epi);
+    }
   }
 };
-template <int LG, int MAXLR, int NT = 0>
-__device__ __forceinline__ void block_cfft_dit_static(cplx *z, const TwLds &tw) {
-  DitStages<LG, MAXLR, 0, NT>::run(z, tw);
+template <int LG, int MAXLR, int NT = 0, class Epi = FftNoEpilogue>
+__device__ __forceinline__ void block_cfft_dit_static(cplx *z, const TwLds &tw, Epi epi = Epi()) {
+  DitStages<LG, MAXLR, 0, NT>::run(z, tw, epi);
   __syncthreads();
 }
 
@@ -702,6 +713,36 @@ __device__ __forceinline__ void irfft_pretwiddle_items(cplx *z, int lgn, const F
     } else if (k == q) {
       const cplx x = spec(q);                                 // k = h/2: w = +i
       cplx r; r.re = 2.0 * x.re; r.im = -2.0 * x.im;
+      z[fft_slot(plan, q)] = r;
+    }
+  }
+}
+// The same for callers that hold part of the product in registers and know their twiddles: pair(m, k, &x, &y, &w) supplies
+// X[k], X[h-k] and w_k = e^{+2 pi i k / N} for item m (k = tid + m NT; k = 0: x = X[0], y = X[h]; k = h/2: x only).
+template <int KITEMS, int NT, class Pair>
+__device__ __forceinline__ void irfft_pretwiddle_items_w(cplx *z, int lgn, const FftPlan &plan, Pair pair) {
+  const int lgh = lgn - 1, h = 1 << lgh, q = h >> 1;
+  const int tid = wg_thread<NT>(), nt = wg_size<NT>();
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < KITEMS; ++m) {
+    const int k = tid + m * nt;
+    cplx x, y, w;
+    if (k <= q) pair(m, k, x, y, w);
+    if (k == 0) {
+      cplx r; r.re = x.re + y.re; r.im = x.re - y.re;        // imaginary parts of DC / Nyquist ignored
+      z[fft_slot(plan, 0)] = r;
+    } else if (k < q) {
+      y.im = -y.im;                                           // conj(X[h-k])
+      const cplx s = cadd(x, y), d = csub(x, y);
+      const cplx t = cmul(d, w);
+      cplx r, rm;
+      r.re = s.re - t.im; r.im = s.im + t.re;
+      rm.re = s.re + t.im; rm.im = t.re - s.im;
+      z[fft_slot(plan, k)] = r;
+      z[fft_slot(plan, h - k)] = rm;
+    } else if (k == q) {
+      cplx r; r.re = 2.0 * x.re; r.im = -2.0 * x.im;         // k = h/2: w = +i
       z[fft_slot(plan, q)] = r;
     }
   }

@@ -29,7 +29,7 @@ struct HarvestParams {
   const double *band_taps; // Nuttall * cos band-pass FIRs (harvest.cpp:101-108), built on the host
   // FFT path of the filter bank (harvest.hip: hv_block_spectra / hv_band_events_fft); fft_seg == 0: direct FIR
   const double2 *band_spec;// [nch][kBandFftBins] spectrum of every band's taps / kBandFft, built once per band set
-  double2 *blk_spec;       // [n_utt][nseg][kBandFftBins] spectra of the signal's overlapping blocks (workspace)
+  double2 *blk_spec;       // [n_utt][nblk][kBandFftBins] spectra of the signal's overlapping blocks (workspace)
   int fft_seg;             // filtered samples one block yields: kBandFft - 2 max_half - 2
   int fft_pre;             // samples a block starts before its first output: max_half - 1
   int max_half;            // max L
@@ -43,9 +43,12 @@ struct HarvestParams {
   double *fwd;             // [n_utt][m_stride] forward-filtered padded signal
   int m_stride;
   double *y;               // [n_utt][y_stride]
-  double *seg_events;      // [n_utt][nch][4][nseg][segment capacity] per-segment crossing times
+  double *seg_events;      // [n_utt][nch][4][nseg][seg_cap] per-segment crossing times (nseg == 1 on the FFT path: the final lists)
   int *seg_count;          // [n_utt][nch][4][nseg]
-  int nseg;                // time segments per utterance slot
+  int nseg;                // segment lists per (utterance, band, family): chunks of blocks (FFT path) or FIR segments
+  int seg_cap;             // capacity of one segment list
+  int nblk;                // FFT path: blocks per utterance slot
+  int chunk_blocks;        // FFT path: consecutive blocks one workgroup filters (its events form one segment list)
   double *events;          // [n_utt][nch][4][ev_cap] fine zero-crossing positions
   int *ev_count;           // [n_utt][nch][4]
   double *raw;             // [n_utt][nch][fb_stride]
@@ -67,8 +70,6 @@ constexpr int kBandFftLg = 12, kBandFft = 1 << kBandFftLg, kBandFftBins = kBandF
 int hv_fft_segment(int max_half);          // outputs per block of the FFT path, 0 = filters too long for it
 void launch_band_spectra(const double *d_taps, const int *d_off, const int *d_half, int nch, double2 *d_spec,
                          const Tables &tab, hipStream_t stream);
-int hv_segments(int max_y_len, int fft_seg);
-size_t hv_segment_list_doubles(int nseg);
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
                     hipStream_t stream);
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream);

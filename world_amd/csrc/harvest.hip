@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
   job.shift = p.band_half[band] + 1;             // delay compensation L+1 (harvest.cpp:140-142)
   job.max_ntap = 2 * p.max_half + 1;
   job.nseg = p.nseg;
-  job.seg_events = p.seg_events + ((size_t)(u * p.nch + band) * 4) * p.nseg * kSegCap;
+  job.seg_events = p.seg_events + ((size_t)(u * p.nch + band) * 4) * p.nseg * kSegCap;   // seg_cap == kSegCap on this path
   job.seg_count = p.seg_count + ((size_t)(u * p.nch + band) * 4) * p.nseg;
   job.quirk = p.quirk + ((size_t)u * p.nch + band) * 4;
   job.quirk_delay = job.shift;                     // the term is a function of the undelayed index
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) hv_block_spectra(HarvestParams p) {
     const int idx = m0 + i;
     rfft_in(Z, i) = (idx >= 0 && idx < n) ? y[idx] : 0.0;
   }
-  double2 *out = p.blk_spec + ((size_t)u * p.nseg + blk) * kBandFftBins;
+  double2 *out = p.blk_spec + ((size_t)u * p.nblk + blk) * kBandFftBins;
 #ifdef WORLD_EMU
   block_rfft<3>(Z, kBandFftLg, tw, [&](int k, double re, double im) { out[k] = make_double2(re, im); });
 #else
@@ -185,74 +185,121 @@ __global__ void __launch_bounds__(256) hv_block_spectra(HarvestParams p) {
 #endif
 }
 
-__global__ void __launch_bounds__(256, 4) hv_band_events_fft(HarvestParams p) {
+// One workgroup = one band x one run of `chunk_blocks` consecutive blocks x one utterance.  The band's spectrum H waits in
+// registers (natural-order items: 40 VGPRs) while the blocks' spectra stream past it -- consecutive workgroups are the
+// bands of one utterance, so a block's spectrum is fetched from HBM once and served to its 152 readers by L2 (the
+// previous launch order re-read X and H per (block, band): 8.7 x the whole pipeline's algorithmic traffic) -- the
+// twiddle table, the merge twiddles and the mirror-store constants are set up once, and the crossings of block after
+// block are APPENDED to the chunk's lists: with one chunk per utterance (batches) those are the final lists and
+// hv_compact_events does not run at all.
+__global__ void __launch_bounds__(256, 3) hv_band_events_fft(HarvestParams p) {
   DYN_LDS(lds);
-  const int seg = blockIdx.x, band = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+  const int band = blockIdx.x, chunk = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
   const int n = p.y_len[u];
   const size_t list = ((size_t)(u * p.nch + band) * 4);
-  int *cnt_out = p.seg_count + list * p.nseg + seg;
-  const int t0 = seg * p.fft_seg;
-  if (t0 >= n) {
+  int *cnt_out = p.seg_count + list * p.nseg + chunk;
+  const int blk0 = chunk * p.chunk_blocks;
+  if (blk0 * p.fft_seg >= n) {
     if (tid == 0) for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = 0;
     return;
   }
-  const bool trace_me = blockIdx.x == 5 && blockIdx.y == 20; (void)trace_me;
+  const int blk1 = imin(blk0 + p.chunk_blocks, (n + p.fft_seg - 1) / p.fft_seg);
+  const bool trace_me = blockIdx.x == 20 && blockIdx.y == 0; (void)trace_me;
   WH_STAMP(24, 0);
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *scratch = reinterpret_cast<double *>(lds) + kBandFft;
   const TwLds tw = stage_twiddles(scratch + 64, kBandFftLg - 1, p.tab.tw);
   WH_STAMP(24, 1);
-  const double2 *X = p.blk_spec + ((size_t)u * p.nseg + seg) * kBandFftBins;
   const double2 *H = p.band_spec + (size_t)band * kBandFftBins;
-  auto product = [&](int k) { const double2 x = X[k], h = H[k]; cplx a, b; a.re = x.x; a.im = x.y; b.re = h.x; b.im = h.y; return cmul(a, b); };
-#ifdef WORLD_EMU
-  block_irfft<3>(Z, kBandFftLg, tw, product);
-#else
-  {
-    constexpr FftPlan plan = make_plan_max(kBandFftLg - 1, 3);
-    irfft_pretwiddle_items<(kBandFft / 4 + 1 + 255) / 256, 256>(Z, kBandFftLg, plan, tw, product);   // 256 threads: launch_harvest
-    WH_STAMP(24, 5);
-    block_cfft_dit_static<kBandFftLg - 1, 3, 256>(Z, tw);
-  }
-#endif
-  WH_STAMP(24, 2);
   // filtered[t0 + k] = block sample k + fft_pre + shift, shift = L + 1 (delay compensation, harvest.cpp:140-142)
   const int shift = p.band_half[band] + 1;
   const int at0 = p.fft_pre + shift;
-  const int len = imin(p.fft_seg, n - t0);
-  {
-    // the reference's mirror-store term (bandfilter.h), a function of the undelayed index t0 + k + shift
-    const double *q = p.quirk + ((size_t)u * p.nch + band) * 4;
-    const double qc = q[0], qs = q[1], q0 = q[2], w = q[3];
-    const int n0 = t0 + tid + shift;
-    double sn, cs, sr, cr;
-    sincospi(n0 * w, &sn, &cs);
-    sincospi(nt * w, &sr, &cr);
-    const double sign = (n0 & 1) ? -1.0 : 1.0;
-    for (int k = tid, j = 0; k < len + 2; k += nt, ++j) {
-      const double flip = ((nt & 1) && (j & 1)) ? -sign : sign;     // (-1)^(n0 + j nt)
-      rfft_in(Z, k + at0) += flip * (qc * cs + qs * sn + q0);
-      const double c2 = cs * cr - sn * sr;
-      sn = sn * cr + cs * sr;
-      cs = c2;
-    }
-    __syncthreads();
-  }
-  WH_STAMP(24, 3);
-  double *ev = p.seg_events + (list * p.nseg + seg) * kSegCap;
-  const size_t fam_stride = (size_t)p.nseg * kSegCap;
+  // the reference's mirror-store term (bandfilter.h), a function of the undelayed index t0 + k + shift:
+  //   (-1)^n (qc cos(pi w n) + qs sin(pi w n) + q0),  n = t0 + (s - at0) + shift for block sample s.
+  const double *qc4 = p.quirk + ((size_t)u * p.nch + band) * 4;
+  const double qc = qc4[0], qs = qc4[1], q0 = qc4[2], w = qc4[3];
+  double *ev = p.seg_events + (list * p.nseg + chunk) * p.seg_cap;
+  const size_t fam_stride = (size_t)p.nseg * p.seg_cap;
   int count[4] = {0, 0, 0, 0};
-  tile_events<16>([&](int k) { return rfft_in(Z, k + at0); }, t0, len, n, ev, fam_stride, count, scratch, trace_me);
-  WH_STAMP(24, 4);
+#ifdef WORLD_EMU
+  for (int blk = blk0; blk < blk1; ++blk) {
+    const int t0 = blk * p.fft_seg;
+    const double2 *X = p.blk_spec + ((size_t)u * p.nblk + blk) * kBandFftBins;
+    auto product = [&](int k) { const double2 x = X[k], h = H[k]; cplx a, b; a.re = x.x; a.im = x.y; b.re = h.x; b.im = h.y; return cmul(a, b); };
+    block_irfft<3>(Z, kBandFftLg, tw, product);
+    const int len = imin(p.fft_seg, n - t0);
+    for (int k = tid; k < len + 2; k += nt) {
+      const int ng = t0 + k + shift;
+      double sn, cs;
+      sincospi(ng * w, &sn, &cs);
+      rfft_in(Z, k + at0) += ((ng & 1) ? -1.0 : 1.0) * (qc * cs + qs * sn + q0);
+    }
+    tile_events<16, false>([&](int k) { return rfft_in(Z, k + at0); }, t0, len, n, ev, fam_stride, count, p.seg_cap, scratch);
+  }
+#else
+  // cos / sin of the term's phase at the thread's first sample of the first block; from block to block and from sample
+  // to sample they advance by rotation (a sincospi per block sat in the loop with the filter spectrum's 40 registers live)
+  double sr, cr, sb, cb, sn0, cs0;
+  sincospi(nt * w, &sr, &cr);
+  sincospi(p.fft_seg * w, &sb, &cb);
+  sincospi((blk0 * p.fft_seg + tid + shift) * w, &sn0, &cs0);
+  constexpr int NT = 256, kItems = (kBandFft / 4 + 1 + NT - 1) / NT;   // 256 threads: launch_harvest
+  constexpr int hh = kBandFft / 2, qq = hh / 2;
+  constexpr FftPlan plan = make_plan_max(kBandFftLg - 1, 3);
+  cplx hk[kItems], hm[kItems];                           // the band's spectrum: natural-order items, 40 VGPRs
+#pragma unroll
+  for (int m = 0; m < kItems; ++m) {
+    const int k = tid + m * NT;
+    hk[m].re = hk[m].im = hm[m].re = hm[m].im = 0.0;
+    if (k <= qq) {
+      const double2 a = H[k], b = H[hh - k];
+      hk[m].re = a.x; hk[m].im = a.y; hm[m].re = b.x; hm[m].im = b.y;
+    }
+  }
+  const cplx wbf = twiddle(tw, tid, kBandFftLg, -1);     // e^{-2 pi i tid / N}; item m's inverse twiddle is conj(wbf W16^m)
+  WH_STAMP(24, 2);
+  for (int blk = blk0; blk < blk1; ++blk) {
+    const int t0 = blk * p.fft_seg;
+    const double2 *X = p.blk_spec + ((size_t)u * p.nblk + blk) * kBandFftBins;
+    irfft_pretwiddle_items_w<kItems, NT>(Z, kBandFftLg, plan, [&](int m, int k, cplx &x, cplx &y, cplx &wk) {
+      const double2 a = X[k], b = X[hh - k];
+      cplx ca, cb2; ca.re = a.x; ca.im = a.y; cb2.re = b.x; cb2.im = b.y;
+      x = cmul(ca, hk[m]); y = cmul(cb2, hm[m]);
+      wk = cconj(mul_w16_fwd(wbf, m));
+    });
+    if (blk == blk0) WH_STAMP(24, 3);
+    block_cfft_dit_static<kBandFftLg - 1, 3, NT>(Z, tw);
+    if (blk == blk0) WH_STAMP(24, 4);
+    const int len = imin(p.fft_seg, n - t0);
+    {
+      const int n0 = t0 + tid + shift;
+      double sn = sn0, cs = cs0;
+      { const double c2 = cs0 * cb - sn0 * sb; sn0 = sn0 * cb + cs0 * sb; cs0 = c2; }     // the next block's phase
+      const double sign = (n0 & 1) ? -1.0 : 1.0;
+      for (int k = tid, j = 0; k < len + 2; k += nt, ++j) {
+        const double flip = ((nt & 1) && (j & 1)) ? -sign : sign;     // (-1)^(n0 + j nt)
+        rfft_in(Z, k + at0) += flip * (qc * cs + qs * sn + q0);
+        const double c2 = cs * cr - sn * sr;
+        sn = sn * cr + cs * sr;
+        cs = c2;
+      }
+      __syncthreads();
+    }
+    if (blk == blk0) WH_STAMP(24, 5);
+    tile_events<16, false>([&](int k) { return rfft_in(Z, k + at0); }, t0, len, n, ev, fam_stride, count, p.seg_cap, scratch,
+                           trace_me && blk == blk0);
+    if (blk == blk0) WH_STAMP(24, 6);
+  }
+#endif
   if (tid == 0)
-    for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = imin(count[fam], kSegCap);
+    for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * p.nseg] = imin(count[fam], p.seg_cap);
 }
 
 // concatenate the per-segment lists of one (family, band, utterance) in time order
 __global__ void hv_compact_events(HarvestParams p) {
   const int bf = blockIdx.x, u = blockIdx.y;        // bf = band * 4 + family
   const size_t list = (size_t)u * p.nch * 4 + bf;
-  compact_event_segments(p.seg_events + list * p.nseg * kSegCap, p.seg_count + list * p.nseg, p.nseg,
+  compact_event_segments(p.seg_events + list * p.nseg * p.seg_cap, p.seg_count + list * p.nseg, p.nseg, p.seg_cap,
                          p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list);
 }
 
@@ -655,8 +702,6 @@ __global__ void hv_prune(HarvestParams p) {
 
 // ---------------------------------------------------------------------------
 size_t hv_band_lds_bytes(int max_half) { return band_lds_bytes(2 * max_half + 1); }
-int hv_segments(int max_y_len, int fft_seg) { return fft_seg > 0 ? (max_y_len + fft_seg - 1) / fft_seg : band_segments(max_y_len); }
-size_t hv_segment_list_doubles(int nseg) { return (size_t)nseg * kSegCap; }
 
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
                     hipStream_t stream) {
@@ -678,12 +723,13 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
   if (p.fft_seg > 0) {
     const size_t lds = sizeof(double) * (kBandFft + 64 + twiddle_lds_doubles(kBandFftLg - 1));
-    WH_BLOCKS(hv_block_spectra, dim3(p.nseg, B), 256, lds, stream, p);
-    WH_BLOCKS(hv_band_events_fft, dim3(p.nseg, p.nch, B), 256, lds, stream, p);
+    WH_BLOCKS(hv_block_spectra, dim3(p.nblk, B), 256, lds, stream, p);
+    WH_BLOCKS(hv_band_events_fft, dim3(p.nch, p.nseg, B), 256, lds, stream, p);
   } else {
     WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
   }
-  WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);
+  // one chunk per utterance: the kernel above appended straight into the final lists (seg_events == events)
+  if (!(p.fft_seg > 0 && p.nseg == 1)) WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);
   WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawFrames - 1) / kRawFrames, p.nch, B), kRawFrames,
             8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);

@@ -227,7 +227,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
     ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis / host-pointer legs")
     ap.add_argument("--job-utterances", type=int, default=1024, help="N > 1: utterances of the configs[3] job")
-    ap.add_argument("--sub-batch", type=int, default=128, help="N > 1: utterances per batched call on a rank")
+    ap.add_argument("--sub-batch", type=int, default=32,
+                    help="configs[3] job (N > 1, and the N = 1 anchor configs['3_full']): utterances per batched call = per all-gather")
     ap.add_argument("--streams", type=int, default=12,
                     help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
                          "stream with its own workspace; 1 = strictly one after the other)")
@@ -323,19 +324,19 @@ def main():
         mine = parts[rank]
         xs = {i: synth.utterance(i, FS, sec, device=dev) for i in mine}        # only this rank's share exists here
         wh = WorldHip(device=local)
-        phases = {"compute_ms": 0.0, "exchange_ms": 0.0, "steps": 0}
+        phases = {"compute_ms": 0.0, "exchange_ms": 0.0, "exchange_exposed_ms": 0.0, "steps": 0}
 
         last = [None]
 
         def step():
-            last[0] = wd.analyze_sharded(xs, FS, lengths=lengths, analyze=wh.analyze, packer=wh, sub_batch=args.sub_batch,
+            last[0] = wd.analyze_sharded(xs, FS, lengths=lengths, analyze_packed=wh.analyze_packed, sub_batch=args.sub_batch,
                                          gather=not args.no_gather, timings=phases)
 
         for _ in range(max(1, args.warmup)):
             step()
-        phases.update(compute_ms=0.0, exchange_ms=0.0, steps=0)
+        phases.update(compute_ms=0.0, exchange_ms=0.0, exchange_exposed_ms=0.0, steps=0)
         est = estimate(step, lambda: None, 1)
-        phases.update(compute_ms=0.0, exchange_ms=0.0, steps=0)
+        phases.update(compute_ms=0.0, exchange_ms=0.0, exchange_exposed_ms=0.0, steps=0)
         dt, repeats = timed_region(step, lambda: None, args.steps, est)
         frames_per_step = sum(frame_count(FS, n, FRAME_PERIOD) for n in lengths)
         nsteps = args.steps * repeats
@@ -383,10 +384,12 @@ def main():
                            "frames_per_step": frames_per_step, "utterances_per_gpu": len(mine),
                            "parallelism": f"utterance-sharded x{world}" + (
                                ", no collective" if args.no_gather else
-                               f", ONE RCCL all-gather of a packed [frames][{2 + 2 * nb}] f64 block per rank per step "
+                               f", one in-place RCCL all-gather of packed [frames][{2 + 2 * nb}] f64 records per sub-batch, overlapped with the next sub-batch's analysis "
                                f"({frames_per_step * (2 + 2 * nb) * 8 / 1e9:.1f} GB reassembled on every rank)")},
-                "phases": {"compute_ms_per_step_max_over_ranks": float(ph_max[0]), "exchange_ms_per_step_max_over_ranks": float(ph_max[1]),
-                           "note": "host wall clock around the analysis calls (synchronised) and around pack + all-gather"},
+                "phases": {"compute_ms_per_step_max_over_ranks": float(ph_max[0]),
+                           "exchange_exposed_ms_per_step_max_over_ranks": float(ph_max[1]),
+                           "note": "chunk k's all-gather runs while chunk k+1 is analysed; exposed = device time the compute stream "
+                                   "waited for all-gathers after its last analysis (HIP events), compute = the rest of the step"},
                 "parity_in_run": parity, "roofline": roofline, "cpu_baseline": None}))
             if parity is not None and not (parity["every_rank_bit_identical_to_lone_analysis"] and parity["randn_table_intact"]):
                 sys.stderr.write("bench.py: parity_in_run failed: " + json.dumps(parity) + "\n")
@@ -464,6 +467,88 @@ def main():
                        lambda wh, x: wh.analyze(x, fs, f0_method="dio", frame_period=FRAME_PERIOD), lambda o: int(o[4].sum()),
                        BYTES_PER_FRAME_16K)
 
+    def leg_config0():
+        """BASELINE configs[0]: test/vaiueo2d.wav (the samples committed in tests/golden/vaiueo2d_dio.npz) through test.cpp's
+        DIO plumbing -- Dio(f0_floor 40) -> StoneMask -> CheapTrick(q1 -0.15) -> D4C(0.85) -- on HOST pointers: the drop-in
+        symbols of libworld_hip.so beside the unmodified reference on one host core (reference test/test.cpp:89-219)"""
+        from world_amd.api import HostAPI
+        g = np.load(os.path.join(ROOT, "tests", "golden", "vaiueo2d_dio.npz"))
+        xw, fsw, fftw = g["q"].astype(np.float64) / 32768.0, int(g["fs"]), int(g["fft_size"])
+
+        def job(api):
+            tp, f0 = api.dio(xw, fsw, f0_floor=float(g["f0_floor_est"]), frame_period=float(g["frame_period"]))
+            f0 = api.stonemask(xw, fsw, tp, f0)
+            sp = api.cheaptrick(xw, fsw, tp, f0, q1=float(g["q1"]), f0_floor=71.0, fft_size=fftw)
+            ap = api.d4c(xw, fsw, tp, f0, fftw, threshold=float(g["threshold"]))
+            return tp, f0, sp, ap
+        H = HostAPI()
+        job(H)
+        reps = 20
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            tp, f0, sp, ap = job(H)
+        ms = (time.perf_counter() - t1) / reps * 1e3
+        leg = {"workload": "configs[0]: test/vaiueo2d.wav (22.05 kHz, 17 500 samples, 159 frames), Dio + StoneMask + CheapTrick + D4C "
+                           "as test/test.cpp calls them, host pointers in and out (PCIe and one synchronisation per stage included)",
+               "frames_per_step": int(len(f0)), "ms_per_utterance": ms, "value": len(f0) / (ms * 1e-3), "unit": "frames/s",
+               "golden": {"f0": rel_err(f0[g["f0"] > 0], g["f0"][g["f0"] > 0]), "vuv_flips": int(np.sum((f0 > 0) != (g["f0"] > 0))),
+                          "sp": rel_err(sp[g["rows"]], g["sp_rows"]), "ap": rel_err(ap[g["rows"]], g["ap_rows"]), "tolerance": RTOL}}
+        if not args.no_cpu_baseline:
+            from oracle.loader import PortOracle, RefOracle, ref_available
+            o = RefOracle() if ref_available() else PortOracle()
+            job(o)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                job(o)
+            ms_ref = (time.perf_counter() - t1) / 3 * 1e3
+            leg["cpu_reference"] = {"kind": o.kind, "cores": 1, "ms_per_utterance": ms_ref, "frames_per_s": len(f0) / (ms_ref * 1e-3)}
+        return leg
+
+    def leg_config3_full():
+        """BASELINE configs[3] as ONE job on ONE GPU: 1024 x (48 kHz, 5 s) utterances through world_amd.distributed.analyze_sharded
+        -- the code path of `--gpus N`, with a world of one: the N = 1 anchor of the strong-scaling curve."""
+        n_job, sec = args.job_utterances, 5.0
+        lengths = [int(round(FS * sec))] * n_job
+        xs_job = {i: synth.utterance(i, FS, sec, device=dev) for i in range(n_job)}
+        whj = WorldHip(device=local)
+        phases = {}
+
+        def step():
+            return wd.analyze_sharded(xs_job, FS, lengths=lengths, analyze_packed=whj.analyze_packed, sub_batch=args.sub_batch,
+                                      timings=phases)
+        res = step()
+        phases.clear()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        steps = 0
+        while steps < 2 or time.perf_counter() - t1 < args.min_wall:
+            res = step()
+            steps += 1
+        torch.cuda.synchronize()
+        dtj = time.perf_counter() - t1
+        frames = sum(res.n_frames)
+        # the job checks itself: three utterances against lone analyses (bit-identical: batched == single)
+        same = True
+        for i in (0, n_job // 2 + 1, n_job - 1):
+            tp1, f01, sp1, ap1, nf1 = whj.analyze(xs_job[i].unsqueeze(0), FS)
+            tp, f0, sp, ap = res.utterance(i)
+            k = int(nf1[0])
+            same = same and tp.shape[0] == k and torch.equal(tp, tp1[0, :k]) and torch.equal(f0, f01[0, :k]) and \
+                torch.equal(sp, sp1[0, :k]) and torch.equal(ap, ap1[0, :k])
+        leg = {"workload": f"configs[3] full job on one GPU: {n_job} x (48 kHz, {sec:g} s), Harvest+CheapTrick+D4C, sub-batches of "
+                           f"{args.sub_batch} written straight into packed [frames][2052] records (no pack pass, no collective)",
+               "value": frames * steps / dtj, "unit": "frames/s", "frames_per_step": frames, "steps": steps,
+               "ms_per_step": dtj / steps * 1e3, "timed_wall_s": dtj,
+               "phases": {"compute_ms_per_step": phases.get("compute_ms", 0.0) / max(1, phases.get("steps", 1)),
+                          "exchange_exposed_ms_per_step": phases.get("exchange_exposed_ms", 0.0) / max(1, phases.get("steps", 1))},
+               "utterances_bit_identical_to_lone_analysis": bool(same),
+               "result_bytes": frames * (2 + 2 * (FFT_SIZE // 2 + 1)) * 8, "workspace_bytes": whj.workspace_bytes()}
+        whj.close()
+        wd._buffers.clear()
+        del xs_job, res
+        torch.cuda.empty_cache()
+        return leg
+
     if args.only_config:
         leg = {2: leg_config2, 3: leg_config3, 4: leg_config4}[args.only_config]()
         print(json.dumps(leg))
@@ -471,16 +556,24 @@ def main():
 
     # ---- the headline leg: configs[1] ---------------------------------------------------------------------
     B = args.batch
-    xs = [synth.vowel(FS, args.seconds, seed=12345, device=dev) if i == 0
-          else synth.utterance(i, FS, args.seconds, device=dev) for i in range(B)]
-    x = torch.stack(xs).contiguous()
+    S = max(1, args.streams)
+
+    def slot_input(k):
+        """slot k's own job: slot 0 analyses SURVEY.md 8d's configs[1] vowel (seed 12345, 140 Hz: the utterance the CPU
+        reference is timed and checked on), every other slot the same kind of vowel with its own seed and pitch -- twelve
+        different WAVs in flight, not one tensor read twelve times (shared L2 / Infinity-Cache lines, identical windows)"""
+        xs_k = [synth.vowel(FS, args.seconds, seed=12345 + 977 * k + i, base_f0=140.0 + 7.0 * ((5 * k + i) % 12), device=dev)
+                for i in range(B)]
+        return xs_k
+    xs = slot_input(0)
+    x_slots = [torch.stack(slot_input(k)).contiguous() for k in range(S)]
+    x = x_slots[0]
     n = x.shape[1]
     nf = frame_count(FS, n, FRAME_PERIOD)
     # Steps are independent analysis jobs.  `--streams S` keeps S of them in flight: job k
     # runs on HIP stream k % S with its own library context (workspace) and output buffers,
     # so one job's short serial kernels (contour logic, decimation) overlap another job's
     # wide ones.  Every job still does the full work; nothing is cached between steps.
-    S = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     whs = [WorldHip(device=local) for _ in range(S)]
     wh = whs[0]
@@ -493,7 +586,7 @@ def main():
         k = counter[0] % S
         counter[0] += 1
         with torch.cuda.stream(streams[k]):
-            last[k] = whs[k].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k], ap_out=ap_bufs[k])
+            last[k] = whs[k].analyze(x_slots[k], FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[k], ap_out=ap_bufs[k])
 
     # one-time initialisation of every slot (workspace allocation, constant tables): not a step
     for _ in range(S):
@@ -511,14 +604,16 @@ def main():
     torch.cuda.synchronize()
     sp_ser, ap_ser = torch.empty_like(sp_bufs[0]), torch.empty_like(sp_bufs[0])
     ser = WorldHip(device=local)
-    tpos_ser, f0_ser, _, _, _ = ser.analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_ser, ap_out=ap_ser)
-    torch.cuda.synchronize()
-    slots_equal = all(last[k] is not None and torch.equal(last[k][0], tpos_ser) and torch.equal(last[k][1], f0_ser) and
-                      torch.equal(sp_bufs[k], sp_ser) and torch.equal(ap_bufs[k], ap_ser) for k in range(S))
+    slots_equal = True
+    for k in range(S - 1, -1, -1):                       # every slot's own utterance, serially, on one fresh context; slot 0 last
+        tpos_ser, f0_ser, _, _, _ = ser.analyze(x_slots[k], FS, frame_period=FRAME_PERIOD, sp_out=sp_ser, ap_out=ap_ser)
+        torch.cuda.synchronize()
+        slots_equal = slots_equal and last[k] is not None and torch.equal(last[k][0], tpos_ser) and \
+            torch.equal(last[k][1], f0_ser) and torch.equal(sp_bufs[k], sp_ser) and torch.equal(ap_bufs[k], ap_ser)
     tables_ok = ser.verify_tables()
     ser.close()
-    parity = {"slots": S, "slots_bit_identical_to_serial_run": bool(slots_equal), "randn_table_intact": bool(tables_ok),
-              "frames": nf * B}
+    parity = {"slots": S, "distinct_utterances": S, "slots_bit_identical_to_serial_run": bool(slots_equal),
+              "randn_table_intact": bool(tables_ok), "frames": nf * B}
 
     # latency of ONE job with nothing else in flight (not the headline number)
     def lone_job():
@@ -614,7 +709,8 @@ def main():
             w.close()
         del sp_bufs, ap_bufs, last
         torch.cuda.empty_cache()
-        configs = {"2": leg_config2(), "3_share": leg_config3(), "4": leg_config4()}
+        configs = {"0": leg_config0(), "2": leg_config2(), "3_share": leg_config3(), "3_full": leg_config3_full(),
+                   "4": leg_config4()}
     else:
         f0_k, sp_k, ap_k = f0_ser[0].cpu().numpy(), sp_ser[0].cpu().numpy(), ap_ser[0].cpu().numpy()
         tp_k = tpos_ser[0].cpu().numpy()
@@ -647,7 +743,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"configs[1]: {B} x (48 kHz, {args.seconds:g} s) utterance(s) per step, "
                                f"Harvest+CheapTrick+D4C, fft_size=2048, frame_period=5 ms, inputs/outputs in HBM, "
-                               f"{S} independent jobs in flight (one HIP stream + context each)",
+                               f"{S} independent jobs in flight (one HIP stream + context each, a different utterance per job)",
                    "frames_per_step": frames_per_step, "utterances_per_gpu": B, "jobs_in_flight": S,
                    "parallelism": "single GPU, no collective"},
         "value_single_job": frames_per_step / (lat * 1e-3), "single_job_latency_ms": lat,

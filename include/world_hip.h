@@ -233,6 +233,15 @@ WORLD_HIP_API int world_hip_probe_irfft(WorldHipContext *ctx, int lg_n, int max_
  * destination is valid, and the sources reusable, in the respective context's stream order).
  * With one process PER GPU (torch.distributed / RCCL) the same blocks go through one all-gather:
  * world_amd/distributed.py. */
+/* Harvest + CheapTrick + D4C of one batch written STRAIGHT into packed records: utterance u's frames occupy rows
+ * first_row + sum_{v<u} n_frames[v] ... of d_block ([rows][cols] doubles, cols = 2 + 2 (fft_size/2 + 1) =
+ * [tpos, f0, sp row, ap row]); n_frames[u] = GetSamplesForHarvest(fs, x_length[u], frame_period).  The stage kernels
+ * store their rows at the records' stride, so no pack pass runs (world_hip_pack_results is for results that already
+ * exist in the dense layout).  Same stream semantics as the *_batch calls. */
+WORLD_HIP_API int world_hip_analyze_packed(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
+                                           const int *x_length, const HarvestOption *harvest_option,
+                                           const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
+                                           long long first_row, double *d_block, int cols);
 WORLD_HIP_API int world_hip_pack_results(WorldHipContext *ctx, int n_utt, const int *n_frames, int f_stride,
                                          int bins, const double *d_tpos, const double *d_f0,
                                          const double *d_spectrogram, const double *d_aperiodicity,
@@ -242,6 +251,19 @@ WORLD_HIP_API int world_hip_unpack_results(WorldHipContext *ctx, int n_utt, cons
                                            double *d_f0, double *d_spectrogram, double *d_aperiodicity);
 WORLD_HIP_API int world_hip_allgather_blocks(int n_dev, WorldHipContext *const *ctxs, const double *const *d_src,
                                              const long long *rows, int cols, double *const *d_dst);
+
+/* ONE process driving n_dev GPUs (one context each; host side in C/C++, no torch, no RCCL): Harvest + CheapTrick + D4C of
+ * a whole job of utterances in HOST memory, sharded longest-first over the devices.  One host thread per device uploads
+ * its share in sub-batches of `sub_batch` utterances and analyses each straight into packed records; every other device
+ * pulls a finished sub-batch's rows over xGMI (peer copies on its own exchange stream) while the next one is analysed.
+ * d_blocks[d]: device d's buffer of rows_capacity x cols doubles, cols = 2 + 2 (fft_size/2 + 1); on return every device
+ * holds ALL records at the same rows, where[3 i .. 3 i + 2] = {device index that analysed utterance i, its first row,
+ * its frame count}.  Blocking (the inputs are host memory); 0 on success, else world_hip_last_error(). */
+WORLD_HIP_API int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *ctxs, int n_utt, int fs,
+                                            const double *const *x, const int *x_length,
+                                            const HarvestOption *harvest_option, const CheapTrickOption *cheaptrick_option,
+                                            const D4COption *d4c_option, int sub_batch, double *const *d_blocks,
+                                            long long rows_capacity, int cols, long long *where);
 
 WORLD_HIP_API int world_hip_set_synthesis_pulse_capacity(WorldHipContext *ctx, int pulses_per_utterance);
 WORLD_HIP_API int world_hip_synthesis_pulses_dropped(WorldHipContext *ctx, int *needed);

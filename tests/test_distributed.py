@@ -35,11 +35,19 @@ def _worker(rank, world, port, tmp):
             return (torch.arange(6 * 4, dtype=torch.float64).reshape(6, 4) + 1000.0 * i)
         local = torch.stack([fake(i) for i in mine]) if mine else torch.zeros((0, 6, 4), dtype=torch.float64)
         f0_local = torch.stack([fake(i)[:, 0] for i in mine]) if mine else torch.zeros((0, 6), dtype=torch.float64)
-        (g_sp, g_f0), works = wd.all_gather_results([wd.pad_shard(local, rows), wd.pad_shard(f0_local, rows)],
-                                                   async_op=True)
+        def pad(t):                                   # ranks may own different numbers of utterances
+            return torch.cat([t, torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)], 0)
+
+        def assemble(g):                              # undo partition(): [world, rows, ...] -> utterance order
+            out = torch.empty((len(lengths),) + tuple(g.shape[2:]), dtype=g.dtype)
+            for r, idx in enumerate(parts):
+                for j, i in enumerate(idx):
+                    out[i] = g[r, j]
+            return out
+        (g_sp, g_f0), works = wd.all_gather_results([pad(local), pad(f0_local)], async_op=True)
         wd.wait_all(works)
-        full = wd.assemble(g_sp, parts, len(lengths))
-        full_f0 = wd.assemble(g_f0, parts, len(lengths))
+        full = assemble(g_sp)
+        full_f0 = assemble(g_f0)
         for i in range(len(lengths)):
             assert torch.equal(full[i], fake(i))
             assert torch.equal(full_f0[i], fake(i)[:, 0])

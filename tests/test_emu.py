@@ -163,3 +163,42 @@ def test_emulated_fft_matches_numpy():
                 assert np.abs(y / n - x).max() < 1e-13
     finally:
         L.world_hip_destroy(ctx)
+
+
+def test_emulated_c_driver_shards_a_job_over_two_contexts(emu):
+    """world_hip_analyze_sharded (the C/C++ host side of SURVEY.md 8e: one host thread per device, sub-batches analysed
+    straight into packed records, every finished sub-batch copied to the other devices) with two contexts of the
+    host-compiled library: every utterance's records, in BOTH blocks, bit-identical to a lone analysis"""
+    import ctypes as C
+    from world_amd import synth
+    from world_amd.api import analyze_sharded_c, cheaptrick_fft_size, load_library
+    L = load_library(os.path.join(EMU_DIR, "libworld_emu.so"))
+    fs = 16000
+    lengths = [4000, 2600, 3300, 1800]
+    xs = [synth.utterance(i, fs, n / fs).numpy() for i, n in enumerate(lengths)]
+    fft = cheaptrick_fft_size(fs)
+    nb = fft // 2 + 1
+    ctxs = [L.world_hip_create(0, None) for _ in range(2)]
+    try:
+        rows = sum(emu.frame_count(fs, n, 5.0) for n in lengths)
+        blocks = [np.full((rows + 3, 2 + 2 * nb), np.nan) for _ in ctxs]
+        where = analyze_sharded_c(L, ctxs, xs, fs, [b.ctypes.data for b in blocks], rows + 3, sub_batch=1)
+        assert sorted(set(where[:, 0])) == [0, 1]                       # both contexts got work
+        assert np.array_equal(blocks[0][:rows], blocks[1][:rows])       # the exchange left identical blocks
+        for i, x in enumerate(xs):
+            tp, f0 = emu.harvest(x, fs)
+            sp = emu.cheaptrick(x, fs, tp, f0, fft_size=fft)
+            ap = emu.d4c(x, fs, tp, f0, fft)
+            dev, first, n = (int(v) for v in where[i])
+            rec = blocks[1 - dev][first:first + n]                      # as the OTHER context received it
+            assert n == len(f0)
+            assert np.array_equal(rec[:, 0], tp) and np.array_equal(rec[:, 1], f0)
+            assert np.array_equal(rec[:, 2:2 + nb], sp) and np.array_equal(rec[:, 2 + nb:], ap)
+        # rows are a partition of [0, rows)
+        covered = np.zeros(rows, dtype=int)
+        for dev, first, n in where:
+            covered[first:first + n] += 1
+        assert np.all(covered == 1)
+    finally:
+        for c in ctxs:
+            L.world_hip_destroy(c)

@@ -465,6 +465,72 @@ def test_analyze_sharded_on_one_gpu_equals_per_utterance_calls():
 
 
 @pytest.mark.gpu
+def test_analyze_packed_writes_the_same_bits_as_the_dense_stages():
+    """world_hip_analyze_packed: the stage kernels store their rows at the records' stride (no dense spectrogram, no pack
+    pass) -- every record equals what the dense batched calls produce, ragged utterances, a non-zero first row, and the
+    rows outside the batch's records stay untouched"""
+    import torch
+    from world_amd import synth
+    from world_amd.api import WorldHip, cheaptrick_fft_size
+    fs = 48000
+    lens = [24000, 10100, 17777]
+    x = torch.zeros((3, max(lens)), dtype=torch.float64)
+    for i, n in enumerate(lens):
+        x[i, :n] = synth.utterance(i + 3, fs, max(lens) / fs)[:n]
+    x = x.cuda().contiguous()
+    wh = WorldHip()
+    tp, f0, sp, ap, nf = wh.analyze(x, fs, x_len=lens)
+    nb = cheaptrick_fft_size(fs) // 2 + 1
+    rows = int(sum(int(n) for n in nf))
+    block = torch.full((rows + 9, 2 + 2 * nb), -7.0, dtype=torch.float64, device="cuda")
+    nf2 = wh.analyze_packed(x, fs, block, first_row=4, x_len=lens)
+    torch.cuda.synchronize()
+    assert [int(n) for n in nf] == nf2
+    assert torch.all(block[:4] == -7.0) and torch.all(block[4 + rows:] == -7.0)
+    row = 4
+    for u, n in enumerate(nf2):
+        rec = block[row:row + n]
+        assert torch.equal(rec[:, 0], tp[u, :n]) and torch.equal(rec[:, 1], f0[u, :n])
+        assert torch.equal(rec[:, 2:2 + nb], sp[u, :n]) and torch.equal(rec[:, 2 + nb:], ap[u, :n])
+        row += n
+
+
+@pytest.mark.gpu
+def test_c_driver_shards_a_job_over_two_contexts_of_one_gpu():
+    """world_hip_analyze_sharded (host threads, sub-batches into packed records, peer copies on exchange streams): two
+    contexts on the one GPU -- the peer copies degenerate to device-to-device copies -- both blocks complete and every
+    utterance bit-identical to a lone analysis"""
+    import torch
+    from world_amd import synth
+    from world_amd.api import WorldHip, analyze_sharded_c, cheaptrick_fft_size, frame_count
+    fs = 48000
+    secs = [0.5, 0.21, 0.37, 0.44, 0.3]
+    xs = [synth.utterance(i, fs, d) for i, d in enumerate(secs)]
+    nb = cheaptrick_fft_size(fs) // 2 + 1
+    rows = sum(frame_count(fs, x.numel(), 5.0) for x in xs)
+    a, b = WorldHip(), WorldHip()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    with torch.cuda.stream(streams[0]):
+        ca = a._context()
+    with torch.cuda.stream(streams[1]):
+        cb = b._context()
+    blocks = [torch.full((rows, 2 + 2 * nb), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    where = analyze_sharded_c(a.lib, [ca, cb], [x.numpy() for x in xs], fs, [t.data_ptr() for t in blocks], rows, sub_batch=2)
+    torch.cuda.synchronize()
+    assert sorted(set(int(d) for d in where[:, 0])) == [0, 1]
+    assert torch.equal(blocks[0], blocks[1])
+    wh = WorldHip()
+    for i, x in enumerate(xs):
+        tp_i, f0_i, sp_i, ap_i, nf_i = wh.analyze(x[None].cuda().contiguous(), fs)
+        dev, first, n = (int(v) for v in where[i])
+        assert n == int(nf_i[0])
+        rec = blocks[1 - dev][first:first + n]
+        assert torch.equal(rec[:, 0], tp_i[0, :n]) and torch.equal(rec[:, 1], f0_i[0, :n])
+        assert torch.equal(rec[:, 2:2 + nb], sp_i[0, :n]) and torch.equal(rec[:, 2 + nb:], ap_i[0, :n])
+
+
+@pytest.mark.gpu
 def test_pack_unpack_and_peer_allgather_from_the_c_abi():
     """include/world_hip.h's exchange entries: pack -> world_hip_allgather_blocks (here: two contexts on two
     streams of the one GPU, the peer copies degenerate to device-to-device copies) -> unpack gives back every

@@ -84,6 +84,11 @@ def load_library(path=LIB_PATH):
     lib.world_hip_synthesis_pulses_dropped.argtypes = [vp, _ip]
     lib.world_hip_probe_rfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
     lib.world_hip_probe_irfft.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp]
+    lib.world_hip_analyze_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(HarvestOption),
+                                             C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_longlong, vp, C.c_int]
+    lib.world_hip_analyze_sharded.argtypes = [C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp), _ip,
+                                              C.POINTER(HarvestOption), C.POINTER(CheapTrickOption), C.POINTER(D4COption),
+                                              C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
     lib.world_hip_pack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, vp, vp, vp, C.c_longlong, vp]
     lib.world_hip_unpack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, C.c_longlong, vp, vp, vp, vp]
     lib.world_hip_allgather_blocks.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_longlong), C.c_int,
@@ -522,6 +527,23 @@ class WorldHip:
         return out
 
     # ---- multi-GPU exchange records (include/world_hip.h: world_hip_pack_results) ----
+    def analyze_packed(self, x, fs, block, first_row=0, x_len=None, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
+                       q1=-0.15, threshold=0.85):
+        """Harvest -> CheapTrick -> D4C of one batch written straight into packed records (no dense sp / ap, no pack
+        pass): utterance u's n_frames[u] records start at block[first_row + sum(n_frames[:u])].  Returns n_frames."""
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        fft_size = cheaptrick_fft_size(fs, 71.0)
+        nb = fft_size // 2 + 1
+        nf = [frame_count(fs, int(n), frame_period) for n in xl]
+        assert block.dtype == t.float64 and block.is_contiguous() and block.shape[-1] == 2 + 2 * nb and block.device == x.device
+        assert first_row + sum(nf) <= block.shape[0]
+        hopt, copt, dopt = HarvestOption(f0_floor, f0_ceil, frame_period), CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
+        self._check(self.lib.world_hip_analyze_packed(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
+                                                      C.byref(hopt), C.byref(copt), C.byref(dopt), first_row,
+                                                      block.data_ptr(), 2 + 2 * nb), "analyze_packed")
+        return nf
+
     def pack_results(self, tpos, f0, sp, ap, n_frames, block, first_row=0):
         """valid frames of a batched analysis -> records [tpos, f0, sp row, ap row] in block[first_row:] (device)"""
         t = self.torch
@@ -654,3 +676,28 @@ class WorldHip:
         sp = self.cheaptrick(x, fs, tpos, f0, nf, x_len, q1=q1, fft_size=fft_size, out=sp_out)
         ap = self.d4c(x, fs, tpos, f0, nf, fft_size, x_len, threshold=threshold, out=ap_out)
         return tpos, f0, sp, ap, nf
+
+
+def analyze_sharded_c(lib, ctxs, xs, fs, block_ptrs, rows_capacity, sub_batch=32, frame_period=5.0, f0_floor=71.0,
+                      f0_ceil=800.0, q1=-0.15, threshold=0.85):
+    """world_hip_analyze_sharded (include/world_hip.h): ONE process, several contexts (normally one per GPU), the job's
+    utterances as host arrays.  ctxs: library contexts; xs: list of 1-D float64 numpy arrays; block_ptrs: one device
+    pointer per context to rows_capacity x (2 + 2 (fft/2+1)) doubles.  Returns where [n_utt, 3] = (context index, first
+    row, n_frames): every block then holds ALL records at those rows."""
+    n = len(xs)
+    fft_size = cheaptrick_fft_size(fs, 71.0)
+    cols = 2 + 2 * (fft_size // 2 + 1)
+    xs = [np.ascontiguousarray(x, dtype=np.float64) for x in xs]
+    vp = C.c_void_p
+    xp = (vp * max(1, n))(*[x.ctypes.data for x in xs])
+    xl = np.ascontiguousarray([len(x) for x in xs], dtype=np.int32)
+    cp = (vp * len(ctxs))(*ctxs)
+    bp = (vp * len(ctxs))(*block_ptrs)
+    where = np.zeros((max(1, n), 3), dtype=np.int64)
+    hopt, copt, dopt = HarvestOption(f0_floor, f0_ceil, frame_period), CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
+    rc = lib.world_hip_analyze_sharded(len(ctxs), cp, n, fs, xp, xl.ctypes.data_as(_ip), C.byref(hopt), C.byref(copt),
+                                       C.byref(dopt), sub_batch, bp, rows_capacity, cols,
+                                       where.ctypes.data_as(C.POINTER(C.c_longlong)))
+    if rc != 0:
+        raise RuntimeError("analyze_sharded: " + lib.world_hip_last_error().decode())
+    return where[:n]

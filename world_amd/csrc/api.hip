@@ -14,6 +14,7 @@
 #include <cstring>
 #include <cstdarg>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -96,6 +97,12 @@ struct WorldHipContext {
   size_t stage_cap = 0, stage_used = 0;
   int stage_cur = 0;
   void *xchg_ready = nullptr, *xchg_done = nullptr;   // events of world_hip_allgather_blocks
+  double *d_pk = nullptr;        // dense (tpos, f0) of world_hip_analyze_packed: [2][n_utt][f_stride], grow-only
+  size_t pk_cap = 0;
+  // world_hip_analyze_sharded: this device's exchange stream, input staging (two pinned halves) and device input, grow-only
+  hipStream_t xstream = nullptr;
+  double *h_xin = nullptr, *d_xin = nullptr;
+  size_t xin_cap = 0;            // doubles per half
   std::mutex lock;               // one call at a time per context
 };
 
@@ -172,12 +179,22 @@ static void check_batch(int n_utt, int fs, const void *d_x, int x_stride, const 
     if (x_length[u] <= 0 || x_length[u] > x_stride) fail("x_length[%d]=%d outside (0, x_stride=%d]", u, x_length[u], x_stride);
 }
 
+// Where a per-frame stage writes its rows: the dense [n_utt][f_stride][bins] array of the batched API (rows == nullptr),
+// or rows of packed records -- frame f of utterance u at row rows[u] + f, `stride` doubles apart (exchange.hip's layout,
+// written by the stage kernels themselves instead of a pack pass over 2 x 16 KB per frame).
+struct RowLayout {
+  const int *rows = nullptr;     // host, [n_utt]
+  size_t stride = 0;             // 0: bins
+  double *rec = nullptr;         // D4C only: records' base for the (tpos, f0) head of every record
+};
+
 // ---------------------------------------------------------------------------
 // CheapTrick
 // ---------------------------------------------------------------------------
 static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride,
                            const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
-                           const double *d_f0, const CheapTrickOption *opt, double *d_sp, bool own_arena) {
+                           const double *d_f0, const CheapTrickOption *opt, double *d_sp, bool own_arena,
+                           const RowLayout &lay = RowLayout()) {
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   const int lg = ilog2_exact(opt->fft_size);
   if (lg < 7 || lg > 12) fail("CheapTrick fft_size %d unsupported (128..4096: one frame must fit LDS)", opt->fft_size);
@@ -187,15 +204,17 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
     max_frames = std::max(max_frames, n_frames[u]);
   }
   const int seg_stride = ct_seg_stride(opt->fft_size);
-  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 3 * pad256(sizeof(int) * n_utt) +
+  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 4 * pad256(sizeof(int) * n_utt) +
                 pad256(sizeof(double) * (size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * seg_stride);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
-  CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
+  CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
   CtParams p;
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, std::vector<int>(x_length, x_length + n_utt));
   p.b.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
   p.tpos = d_tpos; p.f0 = d_f0; p.spectrogram = d_sp;
+  p.out_row = lay.rows ? upload(c, std::vector<int>(lay.rows, lay.rows + n_utt)) : nullptr;
+  p.out_stride = lay.stride ? lay.stride : (size_t)(opt->fft_size / 2 + 1);
   p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
   p.seg = c->arena.take<double>((size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * seg_stride);
   p.seg_stride = seg_stride;
@@ -212,7 +231,7 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
 // ---------------------------------------------------------------------------
 static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
                     const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0, int fft_size,
-                    const D4COption *opt, double *d_ap, bool own_arena) {
+                    const D4COption *opt, double *d_ap, bool own_arena, const RowLayout &lay = RowLayout()) {
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   ilog2_exact(fft_size);
   int max_frames = 0;
@@ -242,15 +261,18 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     c->nuttall_len = wl;
   }
   size_t fr = (size_t)n_utt * f_stride;
-  size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 4 * pad256(sizeof(int) * n_utt) +
+  size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 5 * pad256(sizeof(int) * n_utt) +
                 pad256(sizeof(double) * fr * 16);
   if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
-  CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
+  CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
   D4cParams p;
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, std::vector<int>(x_length, x_length + n_utt));
   p.b.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
   p.tpos = d_tpos; p.f0 = d_f0; p.aperiodicity = d_ap;
+  p.out_row = lay.rows ? upload(c, std::vector<int>(lay.rows, lay.rows + n_utt)) : nullptr;
+  p.out_stride = lay.stride ? lay.stride : (size_t)(fft_size / 2 + 1);
+  p.rec = lay.rec;
   p.ap0 = c->arena.take<double>(fr);
   p.offsets1 = c->arena.take<unsigned>(fr);
   p.offsets2 = c->arena.take<unsigned>(fr);
@@ -879,6 +901,44 @@ static void run_pack(WorldHipContext *c, bool unpack, int n_utt, const int *n_fr
 }
 
 // ---------------------------------------------------------------------------
+// Harvest + CheapTrick + D4C of one batch straight into packed records (include/world_hip.h: world_hip_analyze_packed)
+// ---------------------------------------------------------------------------
+static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                               const HarvestOption *hopt, const CheapTrickOption *copt, const D4COption *dopt,
+                               long long first_row, double *d_block, int cols) {
+  check_batch(n_utt, fs, d_x, x_stride, x_length);
+  const int nb = copt->fft_size / 2 + 1;
+  if (cols != 2 + 2 * nb) fail("analyze_packed: %d columns, fft_size %d needs %d", cols, copt->fft_size, 2 + 2 * nb);
+  if (!d_block) fail("analyze_packed: null block");
+  std::vector<int> nf(n_utt), rows(n_utt);
+  long long row = first_row;
+  int f_stride = 1;
+  for (int u = 0; u < n_utt; ++u) {
+    nf[u] = frame_count(fs, x_length[u], hopt->frame_period);
+    if (row + nf[u] > 0x7FFFFFFFll) fail("block exceeds 2^31 records");
+    rows[u] = static_cast<int>(row);
+    row += nf[u];
+    f_stride = std::max(f_stride, nf[u]);
+  }
+  // the time axis and F0 stay dense ([n_utt][f_stride]: what CheapTrick and D4C read); they outlive the stages' arenas
+  const size_t fr = (size_t)n_utt * f_stride;
+  if (c->pk_cap < 2 * fr) {
+    devrt::sync(c->stream);
+    if (c->d_pk) devrt::dfree(c->d_pk);
+    c->pk_cap = 2 * fr + fr / 4;
+    c->d_pk = static_cast<double *>(devrt::dmalloc(sizeof(double) * c->pk_cap));
+  }
+  double *d_tpos = c->d_pk, *d_f0 = c->d_pk + fr;
+  run_harvest(c, n_utt, fs, d_x, x_stride, x_length, hopt, f_stride, d_tpos, d_f0);
+  RowLayout lay;
+  lay.rows = rows.data(); lay.stride = (size_t)cols;
+  run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, d_block + 2, true, lay);
+  lay.rec = d_block;
+  run_d4c(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt->fft_size, dopt, d_block + 2 + nb, true,
+          lay);
+}
+
+// ---------------------------------------------------------------------------
 // error plumbing for the C ABI
 // ---------------------------------------------------------------------------
 // A context's allocations and launches belong to ITS device: a thread that drives several GPUs calls in
@@ -946,13 +1006,20 @@ WorldHipContext *world_hip_create(int device, void *stream) {
 
 void world_hip_destroy(WorldHipContext *c) {
   if (!c) return;
+  // the device's shared randn table is reference counted: give the reference back whatever happens below
+  try { DeviceScope on_device(c->device); devrt::sync(c->stream); } catch (...) {}
+  try { DeviceScope on_device(c->device); noise_table_release(c->device); } catch (...) {}
   try {
+    DeviceScope on_device(c->device);    // the context's allocations belong to ITS device, not to the caller's current one
     devrt::sync(c->stream);
     devrt::dfree(const_cast<double2 *>(c->tab.tw));
     devrt::dfree(const_cast<uint4 *>(c->tab.jump));
     if (c->arena.base) devrt::dfree(c->arena.base);
     if (c->d_nuttall) devrt::dfree(c->d_nuttall);
-    noise_table_release(c->device);
+    if (c->d_pk) devrt::dfree(c->d_pk);
+    if (c->d_xin) devrt::dfree(c->d_xin);
+    if (c->h_xin) devrt::hfree_pinned(c->h_xin);
+    if (c->xstream) { devrt::sync(c->xstream); devrt::stream_destroy(c->xstream); }
     if (c->dio_bands) {
       DioBands *db = static_cast<DioBands *>(c->dio_bands);
       if (db->d_band_f0) {
@@ -1092,6 +1159,15 @@ int world_hip_d4c_batch(WorldHipContext *c, int n_utt, int fs, const double *d_x
   });
 }
 
+int world_hip_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                             const HarvestOption *harvest_option, const CheapTrickOption *cheaptrick_option,
+                             const D4COption *d4c_option, long long first_row, double *d_block, int cols) {
+  return guarded(c, [&] {
+    run_analyze_packed(c, n_utt, fs, d_x, x_stride, x_length, harvest_option, cheaptrick_option, d4c_option, first_row,
+                       d_block, cols);
+  });
+}
+
 int world_hip_synthesis_batch(WorldHipContext *c, int n_utt, int fs, double frame_period, int fft_size,
                               const int *n_frames, int f_stride, const double *d_f0, const double *d_spectrogram,
                               const double *d_aperiodicity, const int *y_length, int y_stride, double *d_y) {
@@ -1185,6 +1261,156 @@ int world_hip_allgather_blocks(int n_dev, WorldHipContext *const *ctxs, const do
       for (int d = 0; d < n_dev; ++d)
         if (d != s) devrt::stream_wait_event(ctxs[s]->stream, ctxs[d]->xchg_done);
     }
+    return 0;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return 1;
+  }
+}
+
+// One PROCESS, n_dev GPUs ("one host thread + stream per GPU"): the C/C++ counterpart of
+// world_amd/distributed.py.  Utterances (host memory) are partitioned longest-first over the contexts' devices; a host
+// thread per device uploads its share in sub-batches (pinned double buffer), analyses each straight into packed records
+// (world_hip_analyze_packed) at the sub-batch's rows of ITS copy of the job's one record block, and as soon as a
+// sub-batch is enqueued every other device pulls those rows over xGMI on its own exchange stream (peer copies by the
+// copy engines) -- the exchange of sub-batch k runs under the analysis of sub-batch k + 1.  Every device ends up with
+// ALL records at identical offsets.  where[3 i .. 3 i + 2] = {device index, first row, n_frames} of utterance i.
+// Returns when every device's block is complete (the streams are synchronised: the inputs are host memory anyway).
+int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *ctxs, int n_utt, int fs, const double *const *x,
+                              const int *x_length, const HarvestOption *hopt, const CheapTrickOption *copt,
+                              const D4COption *dopt, int sub_batch, double *const *d_blocks, long long rows_capacity, int cols,
+                              long long *where) {
+  try {
+    if (n_dev <= 0 || !ctxs || n_utt < 0 || !x_length || !hopt || !copt || !dopt || !d_blocks || !where) fail("bad arguments");
+    if (n_utt > 0 && !x) fail("null input");
+    if (cols != 2 + 2 * (copt->fft_size / 2 + 1)) fail("analyze_sharded: %d columns do not fit fft_size %d", cols, copt->fft_size);
+    for (int d = 0; d < n_dev; ++d) {
+      if (!ctxs[d] || !d_blocks[d]) fail("bad device entry %d", d);
+      for (int e = 0; e < d; ++e) {
+        if (ctxs[e] == ctxs[d]) fail("context %d listed twice", d);
+        if (d_blocks[e] == d_blocks[d]) fail("devices %d and %d share a block", e, d);
+      }
+    }
+    const int sb = std::max(1, sub_batch);
+    // greedy longest-first partition (world_amd/distributed.py: partition), utterances of a device in index order
+    std::vector<int> order(n_utt);
+    for (int i = 0; i < n_utt; ++i) {
+      if (x_length[i] <= 0 || !x[i]) fail("utterance %d is empty", i);
+      order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return x_length[a] > x_length[b]; });
+    std::vector<std::vector<int>> part(n_dev);
+    std::vector<long long> load(n_dev, 0);
+    for (int i : order) {
+      int r = 0;
+      for (int d = 1; d < n_dev; ++d) if (load[d] < load[r]) r = d;
+      part[r].push_back(i);
+      load[r] += x_length[i];
+    }
+    // rows: device after device, sub-batch after sub-batch, utterance after utterance
+    struct Chunk { int dev, lo, hi; long long first, rows; int max_len; };
+    std::vector<Chunk> chunks;
+    long long row = 0;
+    for (int r = 0; r < n_dev; ++r) {
+      std::sort(part[r].begin(), part[r].end());
+      for (size_t lo = 0; lo < part[r].size(); lo += sb) {
+        Chunk c{r, (int)lo, (int)std::min(part[r].size(), lo + sb), row, 0, 0};
+        for (int j = c.lo; j < c.hi; ++j) {
+          const int i = part[r][j], nf = frame_count(fs, x_length[i], hopt->frame_period);
+          where[3 * i] = r; where[3 * i + 1] = row; where[3 * i + 2] = nf;
+          row += nf;
+          c.max_len = std::max(c.max_len, x_length[i]);
+        }
+        c.rows = row - c.first;
+        chunks.push_back(c);
+      }
+    }
+    if (row > rows_capacity) fail("analyze_sharded: the job has %lld records, the blocks hold %lld", row, rows_capacity);
+    if (n_utt == 0) return 0;
+    std::vector<std::unique_lock<std::mutex>> locks;
+    {                                                       // a fixed global order keeps concurrent callers deadlock-free
+      std::vector<WorldHipContext *> ord(ctxs, ctxs + n_dev);
+      std::sort(ord.begin(), ord.end());
+      for (WorldHipContext *c : ord) locks.emplace_back(c->lock);
+    }
+    // per-device set-up on the calling thread: exchange stream, peer access, one event per sub-batch
+    std::vector<void *> done(chunks.size(), nullptr);
+    for (int d = 0; d < n_dev; ++d) {
+      WorldHipContext *c = ctxs[d];
+      DeviceScope on_device(c->device);
+      if (!c->xstream) c->xstream = devrt::stream_create();
+      for (int e = 0; e < n_dev; ++e) devrt::enable_peer_access(c->device, ctxs[e]->device);
+    }
+    for (size_t k = 0; k < chunks.size(); ++k) {
+      DeviceScope on_device(ctxs[chunks[k].dev]->device);
+      done[k] = devrt::event_create();
+    }
+    std::vector<std::string> errors(n_dev);
+    std::mutex xlock;                                       // enqueues on another device's exchange stream, one thread at a time
+    auto worker = [&](int r) {
+      WorldHipContext *c = ctxs[r];
+      try {
+        devrt::set_device(c->device);
+        size_t need = 0;
+        for (const Chunk &ch : chunks) if (ch.dev == r) need = std::max(need, (size_t)(ch.hi - ch.lo) * ch.max_len);
+        if (need > c->xin_cap) {
+          devrt::sync(c->stream);
+          if (c->d_xin) devrt::dfree(c->d_xin);
+          if (c->h_xin) devrt::hfree_pinned(c->h_xin);
+          c->xin_cap = need + need / 8;
+          c->d_xin = static_cast<double *>(devrt::dmalloc(sizeof(double) * 2 * c->xin_cap));
+          c->h_xin = static_cast<double *>(devrt::hmalloc_pinned(sizeof(double) * 2 * c->xin_cap));
+        }
+        void *staged[2] = {devrt::event_create(), devrt::event_create()};   // half h of the staging buffers is free again
+        int turn = 0;
+        for (size_t k = 0; k < chunks.size(); ++k) {
+          const Chunk &ch = chunks[k];
+          if (ch.dev != r) continue;
+          const int b = ch.hi - ch.lo, half = turn & 1;
+          if (turn >= 2) devrt::event_sync(staged[half]);  // the analysis that read this half two sub-batches ago is done
+          double *h = c->h_xin + (size_t)half * c->xin_cap, *dx = c->d_xin + (size_t)half * c->xin_cap;
+          std::vector<int> xl(b);
+          for (int j = 0; j < b; ++j) {
+            const int i = part[r][ch.lo + j];
+            xl[j] = x_length[i];
+            memcpy(h + (size_t)j * ch.max_len, x[i], sizeof(double) * x_length[i]);
+            if (x_length[i] < ch.max_len) memset(h + (size_t)j * ch.max_len + x_length[i], 0, sizeof(double) * (ch.max_len - x_length[i]));
+          }
+          devrt::h2d(dx, h, sizeof(double) * (size_t)b * ch.max_len, c->stream);
+          run_analyze_packed(c, b, fs, dx, ch.max_len, xl.data(), hopt, copt, dopt, ch.first, d_blocks[r], cols);
+          devrt::event_record(staged[half], c->stream);
+          devrt::event_record(done[k], c->stream);
+          ++turn;
+          // every other device pulls this sub-batch's rows on its exchange stream, the neighbour first
+          std::lock_guard<std::mutex> g(xlock);
+          for (int s = 1; s < n_dev; ++s) {
+            const int d = (r + s) % n_dev;
+            DeviceScope on_dst(ctxs[d]->device);
+            devrt::stream_wait_event(ctxs[d]->xstream, done[k]);
+            devrt::peer_copy(d_blocks[d] + ch.first * cols, ctxs[d]->device, d_blocks[r] + ch.first * cols, c->device,
+                             sizeof(double) * (size_t)ch.rows * cols, ctxs[d]->xstream);
+          }
+        }
+        devrt::sync(c->stream);
+        devrt::event_destroy(staged[0]); devrt::event_destroy(staged[1]);
+      } catch (const std::exception &e) {
+        errors[r] = e.what();
+      }
+    };
+    std::vector<std::thread> threads;
+    for (int r = 1; r < n_dev; ++r) threads.emplace_back(worker, r);
+    const int before = devrt::current_device();
+    worker(0);                                              // the calling thread drives device 0
+    for (std::thread &t : threads) t.join();
+    for (int d = 0; d < n_dev; ++d) {
+      try { devrt::set_device(ctxs[d]->device); devrt::sync(ctxs[d]->xstream); } catch (const std::exception &e) { if (errors[d].empty()) errors[d] = e.what(); }
+    }
+    for (size_t k = 0; k < chunks.size(); ++k) {
+      try { devrt::set_device(ctxs[chunks[k].dev]->device); devrt::event_destroy(done[k]); } catch (...) {}
+    }
+    try { devrt::set_device(before); } catch (...) {}
+    for (int d = 0; d < n_dev; ++d)
+      if (!errors[d].empty()) fail("device %d: %s", d, errors[d].c_str());
     return 0;
   } catch (const std::exception &e) {
     g_last_error = e.what();

@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256, 4) ct_envelope(CtParams p) {
   WH_STAMP(0, 8);
   block_irfft<kCtMaxLr, LGN>(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   WH_STAMP(0, 9);
-  double *out = p.spectrogram + fi * nb;
+  double *out = p.spectrogram + (p.out_row ? (size_t)p.out_row[u] + f : fi) * p.out_stride;
   block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = v; });
   WH_STAMP(0, 10);
 }

@@ -747,8 +747,10 @@ __global__ void d4c_finish(D4cParams p) {
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const int tid = threadIdx.x, nt = blockDim.x, fs = p.b.fs;
   const int nb_out = p.fft_out / 2 + 1;
-  double *row = p.aperiodicity + fi * nb_out;
+  const size_t orow = p.out_row ? (size_t)p.out_row[u] + f : fi;
+  double *row = p.aperiodicity + orow * p.out_stride;
   const double f0 = p.f0[fi];
+  if (p.rec && tid == 0) { double *r = p.rec + orow * p.out_stride; r[0] = p.tpos[fi]; r[1] = f0; }   // the record's head
   if (f0 == 0 || p.ap0[fi] <= p.threshold) {                          // d4c.cpp:323-328,386
     for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny;
     return;

@@ -91,6 +91,12 @@ void event_destroy(void *ev) { if (ev) check(hipEventDestroy(static_cast<hipEven
 void event_record(void *ev, hipStream_t s) { Timed t_("api:event_record"); check(hipEventRecord(static_cast<hipEvent_t>(ev), s), "hipEventRecord"); }
 void event_sync(void *ev) { Timed t_("api:event_sync"); check(hipEventSynchronize(static_cast<hipEvent_t>(ev)), "hipEventSynchronize"); }
 void stream_wait_event(hipStream_t s, void *ev) { check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev), 0), "hipStreamWaitEvent"); }
+hipStream_t stream_create() {
+  hipStream_t s = nullptr;
+  check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+  return s;
+}
+void stream_destroy(hipStream_t s) { if (s) check(hipStreamDestroy(s), "hipStreamDestroy"); }
 void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_t n, hipStream_t s) {
   if (!n) return;
   if (dst_device == src_device) check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync D2D");
@@ -98,6 +104,15 @@ void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_
 }
 void enable_peer_access(int device, int peer) {
   if (device == peer) return;
+  // once per pair and process: the query, the device switch and the enable are host calls that a path advertised as
+  // host-wait-free should not repeat on every exchange
+  static std::mutex lock;
+  static std::map<std::pair<int, int>, bool> done;
+  {
+    std::lock_guard<std::mutex> g(lock);
+    if (done.count({device, peer})) return;
+    done[{device, peer}] = true;
+  }
   int can = 0;
   if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can) return;
   int before = 0;

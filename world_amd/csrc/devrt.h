@@ -78,6 +78,8 @@ static inline void event_destroy(void *) {}
 static inline void event_record(void *, hipStream_t) {}
 static inline void event_sync(void *) {}
 static inline void stream_wait_event(hipStream_t, void *) {}
+static inline hipStream_t stream_create() { return nullptr; }
+static inline void stream_destroy(hipStream_t) {}
 static inline void peer_copy(void *dst, int, const void *src, int, size_t n, hipStream_t) { memcpy(dst, src, n); }
 static inline void enable_peer_access(int, int) {}
 void emu_run_begin(size_t lds_bytes);
@@ -124,6 +126,8 @@ void event_destroy(void *ev);
 void event_record(void *ev, hipStream_t s);
 void event_sync(void *ev);
 void stream_wait_event(hipStream_t s, void *ev);
+hipStream_t stream_create();                 // non-blocking stream on the current device
+void stream_destroy(hipStream_t s);
 // copy between devices (xGMI when peer access is enabled, staged otherwise); same device = plain D2D
 void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_t n, hipStream_t s);
 void enable_peer_access(int device, int peer);    // idempotent; a refusal is not an error (copies are then staged)

@@ -1,16 +1,20 @@
 """Multi-GPU plumbing: one process per GPU, utterances sharded across
 ranks (they are the independent unit: Harvest/DIO need whole utterances), results
-reassembled on every rank with ONE all-gather over xGMI of one packed block per rank
+reassembled on every rank by all-gathers over xGMI of packed record blocks
 
     row = [ tpos, f0, sp[0 .. nb), ap[0 .. nb) ]          (2 + 2 nb float64)
 
-holding the rank's valid frames back to back (include/world_hip.h: world_hip_pack_results;
-no padding to the longest utterance -- only the ranks' total frame counts are equalised,
-and longest-first partitioning keeps those within one utterance of each other).
+A rank's share runs in sub-batches ("chunks"); chunk k's records are written by the
+stage kernels STRAIGHT into the rank's slice of chunk k's receive buffer
+(include/world_hip.h: world_hip_analyze_packed -- no dense spectrogram, no pack pass),
+and chunk k is all-gathered -- in place, asynchronously -- while chunk k + 1 is being
+analysed: the exchange hides behind the compute except for the last chunk's.  Only
+the chunks' row counts are equalised across ranks (longest-first partitioning keeps
+them within an utterance of each other); utterances are never padded.
 
 torch.distributed only (backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests).
 Nothing here touches the data path of a single GPU.  A single PROCESS driving several
-GPUs does the same exchange without torch: world_hip_allgather_blocks (peer copies).
+GPUs does the same without torch: world_hip_analyze_sharded (host threads + peer copies).
 """
 import time
 
@@ -33,30 +37,38 @@ def partition(lengths, world_size):
     return parts
 
 
-def _gather_one(t, group, async_op):
-    world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    if dist.get_backend(group) == "gloo":        # CPU tests; device tensors are staged through the host (gloo has no
-        if t.is_cuda:                            # device all-gather): the functional check of bench.py --gpus N on a 1-GPU box
-            host = torch.empty((world,) + tuple(t.shape), dtype=t.dtype)
-            dist.all_gather(list(host.unbind(0)), t.contiguous().cpu(), group=group)
+def chunks_of(parts, sub_batch):
+    """parts[r] cut into runs of <= sub_batch utterances: chunks[k][r] = rank r's utterances of chunk k
+    (every rank has the same number of chunks; late ones may be empty on some ranks)"""
+    sb = max(1, int(sub_batch))
+    n = max((len(p) + sb - 1) // sb for p in parts) if parts else 0
+    return [[p[k * sb:(k + 1) * sb] for p in parts] for k in range(n)]
+
+
+def _gather_in_place(out, rank, group, async_op):
+    """all-gather where rank r's contribution already sits in out[r] (no send buffer, no copy)"""
+    if dist.get_backend(group) == "gloo":
+        src = out[rank].clone()                  # gloo: CPU tests and the 1-GPU functional check (host staging)
+        if out.is_cuda:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather(list(host.unbind(0)), src.cpu(), group=group)
             out.copy_(host)
-            return out, None
-        chunks = list(out.unbind(0))
-        work = dist.all_gather(chunks, t.contiguous(), group=group, async_op=async_op)
-    else:
-        work = dist.all_gather_into_tensor(out, t.contiguous(), group=group, async_op=async_op)
-    return out, work
+            return None
+        return dist.all_gather(list(out.unbind(0)), src, group=group, async_op=async_op)
+    return dist.all_gather_into_tensor(out, out[rank], group=group, async_op=async_op)
 
 
 def all_gather_results(tensors, group=None, async_op=False):
     """All-gather equally-shaped per-rank tensors.  Returns ([world, ...] tensors, works); with async_op
     the collectives overlap whatever is enqueued next -- call wait_all(works) before use."""
     outs, works = [], []
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
     for t in tensors:
-        o, w = _gather_one(t, group, async_op)
-        outs.append(o)
-        works.append(w)
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        out[rank].copy_(t)
+        works.append(_gather_in_place(out, rank, group, async_op))
+        outs.append(out)
     return outs, works
 
 
@@ -66,28 +78,11 @@ def wait_all(works):
             w.wait()
 
 
-def pad_shard(t, rows):
-    """Pad dim 0 of a shard to `rows` (ranks may own different numbers of utterances)."""
-    if t.shape[0] == rows:
-        return t
-    pad = torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    return torch.cat([t, pad], 0)
-
-
-def assemble(gathered, parts, n_total):
-    """Undo `partition`: gathered [world, rows, ...] -> [n_total, ...] in utterance order."""
-    out = torch.empty((n_total,) + tuple(gathered.shape[2:]), dtype=gathered.dtype, device=gathered.device)
-    for r, idx in enumerate(parts):
-        if idx:
-            out[torch.tensor(idx, device=gathered.device)] = gathered[r, :len(idx)]
-    return out
-
-
 class ShardedResult:
-    """Every utterance's analysis on this rank, as views into the gathered blocks (nothing is copied again).
+    """Every utterance's analysis on this rank, as views into the gathered chunk buffers (nothing is copied again).
 
-    blocks  [world][rows_max][2 + 2 nb] float64 -- rank r's records are blocks[r, :rank_rows[r]]
-    where    {utterance index: (rank, first record, n_frames)}
+    blocks  list over chunks of [world][rows_k][2 + 2 nb] float64
+    where   {utterance index: (chunk, rank, first record, n_frames)}
     """
 
     def __init__(self, blocks, where, n_frames, nb):
@@ -98,15 +93,15 @@ class ShardedResult:
 
     def utterance(self, i):
         """(tpos [n], f0 [n], sp [n, nb], ap [n, nb]) of utterance i: views, no copy"""
-        r, first, n = self.where[i]
-        rec = self.blocks[r, first:first + n]
+        k, r, first, n = self.where[i]
+        rec = self.blocks[k][r, first:first + n]
         return rec[:, 0], rec[:, 1], rec[:, 2:2 + self.nb], rec[:, 2 + self.nb:2 + 2 * self.nb]
 
     def dense(self):
         """(f0 [n_utt, F], sp [n_utt, F, nb], ap [n_utt, F, nb], n_frames) padded to the longest utterance
         (one more full-size copy: for callers that want the batched API's layout back)"""
         n, F = len(self.n_frames), (max(self.n_frames) if self.n_frames else 0)
-        dev = self.blocks.device
+        dev = self.blocks[0].device if self.blocks else torch.device("cpu")
         f0 = torch.zeros((n, F), dtype=torch.float64, device=dev)
         sp = torch.zeros((n, F, self.nb), dtype=torch.float64, device=dev)
         ap = torch.zeros((n, F, self.nb), dtype=torch.float64, device=dev)
@@ -119,6 +114,7 @@ class ShardedResult:
 
 
 _analyzers = {}
+_buffers = {}       # (device, world, rows per chunk, columns) -> the chunks' receive buffers, reused from step to step
 
 
 def _default_analyzer():
@@ -136,16 +132,13 @@ def _default_analyzer():
     return _analyzers[device]
 
 
-def _pack(wh, tpos, f0, sp, ap, nf, block, first_row):
-    """records of one batched analysis into block[first_row:]: the library's kernel on the GPU, indexing on
-    CPU tensors (the gloo tests)"""
+def _store_records(packer, tpos, f0, sp, ap, nf, block):
+    """records of one batched analysis into block[0:]: the library's kernel on the GPU, indexing on CPU tensors"""
     nb = sp.shape[-1]
     if block.is_cuda:
-        if wh is None:
-            wh = _default_analyzer()
-        wh.pack_results(tpos, f0, sp, ap, nf, block, first_row)
+        (packer or _default_analyzer()).pack_results(tpos, f0, sp, ap, nf, block, 0)
         return
-    row = first_row
+    row = 0
     for u, n in enumerate(int(k) for k in nf):
         rec = block[row:row + n]
         rec[:, 0], rec[:, 1] = (tpos[u, :n] if tpos is not None else 0.0), f0[u, :n]
@@ -153,23 +146,26 @@ def _pack(wh, tpos, f0, sp, ap, nf, block, first_row):
         row += n
 
 
-def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, lengths=None, sub_batch=128, gather=True,
-                    timings=None, packer=None, bins=None, **options):
+def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, lengths=None, sub_batch=32, gather=True,
+                    timings=None, packer=None, bins=None, analyze_packed=None, **options):
     """The whole multi-GPU recipe in one call (BASELINE configs[3]).
 
     x_list   every utterance of the job as a 1-D float64 tensor: a list (the same on every rank), or -- with
              `lengths` given for ALL utterances -- a dict {index: tensor} that need only hold this rank's share
              (what partition(lengths, world)[rank] names), so that no rank materialises the whole job.
-    analyze  (x [b, L] on the device, fs, x_len=..., frame_period=..., **options) -> (tpos, f0, sp, ap, n_frames);
-             WorldHip.analyze unless given.  A rank's share runs in batched calls of <= sub_batch utterances.
-    bins     spectrogram bins per frame; needed only by a rank that owns no utterance (default: fft/2+1 of fs)
-    timings  optional dict: accumulates "compute_ms", "exchange_ms" (host wall clock, device synchronised) and "steps"
-    Returns a ShardedResult covering ALL utterances on every rank (gather=False: this rank's only): utterances go
-    to ranks longest-first, every rank packs its frames into one block, one all-gather moves the blocks.
+    analyze_packed  (x [b, L], fs, block [rows, 2 + 2 nb], x_len=..., frame_period=..., **options) -> n_frames: writes
+             the batch's records straight into `block` (WorldHip.analyze_packed: the default on a GPU).
+    analyze  alternative for callers without a packed analysis (the CPU tests): (x, fs, x_len=..., frame_period=...,
+             **options) -> (tpos, f0, sp, ap, n_frames); its dense results are packed by `packer` / on the host.
+    sub_batch  utterances per chunk = per batched call AND per all-gather (chunk k's exchange overlaps chunk k+1's compute)
+    bins     spectrogram bins per frame (default: fft/2+1 of fs)
+    timings  optional dict, accumulates: "compute_ms" (host wall clock of the analysis calls, device synchronised at the
+             end), "exchange_exposed_ms" (device time the compute stream spent waiting for all-gathers after its last
+             analysis: what the overlap did NOT hide), "exchange_ms" (= exposed), "steps"
+    Returns a ShardedResult covering ALL utterances on every rank (gather=False: this rank's only).  Its views point into
+    receive buffers that the next call for the same job shape reuses (a 16.8 GB set is not reallocated every step).
     """
     from .api import cheaptrick_fft_size, frame_count
-    if analyze is None:
-        analyze = _default_analyzer().analyze
     on = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if on else 1
     rank = dist.get_rank(group) if on else 0
@@ -178,56 +174,67 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
     n_utt = len(lengths)
     n_frames = [frame_count(fs, n, frame_period) for n in lengths]
     nb = bins or cheaptrick_fft_size(fs) // 2 + 1
+    cols = 2 + 2 * nb
     device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     if n_utt == 0:
-        return ShardedResult(torch.zeros((world, 0, 2 + 2 * nb), dtype=torch.float64, device=device), {}, [], nb)
+        return ShardedResult([], {}, [], nb)
+    if analyze is None and analyze_packed is None:
+        analyze_packed = (packer or _default_analyzer()).analyze_packed
     parts = partition(lengths, world)
-    mine = parts[rank]
-    rank_rows = [sum(n_frames[i] for i in p) for p in parts]
-    rows_max = max(rank_rows)
+    chunks = chunks_of(parts, sub_batch)
+    rows = [[sum(n_frames[i] for i in c[r]) for r in range(world)] for c in chunks]
+    rows_k = [max(r) for r in rows]
     where = {}
-    for r, p in enumerate(parts):
-        row = 0
-        for i in p:
-            where[i] = (r, row, n_frames[i])
-            row += n_frames[i]
-
-    def sync():
-        if timings is not None and device.type == "cuda":
-            torch.cuda.synchronize()
-
-    sync()
+    for k, c in enumerate(chunks):
+        for r in range(world):
+            row = 0
+            for i in c[r]:
+                where[i] = (k, r, row, n_frames[i])
+                row += n_frames[i]
+    exchange = world > 1 and gather
+    key = (str(device), world if exchange else 1, tuple(rows_k), cols)
+    bufs = _buffers.get(key)
+    if bufs is None:
+        _buffers.clear()                           # one job shape at a time: a 16.8 GB set is not kept beside the next one
+        bufs = [torch.zeros((key[1], max(1, rk), cols), dtype=torch.float64, device=device) for rk in rows_k]
+        _buffers[key] = bufs
+    me = rank if exchange else 0
+    cuda = device.type == "cuda"
+    if timings is not None and cuda:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    block = None
-    row = 0
-    for lo in range(0, len(mine), max(1, sub_batch)):
-        idx = mine[lo:lo + max(1, sub_batch)]
-        xb = torch.zeros((len(idx), max(lengths[i] for i in idx)), dtype=torch.float64, device=device)
-        for k, i in enumerate(idx):
-            xb[k, :lengths[i]] = x_list[i].to(device)
-        tpos, f0, sp, ap, nf = analyze(xb, fs, x_len=[lengths[i] for i in idx], frame_period=frame_period, **options)
-        if block is None:
-            nb = sp.shape[-1]
-            block = torch.zeros((rows_max, 2 + 2 * nb), dtype=torch.float64, device=device)
-        _pack(packer, tpos, f0, sp, ap, [n_frames[i] for i in idx], block, row)
-        row += sum(n_frames[i] for i in idx)
-    if block is None:                          # a rank that owns nothing still takes part in the collective
-        block = torch.zeros((rows_max, 2 + 2 * nb), dtype=torch.float64, device=device)
-    sync()
+    works = []
+    for k, c in enumerate(chunks):
+        idx = c[rank]
+        block = bufs[k][me]
+        if idx:
+            xb = torch.zeros((len(idx), max(lengths[i] for i in idx)), dtype=torch.float64, device=device)
+            for j, i in enumerate(idx):
+                xb[j, :lengths[i]] = x_list[i].to(device)
+            xl = [lengths[i] for i in idx]
+            if analyze_packed is not None:
+                analyze_packed(xb, fs, block, x_len=xl, frame_period=frame_period, **options)
+            else:
+                tpos, f0, sp, ap, _ = analyze(xb, fs, x_len=xl, frame_period=frame_period, **options)
+                _store_records(packer, tpos, f0, sp, ap, [n_frames[i] for i in idx], block)
+        if exchange:
+            works.append(_gather_in_place(bufs[k], rank, group, True))     # in flight while the next chunk is analysed
+    ev0 = ev1 = None
+    if timings is not None and cuda:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    wait_all(works)
+    if ev1 is not None:
+        ev1.record()
+        torch.cuda.synchronize()
     t1 = time.perf_counter()
-    if world > 1 and gather:
-        (blocks,), works = all_gather_results([block], group=group, async_op=True)
-        wait_all(works)
-    elif world > 1:
-        blocks = None                          # nothing exchanged
-    else:
-        blocks = block.unsqueeze(0)
-    sync()
     if timings is not None:
-        timings["compute_ms"] = timings.get("compute_ms", 0.0) + (t1 - t0) * 1e3
-        timings["exchange_ms"] = timings.get("exchange_ms", 0.0) + (time.perf_counter() - t1) * 1e3
+        exposed = ev0.elapsed_time(ev1) if ev0 is not None else 0.0
+        timings["compute_ms"] = timings.get("compute_ms", 0.0) + (t1 - t0) * 1e3 - exposed
+        timings["exchange_exposed_ms"] = timings.get("exchange_exposed_ms", 0.0) + exposed
+        timings["exchange_ms"] = timings.get("exchange_ms", 0.0) + exposed
         timings["steps"] = timings.get("steps", 0) + 1
-    if blocks is None:                          # gather=False at world > 1: this rank's utterances only
-        local = {i: (0, w[1], w[2]) for i, w in where.items() if w[0] == rank}
-        return ShardedResult(block.unsqueeze(0), local, n_frames, nb)
-    return ShardedResult(blocks, where, n_frames, nb)
+    if world > 1 and not gather:                  # this rank's utterances only
+        local = {i: (w[0], 0, w[2], w[3]) for i, w in where.items() if w[1] == rank}
+        return ShardedResult(bufs, local, n_frames, nb)
+    return ShardedResult(bufs, where, n_frames, nb)

@@ -627,6 +627,45 @@ def main():
         lone_job()
     lat = (time.perf_counter() - t1) / 20 * 1e3
 
+    # ---- the same job captured into a HIP graph (world_hip_graph_*): one host launch per job --------------------
+    graph_leg = None
+    if not args.no_extras:
+        blk = torch.zeros((nf * B, 2 + 2 * (FFT_SIZE // 2 + 1)), dtype=torch.float64, device=dev)
+        with torch.cuda.stream(streams[0]):
+            for _ in range(2):
+                whs[0].analyze_packed(x, FS, blk, frame_period=FRAME_PERIOD)
+            torch.cuda.synchronize()
+            want = blk.clone()
+            g = whs[0].capture(lambda: whs[0].analyze_packed(x, FS, blk, frame_period=FRAME_PERIOD))
+            blk.fill_(-1.0)
+            g.launch()
+            torch.cuda.synchronize()
+            same = bool(torch.equal(blk, want))
+            for _ in range(3):
+                g.launch()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                g.launch()
+                torch.cuda.synchronize()
+            lat_g = (time.perf_counter() - t1) / 20 * 1e3
+            t1 = time.perf_counter()
+            for _ in range(50):
+                g.launch()
+            host_g = (time.perf_counter() - t1) / 50 * 1e3
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                whs[0].analyze_packed(x, FS, blk, frame_period=FRAME_PERIOD)
+            host_e = (time.perf_counter() - t1) / 50 * 1e3
+            torch.cuda.synchronize()
+        g.close()
+        graph_leg = {"workload": "the configs[1] job (analyze_packed: records written by the stage kernels) captured into one HIP graph",
+                     "replay_bit_identical_to_eager": same, "single_job_latency_ms": lat_g,
+                     "host_ms_per_job": {"graph_launch": host_g, "eager_calls": host_e},
+                     "note": "host ms = time to enqueue 50 jobs back to back on one stream / 50 (queue back-pressure included)"}
+        del blk, want
+
     # ---- roofline leg: per-kernel HIP-event timing of a few extra steps ------------------------------------
     def lone():
         with torch.cuda.stream(streams[0]):
@@ -752,7 +791,7 @@ def main():
         "cpu_baseline_all_cores": cpu_all, "cpu_baseline_all_cores_o3": cpu_all_o3,
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
             kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-        "configs": configs, "codec": codec, "synthesis": synthesis, "host_to_host": host_to_host,
+        "configs": configs, "graph": graph_leg, "codec": codec, "synthesis": synthesis, "host_to_host": host_to_host,
         "workspace_bytes": workspace, "randn_table_bytes": table_bytes, "csrc_hash": csrc_hash(),
     }
     print(json.dumps(out))

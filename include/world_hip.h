@@ -265,6 +265,15 @@ WORLD_HIP_API int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *c
                                             const D4COption *d4c_option, int sub_batch, double *const *d_blocks,
                                             long long rows_capacity, int cols, long long *where);
 
+/* HIP graphs: the batched calls enqueued on ctx between _begin and _end are captured into ONE executable graph (bound to
+ * the device buffers they were given) instead of being run; _launch replays it on the context's stream at the cost of one
+ * host launch (a Harvest + CheapTrick + D4C job is ~45 kernel launches otherwise).  Every call shape must have run once
+ * before capture (a captured call may not allocate, copy from the host or wait); an error inside a capture invalidates it. */
+WORLD_HIP_API int world_hip_graph_begin(WorldHipContext *ctx);
+WORLD_HIP_API int world_hip_graph_end(WorldHipContext *ctx, void **graph);
+WORLD_HIP_API int world_hip_graph_launch(WorldHipContext *ctx, void *graph);
+WORLD_HIP_API int world_hip_graph_destroy(void *graph);
+
 WORLD_HIP_API int world_hip_set_synthesis_pulse_capacity(WorldHipContext *ctx, int pulses_per_utterance);
 WORLD_HIP_API int world_hip_synthesis_pulses_dropped(WorldHipContext *ctx, int *needed);
 

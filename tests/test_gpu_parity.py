@@ -496,6 +496,41 @@ def test_analyze_packed_writes_the_same_bits_as_the_dense_stages():
 
 
 @pytest.mark.gpu
+def test_a_captured_job_replays_bit_identically():
+    """world_hip_graph_begin / _end / _launch: a whole Harvest + CheapTrick + D4C job captured into one HIP graph (the
+    batched calls neither allocate nor copy nor wait once their shape has run) and replayed twice on fresh output memory"""
+    import torch
+    from world_amd import synth
+    from world_amd.api import WorldHip, cheaptrick_fft_size, frame_count
+    fs = 48000
+    x = synth.vowel(fs, 0.8, seed=5)[None].cuda().contiguous()
+    nb = cheaptrick_fft_size(fs) // 2 + 1
+    nf = frame_count(fs, x.shape[1], 5.0)
+    wh = WorldHip()
+    block = torch.zeros((nf, 2 + 2 * nb), dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        wh.analyze_packed(x, fs, block)
+        wh.analyze_packed(x, fs, block)
+        torch.cuda.synchronize()
+        ref = block.clone()
+        g = wh.capture(lambda: wh.analyze_packed(x, fs, block))
+        for _ in range(2):
+            block.fill_(-3.0)
+            g.launch()
+            torch.cuda.synchronize()
+            assert torch.equal(block, ref)
+        # a shape that never ran cannot be captured: a clean error, not a broken stream
+        x2 = synth.vowel(fs, 0.5, seed=6)[None].cuda().contiguous()
+        b2 = torch.zeros((frame_count(fs, x2.shape[1], 5.0), 2 + 2 * nb), dtype=torch.float64, device="cuda")
+        with pytest.raises(RuntimeError):
+            wh.capture(lambda: wh.analyze_packed(x2, fs, b2))
+        wh.analyze_packed(x2, fs, b2)                      # the context still works
+        torch.cuda.synchronize()
+    g.close()
+
+
+@pytest.mark.gpu
 def test_c_driver_shards_a_job_over_two_contexts_of_one_gpu():
     """world_hip_analyze_sharded (host threads, sub-batches into packed records, peer copies on exchange streams): two
     contexts on the one GPU -- the peer copies degenerate to device-to-device copies -- both blocks complete and every

@@ -89,6 +89,10 @@ def load_library(path=LIB_PATH):
     lib.world_hip_analyze_sharded.argtypes = [C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp), _ip,
                                               C.POINTER(HarvestOption), C.POINTER(CheapTrickOption), C.POINTER(D4COption),
                                               C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
+    lib.world_hip_graph_begin.argtypes = [vp]
+    lib.world_hip_graph_end.argtypes = [vp, C.POINTER(vp)]
+    lib.world_hip_graph_launch.argtypes = [vp, vp]
+    lib.world_hip_graph_destroy.argtypes = [vp]
     lib.world_hip_pack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, vp, vp, vp, C.c_longlong, vp]
     lib.world_hip_unpack_results.argtypes = [vp, C.c_int, _ip, C.c_int, C.c_int, vp, C.c_longlong, vp, vp, vp, vp]
     lib.world_hip_allgather_blocks.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_longlong), C.c_int,
@@ -338,6 +342,27 @@ class FileAPI:
         return self._read_matrix(self.lib.ReadAperiodicity, path)
 
 
+class Graph:
+    """a captured sequence of batched calls (WorldHip.capture): launch() replays it on the stream it was captured on"""
+
+    def __init__(self, wh, ctx, handle):
+        self.wh, self.ctx, self.handle = wh, ctx, handle
+
+    def launch(self):
+        self.wh._check(self.wh.lib.world_hip_graph_launch(self.ctx, self.handle), "graph_launch")
+
+    def close(self):
+        if self.handle:
+            self.wh.lib.world_hip_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class WorldHip:
     """Batched analysis on one GPU.  Tensors: x [B, L] float64 on the GPU."""
 
@@ -527,6 +552,19 @@ class WorldHip:
         return out
 
     # ---- multi-GPU exchange records (include/world_hip.h: world_hip_pack_results) ----
+    def capture(self, fn):
+        """Run fn() -- batched calls of this object on torch's current stream, on preallocated tensors, shapes that ran before --
+        inside a HIP graph capture; returns a Graph whose launch() replays all of it with one host call."""
+        ctx = self._context()
+        self._check(self.lib.world_hip_graph_begin(ctx), "graph_begin")
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = self.lib.world_hip_graph_end(ctx, C.byref(g))
+        self._check(rc, "graph_end")
+        return Graph(self, ctx, g)
+
     def analyze_packed(self, x, fs, block, first_row=0, x_len=None, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
                        q1=-0.15, threshold=0.85):
         """Harvest -> CheapTrick -> D4C of one batch written straight into packed records (no dense sp / ap, no pack

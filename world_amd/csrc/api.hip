@@ -72,10 +72,17 @@ struct HarvestBands {            // cached per (fs, f0_floor, f0_ceil)
 
 }  // namespace world_hip
 
-// Calls reuse a staging buffer only kStageRing calls later, so the host never waits for the GPU
-// in steady state (with two buffers, D4C's call waited for the same job's Harvest to finish:
-// ~1.2 ms of host stall per job, which also kept concurrent jobs from overlapping).
-constexpr int kStageRing = 12;
+// The small per-call host arrays (lengths, frame counts, row offsets: a few ints per utterance) depend only on the
+// call's shape, and a service sees the same shapes again and again: every distinct array is uploaded ONCE into a
+// persistent slab and found again by content.  A call in steady state therefore does no host-to-device copy, touches no
+// staging buffer and waits for no event -- which is also what makes the batched calls capturable into a HIP graph
+// (round 2 staged them through a ring of pinned buffers guarded by events; hipErrorStreamCaptureInvalidated).
+struct SmallArrays {
+  struct Entry { std::vector<char> bytes; char *dev; };
+  std::vector<Entry> entries;
+  char *slab = nullptr;
+  size_t cap = 0, used = 0;
+};
 
 struct WorldHipContext {
   int device = 0;
@@ -91,11 +98,7 @@ struct WorldHipContext {
   int *d_synth_need = nullptr;   // largest pulse count a synthesis call could not hold (0 = nothing was dropped)
   int synth_pulse_cap = 0;       // caller's capacity per utterance (0 = automatic)
   void *codec_tables = nullptr;  // world_hip::CodecTableSet (cached interp1 / DCT tables of the coders)
-  // pinned ring of staging buffers for the small per-call host arrays
-  char *stage[kStageRing] = {};
-  void *stage_ev[kStageRing] = {};
-  size_t stage_cap = 0, stage_used = 0;
-  int stage_cur = 0;
+  SmallArrays small;             // the per-call host arrays, uploaded once per distinct content
   void *xchg_ready = nullptr, *xchg_done = nullptr;   // events of world_hip_allgather_blocks
   double *d_pk = nullptr;        // dense (tpos, f0) of world_hip_analyze_packed: [2][n_utt][f_stride], grow-only
   size_t pk_cap = 0;
@@ -125,39 +128,41 @@ static const uint32_t *ensure_noise(WorldHipContext *c, size_t draws) {
   return noise_table_acquire(c->device, draws, c->tab.jump, c->stream);
 }
 
-// Small host arrays travel through pinned staging so the async copy never reads
-// memory the caller (or a destroyed std::vector) owns.  The buffers form a ring, one
-// per call; a buffer is reused only after the event recorded behind its copies fired.
-struct CallScope {
-  WorldHipContext *c;
-  explicit CallScope(WorldHipContext *ctx, size_t staging_bytes) : c(ctx) {
-    if (staging_bytes > c->stage_cap) {
-      devrt::sync(c->stream);
-      for (int k = 0; k < kStageRing; ++k) {
-        if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
-        c->stage[k] = static_cast<char *>(devrt::hmalloc_pinned(staging_bytes * 2));
-        if (!c->stage_ev[k]) c->stage_ev[k] = devrt::event_create();
-      }
-      c->stage_cap = staging_bytes * 2;
-    }
-    c->stage_cur = (c->stage_cur + 1) % kStageRing;
-    devrt::event_sync(c->stage_ev[c->stage_cur]);
-    c->stage_used = 0;
-  }
-  ~CallScope() { devrt::event_record(c->stage_ev[c->stage_cur], c->stream); }
+// A small host array on the device: found by content in the context's slab, or appended to it (one H2D copy from a
+// host copy that lives as long as the entry).  The slab only ever grows by being replaced when full (stream drained first).
+struct CallScope {                       // kept as the marker of a call's upload section (nothing to acquire any more)
+  explicit CallScope(WorldHipContext *, size_t) {}
 };
 
-template <class T> static T *upload(WorldHipContext *c, const std::vector<T> &v) {
-  T *d = c->arena.take<T>(v.size() ? v.size() : 1);
-  if (!v.empty()) {
-    size_t bytes = sizeof(T) * v.size();
-    if (c->stage_used + bytes > c->stage_cap) fail("staging overflow");
-    char *h = c->stage[c->stage_cur] + c->stage_used;
-    memcpy(h, v.data(), bytes);
-    c->stage_used += (bytes + 63) & ~size_t(63);
-    devrt::h2d(d, h, bytes, c->stream);
+static char *small_array(WorldHipContext *c, const void *data, size_t bytes) {
+  SmallArrays &sa = c->small;
+  for (const SmallArrays::Entry &e : sa.entries)
+    if (e.bytes.size() == bytes && memcmp(e.bytes.data(), data, bytes) == 0) return e.dev;
+  // a miss uploads (and may replace the slab): neither is possible while the stream is being captured into a graph
+  if (devrt::is_capturing(c->stream)) fail("a call shape that was never run before cannot be captured: run it once first");
+  const size_t padded = (bytes + 255) & ~size_t(255);
+  if (sa.used + padded > sa.cap) {
+    // full (or first use): a fresh slab; nobody may still be reading the old entries
+    devrt::sync(c->stream);
+    if (sa.slab) devrt::dfree(sa.slab);
+    sa.entries.clear();
+    sa.cap = std::max<size_t>(size_t(4) << 20, 16 * padded);
+    sa.slab = static_cast<char *>(devrt::dmalloc(sa.cap));
+    sa.used = 0;
   }
-  return d;
+  SmallArrays::Entry e;
+  e.bytes.assign(static_cast<const char *>(data), static_cast<const char *>(data) + bytes);
+  e.dev = sa.slab + sa.used;
+  sa.used += padded;
+  sa.entries.push_back(std::move(e));
+  const SmallArrays::Entry &kept = sa.entries.back();
+  devrt::h2d(kept.dev, kept.bytes.data(), bytes, c->stream);      // the source outlives the copy
+  return kept.dev;
+}
+
+template <class T> static T *upload(WorldHipContext *c, const std::vector<T> &v) {
+  if (v.empty()) return reinterpret_cast<T *>(small_array(c, "", 1));
+  return reinterpret_cast<T *>(small_array(c, v.data(), sizeof(T) * v.size()));
 }
 
 static int ilog2_exact(int n) {
@@ -1031,10 +1036,7 @@ void world_hip_destroy(WorldHipContext *c) {
     free_codec_tables(c);
     if (c->d_dc_remover) devrt::dfree(c->d_dc_remover);
     if (c->d_synth_need) devrt::dfree(c->d_synth_need);
-    for (int k = 0; k < kStageRing; ++k) {
-      if (c->stage[k]) devrt::hfree_pinned(c->stage[k]);
-      if (c->stage_ev[k]) devrt::event_destroy(c->stage_ev[k]);
-    }
+    if (c->small.slab) devrt::dfree(c->small.slab);
     HarvestBands &hb = c->bands;
     if (hb.d_band_f0) { devrt::dfree(hb.d_band_f0); devrt::dfree(hb.d_taps); devrt::dfree(hb.d_half); devrt::dfree(hb.d_off); }
     if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
@@ -1166,6 +1168,29 @@ int world_hip_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double
     run_analyze_packed(c, n_utt, fs, d_x, x_stride, x_length, harvest_option, cheaptrick_option, d4c_option, first_row,
                        d_block, cols);
   });
+}
+
+// HIP graphs: every batched call enqueued on the context between begin and end -- a whole
+// Harvest + CheapTrick + D4C job is ~45 launches -- becomes ONE replayable graph bound to the buffers it was captured with.
+// The shapes must have run once before (workspace, tables and the small per-call arrays are then resident and a call
+// neither allocates nor copies nor waits); a replay costs the host one launch.
+int world_hip_graph_begin(WorldHipContext *c) {
+  return guarded(c, [&] { devrt::graph_begin(c->stream); });
+}
+int world_hip_graph_end(WorldHipContext *c, void **graph) {
+  return guarded(c, [&] {
+    if (!graph) fail("null graph handle");
+    *graph = devrt::graph_end(c->stream);
+  });
+}
+int world_hip_graph_launch(WorldHipContext *c, void *graph) {
+  return guarded(c, [&] {
+    if (!graph) fail("null graph");
+    devrt::graph_launch(graph, c->stream);
+  });
+}
+int world_hip_graph_destroy(void *graph) {
+  try { devrt::graph_destroy(graph); return 0; } catch (const std::exception &e) { g_last_error = e.what(); return 1; }
 }
 
 int world_hip_synthesis_batch(WorldHipContext *c, int n_utt, int fs, double frame_period, int fft_size,

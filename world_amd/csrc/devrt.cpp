@@ -97,6 +97,23 @@ hipStream_t stream_create() {
   return s;
 }
 void stream_destroy(hipStream_t s) { if (s) check(hipStreamDestroy(s), "hipStreamDestroy"); }
+bool is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+void graph_begin(hipStream_t s) { check(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture"); }
+void *graph_end(hipStream_t s) {
+  hipGraph_t g = nullptr;
+  check(hipStreamEndCapture(s, &g), "hipStreamEndCapture");
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  check(e, "hipGraphInstantiate");
+  return exec;
+}
+void graph_launch(void *exec, hipStream_t s) { check(hipGraphLaunch(static_cast<hipGraphExec_t>(exec), s), "hipGraphLaunch"); }
+void graph_destroy(void *exec) { if (exec) check(hipGraphExecDestroy(static_cast<hipGraphExec_t>(exec)), "hipGraphExecDestroy"); }
 void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_t n, hipStream_t s) {
   if (!n) return;
   if (dst_device == src_device) check(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync D2D");

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 
 #ifdef WORLD_EMU
 // ------------------------------------------------------------------ emulation
@@ -80,6 +81,11 @@ static inline void event_sync(void *) {}
 static inline void stream_wait_event(hipStream_t, void *) {}
 static inline hipStream_t stream_create() { return nullptr; }
 static inline void stream_destroy(hipStream_t) {}
+static inline bool is_capturing(hipStream_t) { return false; }
+[[noreturn]] static inline void graph_begin(hipStream_t) { throw std::runtime_error("HIP graphs do not exist in the host emulation"); }
+static inline void *graph_end(hipStream_t) { return nullptr; }
+static inline void graph_launch(void *, hipStream_t) {}
+static inline void graph_destroy(void *) {}
 static inline void peer_copy(void *dst, int, const void *src, int, size_t n, hipStream_t) { memcpy(dst, src, n); }
 static inline void enable_peer_access(int, int) {}
 void emu_run_begin(size_t lds_bytes);
@@ -128,6 +134,12 @@ void event_sync(void *ev);
 void stream_wait_event(hipStream_t s, void *ev);
 hipStream_t stream_create();                 // non-blocking stream on the current device
 void stream_destroy(hipStream_t s);
+// HIP graphs: everything a context enqueues between begin and end becomes one replayable graph
+bool is_capturing(hipStream_t s);
+void graph_begin(hipStream_t s);
+void *graph_end(hipStream_t s);              // -> executable graph
+void graph_launch(void *exec, hipStream_t s);
+void graph_destroy(void *exec);
 // copy between devices (xGMI when peer access is enabled, staged otherwise); same device = plain D2D
 void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_t n, hipStream_t s);
 void enable_peer_access(int device, int peer);    // idempotent; a refusal is not an error (copies are then staged)

@@ -265,6 +265,12 @@ WORLD_HIP_API int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *c
                                             const D4COption *d4c_option, int sub_batch, double *const *d_blocks,
                                             long long rows_capacity, int cols, long long *where);
 
+/* Shape limits of the GPU path (the reference has none): 0 = StoneMask, CheapTrick(cheaptrick_fft_size) and D4C all run at
+ * this fs; 1 = one of them does not, `why` names the stage and the limit (fs <= 96 kHz for D4C and for CheapTrick's default
+ * fft_size, fs >= 15.8 kHz for D4C, fs <= 180 kHz for StoneMask).  Pure host arithmetic.  The drop-in symbols make the
+ * same check before any GPU work and abort with that message -- the reference API has no error channel. */
+WORLD_HIP_API int world_hip_check_shape(int fs, int cheaptrick_fft_size, char *why, int why_capacity);
+
 /* HIP graphs: the batched calls enqueued on ctx between _begin and _end are captured into ONE executable graph (bound to
  * the device buffers they were given) instead of being run; _launch replays it on the context's stream at the cost of one
  * host launch (a Harvest + CheapTrick + D4C job is ~45 kernel launches otherwise).  Every call shape must have run once

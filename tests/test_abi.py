@@ -163,3 +163,19 @@ int uses_everything(const double *x, int n, int fs, double *tp, double *f0, doub
         r = subprocess.run([cc, std, "-x", "c" if cc == "gcc" else "c++", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_shape_limits_are_answered_on_the_host():
+    """world_hip_check_shape: the limits of the GPU path as pure host arithmetic -- what the drop-in symbols
+    check before any GPU work"""
+    import ctypes as C
+    from world_amd.api import load_library
+    lib = load_library()
+    why = C.create_string_buffer(256)
+    assert lib.world_hip_check_shape(48000, 2048, why, 256) == 0 and why.value == b""
+    assert lib.world_hip_check_shape(16000, 1024, why, 256) == 0
+    assert lib.world_hip_check_shape(192000, 8192, why, 256) == 1 and b"StoneMask" in why.value     # the first limit met
+    assert lib.world_hip_check_shape(96000, 8192, why, 256) == 1 and b"CheapTrick" in why.value
+    assert lib.world_hip_check_shape(120000, 4096, why, 256) == 1 and b"D4C" in why.value
+    assert lib.world_hip_check_shape(8000, 512, why, 256) == 1 and b"15.8" in why.value
+    assert lib.world_hip_check_shape(96000, 4096, why, 256) == 0

@@ -89,6 +89,7 @@ def load_library(path=LIB_PATH):
     lib.world_hip_analyze_sharded.argtypes = [C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp), _ip,
                                               C.POINTER(HarvestOption), C.POINTER(CheapTrickOption), C.POINTER(D4COption),
                                               C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
+    lib.world_hip_check_shape.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
     lib.world_hip_graph_begin.argtypes = [vp]
     lib.world_hip_graph_end.argtypes = [vp, C.POINTER(vp)]
     lib.world_hip_graph_launch.argtypes = [vp, vp]
@@ -508,9 +509,10 @@ class WorldHip:
                                                  fft_size, C.byref(opt), ap.data_ptr()), "d4c")
         return ap
 
-    def synthesis(self, f0, sp, ap, n_frames, fft_size, frame_period, fs, y_length):
+    def synthesis(self, f0, sp, ap, n_frames, fft_size, frame_period, fs, y_length, check_pulses=True):
         """reference Synthesis() on a batch: f0 [B, F], sp / ap [B, F, fft/2+1] (float64, device);
-        n_frames and y_length are per-utterance ints; returns y [B, max(y_length)]"""
+        n_frames and y_length are per-utterance ints; returns y [B, max(y_length)].  check_pulses=False skips the (synchronising)
+        check that every pitch pulse found room in the workspace -- the caller then asks synthesis_pulses_dropped() itself"""
         t = self.torch
         f0, sp, ap = f0.contiguous(), sp.contiguous(), ap.contiguous()
         B, F = f0.shape
@@ -518,10 +520,26 @@ class WorldHip:
         yl = np.ascontiguousarray(np.broadcast_to(y_length, (B,)), dtype=np.int32)
         Y = int(yl.max())
         y = t.zeros((B, Y), dtype=t.float64, device=f0.device)
-        self._check(self.lib.world_hip_synthesis_batch(self._context(), B, fs, float(frame_period), fft_size,
-                                                       nf.ctypes.data_as(_ip), F, f0.data_ptr(), sp.data_ptr(),
-                                                       ap.data_ptr(), yl.ctypes.data_as(_ip), Y, y.data_ptr()),
-                    "synthesis")
+        def run():
+            self._check(self.lib.world_hip_synthesis_batch(self._context(), B, fs, float(frame_period), fft_size,
+                                                           nf.ctypes.data_as(_ip), F, f0.data_ptr(), sp.data_ptr(),
+                                                           ap.data_ptr(), yl.ctypes.data_as(_ip), Y, y.data_ptr()),
+                        "synthesis")
+        run()
+        if check_pulses:
+            # the pulse count is data dependent and only known on the device: a call that had no room for some says so
+            # (this synchronises); repeat it once with exactly the capacity it asked for -- never a silently truncated waveform
+            need = self.synthesis_pulses_dropped()
+            if need:
+                if need > Y:
+                    raise RuntimeError(f"synthesis: {need} pitch pulses for {Y} output samples")
+                self.set_synthesis_pulse_capacity(need + 16)
+                try:
+                    run()
+                    if self.synthesis_pulses_dropped():
+                        raise RuntimeError("synthesis: pulses dropped even at the requested capacity")
+                finally:
+                    self.set_synthesis_pulse_capacity(0)
         return y
 
     # ---- the per-frame FFT in isolation (include/world_hip.h: world_hip_probe_rfft) ----

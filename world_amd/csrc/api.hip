@@ -944,6 +944,43 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
 }
 
 // ---------------------------------------------------------------------------
+// Shape limits of the GPU path (the reference has none: it allocates whatever fs asks for).  One function states them,
+// the stages and world_hip_check_shape ask it, and the drop-in entries ask it BEFORE any upload or launch.
+// what: bit 0 StoneMask, bit 1 CheapTrick (needs fft_size), bit 2 D4C.  Returns nullptr or the reason.
+// ---------------------------------------------------------------------------
+static std::string shape_limit(int what, int fs, int fft_size) {
+  char msg[256];
+  if (fs <= 0) return "fs must be positive";
+  if (what & 1) {
+    const int win_cap = 2 * static_cast<int>(1.5 * fs / 40.0 + 1.0) + 4;
+    if (stonemask_lds_bytes(win_cap) > 160 * 1024) {
+      snprintf(msg, sizeof msg, "StoneMask: fs=%d needs a %d-sample window, more LDS than a CU has; fs <= 180 kHz supported", fs, win_cap);
+      return msg;
+    }
+  }
+  if (what & 2) {
+    int lg = 0;
+    while ((1 << lg) < fft_size) ++lg;
+    if ((1 << lg) != fft_size || lg < 7 || lg > 12) {
+      snprintf(msg, sizeof msg, "CheapTrick: fft_size %d unsupported (a power of two, 128..4096: one frame must fit LDS; fs <= 96 kHz at the default f0 floor)", fft_size);
+      return msg;
+    }
+  }
+  if (what & 4) {
+    const int fft_d4c = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(4.0 * fs / kFloorF0D4C + 1) / kLog2)));
+    if (fft_d4c > 8192) {
+      snprintf(msg, sizeof msg, "D4C: fs=%d needs an internal FFT of %d > 8192 points (LDS budget); fs <= 96 kHz supported", fs, fft_d4c);
+      return msg;
+    }
+    if (fs < 15800) {
+      snprintf(msg, sizeof msg, "D4C: fs=%d is below the 15.8 kHz the reference's LoveTrain band edges require (the reference reads out of bounds there)", fs);
+      return msg;
+    }
+  }
+  return std::string();
+}
+
+// ---------------------------------------------------------------------------
 // error plumbing for the C ABI
 // ---------------------------------------------------------------------------
 // A context's allocations and launches belong to ITS device: a thread that drives several GPUs calls in
@@ -1191,6 +1228,14 @@ int world_hip_graph_launch(WorldHipContext *c, void *graph) {
 }
 int world_hip_graph_destroy(void *graph) {
   try { devrt::graph_destroy(graph); return 0; } catch (const std::exception &e) { g_last_error = e.what(); return 1; }
+}
+
+// 0: every stage of the analysis path supports (fs, cheaptrick_fft_size); 1: it does not, and why (<= cap bytes) says which
+// stage and limit.  Pure host arithmetic: callers (and the drop-in symbols) ask before any GPU work.
+int world_hip_check_shape(int fs, int cheaptrick_fft_size, char *why, int cap) {
+  const std::string r = shape_limit(7, fs, cheaptrick_fft_size);
+  if (why && cap > 0) { snprintf(why, (size_t)cap, "%s", r.c_str()); }
+  return r.empty() ? 0 : 1;
 }
 
 int world_hip_synthesis_batch(WorldHipContext *c, int n_utt, int fs, double frame_period, int fft_size,

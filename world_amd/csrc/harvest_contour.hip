@@ -116,10 +116,21 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
       prev = cur; cur = next;
     }
   }
-  int tot, at = block_excl_scan_int(mine, &tot, scratch);
-  const int n_start = tot & 0xFFFF;
+  // the two counts share one scan as 16-bit halves while they cannot overflow them (fewer than 2^15 sections: any
+  // utterance below 65 s); longer ones pay a second scan instead of corrupting the end offsets
+  int n_start, at_s0, at_e0;
+  if (nf < 65536) {
+    int tot;
+    const int at = block_excl_scan_int(mine, &tot, scratch);
+    n_start = tot & 0xFFFF; at_s0 = at & 0xFFFF; at_e0 = at >> 16;
+  } else {
+    int tot_s, tot_e;
+    at_s0 = block_excl_scan_int(mine & 0xFFFF, &tot_s, scratch);
+    at_e0 = block_excl_scan_int(mine >> 16, &tot_e, scratch);
+    n_start = tot_s;
+  }
   {
-    int at_s = at & 0xFFFF, at_e = at >> 16;
+    int at_s = at_s0, at_e = at_e0;
     bool prev = voiced(lo - 1), cur = voiced(lo);
     for (int f = lo; f < hi; ++f) {
       const bool next = voiced(f + 1);

@@ -5,6 +5,7 @@
 #include "rng.h"
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -88,8 +89,24 @@ struct DeviceNoise {
   std::vector<unsigned long long> host_sums;
 };
 
+// g_noise_lock guards the map and the reference counts only; a device's table is grown, verified and re-verified under
+// ITS OWN lock, so a long host statement (12 ns per new draw, sequential) for one device never stalls the contexts of
+// another.  Entries are heap objects: the map may rehash while a table is being built.
 std::mutex g_noise_lock;
-std::map<int, DeviceNoise> g_noise;
+struct DeviceEntry { std::mutex lock; DeviceNoise d; };
+std::map<int, std::unique_ptr<DeviceEntry>> g_noise;
+
+DeviceEntry &entry_of(int device) {
+  std::lock_guard<std::mutex> g(g_noise_lock);
+  std::unique_ptr<DeviceEntry> &e = g_noise[device];
+  if (!e) e.reset(new DeviceEntry);
+  return *e;
+}
+DeviceEntry *find_entry(int device) {
+  std::lock_guard<std::mutex> g(g_noise_lock);
+  auto it = g_noise.find(device);
+  return it == g_noise.end() ? nullptr : it->second.get();
+}
 
 void host_extend(DeviceNoise &d, size_t upto) {
   while (d.host_pos < upto) {
@@ -136,26 +153,29 @@ void check_table(DeviceNoise &d, const uint32_t *table, size_t len, hipStream_t 
 }  // namespace
 
 void noise_table_retain(int device) {
-  std::lock_guard<std::mutex> g(g_noise_lock);
-  g_noise[device].refs += 1;
+  DeviceEntry &e = entry_of(device);
+  std::lock_guard<std::mutex> g(e.lock);
+  e.d.refs += 1;
 }
 
 void noise_table_release(int device) {
-  std::lock_guard<std::mutex> g(g_noise_lock);
-  auto it = g_noise.find(device);
-  if (it == g_noise.end()) return;
-  DeviceNoise &d = it->second;
+  DeviceEntry *e = find_entry(device);
+  if (!e) return;
+  std::lock_guard<std::mutex> g(e->lock);
+  DeviceNoise &d = e->d;
   if (--d.refs > 0) return;
-  // the device's last context is gone (it drained its stream before releasing): nobody reads these any more
+  // the device's last context is gone (it drained its stream before releasing): nobody reads these any more.  The entry
+  // itself stays (an empty table costs nothing and a concurrent retain may already hold its address).
   if (d.live) devrt::dfree(d.live);
   for (uint32_t *p : d.superseded) devrt::dfree(p);
-  g_noise.erase(it);
+  d = DeviceNoise();
 }
 
 const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jump, hipStream_t stream) {
   if (draws > kNoiseMaxDraws) throw std::runtime_error("utterance consumes more than 2^32 randn() draws");
-  std::lock_guard<std::mutex> g(g_noise_lock);
-  DeviceNoise &d = g_noise[device];
+  DeviceEntry &e = entry_of(device);
+  std::lock_guard<std::mutex> g(e.lock);
+  DeviceNoise &d = e.d;
   if (draws <= d.len) return d.live;
   // grow: at least double, whole chunks (only the final 32-bit clamp leaves a partial chunk, and nothing grows past it)
   size_t cap = draws > 2 * d.len ? draws : 2 * d.len;
@@ -167,11 +187,12 @@ const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jum
     // every word comes from the fill kernel (nothing is copied over from the shorter table) ...
     RngFillArgs fill = {fresh, 0, cap, d_jump};
     launch_rng_fill(fill, stream);
-    // ... and every word is accounted for before the table is published
+    // ... and every word is accounted for before the table is published (the host statement only steps the draws beyond
+    // those it has already summed: growth costs the host the NEW draws, not the whole stream)
     check_table(d, fresh, cap, stream, "new table");
   } catch (...) {
-    devrt::sync(stream);
-    devrt::dfree(fresh);
+    try { devrt::sync(stream); } catch (...) {}      // a failing sync must not leak the table
+    try { devrt::dfree(fresh); } catch (...) {}
     throw;
   }
   if (d.live) {
@@ -184,16 +205,18 @@ const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jum
 }
 
 void noise_table_verify(int device, hipStream_t stream) {
-  std::lock_guard<std::mutex> g(g_noise_lock);
-  auto it = g_noise.find(device);
-  if (it == g_noise.end() || !it->second.live) return;
-  check_table(it->second, it->second.live, it->second.len, stream, "re-check of the live table");
+  DeviceEntry *e = find_entry(device);
+  if (!e) return;
+  std::lock_guard<std::mutex> g(e->lock);
+  if (!e->d.live) return;
+  check_table(e->d, e->d.live, e->d.len, stream, "re-check of the live table");
 }
 
 size_t noise_table_bytes(int device) {
-  std::lock_guard<std::mutex> g(g_noise_lock);
-  auto it = g_noise.find(device);
-  return it == g_noise.end() ? 0 : sizeof(uint32_t) * it->second.len + it->second.superseded_bytes;
+  DeviceEntry *e = find_entry(device);
+  if (!e) return 0;
+  std::lock_guard<std::mutex> g(e->lock);
+  return sizeof(uint32_t) * e->d.len + e->d.superseded_bytes;
 }
 
 }  // namespace world_hip

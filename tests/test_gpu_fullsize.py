@@ -60,6 +60,11 @@ def _check_full(tag, got, want):
     assert max_rel(ap[:n], ap_r) <= RTOL, f"{tag}: aperiodicity rel err {max_rel(ap[:n], ap_r)}"
 
 
+def _lone_context():
+    from world_amd.api import WorldHip
+    return WorldHip()
+
+
 def test_config1_full_size_against_the_reference(wh, ref, pool):
     """BASELINE configs[1] at the size the metric is quoted on: 480 000 samples, 2001 frames, every frame"""
     import torch
@@ -90,6 +95,13 @@ def test_config2_harvest_batch_of_256(wh, ref, pool):
         tp_r, f0_r = jobs[i].result()
         assert np.array_equal(tpos[i].cpu().numpy(), tp_r)
         assert_f0_close(f0[i].cpu().numpy(), f0_r, what=f"configs[2] utterance {i}")
+    # ... and EVERY utterance of the batch is bit-identical to its own single call: with the reference-checked ones above
+    # that covers the whole batch (batched == single is the library's invariant)
+    lone = _lone_context()
+    for i in range(B):
+        tp1, f01, _ = lone.harvest(xs[i][None].contiguous(), FS)
+        assert torch.equal(f01[0], f0[i]) and torch.equal(tp1[0], tpos[i]), f"configs[2] utterance {i}: batched != single"
+    lone.close()
 
 
 def test_config3_per_gpu_share_128(wh, ref, pool):
@@ -106,7 +118,13 @@ def test_config3_per_gpu_share_128(wh, ref, pool):
     for i in picks:
         _check_full(f"configs[3] utterance {i}", (tpos[i].cpu().numpy(), f0[i].cpu().numpy(), sp[i].cpu().numpy(),
                                                   ap[i].cpu().numpy()), jobs[i].result())
-    wh.close()                                                    # 32 GB of workspace back to the pool
+    lone = _lone_context()                                        # the whole batch: every utterance == its own single call
+    for i in range(B):
+        tp1, f01, sp1, ap1, _ = lone.analyze(xs[i][None].contiguous(), FS)
+        assert torch.equal(f01[0], f0[i]) and torch.equal(sp1[0], sp[i]) and torch.equal(ap1[0], ap[i]), \
+            f"configs[3] utterance {i}: batched != single"
+    lone.close()
+    wh.close()                                                    # the batch's workspace back to the pool
 
 
 def test_config4_dio_path_64_x_16k(wh, ref, pool):
@@ -127,6 +145,12 @@ def test_config4_dio_path_64_x_16k(wh, ref, pool):
     for i in picks:
         _check_full(f"configs[4] utterance {i}", (tpos[i].cpu().numpy(), f0[i].cpu().numpy(), sp[i].cpu().numpy(),
                                                   ap[i].cpu().numpy()), jobs[i].result())
+    lone = _lone_context()                                        # the whole batch: every utterance == its own single call
+    for i in range(B):
+        tp1, f01, sp1, ap1, _ = lone.analyze(xs[i][None].contiguous(), fs, f0_method="dio", q1=-0.15, threshold=0.85)
+        assert torch.equal(f01[0], f0[i]) and torch.equal(sp1[0], sp[i]) and torch.equal(ap1[0], ap[i]), \
+            f"configs[4] utterance {i}: batched != single"
+    lone.close()
 
 
 def test_eight_contexts_on_eight_streams_equal_serial_runs():

@@ -121,7 +121,20 @@ __host__ __device__ __forceinline__ FftPlan make_plan_r8(int lg) { return make_p
 // a butterfly computes swz(base) once and reaches its R elements with one XOR each against constants that are
 // uniform over the workgroup (scalar registers) -- the address arithmetic was two thirds of the FFT kernels'
 // VALU instructions (profiles/r02, SQ_INSTS_VALU against the FP64 counters).
-__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 4) & 15); }
+#ifndef WH_SWZ
+#define WH_SWZ 0
+#endif
+__device__ __forceinline__ int swz(int i) {
+#if WH_SWZ == 1
+  // candidate of tools/lds_swizzle_search.py for the radix-8 plans: low nibble ^= rotl1(bits 4..7) ^ rotl3(bits 8..11)
+  return i ^ (((i >> 3) & 14) | ((i >> 7) & 1)) ^ (((i >> 9) & 7) | ((i >> 5) & 8));
+#elif WH_SWZ == 2
+  // low nibble ^= rotl1(bits 4..7) ^ (bits 8..11 ^ rotl2(bits 8..11))
+  return i ^ (((i >> 3) & 14) | ((i >> 7) & 1)) ^ ((i >> 8) & 15) ^ (((i >> 6) & 12) | ((i >> 10) & 3));
+#else
+  return i ^ ((i >> 4) & 15);
+#endif
+}
 // slot that holds bin k after the forward (DIF) transform = slot the inverse (DIT)
 // transform expects bin k in: the digits of k, least significant first, select
 // nested blocks.

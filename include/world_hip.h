@@ -233,6 +233,15 @@ WORLD_HIP_API int world_hip_probe_irfft(WorldHipContext *ctx, int lg_n, int max_
  * destination is valid, and the sources reusable, in the respective context's stream order).
  * With one process PER GPU (torch.distributed / RCCL) the same blocks go through one all-gather:
  * world_amd/distributed.py. */
+/* Harvest -> CheapTrick + D4C of one batch in ONE call, into the dense arrays of the *_batch calls (tpos, f0:
+ * [n_utt][f_stride]; spectrogram, aperiodicity: [n_utt][f_stride][fft_size/2+1], fft_size = cheaptrick_option->fft_size).
+ * Same results, bit for bit, as the three calls in sequence at a third of their host cost (one lock, one set of
+ * small-array look-ups). */
+WORLD_HIP_API int world_hip_analyze_batch(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
+                                          const int *x_length, const HarvestOption *harvest_option,
+                                          const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
+                                          int f_stride, double *d_tpos, double *d_f0, double *d_spectrogram,
+                                          double *d_aperiodicity);
 /* Harvest + CheapTrick + D4C of one batch written STRAIGHT into packed records: utterance u's frames occupy rows
  * first_row + sum_{v<u} n_frames[v] ... of d_block ([rows][cols] doubles, cols = 2 + 2 (fft_size/2 + 1) =
  * [tpos, f0, sp row, ap row]); n_frames[u] = GetSamplesForHarvest(fs, x_length[u], frame_period).  The stage kernels

@@ -90,6 +90,8 @@ def load_library(path=LIB_PATH):
                                               C.POINTER(HarvestOption), C.POINTER(CheapTrickOption), C.POINTER(D4COption),
                                               C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
     lib.world_hip_check_shape.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    lib.world_hip_analyze_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(HarvestOption),
+                                            C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, vp, vp, vp, vp]
     lib.world_hip_graph_begin.argtypes = [vp]
     lib.world_hip_graph_end.argtypes = [vp, C.POINTER(vp)]
     lib.world_hip_graph_launch.argtypes = [vp, vp]
@@ -722,7 +724,23 @@ class WorldHip:
                 q1=-0.15, threshold=0.85, sp_out=None, ap_out=None):
         """The north-star pipeline: F0 (Harvest, or DIO+StoneMask) -> CheapTrick -> D4C."""
         if f0_method == "harvest":
-            tpos, f0, nf = self.harvest(x, fs, x_len, f0_floor, f0_ceil, frame_period)
+            # one library call: Harvest, then CheapTrick beside D4C on two streams of the context
+            t = self.torch
+            B, L, xl = self._prep(x, x_len)
+            fft_size = cheaptrick_fft_size(fs, 71.0)
+            nb = fft_size // 2 + 1
+            nf = np.array([frame_count(fs, int(n), frame_period) for n in xl], dtype=np.int32)
+            F = int(nf.max())
+            tpos = t.zeros((B, F), dtype=t.float64, device=x.device)
+            f0 = t.zeros((B, F), dtype=t.float64, device=x.device)
+            sp = sp_out if sp_out is not None else t.zeros((B, F, nb), dtype=t.float64, device=x.device)
+            ap = ap_out if ap_out is not None else t.zeros((B, F, nb), dtype=t.float64, device=x.device)
+            assert sp.shape == (B, F, nb) and ap.shape == (B, F, nb) and sp.is_contiguous() and ap.is_contiguous()
+            hopt, copt, dopt = HarvestOption(f0_floor, f0_ceil, frame_period), CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
+            self._check(self.lib.world_hip_analyze_batch(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
+                                                         C.byref(hopt), C.byref(copt), C.byref(dopt), F, tpos.data_ptr(),
+                                                         f0.data_ptr(), sp.data_ptr(), ap.data_ptr()), "analyze")
+            return tpos, f0, sp, ap, nf
         elif f0_method == "dio":
             tpos, f0_raw, nf = self.dio(x, fs, x_len, f0_floor, f0_ceil, frame_period=frame_period)
             f0 = self.stonemask(x, fs, tpos, f0_raw, nf, x_len)

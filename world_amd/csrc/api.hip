@@ -193,6 +193,16 @@ struct RowLayout {
   double *rec = nullptr;         // D4C only: records' base for the (tpos, f0) head of every record
 };
 
+static size_t cheaptrick_arena_bytes(int n_utt, int f_stride, int fft_size) {
+  return pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 4 * pad256(sizeof(int) * n_utt) +
+         pad256(sizeof(double) * (size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * ct_seg_stride(fft_size));
+}
+static size_t d4c_arena_bytes(int n_utt, int f_stride) {
+  const size_t fr = (size_t)n_utt * f_stride;
+  return 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 5 * pad256(sizeof(int) * n_utt) +
+         pad256(sizeof(double) * fr * 16);
+}
+
 // ---------------------------------------------------------------------------
 // CheapTrick
 // ---------------------------------------------------------------------------
@@ -209,9 +219,7 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
     max_frames = std::max(max_frames, n_frames[u]);
   }
   const int seg_stride = ct_seg_stride(opt->fft_size);
-  size_t need = pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 4 * pad256(sizeof(int) * n_utt) +
-                pad256(sizeof(double) * (size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * seg_stride);
-  if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
+  if (own_arena) { ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, opt->fft_size)); c->arena.reset(); }
   CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
   CtParams p;
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
@@ -266,9 +274,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     c->nuttall_len = wl;
   }
   size_t fr = (size_t)n_utt * f_stride;
-  size_t need = 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 5 * pad256(sizeof(int) * n_utt) +
-                pad256(sizeof(double) * fr * 16);
-  if (own_arena) { ensure_arena(c, need); c->arena.reset(); }
+  if (own_arena) { ensure_arena(c, d4c_arena_bytes(n_utt, f_stride)); c->arena.reset(); }
   CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
   D4cParams p;
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
@@ -906,6 +912,34 @@ static void run_pack(WorldHipContext *c, bool unpack, int n_utt, const int *n_fr
 }
 
 // ---------------------------------------------------------------------------
+// CheapTrick, then D4C, of one batch.  (Measured in round 3: CheapTrick on a second stream of the context beside D4C --
+// they are independent given F0 -- gains nothing: d4c_frame fills the chip by itself, a lone job stayed at 1.11 ms, and
+// twelve jobs in flight dropped from 3.67 to 3.11 M frames/s with 24 streams contending for the hardware queues.)
+// ---------------------------------------------------------------------------
+static void run_spectral_stages(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                                const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0,
+                                const CheapTrickOption *copt, const D4COption *dopt, double *d_sp, double *d_ap,
+                                const RowLayout &lay_sp, const RowLayout &lay_ap) {
+  run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt, d_sp, true, lay_sp);
+  run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt->fft_size, dopt, d_ap, true, lay_ap);
+}
+
+// Harvest + CheapTrick + D4C of one batch into the dense arrays of the *_batch calls (world_hip_analyze_batch)
+static void run_analyze_dense(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                              const HarvestOption *hopt, const CheapTrickOption *copt, const D4COption *dopt, int f_stride,
+                              double *d_tpos, double *d_f0, double *d_sp, double *d_ap) {
+  check_batch(n_utt, fs, d_x, x_stride, x_length);
+  std::vector<int> nf(n_utt);
+  for (int u = 0; u < n_utt; ++u) {
+    nf[u] = frame_count(fs, x_length[u], hopt->frame_period);
+    if (nf[u] > f_stride) fail("f_stride %d too small for %d frames", f_stride, nf[u]);
+  }
+  run_harvest(c, n_utt, fs, d_x, x_stride, x_length, hopt, f_stride, d_tpos, d_f0);
+  run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, dopt, d_sp, d_ap,
+                      RowLayout(), RowLayout());
+}
+
+// ---------------------------------------------------------------------------
 // Harvest + CheapTrick + D4C of one batch straight into packed records (include/world_hip.h: world_hip_analyze_packed)
 // ---------------------------------------------------------------------------
 static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
@@ -935,12 +969,11 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
   }
   double *d_tpos = c->d_pk, *d_f0 = c->d_pk + fr;
   run_harvest(c, n_utt, fs, d_x, x_stride, x_length, hopt, f_stride, d_tpos, d_f0);
-  RowLayout lay;
-  lay.rows = rows.data(); lay.stride = (size_t)cols;
-  run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, d_block + 2, true, lay);
-  lay.rec = d_block;
-  run_d4c(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt->fft_size, dopt, d_block + 2 + nb, true,
-          lay);
+  RowLayout lay_sp, lay_ap;
+  lay_sp.rows = lay_ap.rows = rows.data(); lay_sp.stride = lay_ap.stride = (size_t)cols;
+  lay_ap.rec = d_block;
+  run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, dopt, d_block + 2,
+                      d_block + 2 + nb, lay_sp, lay_ap);
 }
 
 // ---------------------------------------------------------------------------
@@ -1195,6 +1228,16 @@ int world_hip_d4c_batch(WorldHipContext *c, int n_utt, int fs, const double *d_x
                         const double *d_f0, int fft_size, const D4COption *option, double *d_ap) {
   return guarded(c, [&] {
     run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, true);
+  });
+}
+
+int world_hip_analyze_batch(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                            const HarvestOption *harvest_option, const CheapTrickOption *cheaptrick_option,
+                            const D4COption *d4c_option, int f_stride, double *d_tpos, double *d_f0, double *d_spectrogram,
+                            double *d_aperiodicity) {
+  return guarded(c, [&] {
+    run_analyze_dense(c, n_utt, fs, d_x, x_stride, x_length, harvest_option, cheaptrick_option, d4c_option, f_stride, d_tpos,
+                      d_f0, d_spectrogram, d_aperiodicity);
   });
 }
 

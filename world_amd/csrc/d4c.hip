@@ -330,23 +330,56 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   const D4cWin w = d4c_win(p.b.x + (size_t)u * p.b.x_stride, p.b.x_len[u], fs, cf0, p.tpos[fi], kBlackman, 3.0,
                            p.noise + p.offsets1[fi]);
   const D4cWinRot rot0 = d4c_win_rot(w, threadIdx.x, blockDim.x);
-  const double coef = d4c_window_to_lds(w, rot0, Z, scratch);
-  {
-    D4cWinRot rot = rot0;
-    for (int i = threadIdx.x; i < M; i += blockDim.x)
-      rfft_in(Z, i) = i < w.wlen ? rfft_in(Z, i) - d4c_win_next(w, rot) * coef : 0.0;
-  }
   const int b0 = static_cast<int>(ceil(100.0 * M / fs));
   const int b1 = static_cast<int>(ceil(4000.0 * M / fs));
   const int b2 = static_cast<int>(ceil(7900.0 * M / fs));
   double lo = 0.0, hi = 0.0;     // cumulative power (b0, b1] and (b0, b2]   (d4c.cpp:241-249)
-  block_rfft<3, LGN>(Z, lgn, tw, [&](int k, double re, double im) {
+  auto band_power = [&](int k, double re, double im) __attribute__((always_inline)) {
     if (k > b0 && k <= b2) {
-      double pw = re * re + im * im;
+      const double pw = re * re + im * im;
       hi += pw;
       if (k <= b1) lo += pw;
     }
-  });
+  };
+  if constexpr (LGN > 0 && (1 << LGN) == 16 * 256) {
+    // the 48 kHz shape (4096 points on 256 threads = N / 16): the window's samples stay in registers between the two
+    // passes (no LDS round trip, the window evaluated once), the transform's inner stages are wave-local, the merge
+    // twiddles come by rotation, and only the items that can hold a bin <= b2 are merged at all
+    constexpr int T = 256, kPer = (1 << LGN) / T, kItems = ((1 << LGN) / 4 + 1 + T - 1) / T;
+    const int tid = wg_thread<T>();
+    double v[kPer], ww[kPer];
+    double s1 = 0.0, s2 = 0.0;
+    {
+      D4cWinRot rot = rot0;
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        const int i = tid + j * T;
+        v[j] = 0.0; ww[j] = 0.0;
+        if (i < w.wlen) { const D4cSample sm = d4c_sample(w, i, rot); v[j] = sm.v; ww[j] = sm.w; s1 += sm.v; s2 += sm.w; }
+      }
+    }
+    block_sum2<T>(s1, s2, scratch);
+    const double coef = s1 / s2;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) rfft_in(Z, tid + j * T) = v[j] - ww[j] * coef;      // 0 beyond the window
+    constexpr FftPlan plan = make_plan_max(LGN - 1, 3);
+    block_cfft_dif_static<LGN - 1, 3, T>(Z, tw);
+    const cplx wb = twiddle(tw, tid, LGN, -1);
+    const int h = 1 << (LGN - 1);
+    rfft_merge_items_w<kItems, T>(Z, LGN, plan, [&](int m, int) { return mul_w16_fwd(wb, m); },
+                                  [&](int, int k, double ar, double ai, bool paired, double br, double bi) {
+      band_power(k, ar, ai);
+      if (paired) band_power(h - k, br, bi);
+    });
+  } else {
+    const double coef = d4c_window_to_lds(w, rot0, Z, scratch);
+    {
+      D4cWinRot rot = rot0;
+      for (int i = threadIdx.x; i < M; i += blockDim.x)
+        rfft_in(Z, i) = i < w.wlen ? rfft_in(Z, i) - d4c_win_next(w, rot) * coef : 0.0;
+    }
+    block_rfft<3, LGN>(Z, lgn, tw, band_power);
+  }
   block_sum2(lo, hi, scratch);
   if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
 }

@@ -329,7 +329,7 @@ def main():
         last = [None]
 
         def step():
-            last[0] = wd.analyze_sharded(xs, FS, lengths=lengths, analyze_packed=wh.analyze_packed, sub_batch=args.sub_batch,
+            last[0] = wd.analyze_sharded(xs, FS, lengths=lengths, packer=wh, sub_batch=args.sub_batch,
                                          gather=not args.no_gather, timings=phases)
 
         for _ in range(max(1, args.warmup)):
@@ -514,8 +514,7 @@ def main():
         phases = {}
 
         def step():
-            return wd.analyze_sharded(xs_job, FS, lengths=lengths, analyze_packed=whj.analyze_packed, sub_batch=args.sub_batch,
-                                      timings=phases)
+            return wd.analyze_sharded(xs_job, FS, lengths=lengths, packer=whj, sub_batch=args.sub_batch, timings=phases)
         res = step()
         phases.clear()
         torch.cuda.synchronize()
@@ -545,6 +544,7 @@ def main():
                "result_bytes": frames * (2 + 2 * (FFT_SIZE // 2 + 1)) * 8, "workspace_bytes": whj.workspace_bytes()}
         whj.close()
         wd._buffers.clear()
+        wd._lanes.clear()
         del xs_job, res
         torch.cuda.empty_cache()
         return leg

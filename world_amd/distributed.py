@@ -132,6 +132,20 @@ def _default_analyzer():
     return _analyzers[device]
 
 
+_lanes = {}
+
+
+def _default_lanes(packer=None):
+    """two (stream, analyze_packed) lanes per device and process: the caller's analyser (or the default one) and a second
+    library context, each bound to its own stream"""
+    device = torch.cuda.current_device()
+    key = (device, id(packer))
+    if key not in _lanes:
+        wh = packer or _default_analyzer()             # a WorldHip keeps one library context per stream it is used on
+        _lanes[key] = [(torch.cuda.Stream(device=device), wh.analyze_packed), (torch.cuda.Stream(device=device), wh.analyze_packed)]
+    return _lanes[key]
+
+
 def _store_records(packer, tpos, f0, sp, ap, nf, block):
     """records of one batched analysis into block[0:]: the library's kernel on the GPU, indexing on CPU tensors"""
     nb = sp.shape[-1]
@@ -147,7 +161,7 @@ def _store_records(packer, tpos, f0, sp, ap, nf, block):
 
 
 def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, lengths=None, sub_batch=32, gather=True,
-                    timings=None, packer=None, bins=None, analyze_packed=None, **options):
+                    timings=None, packer=None, bins=None, analyze_packed=None, lanes=None, **options):
     """The whole multi-GPU recipe in one call (BASELINE configs[3]).
 
     x_list   every utterance of the job as a 1-D float64 tensor: a list (the same on every rank), or -- with
@@ -158,6 +172,10 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
     analyze  alternative for callers without a packed analysis (the CPU tests): (x, fs, x_len=..., frame_period=...,
              **options) -> (tpos, f0, sp, ap, n_frames); its dense results are packed by `packer` / on the host.
     sub_batch  utterances per chunk = per batched call AND per all-gather (chunk k's exchange overlaps chunk k+1's compute)
+    lanes    list of (torch.cuda.Stream, analyze_packed) pairs: consecutive chunks alternate between them, so that the serial
+             tail of one chunk's analysis (Harvest's contour kernels run one wavefront per utterance: a quarter of a
+             32-utterance chunk's time with the chip nearly idle) overlaps the wide kernels of the next chunk.  Default on a
+             GPU: two lanes, each with its own library context.
     bins     spectrogram bins per frame (default: fft/2+1 of fs)
     timings  optional dict, accumulates: "compute_ms" (host wall clock of the analysis calls, device synchronised at the
              end), "exchange_exposed_ms" (device time the compute stream spent waiting for all-gathers after its last
@@ -180,6 +198,10 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
         return ShardedResult([], {}, [], nb)
     if analyze is None and analyze_packed is None:
         analyze_packed = (packer or _default_analyzer()).analyze_packed
+        if lanes is None and device.type == "cuda":
+            lanes = _default_lanes(packer)
+    if lanes is not None and not lanes:
+        lanes = None
     parts = partition(lengths, world)
     chunks = chunks_of(parts, sub_batch)
     rows = [[sum(n_frames[i] for i in c[r]) for r in range(world)] for c in chunks]
@@ -204,7 +226,12 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     works = []
-    for k, c in enumerate(chunks):
+    caller = torch.cuda.current_stream(device) if (lanes and cuda) else None
+    if lanes:
+        for st, _ in lanes:
+            st.wait_stream(caller)                     # the inputs were produced in the caller's stream order
+
+    def one_chunk(k, c, run_packed):
         idx = c[rank]
         block = bufs[k][me]
         if idx:
@@ -212,13 +239,24 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
             for j, i in enumerate(idx):
                 xb[j, :lengths[i]] = x_list[i].to(device)
             xl = [lengths[i] for i in idx]
-            if analyze_packed is not None:
-                analyze_packed(xb, fs, block, x_len=xl, frame_period=frame_period, **options)
+            if run_packed is not None:
+                run_packed(xb, fs, block, x_len=xl, frame_period=frame_period, **options)
             else:
                 tpos, f0, sp, ap, _ = analyze(xb, fs, x_len=xl, frame_period=frame_period, **options)
                 _store_records(packer, tpos, f0, sp, ap, [n_frames[i] for i in idx], block)
         if exchange:
             works.append(_gather_in_place(bufs[k], rank, group, True))     # in flight while the next chunk is analysed
+
+    for k, c in enumerate(chunks):
+        if lanes:
+            st, run = lanes[k % len(lanes)]
+            with torch.cuda.stream(st):
+                one_chunk(k, c, run)
+        else:
+            one_chunk(k, c, analyze_packed)
+    if lanes:
+        for st, _ in lanes:
+            caller.wait_stream(st)                     # the results are complete in the caller's stream order
     ev0 = ev1 = None
     if timings is not None and cuda:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

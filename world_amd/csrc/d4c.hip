@@ -11,15 +11,14 @@
 // per-frame draw counts (d4c_prepare1 / d4c_prepare2) and GF(2) jump-ahead.
 //
 //   d4c_lovetrain : 256-thread workgroup per frame, one r2c FFT, two band sums.
-//   d4c_frame     : one workgroup per selected frame, N/16 threads, one N-point real
-//                   transform buffer in LDS, every spectrum in registers: 4 centroid
-//                   transforms, 1 power spectrum, 2 DC corrections, 3 rectangular
-//                   smoothings (block-parallel prefix sums) -> static group delay ->
-//                   per 3 kHz band: Nuttall-windowed slice -> r2c FFT -> power ->
-//                   radix select in registers replacing the reference's std::sort
-//                   (only the sum of the N/2-boundary smallest powers is used) -> one
-//                   coarse aperiodicity value.  Nothing but that value leaves the CU.
-//   d4c_finish    : the 3 kHz-grid interpolation, every row written once to HBM.
+//   d4c_frame     : one workgroup per selected frame, N/16 threads, one transform buffer of N doubles in LDS: each
+//                   centroid position as ONE packed complex transform (two N/2-point halves, Im(P Q)/2 per bin),
+//                   1 power spectrum, 2 DC corrections, 3 rectangular smoothings (block-parallel prefix sums) ->
+//                   static group delay -> per 3 kHz band: Nuttall-windowed slice -> r2c FFT -> power -> radix select
+//                   in registers replacing the reference's std::sort (only the sum of the N/2-boundary smallest
+//                   powers is used) -> the band's two sums.  Nothing but those leaves the CU.
+//   d4c_finish    : the bands' dB values and the 3 kHz-grid interpolation; every row written once to HBM, dense or
+//                   straight into packed records.
 #include "stage_params.h"
 #include "trace.h"
 WH_TRACE_DEFINE(d4c)
@@ -476,7 +475,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   const uint32_t *noise = p.noise + p.offsets2[fi];
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
-  constexpr bool kParkInLds = true;                                    // centroid sum, then the group delay: N/2 + 1 doubles behind the twiddle table
   double *park = scratch + 64 + twiddle_lds_doubles(lgn - D4C_TW_LEVEL);
   const double inv_n = 1.0 / N;
 
@@ -676,16 +674,9 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   WH_STAMP(32, 14);
   D4C_FRESH_TID();
   smooth(A, for_pair, cf0, B, for_pair);
-  // The group delay waits in LDS behind the twiddle table (natural bin order, N/2 + 1 doubles) where three workgroups
-  // per CU leave room: the band transforms below read their slices from there -- no staging pass, two barriers fewer
-  // per band.  The 8192-point shape has no such room and keeps it in registers.
-  double G[kParkInLds ? 1 : kBins];
-  if constexpr (kParkInLds) {
-    for_pair([&](int slot, int k) { park[k] = A[slot] - B[slot]; });
-  } else {
-#pragma unroll
-    for (int e = 0; e < kBins; ++e) G[e] = A[e] - B[e];
-  }
+  // The group delay takes the centroid sum's place in `park` (natural bin order, N/2 + 1 doubles): the band transforms
+  // below read their slices from there -- no staging pass, and nothing bin-indexed in registers through the hottest loop.
+  for_pair([&](int slot, int k) { park[k] = A[slot] - B[slot]; });
   WH_STAMP(32, 15);
 
   // ---- GetCoarseAperiodicity (d4c.cpp:194-225) per 3 kHz band ------------------
@@ -701,26 +692,16 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     const int lo_k = static_cast<int>(3000.0 * (band + 1) * N / fs) - hwl;
     D4C_FRESH_TID();
     __syncthreads();                                    // the previous band's histograms are done (first band: park is written)
-    if constexpr (!kParkInLds) {
-      for_pair([&](int slot, int k) { const int i = k - lo_k; if (i >= 0 && i < wl) Zr[i] = G[slot] * p.nuttall[i]; });
-      __syncthreads();
-    }
-    // First DIF stage with every input beyond element nz known to be zero.  A slice staged in Z sits in the buffer
-    // the stage writes, so a butterfly's inputs are fetched before anybody writes.
+    // First DIF stage with every input beyond element nz known to be zero: the slice comes straight from `park`.
     auto slice = [&](int n) {
       cplx v;
-      if constexpr (kParkInLds) {
-        const double *g = park + lo_k + 2 * n;
-        if (n == tid) {
-          v.re = g[0] * nut0;
-          v.im = 2 * n + 1 < wl ? g[1] * nut1 : 0.0;
-        } else {
-          v.re = g[0] * p.nuttall[2 * n];
-          v.im = 2 * n + 1 < wl ? g[1] * p.nuttall[2 * n + 1] : 0.0;
-        }
+      const double *g = park + lo_k + 2 * n;
+      if (n == tid) {
+        v.re = g[0] * nut0;
+        v.im = 2 * n + 1 < wl ? g[1] * nut1 : 0.0;
       } else {
-        v.re = Zr[2 * n];
-        v.im = 2 * n + 1 < wl ? Zr[2 * n + 1] : 0.0;
+        v.re = g[0] * p.nuttall[2 * n];
+        v.im = 2 * n + 1 < wl ? g[1] * p.nuttall[2 * n + 1] : 0.0;
       }
       return v;
     };
@@ -738,7 +719,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       const bool single = tid + qq >= nz;
 #pragma unroll
       for (int r = 0; r < R; ++r) { cplx z0; z0.re = 0.0; z0.im = 0.0; a[r] = tid + r * qq < nz ? slice(tid + r * qq) : z0; }
-      if constexpr (!kParkInLds) __syncthreads();
       if (single) {
 #pragma unroll
         for (int r = 1; r < R; ++r) a[r] = a[0];         // DFT of a delta

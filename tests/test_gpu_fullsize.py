@@ -259,6 +259,27 @@ def test_sixty_second_utterance(wh, ref, pool):
     wh.close()
 
 
+def test_voiced_section_longer_than_the_lds_is_smoothed_out_of_hbm(wh, ref):
+    """SmoothF0Contour filters a voiced section in LDS when it fits (up to 18 540 base frames); a steady 24 s tone is one
+    section of ~24 000 and takes the HBM route of hc_smooth -- same contour as the reference either way"""
+    import torch
+    fs, dur = 16000, 24.0
+    t = np.arange(int(fs * dur)) / fs
+    f0_true = 150.0 + 6.0 * np.sin(2 * np.pi * 0.31 * t)
+    ph = 2 * np.pi * np.cumsum(f0_true) / fs
+    x = sum(np.sin(k * ph) / k for k in range(1, 9)) * 0.2
+    x = np.round(x * 32768.0) / 32768.0
+    tp_r, f0_r = ref.harvest(x, fs)
+    voiced = f0_r > 0
+    runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], voiced.astype(np.int8), [0]]))))[::2]
+    assert runs.max() * 5 > 18540, "the tone must stay voiced long enough to leave the LDS route"
+    tpos, f0, nf = wh.harvest(torch.from_numpy(x).cuda().unsqueeze(0), fs)
+    torch.cuda.synchronize()
+    n = len(f0_r)
+    assert int(nf[0]) == n and np.array_equal(tpos[0, :n].cpu().numpy(), tp_r)
+    assert_f0_close(f0[0, :n].cpu().numpy(), f0_r, what="24 s tone f0")
+
+
 def test_bench_multi_rank_path_on_one_gpu():
     """bench.py --gpus 2 end to end (the SCALE run's code path): two ranks share this box's one GPU, the all-gather
     goes through gloo with host staging (a functional check, never a number of record): partition, batched analysis

@@ -63,6 +63,24 @@ __device__ __forceinline__ double fast_div(double a, double b) {
 #endif
 }
 
+// A value passed through keep() counts as used where it is computed: the compiler's sinking pass cannot move its
+// arithmetic down to a later (conditional) use.
+__device__ __forceinline__ double keep(double v) {
+#ifndef WORLD_EMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
+// Nothing is scheduled across this point.  A wavefront issues in order; where a serial recurrence is followed by
+// independent work on its results, the fence keeps the compiler from weaving that work (and its own dependent
+// latencies) back between the recurrence's steps.
+__device__ __forceinline__ void sched_fence() {
+#ifndef WORLD_EMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // NuttallWindow(), src/common.cpp:113-121
 __device__ __forceinline__ double nuttall_at(int i, int len) {
   double t = i / (len - 1.0);

@@ -402,12 +402,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
 // arithmetic of the unconditional items below that branch, next to their first use, while the LDS loads that feed it
 // stay put -- dozens of loaded values wait in registers and spill.  A value passed through keep() is "used" where
 // it is computed, so its arithmetic stays in front of the branch.
-__device__ __forceinline__ double keep(double v) {
-#ifndef WORLD_EMU
-  asm volatile("" : "+v"(v));
-#endif
-  return v;
-}
+// (keep() itself lives in common.h)
 #ifndef WORLD_EMU
 #define D4C_FRESH_TID() do { asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0 && tid < T); } while (0)
 #else

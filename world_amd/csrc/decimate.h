@@ -47,29 +47,29 @@ inline IirCoef decimate_coef(int r) {
   return c;
 }
 
-// sample j of the signal the reference feeds to FilterForDecimate: x edge-padded by
-// `lag` on both sides (Harvest, harvest.cpp:50-59; lag = 0 for DIO) and then
-// reflect-padded by kNFact (matlabfunctions.cpp:183-186).
-__device__ __forceinline__ double dec_padded(const double *x, int n, int lag, int j) {
-  const int m = n + 2 * lag;                    // length handed to decimate()
-  auto px = [&](int i) { return x[imin(n - 1, imax(0, i - lag))]; };
-  if (j < kDecPad) return 2 * px(0) - px(kDecPad - j);
-  if (j >= kDecPad + m) return 2 * px(m - 1) - px(m - 2 - (j - (kDecPad + m)));
-  return px(j - kDecPad);
-}
+// The signal the reference feeds to FilterForDecimate is x edge-padded by `lag` on both sides (Harvest,
+// harvest.cpp:50-59; lag = 0 for DIO) -- px(i) = x[clamp(i - lag)], m = n + 2 lag samples -- and then reflect-padded
+// by kNFact (matlabfunctions.cpp:183-186): padded[j] = 2 px(0) - px(9 - j) for j < 9, px(j - 9) in the middle and
+// 2 px(m-1) - px(m - 2 - (j - (9 + m))) beyond.  dec_forward_block() builds it while staging.
 
 // One step of the 3rd-order recurrence w[n] = in + a0 w[n-1] + a1 w[n-2] + a2 w[n-3] (FilterForDecimate,
 // matlabfunctions.cpp:115-125).  The terms that do not involve w[n-1] are summed first, so the
 // dependent chain from one step to the next is a single FMA (a dependent FP64 op issues every 36
 // cycles on gfx950; left-to-right evaluation would put four of them on the chain).  The different
 // association moves the filtered signal by ~1e-16 relative.
-__device__ __forceinline__ double iir_step(const IirCoef &c, double in, double &w0, double &w1, double &w2) {
+__device__ __forceinline__ void iir_advance(const IirCoef &c, double in, double &w0, double &w1, double &w2) {
   const double t = fma(c.a2, w2, fma(c.a1, w1, in));
   const double wt = fma(c.a0, w0, t);
-  const double out = c.b0 * wt + c.b1 * w0 + c.b1 * w1 + c.b0 * w2;
   w2 = w1; w1 = w0; w0 = wt;
-  return out;
 }
+// the filter's four taps on the recursion's state: wt = w[n], then w[n-1], w[n-2], w[n-3]
+__device__ __forceinline__ double iir_taps(const IirCoef &c, double wt, double w0, double w1, double w2) {
+  return c.b0 * wt + c.b1 * w0 + c.b1 * w1 + c.b0 * w2;
+}
+// A wavefront issues in order, so the taps (three dependent additions) written between two steps of the recursion
+// would hold the next step back by their own latency.  Both sweeps therefore run the recursion alone over the
+// warm-up (whose outputs nobody needs) and over the chunk, keeping the chunk's states in registers, and evaluate the
+// taps afterwards as kDecChunk independent expressions.
 
 // forward sweep over the padded signal of length n + 2*lag + 18: one workgroup
 // stages its span (+ warm-up) in LDS with coalesced loads, then every thread runs
@@ -81,25 +81,52 @@ __device__ __forceinline__ void dec_forward_block(const double *x, int n, int la
   if (b0 >= total) return;
   const int lo = b0 - warm;                              // stage[k] = padded[lo + k]
   const int cnt = imin(total, b0 + kDecSpan) - lo;
-  for (int k = threadIdx.x; k < cnt; k += blockDim.x) stage[dec_pad(k)] = lo + k >= 0 ? dec_padded(x, n, lag, lo + k) : 0.0;
+  {
+    // kDecBatch loads in flight per thread (one load waited for per trip made staging the longest part of the kernel);
+    // dec_padded() without branches: every sample is x[src] or, in the reflected edges, 2 * end - x[src]
+    const int m = n + 2 * lag, nt = (int)blockDim.x;
+    const double head = x[0], tail = x[n - 1];
+    for (int k0 = threadIdx.x; k0 < cnt; k0 += kDecBatch * nt) {
+      double v[kDecBatch];
+#pragma unroll
+      for (int q = 0; q < kDecBatch; ++q) {
+        const int j = imax(0, imin(total - 1, lo + k0 + q * nt));
+        const int i = j < kDecPad ? kDecPad - j : (j >= kDecPad + m ? m - 2 - (j - (kDecPad + m)) : j - kDecPad);
+        v[q] = x[imin(n - 1, imax(0, i - lag))];
+      }
+#pragma unroll
+      for (int q = 0; q < kDecBatch; ++q) {
+        const int k = k0 + q * nt, j = lo + k;
+        if (k < cnt) stage[dec_pad(k)] = j < 0 ? 0.0 : (j < kDecPad ? 2 * head - v[q] : (j >= kDecPad + m ? 2 * tail - v[q] : v[q]));
+      }
+    }
+  }
   __syncthreads();
   for (int t = threadIdx.x; t < kDecThreads; t += blockDim.x) {
     const int c0 = b0 + t * kDecChunk;
     if (c0 >= total) break;
     const int c1 = imin(total, c0 + kDecChunk);
     double w0 = 0, w1 = 0, w2 = 0;
-    for (int j0 = imax(0, c0 - warm); j0 < c1; j0 += kDecBatch) {
+    // c0 and the warm-up lengths are multiples of kDecBatch: the warm-up runs in whole batches
+    for (int j0 = imax(0, c0 - warm); j0 < c0; j0 += kDecBatch) {
       double v[kDecBatch];
 #pragma unroll
-      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 + q < c1 ? stage[dec_pad(j0 + q - lo)] : 0.0;
+      for (int q = 0; q < kDecBatch; ++q) v[q] = stage[dec_pad(j0 + q - lo)];
 #pragma unroll
-      for (int q = 0; q < kDecBatch; ++q) {
-        const int j = j0 + q;
-        if (j >= c1) break;
-        double out = iir_step(c, v[q], w0, w1, w2);
-        if (j >= c0) fwd[j] = out;
-      }
+      for (int q = 0; q < kDecBatch; ++q) iir_advance(c, v[q], w0, w1, w2);
     }
+    double w[kDecChunk + 3];
+    w[0] = w2; w[1] = w1; w[2] = w0;
+#pragma unroll
+    for (int q = 0; q < kDecChunk; ++q) {
+      const double v = stage[dec_pad(imin(c0 + q, c1 - 1) - lo)];
+      iir_advance(c, v, w0, w1, w2);
+      w[q + 3] = keep(w0);           // pinned here: the taps below must not pull the recursion down to them
+    }
+    sched_fence();
+#pragma unroll
+    for (int q = 0; q < kDecChunk; ++q)
+      if (c0 + q < c1) fwd[c0 + q] = iir_taps(c, w[q + 3], w[q + 2], w[q + 1], w[q]);
   }
 }
 
@@ -115,28 +142,54 @@ __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int
   const int b0 = block * kDecSpan;
   if (b0 >= total) return;
   const int hi = imin(total, b0 + kDecSpan + warm);      // stage[k] = fwd[b0 + k], k < hi - b0
-  for (int k = threadIdx.x; k < hi - b0; k += blockDim.x) stage[dec_pad(k)] = fwd[b0 + k];
+  {
+    const int cnt = hi - b0, nt = (int)blockDim.x;
+    for (int k0 = threadIdx.x; k0 < cnt; k0 += kDecBatch * nt) {      // kDecBatch loads in flight per thread
+      double v[kDecBatch];
+#pragma unroll
+      for (int q = 0; q < kDecBatch; ++q) v[q] = fwd[b0 + imin(cnt - 1, k0 + q * nt)];
+#pragma unroll
+      for (int q = 0; q < kDecBatch; ++q) if (k0 + q * nt < cnt) stage[dec_pad(k0 + q * nt)] = v[q];
+    }
+  }
   __syncthreads();
   for (int t = threadIdx.x; t < kDecThreads; t += blockDim.x) {
     const int c0 = b0 + t * kDecChunk;
     if (c0 >= total) break;
     const int c1 = imin(total, c0 + kDecChunk);
     double w0 = 0, w1 = 0, w2 = 0;
-    for (int j0 = imin(total - 1, c1 - 1 + warm); j0 >= c0; j0 -= kDecBatch) {
+    // warm-up from the far end down to c1: the signal's end cuts it to any length, so the odd steps go first
+    int j = imin(total - 1, c1 - 1 + warm);
+    for (int odd = (j - c1 + 1) % kDecBatch; odd > 0; --odd, --j) iir_advance(c, stage[dec_pad(j - b0)], w0, w1, w2);
+    for (; j >= c1; j -= kDecBatch) {
       double v[kDecBatch];
 #pragma unroll
-      for (int q = 0; q < kDecBatch; ++q) v[q] = j0 - q >= c0 ? stage[dec_pad(j0 - q - b0)] : 0.0;
+      for (int q = 0; q < kDecBatch; ++q) v[q] = stage[dec_pad(j - q - b0)];
 #pragma unroll
-      for (int q = 0; q < kDecBatch; ++q) {
-        const int j = j0 - q;
-        if (j < c0) break;
-        double g = iir_step(c, v[q], w0, w1, w2);
-        int d = j - first;
-        if (j < c1 && d >= 0 && d % r == 0 && nbeg + d < m + kDecPad) {   // loop bound of matlabfunctions.cpp:199
-          int k = d / r - skip;
-          if (k >= 0 && k < out_len) out[k] = g;
-        }
+      for (int q = 0; q < kDecBatch; ++q) iir_advance(c, v[q], w0, w1, w2);
+    }
+    double w[kDecChunk + 3];                      // w[q + 3] = state after the step at sample c1 - 1 - q
+    w[0] = w2; w[1] = w1; w[2] = w0;
+#pragma unroll
+    for (int q = 0; q < kDecChunk; ++q) {
+      const double v = stage[dec_pad(imax(c1 - 1 - q, c0) - b0)];
+      iir_advance(c, v, w0, w1, w2);
+      w[q + 3] = keep(w0);           // pinned here: the taps below must not pull the recursion down to them
+    }
+    // the decimated samples among c1-1 .. c0: d = sample - first runs down from d0; its remainder and quotient by r
+    // are carried instead of divided out 32 times
+    sched_fence();
+    const int d0 = c1 - 1 - first;
+    if (d0 < 0) continue;
+    int rem = d0 % r, quo = d0 / r;
+#pragma unroll
+    for (int q = 0; q < kDecChunk; ++q) {
+      const int d = d0 - q;
+      if (c1 - 1 - q >= c0 && d >= 0 && rem == 0 && nbeg + d < m + kDecPad) {   // loop bound of matlabfunctions.cpp:199
+        const int k = quo - skip;
+        if (k >= 0 && k < out_len) out[k] = iir_taps(c, w[q + 3], w[q + 2], w[q + 1], w[q]);
       }
+      if (rem == 0) { rem = r - 1; --quo; } else { --rem; }
     }
   }
 }

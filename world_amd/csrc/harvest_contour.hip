@@ -465,82 +465,156 @@ __global__ void hc_step4(HarvestParams p) {
 constexpr int kSmoothTail = 300;
 // One wavefront per voiced section; every lane filters one chunk of the section,
 // warmed up over the kSmoothTail samples before it (same convergence argument).
-constexpr int kSmoothLds = 3584;        // doubles of LDS per wavefront: sections up to 1642 frames filter out of LDS
-__global__ void hc_smooth(HarvestParams p) {
+//
+// The sweeps are bound by instruction issue, not by the recurrence: a dependent FP64 FMA follows its producer after
+// ~6 cycles and a wave64 FP64 instruction occupies the SIMD for 4 (tools/probe/fp64_chain.hip), so a step costs what
+// stands between two of them.  Hence
+//   * each sweep runs the recursion alone (w[n] = v[n] + a0 w[n-1] + a1 w[n-2], the a1 term folded into the input a
+//     step ahead: two FMAs per step), parks w[n], and applies the three taps (y = b0 w[n] + b1 w[n-1] + b0 w[n-2]) in
+//     a second loop -- the operations and their order are those of a fused sweep, so the output is bit-identical;
+//   * every lane runs the same trip counts (no bounds test per step);
+//   * the staged section carries its held end values with it, so a sample is one LDS load with no index clamping:
+//       buf[0 .. 300) = first, buf[300 .. 300 + len) = section, then `last` up to 300 + len + 600 + kSmoothSlack;
+//     sample j of the held signal is buf[j + 300].
+// The section is filtered IN PLACE in that buffer -- input, forward state, forward output, backward state.  That is
+// safe because the lanes of a wavefront run in lockstep: at step s of a sweep every lane stands s samples into its own
+// stretch, so a lane above (forward; below, backward) has read any sample of this lane's chunk at an earlier step
+// than the one this lane overwrites it at, and within a batch all loads are issued before the first store.
+// A section that does not fit the LDS the launch reserved is filtered out of HBM with clamped indices.
+constexpr int kSmoothSlack = 16;        // loads run up to a batch past the last step of a sweep
+constexpr int kSmoothLdsMax = 19456;    // doubles: 152 of the CU's 160 KB, i.e. sections up to 18 540 frames
+constexpr int kSmoothBlocks = 64;       // wavefronts launched per utterance; they stride over its sections
+__global__ void hc_smooth(HarvestParams p, int lds_doubles) {
   DYN_LDS(lds);
-  const int k = wave_item_x(), u = blockIdx.y;
-  if (k >= p.sec_n[u * 2]) return;
+  const int u = blockIdx.y;
+  const int ns = p.sec_n[u * 2];
   const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345;
   const double a0 = 1.7347257688092754, a1 = -0.76600660094326412;
   const double dc = 1.0 / (1.0 - a0 - a1);             // state of the recursion at rest on a constant 1
   const int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
-  const int st = sec[k], ed = sec[p.sec_cap + k];
   const double *in = hc_row(p.c0, p, u);
-  double *tmp = p.ext + (size_t)u * p.ext_cap + sec[4 * p.sec_cap + k];   // ed-st+1+kSmoothTail
   double *out = hc_row(p.basic_f0, p, u);
-  const int len = ed - st + 1, total = len + kSmoothTail;
-  const int chunk = (total + WAVE - 1) / WAVE;
-  const int j0 = lane_id() * chunk, j1 = imin(total, j0 + chunk);
-  const double first = in[st], last = in[ed];
-  constexpr int kBatch = 8;              // inputs fetched together ahead of the serial recurrence
-  // both sweeps, reading the section from xs[0 .. len) and keeping the forward sweep's output in ts[0 .. total)
-  auto sweeps = [&](auto xs, auto ts) __attribute__((always_inline)) {
-    // forward sweep: the section with its end values held on both sides
-    {
-      auto xin = [&](int j) { return j < 0 ? first : (j < len ? xs[j] : last); };
-      int j = j0 - kSmoothTail;
-      double w0 = xin(j) * dc, w1 = w0;
-      for (; j < j1; j += kBatch) {
-        double v[kBatch];
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) v[q] = j + q < j1 ? xin(j + q) : 0.0;
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-          if (j + q >= j1) break;
-          double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
-          double y = b0 * wt + b1 * w0 + b0 * w1;
-          w1 = w0; w0 = wt;
-          if (j + q >= j0) ts[j + q] = y;
-        }
-      }
-    }
-    wave_sync();
-    // backward sweep over the forward output (which has settled on `last` beyond the tail)
-    {
-      auto tin = [&](int j) { return j >= total ? last : ts[j]; };
-      int j = j1 - 1 + kSmoothTail;
-      double w0 = tin(j) * dc, w1 = w0;
-      for (; j >= j0; j -= kBatch) {
-        double v[kBatch];
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) v[q] = j - q >= j0 ? tin(j - q) : 0.0;
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-          if (j - q < j0) break;
-          double wt = fma(a0, w0, fma(a1, w1, v[q]));   // one dependent FMA per step (w1 is a step old)
-          double y = b0 * wt + b1 * w0 + b0 * w1;
-          w1 = w0; w0 = wt;
-          if (j - q < j1 && j - q < len) out[st + j - q] = y;
-        }
-      }
-    }
+  constexpr int kBatch = 10;             // inputs fetched together ahead of the recurrence; divides kSmoothTail
+  static_assert(kSmoothTail % kBatch == 0, "the warm-up runs in whole batches");
+  static_assert(kSmoothSlack > kBatch, "look-ahead loads stay inside the buffer");
+  // Loads run past a lane's chunk (surplus steps of the whole batches, look-ahead) by at most kBatch + kSmoothSlack
+  // samples at the top and, walking down, by no more than a chunk below sample 0: inside the held ends either way.
+  // One step: `t` arrives holding a1 w[n-2] + v[n]; leaves holding a1 w[n-1] + v[n+1].
+  auto step = [&](double &w0, double &w1, double &t, double vnext) __attribute__((always_inline)) {
+    const double wt = fma(a0, w0, t);
+    t = fma(a1, w0, vnext);
+    w1 = w0; w0 = wt;
   };
-  // Every batch of the recurrences waits for its inputs: out of HBM that is a microsecond per 8 steps (74 us for
-  // the sections of a 10 s utterance).  A section of ordinary length is staged in LDS once (input, then the forward
-  // sweep's output behind it) and filtered with LDS loads; longer ones keep working from HBM.
-  if (2 * len + kSmoothTail <= kSmoothLds) {
-    LDS_PTR(double) mine = (LDS_PTR(double))(reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * kSmoothLds);
-    for (int i0 = lane_id(); i0 < len; i0 += kBatch * WAVE) {     // kBatch loads in flight per lane
-      double v[kBatch];
+  for (int k = wave_item_x(); k < ns; k += (int)gridDim.x * waves_per_block()) {
+    const int st = sec[k], ed = sec[p.sec_cap + k];
+    double *tmp = p.ext + (size_t)u * p.ext_cap + sec[4 * p.sec_cap + k];   // ed-st+1+kSmoothTail
+    const int len = ed - st + 1, total = len + kSmoothTail;
+    // an odd chunk: at any step the lanes stand `chunk` doubles apart, and an odd stride spreads them over all LDS banks
+    const int chunk = ((total + WAVE - 1) / WAVE) | 1;
+    const int steps = (chunk + kBatch - 1) / kBatch * kBatch;          // the same trip count in every lane
+    const int j0 = lane_id() * chunk, j1 = imin(total, j0 + chunk);    // (the topmost lanes may own nothing: j1 <= j0)
+    const double first = in[st], last = in[ed];
+    // both sweeps: xin(j) = held input, tin(j) = forward output with `last` beyond it, ts[0 .. total) = where the forward
+    // state and then output go, ws[0 .. len) = where the backward state goes and wload(j) reads it back
+    auto sweeps = [&](auto xin, auto tin, auto ts, auto ws, auto wload) __attribute__((always_inline)) {
+      {
+        int j = j0 - kSmoothTail;
+        double w0 = xin(j) * dc, w1 = w0;
+        double t = fma(a1, w1, xin(j));
+        for (int s = 0; s < kSmoothTail; s += kBatch, j += kBatch) {        // warm-up: nothing is kept
+          double v[kBatch];
 #pragma unroll
-      for (int q = 0; q < kBatch; ++q) v[q] = i0 + q * WAVE < len ? in[st + i0 + q * WAVE] : 0.0;
+          for (int q = 0; q < kBatch; ++q) v[q] = xin(j + q + 1);
 #pragma unroll
-      for (int q = 0; q < kBatch; ++q) if (i0 + q * WAVE < len) mine[i0 + q * WAVE] = v[q];
+          for (int q = 0; q < kBatch; ++q) step(w0, w1, t, v[q]);
+        }
+        double p1 = w0, p2 = w1;                                            // w[j0-1], w[j0-2]
+        for (int s = 0; s < steps; s += kBatch, j += kBatch) {              // the lane's chunk: w[j] parked in ts[j]
+          double v[kBatch];
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) v[q] = xin(j + q + 1);
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) {
+            step(w0, w1, t, v[q]);
+            if (j + q < j1) ts[j + q] = w0;
+          }
+        }
+        for (int s = 0, i = j0; s < steps; s += kBatch, i += kBatch) {     // three taps, in place, a batch of loads at a time
+          double wv[kBatch];
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) wv[q] = tin(i + q);
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) {
+            const double y = b0 * wv[q] + b1 * p1 + b0 * p2;
+            p2 = p1; p1 = wv[q];
+            if (i + q < j1) ts[i + q] = y;
+          }
+        }
+      }
+      wave_sync();
+      // backward sweep over the forward output (which has settled on `last` beyond the tail)
+      {
+        int j = j1 - 1 + kSmoothTail;
+        double w0 = tin(j) * dc, w1 = w0;
+        double t = fma(a1, w1, tin(j));
+        for (int s = 0; s < kSmoothTail; s += kBatch, j -= kBatch) {
+          double v[kBatch];
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) v[q] = tin(j - q - 1);
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) step(w0, w1, t, v[q]);
+        }
+        // frames of the chunk at and beyond len are not output, but the recursion runs through them: the taps of the
+        // topmost output frame read the state it left
+        const int top = imin(j1, len);
+        double p1 = 0, p2 = 0;
+        for (int s = 0; s < steps; s += kBatch, j -= kBatch) {              // steps below j0 are surplus and not kept
+          double v[kBatch];
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) v[q] = tin(j - q - 1);
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) {
+            if (j - q == top - 1) { p1 = w0; p2 = w1; }                     // w[top], w[top+1]
+            step(w0, w1, t, v[q]);
+            if (j - q >= j0 && j - q < top) ws[j - q] = w0;
+          }
+        }
+        for (int s = 0, i = top - 1; s < steps; s += kBatch, i -= kBatch) {
+          double wv[kBatch];
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) wv[q] = wload(i - q);
+#pragma unroll
+          for (int q = 0; q < kBatch; ++q) {
+            const double y = b0 * wv[q] + b1 * p1 + b0 * p2;
+            p2 = p1; p1 = wv[q];
+            if (i - q >= j0) out[st + i - q] = y;
+          }
+        }
+      }
+    };
+    const int need = total + 2 * kSmoothTail + kSmoothSlack;
+    if (need <= lds_doubles) {
+      LDS_PTR(double) buf = (LDS_PTR(double))(reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * lds_doubles);
+      LDS_PTR(double) held = buf + kSmoothTail;                       // held[j] = sample j
+      for (int i0 = lane_id(); i0 < len; i0 += kBatch * WAVE) {     // kBatch loads in flight per lane
+        double v[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) v[q] = i0 + q * WAVE < len ? in[st + i0 + q * WAVE] : 0.0;
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) if (i0 + q * WAVE < len) held[i0 + q * WAVE] = v[q];
+      }
+      for (int i = lane_id(); i < kSmoothTail; i += WAVE) buf[i] = first;
+      for (int i = len + lane_id(); i < need - kSmoothTail; i += WAVE) held[i] = last;
+      wave_sync();
+      auto at = [&](int j) { return held[j]; };       // -kSmoothTail <= j < total + kSmoothTail + kSmoothSlack in both sweeps
+      sweeps(at, at, held, held, at);
+      wave_sync();                                                   // the next section reuses the buffer
+    } else {
+      auto xin = [&](int j) { const double v = in[st + imin(len - 1, imax(0, j))]; return j < 0 ? first : (j >= len ? last : v); };
+      auto tin = [&](int j) { const double v = tmp[imin(total - 1, imax(0, j))]; return j >= total ? last : v; };
+      auto wload = [&](int j) { return out[st + imin(len - 1, imax(0, j))]; };
+      sweeps(xin, tin, tmp, out + st, wload);
     }
-    wave_sync();
-    sweeps(mine, mine + len);
-  } else {
-    sweeps(in + st, tmp);
   }
 }
 
@@ -572,7 +646,9 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   SecArgs a4 = {p.c0, 0, kSmoothTail};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a4);
   devrt::dzero(p.basic_f0, row_bytes, stream);
-  WH_WAVES(hc_smooth, p.sec_cap, B, 1, kSmoothLds * sizeof(double), stream, p);
+  // one wavefront per block: each reserves LDS for the longest section the batch can hold
+  const int smooth_lds = imin(kSmoothLdsMax, max_fb + 3 * kSmoothTail + kSmoothSlack);
+  WH_BLOCKS(hc_smooth, dim3(imin(p.sec_cap, kSmoothBlocks), B), WAVE, smooth_lds * sizeof(double), stream, p, smooth_lds);
   WH_THREADS(hc_output, max_frames, B, 1, stream, p);
 }
 

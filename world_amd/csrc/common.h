@@ -72,6 +72,13 @@ __device__ __forceinline__ double keep(double v) {
   return v;
 }
 
+__device__ __forceinline__ uint32_t keep_word(uint32_t v) {
+#ifndef WORLD_EMU
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 // Nothing is scheduled across this point.  A wavefront issues in order; where a serial recurrence is followed by
 // independent work on its results, the fence keeps the compiler from weaving that work (and its own dependent
 // latencies) back between the recurrence's steps.

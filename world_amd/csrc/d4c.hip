@@ -532,13 +532,27 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     double wlo[kLo];
     double s1 = 0.0, s2 = 0.0;
     D4cWinRot rot = rot0;
+    // All of the thread's waveform samples and draws are requested before the first is used, at clamped addresses: a
+    // load inside `if (i < wlen)` is waited for where the branch rejoins, so the kLo items queued up one trip to
+    // memory each (24 dependent trips per frame over the three windows).  Items beyond the window contribute 0.
+    double xv[kLo];
+    uint32_t nz[kLo];
+#pragma unroll
+    for (int j = 0; j < kLo; ++j) {
+      const int i = imin(tid + j * nt, w.wlen - 1);
+      xv[j] = w.x[imin(w.x_len - 1, imax(0, w.origin + i - w.hw))];
+      nz[j] = w.noise[i];
+    }
+#pragma unroll
+    for (int j = 0; j < kLo; ++j) { xv[j] = keep(xv[j]); nz[j] = keep_word(nz[j]); }   // fetched here, not down in the branches
 #pragma unroll
     for (int j = 0; j < kLo; ++j) {
       const int i = tid + j * nt;
       ulo[j] = 0.0; wlo[j] = 0.0;
       if (i < w.wlen && i < H) {
-        const D4cSample s = d4c_sample(w, i, rot);
-        ulo[j] = s.v; wlo[j] = s.w; s1 += s.v; s2 += s.w;
+        const double ww = d4c_win_next(w, rot);                        // d4c_sample() on the values already fetched
+        const double v = xv[j] * ww + randn_value(nz[j]) * kSafeGuardD4C;
+        ulo[j] = v; wlo[j] = ww; s1 += v; s2 += ww;
       }
     }
     // a window longer than N/2 has used all kLo steps: rot stands at sample H + tid

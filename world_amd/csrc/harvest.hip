@@ -399,11 +399,14 @@ __global__ void hv_detect(HarvestParams p) {
   double *out = p.cand_a + ((size_t)u * p.fb_stride + frame) * p.maxc;
   int cnt = 0, st = 0, prev = 0;
   double run_sum = 0.0;                 // sum of the current voiced run, in band order (:374-375)
-  constexpr int kBatch = 19;            // bands fetched together: 19 loads in flight per thread (152 bands = 8 batches)
-  for (int j0 = 0; j0 < p.nch; j0 += kBatch) {
-    double v[kBatch];
+  // Bands are fetched kBatch at a time, and the next batch is requested before the current one is walked: a batch
+  // takes ~2 us to arrive from HBM, walking it a fraction of that -- eight exposed trips were most of the kernel.
+  constexpr int kBatch = 19;            // 19 loads in flight per thread and buffer (152 bands = 8 batches)
+  auto fetch = [&](double (&v)[kBatch], int j0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < kBatch; ++q) v[q] = j0 + q < p.nch ? raw[(size_t)(j0 + q) * p.fb_stride] : 0.0;
+    for (int q = 0; q < kBatch; ++q) v[q] = raw[(size_t)imin(j0 + q, p.nch - 1) * p.fb_stride];
+  };
+  auto walk = [&](const double (&v)[kBatch], int j0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < kBatch; ++q) {
       const int j = j0 + q;
@@ -414,6 +417,15 @@ __global__ void hv_detect(HarvestParams p) {
       if (cur) run_sum += v[q];
       prev = cur;
     }
+  };
+  double va[kBatch], vb[kBatch];
+  fetch(va, 0);
+  for (int j0 = 0; j0 < p.nch; j0 += 2 * kBatch) {
+    fetch(vb, j0 + kBatch);              // (past the last band the clamped addresses repeat it: unused)
+    walk(va, j0);
+    if (j0 + kBatch >= p.nch) break;
+    fetch(va, j0 + 2 * kBatch);
+    walk(vb, j0 + kBatch);
   }
   for (int j = cnt; j < p.maxc; ++j) out[j] = 0.0;
   if (cnt > 0) atomicMax(p.nc + u, cnt);

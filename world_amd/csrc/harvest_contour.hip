@@ -97,24 +97,40 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
   const int u = blockIdx.x, nf = p.nfb[u];
   const double *in = a.src + (size_t)u * p.fb_stride;
   int *st = p.sec + (size_t)u * 6 * p.sec_cap, *ed = st + p.sec_cap, *off = st + 4 * p.sec_cap;
-  auto voiced = [&](int i) {
-    if (i < 0 || i >= nf) return false;
-    if (a.force_ends && (i == 0 || i == nf - 1)) return false;
-    return in[i] > 0;
-  };
   // every thread owns a run of consecutive frames: ONE block scan for the whole utterance (a scan per 1024
   // frames cost ten barrier rounds, 22 us per launch)
   const int chunk = (nf + (int)blockDim.x - 1) / (int)blockDim.x;
   const int lo = (int)threadIdx.x * chunk, hi = imin(nf, lo + chunk);
-  int mine = 0;                                            // starts in the low half-word, ends in the high one
-  {
-    bool prev = voiced(lo - 1), cur = voiced(lo);
-    for (int f = lo; f < hi; ++f) {
-      const bool next = voiced(f + 1);
-      if (cur && !prev) mine += 1;
-      if (cur && !next) mine += 1 << 16;
-      prev = cur; cur = next;
+  // The run's voiced flags are fetched once, sixteen loads in flight, into the bits of a word (a walk that waited for
+  // one frame per trip spent 13 us per launch on memory latency, three launches per job); starts and ends of voiced
+  // runs are then bit patterns.  A word covers a piece of <= 62 frames plus a neighbour on either side; longer runs
+  // (utterances beyond 63 488 base frames) take several pieces.
+  constexpr int kPiece = 62, kLoads = 16;
+  typedef unsigned long long u64;
+  auto piece_runs = [&](int base, int n, u64 &starts, u64 &ends) {        // bit i of either <-> frame base + i, i < n
+    u64 m = 0;                                                            // bit i <-> frame base - 1 + i is voiced
+    for (int b = 0; b < n + 2; b += kLoads) {
+      double v[kLoads];
+#pragma unroll
+      for (int q = 0; q < kLoads; ++q) v[q] = in[imax(0, imin(nf - 1, base - 1 + b + q))];
+#pragma unroll
+      for (int q = 0; q < kLoads; ++q) {
+        const int f = base - 1 + b + q;
+        const bool ok = b + q < n + 2 && f >= 0 && f < nf && !(a.force_ends && (f == 0 || f == nf - 1)) && v[q] > 0;
+        m |= (u64)ok << (b + q);
+      }
     }
+    const u64 span = (1ull << n) - 1, cur = (m >> 1) & span;
+    starts = cur & ~m;                                                    // voiced, the frame before is not
+    ends = cur & ~(m >> 2);                                               // voiced, the frame after is not
+  };
+  int mine = 0;                                            // starts in the low half-word, ends in the high one
+  u64 starts0 = 0, ends0 = 0;                              // the first piece's patterns are kept for the second pass
+  for (int base = lo; base < hi; base += kPiece) {
+    u64 s_, e_;
+    piece_runs(base, imin(kPiece, hi - base), s_, e_);
+    if (base == lo) { starts0 = s_; ends0 = e_; }
+    mine += __builtin_popcountll(s_) + (__builtin_popcountll(e_) << 16);
   }
   // the two counts share one scan as 16-bit halves while they cannot overflow them (fewer than 2^15 sections: any
   // utterance below 65 s); longer ones pay a second scan instead of corrupting the end offsets
@@ -131,12 +147,11 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
   }
   {
     int at_s = at_s0, at_e = at_e0;
-    bool prev = voiced(lo - 1), cur = voiced(lo);
-    for (int f = lo; f < hi; ++f) {
-      const bool next = voiced(f + 1);
-      if (cur && !prev) { if (at_s < p.sec_cap) st[at_s] = f; ++at_s; }
-      if (cur && !next) { if (at_e < p.sec_cap) ed[at_e] = f; ++at_e; }
-      prev = cur; cur = next;
+    for (int base = lo; base < hi; base += kPiece) {
+      u64 s_ = starts0, e_ = ends0;
+      if (base != lo) piece_runs(base, imin(kPiece, hi - base), s_, e_);
+      for (; s_; s_ &= s_ - 1, ++at_s) if (at_s < p.sec_cap) st[at_s] = base + __builtin_ctzll(s_);
+      for (; e_; e_ &= e_ - 1, ++at_e) if (at_e < p.sec_cap) ed[at_e] = base + __builtin_ctzll(e_);
     }
   }
   __syncthreads();
@@ -181,9 +196,14 @@ constexpr int kMaxSlots = 256;       // candidate slots per frame handled by the
 constexpr int kExtReach = 100;       // frames a section may grow in each direction (:865)
 constexpr int kExtMargin = kExtReach + 1;
 
-// One workgroup of two wavefronts per section: the forward and the backward extension do not depend on each
-// other (each starts from its end of the section and writes its own side of the slice), so they run side by side.
-__global__ void __launch_bounds__(2 * WAVE) hc_extend(HarvestParams p) {
+// One workgroup per section.  The forward and the backward extension do not depend on each other (each starts from
+// its end of the section and writes its own side of the slice), so two wavefronts walk them side by side; the
+// bulk work around the walks -- copying the section into its slice, summing the extended run -- is spread over all
+// kExtendThreads (two wavefronts took a trip to HBM per 1024 frames: 16 us for an 8 000-frame section).
+constexpr int kExtendThreads = 8 * WAVE;
+__global__ void __launch_bounds__(kExtendThreads) hc_extend(HarvestParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
   const int k = blockIdx.x, u = blockIdx.y;
   if (k >= p.sec_n[u * 2]) return;
   const int nf = p.nfb[u], nslot = p.nc[u] * 7, lane = lane_id();
@@ -209,7 +229,7 @@ __global__ void __launch_bounds__(2 * WAVE) hc_extend(HarvestParams p) {
 #ifdef WORLD_EMU
   const int dir_begin = 0, dir_end = 2;                 // the one emulated thread walks both directions
 #else
-  const int dir_begin = wave_in_block(), dir_end = dir_begin + 1;
+  const int dir_begin = wave_in_block(), dir_end = imin(2, dir_begin + 1);      // wavefronts 2.. do not walk
 #endif
   for (int dir = dir_begin; dir < dir_end; ++dir) {     // 0: forwards from the section's end, 1: backwards from its start
     const int shift = dir == 0 ? 1 : -1;
@@ -218,93 +238,119 @@ __global__ void __launch_bounds__(2 * WAVE) hc_extend(HarvestParams p) {
     const int dist = last > origin ? last - origin : origin - last;
     double cur = e[origin - lo];
     int moved = origin, miss = 0;
-    // The frames to visit do not depend on the tracking result, so their candidate rows are fetched kAhead
-    // frames at a time, one batch ahead of the one being walked (double buffer in registers), and the ordered
-    // part -- nearest candidate of the previous pick -- runs from registers.
-    constexpr int kAhead = 8;
-    constexpr int kSlotsPerLane = (kMaxSlots + WAVE - 1) / WAVE;
+    // The frames to visit do not depend on the tracking result, so their candidate rows are fetched kAhead frames at
+    // a time, batches ahead of the one being walked (a ring of buffers in registers: a batch takes ~2 us to arrive
+    // and ~1 us to walk), and the ordered part -- nearest candidate of the previous pick -- runs from registers.
+    // SPL = slots per lane: 1 while the candidates fit the wavefront (nslot <= 64, the usual case: a quarter of the
+    // loads and compares), kMaxSlots / WAVE otherwise; NBUF = ring size.
     bool stop = false;
-    auto fetch = [&](double (&row)[kAhead][kSlotsPerLane], int i0) __attribute__((always_inline)) {
+    auto track = [&](auto spl_c, auto nbuf_c) __attribute__((always_inline)) {
+      constexpr int SPL = decltype(spl_c)::value, NBUF = decltype(nbuf_c)::value;
+      constexpr int kAhead = 8;
+      auto fetch = [&](double (&row)[kAhead][SPL], int i0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int a = 0; a < kAhead; ++a) {
-        const int t = origin + shift * (i0 + a) + shift;
+        for (int a = 0; a < kAhead; ++a) {
+          // plain loads at clamped addresses: a load under a condition is waited for where its branch rejoins, which
+          // put the rows of a batch in a queue (one trip to HBM each) instead of in flight together.  walk() never
+          // looks at a frame beyond `dist` or a slot beyond nslot, so what the clamped loads fetch there is unused.
+          const int t = imax(0, imin(nf - 1, origin + shift * imin(i0 + a, dist) + shift));
 #pragma unroll
-        for (int r = 0; r < kSlotsPerLane; ++r) {
-          const int sl = lane + r * WAVE;
-          row[a][r] = (i0 + a <= dist && sl < nslot) ? cands[(size_t)t * p.maxc + sl] : 0.0;
+          for (int r = 0; r < SPL; ++r) row[a][r] = cands[(size_t)t * p.maxc + imin(lane + r * WAVE, p.maxc - 1)];
         }
-      }
-    };
-    auto walk = [&](const double (&row)[kAhead][kSlotsPerLane], int i0) __attribute__((always_inline)) {
+      };
+      auto walk = [&](const double (&row)[kAhead][SPL], int i0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int a = 0; a < kAhead; ++a) {
-        if (i0 + a > dist || stop) break;
-        const int t = origin + shift * (i0 + a) + shift;
-        // nearest candidate within 18 %, ties -> the LAST slot (SelectBestF0, :636-650).  The
-        // reference compares err = |cur - c| / cur; cur is common to all slots, so the distances
-        // are ordered first (no division on the frame-to-frame chain) and the 18 % test is made
-        // once, for the winner -- by a product unless it is within 1e-12 of the boundary.
-        double best_d = 1e300, best_v = 0.0;
-        int best_i = -1;
+        for (int a = 0; a < kAhead; ++a) {
+          if (i0 + a > dist || stop) break;
+          const int t = origin + shift * (i0 + a) + shift;
+          // nearest candidate within 18 %, ties -> the LAST slot (SelectBestF0, :636-650).  The
+          // reference compares err = |cur - c| / cur; cur is common to all slots, so the distances
+          // are ordered first (no division on the frame-to-frame chain) and the 18 % test is made
+          // once, for the winner -- by a product unless it is within 1e-12 of the boundary.
+          double best_d = 1e300, best_v = 0.0;
+          int best_i = -1;
 #pragma unroll
-        for (int r = 0; r < kSlotsPerLane; ++r) {
-          const int sl = lane + r * WAVE;
-          if (sl < nslot) {
-            const double d = fabs(cur - row[a][r]);
-            if (!(d > best_d)) { best_d = d; best_i = sl; best_v = row[a][r]; }
+          for (int r = 0; r < SPL; ++r) {
+            const int sl = lane + r * WAVE;
+            if (sl < nslot) {
+              const double d = fabs(cur - row[a][r]);
+              if (!(d > best_d)) { best_d = d; best_i = sl; best_v = row[a][r]; }
+            }
           }
-        }
 #ifndef WORLD_EMU
-        {
-          const double dmin = wave_min(best_d);              // DPP + readlane: no LDS round trips on the frame-to-frame chain
-          const int mine = best_d == dmin ? best_i : -1;        // several lanes tie only exceptionally
-          const unsigned long long tied = __ballot(mine >= 0);
-          // the winner is wave-uniform: v_readlane with a scalar lane index instead of LDS shuffles
-          int win = -1;
-          if (__popcll(tied) > 1) win = wave_max_int(mine);
-          else if (tied) win = __builtin_amdgcn_readlane(mine, __ffsll((long long)tied) - 1);
-          best_v = readlane_f64(best_v, __builtin_amdgcn_readfirstlane(win < 0 ? 0 : win % WAVE));   // that lane's local best IS slot `win`
-          best_i = win;
-          best_d = dmin;
-        }
+          {
+            // One reduction carries distance AND slot: the slot rides in the low mantissa byte of the distance
+            // (255 - slot, so that the later slot of two equal distances is the smaller key).  Distances that agree to
+            // 2^-44 count as equal -- two candidates equally near the previous pick to thirteen digits.  DPP +
+            // readlane, no LDS round trips on the frame-to-frame chain; the winner's exact distance is recomputed.
+            static_assert(kMaxSlots <= 256, "the slot index rides in one byte");
+            const long long kb = (__double_as_longlong(best_d) & ~0xFFll) | (long long)(0xFF - (best_i & 0xFF));
+            const double kmin = wave_min(__longlong_as_double(kb));
+            const int win = 0xFF - (__builtin_amdgcn_readfirstlane(__double2loint(kmin)) & 0xFF);
+            // (keep(): left to itself the compiler turns the selects into one load at a computed index, and an array
+            // indexed at run time lives in scratch memory)
+            double mine = row[a][0];
+#pragma unroll
+            for (int r = 1; r < SPL; ++r) mine = (win >> 6) == r ? keep(row[a][r]) : mine;
+            best_v = readlane_f64(mine, win & (WAVE - 1));
+            best_i = kmin < 1e299 ? win : -1;
+            best_d = fabs(cur - best_v);
+          }
 #endif
-        if (best_i >= 0) {
-          const double bound = 0.18 * cur;
-          bool ok = best_d <= bound;
-          if (fabs(best_d - bound) <= 1e-12 * cur) ok = !(best_d / cur > 0.18);
-          if (!ok) best_i = -1;
+          if (best_i >= 0) {
+            const double bound = 0.18 * cur;
+            bool ok = best_d <= bound;
+            if (fabs(best_d - bound) <= 1e-12 * cur) ok = !(best_d / cur > 0.18);
+            if (!ok) best_i = -1;
+          }
+          const double v = best_i < 0 ? 0.0 : best_v;
+          if (lane == 0) e[t - lo] = v;
+          if (v == 0.0) { miss++; } else { cur = v; miss = 0; moved = t; }
+          if (miss == 4) stop = true;
         }
-        const double v = best_i < 0 ? 0.0 : best_v;
-        if (lane == 0) e[t - lo] = v;
-        if (v == 0.0) { miss++; } else { cur = v; miss = 0; moved = t; }
-        if (miss == 4) stop = true;
+      };
+      static_assert(NBUF == 2 || NBUF == 4, "the ring is written out for two and four buffers");
+      double r0[kAhead][SPL], r1[kAhead][SPL];
+      if constexpr (NBUF == 4) {
+        double r2[kAhead][SPL], r3[kAhead][SPL];
+        fetch(r0, 0); fetch(r1, kAhead); fetch(r2, 2 * kAhead);
+        for (int i0 = 0; i0 <= dist && !stop; i0 += 4 * kAhead) {
+          fetch(r3, i0 + 3 * kAhead); walk(r0, i0);
+          if (stop || i0 + kAhead > dist) break;
+          fetch(r0, i0 + 4 * kAhead); walk(r1, i0 + kAhead);
+          if (stop || i0 + 2 * kAhead > dist) break;
+          fetch(r1, i0 + 5 * kAhead); walk(r2, i0 + 2 * kAhead);
+          if (stop || i0 + 3 * kAhead > dist) break;
+          fetch(r2, i0 + 6 * kAhead); walk(r3, i0 + 3 * kAhead);
+        }
+      } else {
+        fetch(r0, 0);
+        for (int i0 = 0; i0 <= dist && !stop; i0 += 2 * kAhead) {
+          fetch(r1, i0 + kAhead); walk(r0, i0);
+          if (stop || i0 + kAhead > dist) break;
+          fetch(r0, i0 + 2 * kAhead); walk(r1, i0 + kAhead);
+        }
       }
     };
-    double row_a[kAhead][kSlotsPerLane], row_b[kAhead][kSlotsPerLane];
-    fetch(row_a, 0);
-    for (int i0 = 0; i0 <= dist && !stop; i0 += 2 * kAhead) {
-      fetch(row_b, i0 + kAhead);
-      walk(row_a, i0);
-      if (stop || i0 + kAhead > dist) break;
-      fetch(row_a, i0 + 2 * kAhead);
-      walk(row_b, i0 + kAhead);
-    }
+    constexpr int kSlotsPerLane = (kMaxSlots + WAVE - 1) / WAVE;
+    if (kSlotsPerLane > 1 && nslot <= WAVE) track(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+    else track(std::integral_constant<int, kSlotsPerLane>{}, std::integral_constant<int, 2>{});
     if (lane == 0) sec[(dir == 0 ? 3 : 2) * p.sec_cap + k] = moved;     // new end / new start
   }
   __syncthreads();
-  if (wave_in_block() != 0) return;
   const int new_st = sec[2 * p.sec_cap + k], new_ed = sec[3 * p.sec_cap + k];
   // sum over [new_st, new_ed) for ExtendSub's running mean (:850)
   double s = 0.0;
-  for (int f0 = new_st + lane; f0 < new_ed; f0 += 8 * WAVE) {
+  const int nt = blockDim.x;
+  for (int f0 = new_st + (int)threadIdx.x; f0 < new_ed; f0 += 8 * nt) {
     double v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = f0 + q * WAVE < new_ed ? e[f0 + q * WAVE - lo] : 0.0;
+    for (int q = 0; q < 8; ++q) v[q] = f0 + q * nt < new_ed ? e[f0 + q * nt - lo] : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) s += v[q];
   }
-  s = wave_sum(s);
-  if (lane == 0) {
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) {
     sec[5 * p.sec_cap + k] = lo;
     p.sec_sum[(size_t)u * p.sec_cap + k] = s;
   }
@@ -369,10 +415,10 @@ __global__ void hc_merge(HarvestParams p) {
     }
     wave_sync();
     kept = wave_bcast_int(kept, 0);
-    // out[f] = value(f) for f in [lo, hi]: eight loads in flight per lane (a plain loop has each iteration's load
+    // out[f] = value(f) for f in [lo, hi]: 32 loads in flight per lane (a plain loop has each iteration's load
     // wait behind the previous store: one trip to HBM per 64 frames, 80 us for the 10 001 frames of a 10 s utterance)
     auto fill = [&](int lo, int hi, auto value) __attribute__((always_inline)) {
-      constexpr int kB = 8;
+      constexpr int kB = 32;    // the wavefront is alone on its SIMD: registers are free, trips to HBM are not
       for (int f0 = lo + lane; f0 <= hi; f0 += kB * WAVE) {
         double v[kB];
   #pragma unroll
@@ -637,7 +683,7 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   WH_THREADS(hc_step2, max_fb, B, 1, stream, p);
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
-  WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), 2 * WAVE, 0, stream, p);
+  WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), kExtendThreads, 64 * sizeof(double), stream, p);
   WH_WAVES(hc_merge, B, 1, 1, kMergeLdsSections * (5 * sizeof(int) + sizeof(double)), stream, p);
   devrt::d2d(p.c0, p.c3, row_bytes, stream);
   SecArgs a3 = {p.c3, 1, 0};

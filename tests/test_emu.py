@@ -202,3 +202,21 @@ def test_emulated_c_driver_shards_a_job_over_two_contexts(emu):
     finally:
         for c in ctxs:
             L.world_hip_destroy(c)
+
+
+def test_merge_routes_agree(tmp_path):
+    """hc_merge keeps the section records in LDS and copies the contour once at the end; an utterance with more
+    sections than fit takes the reference's copy-as-you-decide route out of HBM.  Same F0, bit for bit."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["make", "-s", "-f", os.path.join(here, "emu", "Makefile")], check=True)
+    a, b = str(tmp_path / "lds.npz"), str(tmp_path / "hbm.npz")
+    env = {k: v for k, v in os.environ.items() if k != "WORLD_HIP_MERGE_LDS_SECTIONS"}
+    subprocess.run([sys.executable, os.path.join(here, "merge_routes.py"), "emu", a], check=True, env=env)
+    subprocess.run([sys.executable, os.path.join(here, "merge_routes.py"), "emu", b], check=True,
+                   env=dict(env, WORLD_HIP_MERGE_LDS_SECTIONS="0"))
+    A, B = np.load(a), np.load(b)
+    for k in A.files:
+        assert np.array_equal(A[k], B[k]), k
+        assert (A[k] > 0).any()

@@ -3,6 +3,8 @@ the golden fixtures generated from the unmodified reference, against the CPU ora
 on seeded inputs, and -- at BASELINE.json's full sizes -- through size-independent
 properties.  Tolerance (north_star): frame counts / temporal positions bit-exact;
 F0, spectral envelope, aperiodicity within 1e-4 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -611,3 +613,20 @@ def test_pack_unpack_and_peer_allgather_from_the_c_abi():
             assert torch.equal(tp_u[u, :n], tpos[u, :n]) and torch.equal(f0_u[u, :n], f0[u, :n])
             assert torch.equal(sp_u[u, :n], sp[u, :n]) and torch.equal(ap_u[u, :n], ap[u, :n])
     w.close()
+
+
+def test_merge_routes_agree_on_the_gpu(tmp_path):
+    """hc_merge's two routes (section records in LDS + one copy at the end / the reference's copy-as-you-decide out
+    of HBM for utterances with more sections than fit) give the same F0 bit for bit, single and batched"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    a, b = str(tmp_path / "lds.npz"), str(tmp_path / "hbm.npz")
+    env = {k: v for k, v in os.environ.items() if k != "WORLD_HIP_MERGE_LDS_SECTIONS"}
+    subprocess.run([sys.executable, os.path.join(here, "merge_routes.py"), "gpu", a], check=True, env=env)
+    subprocess.run([sys.executable, os.path.join(here, "merge_routes.py"), "gpu", b], check=True,
+                   env=dict(env, WORLD_HIP_MERGE_LDS_SECTIONS="0"))
+    A, B = np.load(a), np.load(b)
+    for k in A.files:
+        assert np.array_equal(A[k], B[k]), k
+        assert (A[k] > 0).any()

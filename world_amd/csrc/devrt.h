@@ -402,6 +402,15 @@ __device__ __forceinline__ int wave_excl_scan_int(int v, int *total) {
   return 0;
 #endif
 }
+// lane `src_lane`'s value when the lane index is the same in every lane (a loop counter): v_readlane, no LDS crossbar
+__device__ __forceinline__ double wave_pick(double v, int src_lane) {
+#ifndef WORLD_EMU
+  return readlane_f64(v, __builtin_amdgcn_readfirstlane(src_lane));
+#else
+  (void)src_lane;
+  return v;
+#endif
+}
 __device__ __forceinline__ double wave_bcast(double v, int src_lane) {
 #ifndef WORLD_EMU
   return __shfl(v, src_lane, 64);

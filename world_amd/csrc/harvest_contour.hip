@@ -364,11 +364,10 @@ __device__ __forceinline__ double wave_best_score(double f0, const double *c, co
   return wave_max(r);
 }
 
-constexpr int kMergeLdsSections = 512;   // section records a wavefront keeps in LDS (longer lists stay in HBM)
-__global__ void hc_merge(HarvestParams p) {
-  DYN_LDS(lds);
-  const int u = wave_item_x();
-  if (u >= p.b.n_utt) return;
+// The reference's way -- copy a section into the contour as soon as it is decided, read the contour back in
+// MergeF0Sub -- by one wavefront with the records where hc_extend left them: the route of an utterance with more
+// sections than hc_merge's LDS holds (minutes of speech in one piece).
+__device__ __forceinline__ void hc_merge_in_hbm(const HarvestParams &p, int u) {
   const int lane = lane_id(), nf = p.nfb[u], nslot = p.nc[u] * 7;
   const int ns = p.sec_n[u * 2];
   int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
@@ -376,9 +375,6 @@ __global__ void hc_merge(HarvestParams p) {
   int *b_st = sec + 2 * p.sec_cap, *b_ed = sec + 3 * p.sec_cap;
   int *s_off = sec + 4 * p.sec_cap, *s_lo = sec + 5 * p.sec_cap;
   const double *sums = p.sec_sum + (size_t)u * p.sec_cap;
-  // The ordered part is ONE lane walking the section records; from HBM every dependent access costs a
-  // microsecond (88 us for ~30 sections).  The records of a normal utterance fit LDS; the work is written once
-  // and instantiated for LDS pointers (ds_ accesses) and for the arrays in HBM.
   auto work = [&](auto order, auto b_st, auto b_ed, auto s_off, auto s_lo, auto sums) __attribute__((always_inline)) {
     const double *ext = p.ext + (size_t)u * p.ext_cap;
     const double *step2 = hc_row(p.c2, p, u);
@@ -469,19 +465,174 @@ __global__ void hc_merge(HarvestParams p) {
       wave_sync();
     }
   };
-  if (ns <= kMergeLdsSections) {
-    char *mine = lds + (size_t)wave_in_block() * kMergeLdsSections * (5 * sizeof(int) + sizeof(double));
-    LDS_PTR(double) l_sum = (LDS_PTR(double))reinterpret_cast<double *>(mine);
-    LDS_PTR(int) l = (LDS_PTR(int))reinterpret_cast<int *>(reinterpret_cast<double *>(mine) + kMergeLdsSections);
-    for (int k = lane; k < ns; k += WAVE) {
-      l_sum[k] = sums[k];
-      l[k] = 0; l[kMergeLdsSections + k] = b_st[k]; l[2 * kMergeLdsSections + k] = b_ed[k];
-      l[3 * kMergeLdsSections + k] = s_off[k]; l[4 * kMergeLdsSections + k] = s_lo[k];
+  work(order, b_st, b_ed, s_off, s_lo, sums);
+}
+
+// One workgroup per utterance.  The ordered parts -- ExtendSub's running mean, the sort, the merge decisions -- are
+// walked by the first wavefront over section records staged in LDS; the contour is written once, at the end, by all
+// kMergeThreads threads.  The reference's MergeF0 copies a section into the contour as soon as it is decided and
+// MergeF0Sub reads the contour back; here a decision appends a record (first frame, last frame, channel) to a list,
+// "the contour at frame f" is the last record covering f, and the copy happens when the list is complete: one trip
+// to HBM for the whole contour instead of one per 2 048 frames and section (20 of a lone job's 27 us).  MergeF0Sub's
+// scores are looked up a frame per lane with all slots of the frame in flight, and summed in frame order -- the
+// reference's order -- instead of two dependent trips to HBM per frame (4 us a frame: 1.4 ms for the slowest
+// utterance of a 128-batch).
+constexpr int kMergeThreads = 1024;
+constexpr int kMergeLdsSections = 2048;  // section records kept in LDS; an utterance with more takes hc_merge_in_hbm
+inline size_t hc_merge_lds_bytes(int sections) { return (size_t)(sections + 1) * (sizeof(double) + 8 * sizeof(int)) + 16 * sizeof(int); }
+__global__ void __launch_bounds__(kMergeThreads) hc_merge(HarvestParams p, int cap) {
+  DYN_LDS(lds);
+  const int u = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
+  const int ns = p.sec_n[u * 2];
+  if (ns > cap) {
+    if (wave_in_block() == 0) hc_merge_in_hbm(p, u);
+    return;
+  }
+  const int nf = p.nfb[u], nslot = p.nc[u] * 7;
+  const int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
+  const double *ext = p.ext + (size_t)u * p.ext_cap;
+  double *out = hc_row(p.c3, p, u);
+  const double *cands = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
+  const double *scores = p.score_a + (size_t)u * p.fb_stride * p.maxc;
+  // LDS: sums[cap + 1] | order, b_st, b_ed, s_off, s_lo [cap + 1 each] | fill_lo, fill_hi, fill_ch [cap + 1 each] | misc
+  const int row = cap + 1;
+  LDS_PTR(double) sums = (LDS_PTR(double))reinterpret_cast<double *>(lds);
+  LDS_PTR(int) order = (LDS_PTR(int))reinterpret_cast<int *>(reinterpret_cast<double *>(lds) + row);
+  LDS_PTR(int) b_st = order + row;
+  LDS_PTR(int) b_ed = b_st + row;
+  LDS_PTR(int) s_off = b_ed + row;
+  LDS_PTR(int) s_lo = s_off + row;
+  LDS_PTR(int) fill_lo = s_lo + row;
+  LDS_PTR(int) fill_hi = fill_lo + row;
+  LDS_PTR(int) fill_ch = fill_hi + row;
+  LDS_PTR(int) misc = fill_ch + row;
+  for (int k = tid; k < ns; k += nt) {
+    sums[k] = p.sec_sum[(size_t)u * p.sec_cap + k];
+    order[k] = 0; b_st[k] = sec[2 * p.sec_cap + k]; b_ed[k] = sec[3 * p.sec_cap + k];
+    s_off[k] = sec[4 * p.sec_cap + k]; s_lo[k] = sec[5 * p.sec_cap + k];
+  }
+  __syncthreads();
+  // value of channel `ch` at frame f: its slice inside its extended run, zero elsewhere (a plain load at a clamped
+  // address and a select: nothing waits in a branch)
+  auto chan = [&](int ch, int f) {
+    const int c_st = b_st[ch], c_ed = b_ed[ch];
+    const double v = ext[s_off[ch] + (imax(c_st, imin(c_ed, f)) - s_lo[ch])];
+    return (f >= c_st && f <= c_ed) ? v : 0.0;
+  };
+  // the channel whose copy covers frame f last
+  auto covering = [&](int f, int nfill) {
+    int ch = fill_ch[0];
+    for (int k = nfill - 1; k > 0; --k)
+      if (f >= fill_lo[k] && f <= fill_hi[k]) { ch = fill_ch[k]; break; }
+    return ch;
+  };
+  if (wave_in_block() == 0) {
+    // ExtendSub (:840-856): stable compaction of the sections longer than 2200/mean_f0;
+    // mean_f0 is deliberately NOT reset between sections.
+    int kept = 0;
+    if (lane == 0) {
+      double mean = 0.0;
+      for (int s = 0; s < ns; ++s) {
+        int st = b_st[s], ed = b_ed[s];
+        mean += sums[s];
+        mean /= ed - st;
+        if (2200.0 / mean < ed - st) {
+          int t;
+          t = b_st[kept]; b_st[kept] = b_st[s]; b_st[s] = t;
+          t = b_ed[kept]; b_ed[kept] = b_ed[s]; b_ed[s] = t;
+          t = s_off[kept]; s_off[kept] = s_off[s]; s_off[s] = t;
+          t = s_lo[kept]; s_lo[kept] = s_lo[s]; s_lo[s] = t;
+          kept++;
+        }
+      }
+      p.sec_n[u * 2 + 1] = kept;
+      // MakeSortedOrder (:883-896), quirks included
+      for (int i = 0; i < kept; ++i) order[i] = i;
+      for (int i = 1; i < kept; ++i)
+        for (int j = i - 1; j >= 0; --j) {
+          if (b_st[order[j]] > b_st[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+          else break;
+        }
     }
     wave_sync();
-    work(l, l + kMergeLdsSections, l + 2 * kMergeLdsSections, l + 3 * kMergeLdsSections, l + 4 * kMergeLdsSections, l_sum);
-  } else {
-    work(order, b_st, b_ed, s_off, s_lo, sums);
+    kept = wave_bcast_int(kept, 0);
+    int nfill = 0;
+    if (kept > 0) {
+      // MergeF0 (:937-963)
+      if (lane == 0) { fill_lo[0] = 0; fill_hi[0] = nf - 1; fill_ch[0] = 0; }
+      nfill = 1;
+      wave_sync();
+      int cur_st = b_st[0], cur_ed = b_ed[0];                 // the reference's boundary_list[0], [1]
+      for (int i = 1; i < kept; ++i) {
+        const int o = order[i];
+        // the reference reads boundary_list[o*2(+1)] AFTER possibly having overwritten entry 0
+        const int st2 = o == 0 ? cur_st : b_st[o];
+        const int ed2 = o == 0 ? cur_ed : b_ed[o];
+        int lo_f = st2;
+        if (st2 - cur_ed > 0) {
+          cur_st = st2; cur_ed = ed2;
+        } else {
+          // MergeF0Sub (:912-932)
+          const int st1 = cur_st, ed1 = cur_ed;
+          if (st1 <= st2 && ed1 >= ed2) { cur_ed = ed1; continue; }
+          double s1 = 0.0, s2 = 0.0;
+          for (int base = st2; base <= ed1; base += WAVE) {
+            const int f = imin(base + lane, ed1);              // (the lanes past ed1 repeat it; their scores are not summed)
+            const double v1 = chan(covering(f, nfill), f), v2 = chan(o, f);
+            // SearchScore (:901-907) of both values over the frame's slots, eight slots in flight
+            double r1 = 0.0, r2 = 0.0;
+            const double *c = cands + (size_t)f * p.maxc, *sc = scores + (size_t)f * p.maxc;
+            constexpr int kB = 8;
+            for (int i0 = 0; i0 < nslot; i0 += kB) {
+              double cv[kB], sv[kB];
+#pragma unroll
+              for (int q = 0; q < kB; ++q) { const int k = imin(i0 + q, nslot - 1); cv[q] = c[k]; sv[q] = sc[k]; }
+#pragma unroll
+              for (int q = 0; q < kB; ++q) {
+                if (i0 + q < nslot && v1 == cv[q] && r1 < sv[q]) r1 = sv[q];
+                if (i0 + q < nslot && v2 == cv[q] && r2 < sv[q]) r2 = sv[q];
+              }
+            }
+            const int n = imin(WAVE, ed1 - base + 1);
+            for (int l = 0; l < n; ++l) { s1 += wave_pick(r1, l); s2 += wave_pick(r2, l); }   // in frame order
+          }
+          if (s1 > s2) lo_f = ed1;
+          cur_ed = ed2;
+        }
+        if (lane == 0) { fill_lo[nfill] = lo_f; fill_hi[nfill] = ed2; fill_ch[nfill] = o; }
+        ++nfill;
+        wave_sync();
+      }
+    }
+    if (lane == 0) { misc[0] = kept; misc[1] = nfill; }
+  }
+  __syncthreads();
+  const int kept = misc[0], nfill = misc[1];
+  // the contour: c3[f] = the value of the last copy covering f (step 2's contour when no section survived).  The
+  // copies are walked in order for a batch of frames at a time -- the records are the same for every thread, so
+  // their LDS reads are broadcasts that do not wait on each other (a backward search per frame is a chain of them).
+  constexpr int kB = 10;
+  for (int f0 = tid; f0 < nf; f0 += kB * nt) {
+    double v[kB];
+    if (kept == 0) {
+      const double *step2 = hc_row(p.c2, p, u);
+#pragma unroll
+      for (int q = 0; q < kB; ++q) v[q] = step2[imin(nf - 1, f0 + q * nt)];
+    } else {
+      int ch[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) ch[q] = fill_ch[0];
+      for (int k = 1; k < nfill; ++k) {
+        const int lo = fill_lo[k], hi = fill_hi[k], c = fill_ch[k];
+#pragma unroll
+        for (int q = 0; q < kB; ++q) { const int f = f0 + q * nt; ch[q] = (f >= lo && f <= hi) ? c : ch[q]; }
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) v[q] = chan(ch[q], imin(nf - 1, f0 + q * nt));
+    }
+#pragma unroll
+    for (int q = 0; q < kB; ++q) if (f0 + q * nt < nf) out[f0 + q * nt] = v[q];
   }
 }
 
@@ -684,7 +835,11 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
   WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), kExtendThreads, 64 * sizeof(double), stream, p);
-  WH_WAVES(hc_merge, B, 1, 1, kMergeLdsSections * (5 * sizeof(int) + sizeof(double)), stream, p);
+  // WORLD_HIP_MERGE_LDS_SECTIONS lowers the number of section records hc_merge keeps in LDS (tests use it to send an
+  // ordinary utterance down the route of one with thousands of sections)
+  static const int merge_limit = [] { const char *e = getenv("WORLD_HIP_MERGE_LDS_SECTIONS"); return e ? imax(0, imin(kMergeLdsSections, atoi(e))) : kMergeLdsSections; }();
+  const int merge_cap = imin(p.sec_cap, merge_limit);
+  WH_BLOCKS(hc_merge, dim3(B), kMergeThreads, hc_merge_lds_bytes(merge_cap), stream, p, merge_cap);
   devrt::d2d(p.c0, p.c3, row_bytes, stream);
   SecArgs a3 = {p.c3, 1, 0};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a3);

@@ -715,8 +715,8 @@ def main():
         ms = e0.elapsed_time(e1) / 3
         synthesis = {"workload": f"Synthesis() of {B} x {args.seconds:g} s from the analysis outputs in HBM",
                      "ms": ms, "x_realtime": B * args.seconds / (ms * 1e-3),
-                     "note": "bound by the bit-faithful serial phase accumulation (one FP64 add per sample, "
-                             "36-cycle dependent issue); utterances of a batch share that latency"}
+                     "note": "bound by the bit-faithful serial phase accumulation (one chain of dependent FP64 adds per "
+                             "utterance, ~7 cycles a sample, one wavefront per utterance)"}
         # the same job through the reference's host-pointer API (the drop-in boundary):
         # PCIe-inclusive, reported beside the metric and never part of `value`
         from world_amd.api import HostAPI

@@ -196,12 +196,12 @@ __global__ void __launch_bounds__(256, 4) ct_spectrum(CtParams p) {
 // The cumulative sum of LinearSmoothing (common.cpp:85-86) must round exactly as the reference's left-to-right
 // loop does: `hi - lo` below cancels up to 12 digits where the envelope sits at the noise floor, so any other
 // summation order moves those bins by 1e-4 (tests/test_gpu_parity.py::test_hard_inputs_vs_oracle).
-// A dependent FP64 add issues every ~36 cycles on gfx950 whatever the lanes do, so the chains of 64 frames run
+// A chain of dependent FP64 adds costs the same whatever the other lanes do, so the chains of 64 frames run
 // side by side in one wavefront: 1200 steps for 64 frames instead of 1200 steps per frame with 255 threads of a
 // workgroup waiting at a barrier (round 1: 40k of a frame's 135k cycles).  Rows are read in batches of 8 values
 // per lane, the next batch in flight while the current one is added up.
 constexpr int kScanBatch = 16;     // values per lane and batch (8 loads of 16 bytes)
-constexpr int kScanDepth = 5;      // batches in flight per lane: 4 x 16 adds x 36 cycles of work cover a trip to HBM
+constexpr int kScanDepth = 5;      // batches in flight per lane: enough rows requested ahead to cover a trip to HBM
                                    // (40 loads + a batch of stores stay below the 63 the vmcnt counter can tell apart)
 // A frame's row holds seg_stride values although its segment is shorter: every lane walks to the longest
 // segment of its wavefront, rounded up to whole rings (what lies beyond a frame's own length is scratch that

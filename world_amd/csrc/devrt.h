@@ -499,9 +499,9 @@ template <int NT = 0> __device__ __forceinline__ void block_sum4(double &a, doub
 // Element-wise pass over n items, K per thread at a time: all K `produce(i)` calls (loads +
 // arithmetic, returning a value) are issued before any `consume(i, value)` (the stores).
 // A plain `for (i = tid; i < n; i += T) out[i] = f(in[i])` cannot overlap its iterations -- the
-// compiler must keep each store ahead of the next iteration's loads -- and a dependent FP64 op
-// costs 36 cycles on gfx950 (tools/microbench_fp64.hip), so with 2-4 waves per SIMD such loops
-// run at latency, not throughput.  K independent chains per thread close most of that gap.
+// compiler must keep each store ahead of the next iteration's loads -- so with 2-4 waves per SIMD
+// such loops run at the latency of a trip to memory per iteration, not at throughput.  K loads in
+// flight per thread close most of that gap.
 template <int K, class T, int NT = 0, class Produce, class Consume>
 __device__ __forceinline__ void block_map(int n, Produce produce, Consume consume) {
   const int tid = wg_thread<NT>(), nt = wg_size<NT>();

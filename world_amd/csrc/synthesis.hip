@@ -2,7 +2,7 @@
 //
 //   sy_increments  : per sample, interp1 of f0 / vuv onto the sample grid and the phase
 //                    increment 2 pi f0 / fs                                        (:225-318)
-//   sy_phase_serial: the running phase, ONE LANE PER UTTERANCE, strictly left to right
+//   sy_phase_serial: the running phase, strictly left to right, one wavefront per utterance
 //   sy_detect      : a pulse sits where the wrapped phase jumps by more than pi
 //                    (GetPulseLocationsForTimeBase, :251-290)
 //   sy_compact     : pulse index / fractional time shift lists in time order
@@ -16,9 +16,8 @@
 // The phase accumulation has to round exactly like the reference's loop: unvoiced stretches
 // run at the default 500 Hz, and at fs = 16 / 32 / 48 kHz that is an exact divisor of the
 // sampling rate, so every unvoiced pulse lands within an ulp of the wrap boundary and which
-// sample it is detected at depends on the last bit of the running sum.  A dependent FP64 add
-// issues every ~30-36 cycles on gfx950 (tools/microbench_fp64.hip): 5.8 ms of latency for 10 s
-// of 48 kHz audio on one lane -- but 64 utterances per wavefront cost the same, and everything
+// sample it is detected at depends on the last bit of the running sum: one add chain per
+// utterance (sy_phase_serial), 1.3 ms of dependent adds for 10 s of 48 kHz audio; everything
 // else here is parallel.  The randn stream is consumed strictly in pulse order, noise_size draws per pulse, so pulse
 // p starts at draw pidx[p] - pidx[0].
 #include "synthesis.h"
@@ -72,29 +71,49 @@ __global__ void __launch_bounds__(kSyThreads) sy_increments(SynthParams p) {
   }
 }
 
-// total_phase[i] = total_phase[i-1] + increment[i], in place, one lane per utterance.  The add
-// chain is the floor (36 cycles per sample); memory traffic comes in batches of 64 values so that
-// the load latency exposed between batches is a few percent of a batch's chain.  (Staging through
-// LDS with cooperative loads, or software-pipelining the batches, measured slower: on a lone
-// wavefront every extra instruction lands on the critical path.)
+// total_phase[i] = total_phase[i-1] + increment[i], in place, strictly left to right: one wavefront per utterance.
+// A dependent FP64 add follows its producer after ~6 cycles (tools/probe/fp64_chain.hip), so the chain itself is
+// 1.3 ms for 10 s of 48 kHz audio; a lone lane fetching its own values spent four times that waiting for them.  Here
+// every lane owns kPhaseRun consecutive samples of a chunk of WAVE * kPhaseRun; the lanes take turns in order -- a
+// turn is the kPhaseRun adds of one lane under a one-lane mask, the running sum handed on through a scalar register
+// (~60 cycles of mask, branch and v_readlane per turn: hence the long runs) -- and the next chunk's samples are
+// requested before the turns begin.  Bit for bit the sum of one lane walking the array.
+// (Measured and dropped: a second wavefront doing the stores out of LDS, so that the adder's memory counter only ever
+// holds loads -- 2.9 ms where this takes 2.4 at kPhaseRun = 16: the chunk's store latency is not what is exposed.)
+constexpr int kPhaseRun = 32;
 __global__ void __launch_bounds__(WAVE) sy_phase_serial(SynthParams p) {
-  const int u = flat_thread_x();
-  if (u >= p.n_utt) return;
+  const int u = blockIdx.x, lane = lane_id();
   const int n = p.y_len[u];
+  if (n <= 0) return;
   double *a = p.inc + (size_t)u * p.y_stride;
-  constexpr int kB = 64;
-  double acc = 0.0;
-  int i0 = 0;
-  for (; i0 + kB <= n; i0 += kB) {
-    double v[kB];
+  constexpr int kChunk = WAVE * kPhaseRun;
+  auto fetch = [&](double (&v)[kPhaseRun], int i0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < kB; ++q) v[q] = a[i0 + q];
+    for (int q = 0; q < kPhaseRun; ++q) v[q] = a[imin(n - 1, i0 + lane * kPhaseRun + q)];
+  };
+  double cur[kPhaseRun], nxt[kPhaseRun];
+  fetch(cur, 0);
+  double carry = -0.0;                 // -0.0 + x == x bit for bit: the first sample passes through, as in the reference
+  for (int i0 = 0; i0 < n; i0 += kChunk) {
+    fetch(nxt, i0 + kChunk);           // (past the end the clamped addresses repeat the last sample: unused)
+    double last = 0.0;
+    for (int turn = 0; turn < WAVE; ++turn) {
+      if (lane == turn) {
+        double acc = carry;
 #pragma unroll
-    for (int q = 0; q < kB; ++q) { acc = (i0 + q == 0) ? v[q] : acc + v[q]; v[q] = acc; }
+        for (int q = 0; q < kPhaseRun; ++q) { acc = acc + cur[q]; cur[q] = acc; }
+        last = acc;
+      }
+      carry = wave_pick(last, turn);
+    }
 #pragma unroll
-    for (int q = 0; q < kB; ++q) a[i0 + q] = v[q];
+    for (int q = 0; q < kPhaseRun; ++q) {
+      const int i = i0 + lane * kPhaseRun + q;
+      if (i < n) a[i] = cur[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kPhaseRun; ++q) cur[q] = nxt[q];
   }
-  for (; i0 < n; ++i0) { acc = i0 == 0 ? a[i0] : acc + a[i0]; a[i0] = acc; }
 }
 
 __global__ void __launch_bounds__(kSyThreads) sy_detect(SynthParams p) {
@@ -331,7 +350,7 @@ __global__ void sy_overlap_add(SynthParams p) {
 void launch_synthesis(const SynthParams &p, int max_y, hipStream_t stream) {
   const size_t small = sizeof(double) * 80;
   WH_BLOCKS(sy_increments, dim3(p.nblk, p.n_utt), kSyThreads, 0, stream, p);
-  WH_BLOCKS(sy_phase_serial, dim3((p.n_utt + WAVE - 1) / WAVE), WAVE, 0, stream, p);
+  WH_BLOCKS(sy_phase_serial, dim3(p.n_utt), WAVE, 0, stream, p);
   WH_BLOCKS(sy_detect, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
   WH_BLOCKS(sy_compact, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
   WH_BLOCKS(sy_pulse, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);

@@ -58,6 +58,7 @@ __global__ void hv_partial_sums(HarvestParams p) {
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) s += y[i];
   s = block_sum(s, scratch);
   if (threadIdx.x == 0) p.fwd[(size_t)u * p.m_stride + slice] = s;     // fwd is free after decimation
+  if (threadIdx.x == 0 && slice == 0) p.nc[u] = 0;                      // hv_detect's running maximum starts from here
 }
 __global__ void hv_remove_mean(HarvestParams p) {
   DYN_LDS(lds);
@@ -461,7 +462,16 @@ __global__ void hv_refine(HarvestParams p) {
   WH_ACC_DECL;
   WH_ACC_BEGIN;
   const int origin = mround(pos * fs) - cap / 2;
-  for (int k = lane; k < cap; k += WAVE) yc[k] = y[imax(0, imin(y_len - 1, origin + k))];
+  {
+    constexpr int kB = 6;                                   // loads in flight per lane (a trip to L2 per iteration otherwise)
+    for (int k0 = lane; k0 < cap; k0 += kB * WAVE) {
+      double v[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) v[q] = y[imax(0, imin(y_len - 1, origin + k0 + q * WAVE))];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) if (k0 + q * WAVE < cap) yc[k0 + q * WAVE] = v[q];
+    }
+  }
   wave_sync();
   WH_ACC_END(0);
 
@@ -719,7 +729,6 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
                     hipStream_t stream) {
   const int B = p.b.n_utt;
   devrt::dzero(p.y, sizeof(double) * (size_t)B * p.y_stride, stream);
-  devrt::dzero(p.nc, sizeof(int) * B, stream);
   if (p.ratio == 1) {
     WH_THREADS(hv_copy_signal, max_y_len, B, 1, stream, p);
   } else {

@@ -89,7 +89,11 @@ __global__ void hc_step2(HarvestParams p) {
 // sec[u][0][k] = start, sec[u][1][k] = end of the k-th voiced run of `src`;
 // sec[u][4][k] = offset of the run's private slice (length end-start+1+extra),
 // sec_n[u][0] = number of runs.  One workgroup per utterance.
-struct SecArgs { const double *src; int force_ends; int extra; };
+struct SecArgs {
+  const double *src; int force_ends; int extra;
+  double *copy_to;      // != nullptr: every frame of src is also copied there (the pass reads them all anyway)
+  double *zero_to;      // != nullptr: the unvoiced frames are set to 0 there
+};
 
 __global__ void hc_sections(HarvestParams p, SecArgs a) {
   DYN_LDS(lds);
@@ -107,7 +111,7 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
   // (utterances beyond 63 488 base frames) take several pieces.
   constexpr int kPiece = 62, kLoads = 16;
   typedef unsigned long long u64;
-  auto piece_runs = [&](int base, int n, u64 &starts, u64 &ends) {        // bit i of either <-> frame base + i, i < n
+  auto piece_runs = [&](int base, int n, u64 &starts, u64 &ends, bool side_effects) {   // bit i of either <-> frame base + i, i < n
     u64 m = 0;                                                            // bit i <-> frame base - 1 + i is voiced
     for (int b = 0; b < n + 2; b += kLoads) {
       double v[kLoads];
@@ -118,6 +122,10 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
         const int f = base - 1 + b + q;
         const bool ok = b + q < n + 2 && f >= 0 && f < nf && !(a.force_ends && (f == 0 || f == nf - 1)) && v[q] > 0;
         m |= (u64)ok << (b + q);
+        if (side_effects && b + q >= 1 && b + q <= n) {                 // the piece's own frames, once
+          if (a.copy_to) a.copy_to[(size_t)u * p.fb_stride + f] = v[q];
+          if (a.zero_to && !ok) a.zero_to[(size_t)u * p.fb_stride + f] = 0.0;
+        }
       }
     }
     const u64 span = (1ull << n) - 1, cur = (m >> 1) & span;
@@ -128,7 +136,7 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
   u64 starts0 = 0, ends0 = 0;                              // the first piece's patterns are kept for the second pass
   for (int base = lo; base < hi; base += kPiece) {
     u64 s_, e_;
-    piece_runs(base, imin(kPiece, hi - base), s_, e_);
+    piece_runs(base, imin(kPiece, hi - base), s_, e_, true);
     if (base == lo) { starts0 = s_; ends0 = e_; }
     mine += __builtin_popcountll(s_) + (__builtin_popcountll(e_) << 16);
   }
@@ -149,7 +157,7 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
     int at_s = at_s0, at_e = at_e0;
     for (int base = lo; base < hi; base += kPiece) {
       u64 s_ = starts0, e_ = ends0;
-      if (base != lo) piece_runs(base, imin(kPiece, hi - base), s_, e_);
+      if (base != lo) piece_runs(base, imin(kPiece, hi - base), s_, e_, false);
       for (; s_; s_ &= s_ - 1, ++at_s) if (at_s < p.sec_cap) st[at_s] = base + __builtin_ctzll(s_);
       for (; e_; e_ &= e_ - 1, ++at_e) if (at_e < p.sec_cap) ed[at_e] = base + __builtin_ctzll(e_);
     }
@@ -828,11 +836,10 @@ __global__ void hc_output(HarvestParams p) {
 
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
-  const size_t row_bytes = sizeof(double) * (size_t)B * p.fb_stride;
   WH_WAVES(hc_base, max_fb, B, 1, 0, stream, p);
   WH_THREADS(hc_step1, max_fb, B, 1, stream, p);
   WH_THREADS(hc_step2, max_fb, B, 1, stream, p);
-  SecArgs a2 = {p.c2, 1, 2 * kExtMargin};
+  SecArgs a2 = {p.c2, 1, 2 * kExtMargin, nullptr, nullptr};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
   WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), kExtendThreads, 64 * sizeof(double), stream, p);
   // WORLD_HIP_MERGE_LDS_SECTIONS lowers the number of section records hc_merge keeps in LDS (tests use it to send an
@@ -840,13 +847,11 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   static const int merge_limit = [] { const char *e = getenv("WORLD_HIP_MERGE_LDS_SECTIONS"); return e ? imax(0, imin(kMergeLdsSections, atoi(e))) : kMergeLdsSections; }();
   const int merge_cap = imin(p.sec_cap, merge_limit);
   WH_BLOCKS(hc_merge, dim3(B), kMergeThreads, hc_merge_lds_bytes(merge_cap), stream, p, merge_cap);
-  devrt::d2d(p.c0, p.c3, row_bytes, stream);
-  SecArgs a3 = {p.c3, 1, 0};
+  SecArgs a3 = {p.c3, 1, 0, p.c0, nullptr};            // step 4 patches c0 = a copy of c3
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a3);
   WH_THREADS(hc_step4, p.sec_cap, B, 1, stream, p);
-  SecArgs a4 = {p.c0, 0, kSmoothTail};
+  SecArgs a4 = {p.c0, 0, kSmoothTail, nullptr, p.basic_f0};   // hc_smooth writes the voiced frames of basic_f0
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a4);
-  devrt::dzero(p.basic_f0, row_bytes, stream);
   // one wavefront per block: each reserves LDS for the longest section the batch can hold
   const int smooth_lds = imin(kSmoothLdsMax, max_fb + 3 * kSmoothTail + kSmoothSlack);
   WH_BLOCKS(hc_smooth, dim3(imin(p.sec_cap, kSmoothBlocks), B), WAVE, smooth_lds * sizeof(double), stream, p, smooth_lds);

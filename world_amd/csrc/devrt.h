@@ -359,6 +359,33 @@ __device__ __forceinline__ double wave_min(double v) {
 #endif
   return v;
 }
+// The same for non-negative values (no NaNs) on the shortest path this GPU offers: v_min_f64 itself (no compare and
+// select), four DPP steps inside the rows of 16 lanes, row_bcast:15 and row_bcast:31 to fold the rows into lane 63, one
+// v_readlane pair -- 6 x 3 + 2 instructions where wave_min() spends ~45 and three trips between VALU and SALU.
+__device__ __forceinline__ double wave_min_nonneg(double v) {
+#ifndef WORLD_EMU
+  auto vmin = [](double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  };
+  auto bcast = [](double x, auto ctrl_c, auto rows_c) {      // rows named by the mask take the last lane of the row(s) before
+    constexpr int CTRL = decltype(ctrl_c)::value, ROWS = decltype(rows_c)::value;
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWS, 0xf, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWS, 0xf, false));
+  };
+  v = vmin(v, dpp_f64<kDppXor1>(v));
+  v = vmin(v, dpp_f64<kDppXor2>(v));
+  v = vmin(v, dpp_f64<kDppHalfMirror>(v));
+  v = vmin(v, dpp_f64<kDppMirror>(v));
+  v = vmin(v, bcast(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));   // row_bcast:15
+  v = vmin(v, bcast(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));   // row_bcast:31
+  return readlane_f64(v, 63);
+#else
+  return v;
+#endif
+}
 // Inclusive add-scan over the wavefront by DPP (no LDS crossbar): Kogge-Stone inside each row of 16 lanes (row_shr
 // 1, 2, 4, 8; lanes shifted in from outside the row read 0), then row_bcast:15 hands every odd row the total of the
 // row before it and row_bcast:31 hands rows 2 and 3 the total of rows 0-1.  Six dependent VALU steps where the

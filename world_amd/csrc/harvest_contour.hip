@@ -52,53 +52,59 @@ __global__ void hc_base(HarvestParams p) {
   }
   if (lane == 0) hc_row(p.c0, p, u)[f] = v;
 }
-__global__ void hc_step1(HarvestParams p) {
-  const int f = flat_thread_x(), u = blockIdx.y;
-  if (f >= p.nfb[u]) return;
+// ---- FixStep1 (:710-722) + FixStep2 (:748-762) in one launch -----------------------------------------
+// Step 1 drops a frame whose F0 jumps from the line through its two predecessors; step 2 removes voiced runs with
+// end - start < 6, which needs step 1's result six frames to either side: a workgroup evaluates step 1 for its
+// kStepTile frames and that margin into LDS, then step 2 out of it (two kernels and a contour row in HBM before).
+constexpr int kStepTile = 256, kStepMargin = 6;
+__global__ void __launch_bounds__(kStepTile) hc_step12(HarvestParams p) {
+  DYN_LDS(lds);
+  double *s1 = reinterpret_cast<double *>(lds);            // step 1 of frames f0 - kStepMargin .. f0 + kStepTile + kStepMargin - 1
+  const int u = blockIdx.y, f0 = blockIdx.x * kStepTile, nf = p.nfb[u];
+  if (f0 >= nf) return;
   const double *base = hc_row(p.c0, p, u);
-  double v = 0.0;
-  if (f >= 2) {
-    const double b0 = base[f];
-    if (b0 != 0.0) {
-      const double b1 = base[f - 1], b2 = base[f - 2];
-      double ref = b1 * 2 - b2;
-      v = fabs((b0 - ref) / ref) > 0.008 && fabs((b0 - b1)) / b1 > 0.008 ? 0.0 : b0;
+  for (int i = threadIdx.x; i < kStepTile + 2 * kStepMargin; i += blockDim.x) {
+    const int g = f0 - kStepMargin + i;
+    double v = 0.0;
+    if (g >= 2 && g < nf) {
+      const double b0 = base[g], b1 = base[g - 1], b2 = base[g - 2];   // (all three at once: one trip to memory)
+      if (b0 != 0.0) {
+        double ref = b1 * 2 - b2;
+        v = fabs((b0 - ref) / ref) > 0.008 && fabs((b0 - b1)) / b1 > 0.008 ? 0.0 : b0;
+      }
     }
+    s1[i] = v;
   }
-  hc_row(p.c1, p, u)[f] = v;
-}
-
-// ---- FixStep2: voiced runs with end - start < 6 are removed -------------------
-__global__ void hc_step2(HarvestParams p) {
-  const int f = flat_thread_x(), u = blockIdx.y;
-  const int nf = p.nfb[u];
-  if (f >= nf) return;
-  const double *in = hc_row(p.c1, p, u);
-  auto voiced = [&](int i) { return i > 0 && i < nf - 1 && in[i] > 0; };   // ends forced unvoiced (:733)
-  double v = in[f];
-  if (voiced(f)) {
-    int back = 0, fwd = 0;
-    while (back < 6 && voiced(f - back - 1)) ++back;
-    while (fwd < 6 && voiced(f + fwd + 1)) ++fwd;
-    if (back + fwd < 6) v = 0.0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < kStepTile; t += blockDim.x) {
+    const int f = f0 + t;
+    if (f >= nf) break;
+    auto at = [&](int i) { return s1[i - f0 + kStepMargin]; };
+    auto voiced = [&](int i) { return i > 0 && i < nf - 1 && at(i) > 0; };   // ends forced unvoiced (:733)
+    double v = at(f);
+    if (voiced(f)) {
+      int back = 0, fwd = 0;
+      while (back < 6 && voiced(f - back - 1)) ++back;
+      while (fwd < 6 && voiced(f + fwd + 1)) ++fwd;
+      if (back + fwd < 6) v = 0.0;
+    }
+    hc_row(p.c2, p, u)[f] = v;
   }
-  hc_row(p.c2, p, u)[f] = v;
 }
 
 // ---- GetBoundaryList (:727-743) as a block scan --------------------------------
 // sec[u][0][k] = start, sec[u][1][k] = end of the k-th voiced run of `src`;
 // sec[u][4][k] = offset of the run's private slice (length end-start+1+extra),
 // sec_n[u][0] = number of runs.  One workgroup per utterance.
+constexpr int kSmoothTail = 300;     // samples the smoother holds a section's end values for (SmoothF0Contour, below)
 struct SecArgs {
   const double *src; int force_ends; int extra;
   double *copy_to;      // != nullptr: every frame of src is also copied there (the pass reads them all anyway)
   double *zero_to;      // != nullptr: the unvoiced frames are set to 0 there
 };
 
-__global__ void hc_sections(HarvestParams p, SecArgs a) {
-  DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  const int u = blockIdx.x, nf = p.nfb[u];
+__device__ __forceinline__ void hc_sections_pass(const HarvestParams &p, const SecArgs &a, int u, double *scratch) {
+  const int nf = p.nfb[u];
   const double *in = a.src + (size_t)u * p.fb_stride;
   int *st = p.sec + (size_t)u * 6 * p.sec_cap, *ed = st + p.sec_cap, *off = st + 4 * p.sec_cap;
   // every thread owns a run of consecutive frames: ONE block scan for the whole utterance (a scan per 1024
@@ -178,6 +184,41 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
     if (k < ns) off[k] = running + at;
     running += tot;
   }
+}
+__global__ void hc_sections(HarvestParams p, SecArgs a) {
+  DYN_LDS(lds);
+  hc_sections_pass(p, a, blockIdx.x, reinterpret_cast<double *>(lds));
+}
+
+// FixStep4 (:1000-1022) between two section passes, one launch: the sections of step 3's contour (c3, copied to c0 on
+// the way), the short unvoiced gaps between them bridged linearly in c0, then the sections of the patched contour for
+// the smoother (and basic_f0's unvoiced frames zeroed on the way).  All by the utterance's one workgroup: the patches
+// depend on the first pass's lists, the second pass on the patches.
+__global__ void hc_sections_step4(HarvestParams p) {
+  DYN_LDS(lds);
+  double *scratch = reinterpret_cast<double *>(lds);
+  const int u = blockIdx.x;
+  const SecArgs a3 = {p.c3, 1, 0, p.c0, nullptr};
+  hc_sections_pass(p, a3, u, scratch);
+  __syncthreads();
+  {
+    const int ns = p.sec_n[u * 2];
+    const int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
+    const double *in = hc_row(p.c3, p, u);
+    double *out = hc_row(p.c0, p, u);
+    for (int k = threadIdx.x; k < ns - 1; k += blockDim.x) {
+      const int ed = sec[p.sec_cap + k], nst = sec[k + 1];
+      const int dist = nst - ed - 1;
+      if (dist >= 9) continue;
+      double t0 = in[ed] + 1, t1 = in[nst] - 1;
+      double coef = (t1 - t0) / (dist + 1.0);
+      int c = 1;
+      for (int j = ed + 1; j <= nst - 1; ++j) out[j] = t0 + coef * c++;
+    }
+  }
+  __syncthreads();
+  const SecArgs a4 = {p.c0, 0, kSmoothTail, nullptr, p.basic_f0};
+  hc_sections_pass(p, a4, u, scratch);
 }
 
 // ---- FixStep3, part 1: Extend() per section (:791-878) --------------------------
@@ -293,7 +334,7 @@ __global__ void __launch_bounds__(kExtendThreads) hc_extend(HarvestParams p) {
             // readlane, no LDS round trips on the frame-to-frame chain; the winner's exact distance is recomputed.
             static_assert(kMaxSlots <= 256, "the slot index rides in one byte");
             const long long kb = (__double_as_longlong(best_d) & ~0xFFll) | (long long)(0xFF - (best_i & 0xFF));
-            const double kmin = wave_min(__longlong_as_double(kb));
+            const double kmin = wave_min_nonneg(__longlong_as_double(kb));
             const int win = 0xFF - (__builtin_amdgcn_readfirstlane(__double2loint(kmin)) & 0xFF);
             // (keep(): left to itself the compiler turns the selects into one load at a computed index, and an array
             // indexed at run time lives in scratch memory)
@@ -644,30 +685,12 @@ __global__ void __launch_bounds__(kMergeThreads) hc_merge(HarvestParams p, int c
   }
 }
 
-// ---- FixStep4 (:1000-1022): short unvoiced gaps are bridged linearly ---------------
-__global__ void hc_step4(HarvestParams p) {
-  const int k = flat_thread_x(), u = blockIdx.y;
-  const int ns = p.sec_n[u * 2];
-  if (k >= ns - 1) return;
-  const int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
-  const int ed = sec[p.sec_cap + k], nst = sec[k + 1];
-  const int dist = nst - ed - 1;
-  if (dist >= 9) return;
-  const double *in = hc_row(p.c3, p, u);
-  double *out = hc_row(p.c0, p, u);
-  double t0 = in[ed] + 1, t1 = in[nst] - 1;
-  double coef = (t1 - t0) / (dist + 1.0);
-  int c = 1;
-  for (int j = ed + 1; j <= nst - 1; ++j) out[j] = t0 + coef * c++;
-}
-
 // ---- SmoothF0Contour (:1049-1113): zero-phase 2nd-order Butterworth per section ------
 // The reference pads 300 zeros, holds the section's end values over the whole padded
 // signal and runs the IIR forwards and backwards from rest.  300 samples is ~40 time
 // constants of this filter (pole radius 0.875), so each sweep has converged to the
 // DC steady state of the held value when it reaches the section: starting AT the
 // section edge from that steady state differs by < 1e-17.
-constexpr int kSmoothTail = 300;
 // One wavefront per voiced section; every lane filters one chunk of the section,
 // warmed up over the kSmoothTail samples before it (same convergence argument).
 //
@@ -837,8 +860,7 @@ __global__ void hc_output(HarvestParams p) {
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
   WH_WAVES(hc_base, max_fb, B, 1, 0, stream, p);
-  WH_THREADS(hc_step1, max_fb, B, 1, stream, p);
-  WH_THREADS(hc_step2, max_fb, B, 1, stream, p);
+  WH_BLOCKS(hc_step12, dim3((max_fb + kStepTile - 1) / kStepTile, B), kStepTile, (kStepTile + 2 * kStepMargin) * sizeof(double), stream, p);
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin, nullptr, nullptr};
   WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
   WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), kExtendThreads, 64 * sizeof(double), stream, p);
@@ -847,11 +869,7 @@ void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, 
   static const int merge_limit = [] { const char *e = getenv("WORLD_HIP_MERGE_LDS_SECTIONS"); return e ? imax(0, imin(kMergeLdsSections, atoi(e))) : kMergeLdsSections; }();
   const int merge_cap = imin(p.sec_cap, merge_limit);
   WH_BLOCKS(hc_merge, dim3(B), kMergeThreads, hc_merge_lds_bytes(merge_cap), stream, p, merge_cap);
-  SecArgs a3 = {p.c3, 1, 0, p.c0, nullptr};            // step 4 patches c0 = a copy of c3
-  WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a3);
-  WH_THREADS(hc_step4, p.sec_cap, B, 1, stream, p);
-  SecArgs a4 = {p.c0, 0, kSmoothTail, nullptr, p.basic_f0};   // hc_smooth writes the voiced frames of basic_f0
-  WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a4);
+  WH_BLOCKS(hc_sections_step4, dim3(B), 1024, 64 * sizeof(double), stream, p);     // then hc_smooth writes basic_f0's voiced frames
   // one wavefront per block: each reserves LDS for the longest section the batch can hold
   const int smooth_lds = imin(kSmoothLdsMax, max_fb + 3 * kSmoothTail + kSmoothSlack);
   WH_BLOCKS(hc_smooth, dim3(imin(p.sec_cap, kSmoothBlocks), B), WAVE, smooth_lds * sizeof(double), stream, p, smooth_lds);

@@ -149,6 +149,11 @@ def _default_lanes(packer=None):
 def _store_records(packer, tpos, f0, sp, ap, nf, block):
     """records of one batched analysis into block[0:]: the library's kernel on the GPU, indexing on CPU tensors"""
     nb = sp.shape[-1]
+    if 2 + 2 * nb != block.shape[-1]:
+        # every rank sized its receive buffers from `bins`: a mismatch here would otherwise surface as a hang of the ranks
+        # that own no utterance of this chunk
+        raise ValueError(f"analyze() returned {nb} bins per frame, the job was set up for {(block.shape[-1] - 2) // 2}: "
+                         "pass bins= to analyze_sharded when the analysis does not use the default fft size")
     if block.is_cuda:
         (packer or _default_analyzer()).pack_results(tpos, f0, sp, ap, nf, block, 0)
         return

@@ -439,7 +439,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   need += pad256(sizeof(double) * B * p.nch * p.fb_stride);
   need += 4 * pad256(sizeof(double) * cand_elems);
   need += pad256(sizeof(int) * B);
-  need += 5 * pad256(sizeof(double) * B * p.fb_stride);
+  need += 4 * pad256(sizeof(double) * B * p.fb_stride);
   need += pad256(sizeof(int) * B * 6 * p.sec_cap) + pad256(sizeof(int) * B * 2) + pad256(sizeof(double) * B * p.sec_cap);
   need += pad256(sizeof(double) * B * p.ext_cap);
   ensure_arena(c, need);
@@ -472,7 +472,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.cand_a = c->arena.take<double>(cand_elems); p.score_a = c->arena.take<double>(cand_elems);
   p.cand_b = c->arena.take<double>(cand_elems); p.score_b = c->arena.take<double>(cand_elems);
   p.nc = c->arena.take<int>(B);
-  p.c0 = c->arena.take<double>(B * p.fb_stride); p.c1 = c->arena.take<double>(B * p.fb_stride);
+  p.c0 = c->arena.take<double>(B * p.fb_stride);
   p.c2 = c->arena.take<double>(B * p.fb_stride); p.c3 = c->arena.take<double>(B * p.fb_stride);
   p.basic_f0 = c->arena.take<double>(B * p.fb_stride);
   p.sec = c->arena.take<int>(B * 6 * p.sec_cap);

@@ -358,17 +358,42 @@ __device__ __forceinline__ void band_events_segment(const BandJob &job, int seg)
     for (int fam = 0; fam < 4; ++fam) cnt_out[(size_t)fam * job.nseg] = imin(count[fam], kSegCap);
 }
 
-// concatenate the segment lists of one (channel, family) in time order
+// concatenate the segment lists of one (channel, family) in time order.  The counts become offsets by one block
+// scan, then the copy is ONE flat pass with eight loads in flight per thread (a loop over the segments paid a
+// trip to memory for every segment's count and another for its copy, one after the other).
+// lds: compact_lds_bytes(nseg) bytes.
+inline size_t compact_lds_bytes(int nseg) { return 64 * sizeof(double) + sizeof(int) * (size_t)(nseg + 1); }
 __device__ __forceinline__ void compact_event_segments(const double *seg_events, const int *seg_count, int nseg, int seg_cap,
-                                                       double *events, int ev_cap, int *ev_count) {
-  int base = 0;
-  for (int sgm = 0; sgm < nseg; ++sgm) {
-    const int c = seg_count[sgm];
-    for (int i = threadIdx.x; i < c; i += blockDim.x)
-      if (base + i < ev_cap) events[base + i] = seg_events[(size_t)sgm * seg_cap + i];
-    base += c;
+                                                       double *events, int ev_cap, int *ev_count, char *lds) {
+  double *scratch = reinterpret_cast<double *>(lds);
+  int *pre = reinterpret_cast<int *>(scratch + 64);          // pre[s] = events before segment s, pre[nseg] = all
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int running = 0;
+  for (int s0 = 0; s0 < nseg; s0 += nt) {
+    const int s = s0 + tid;
+    const int c = s < nseg ? seg_count[s] : 0;
+    int tot;
+    const int at = block_excl_scan_int(c, &tot, scratch);
+    if (s < nseg) pre[s] = running + at;
+    running += tot;
   }
-  if (threadIdx.x == 0) *ev_count = imin(base, ev_cap);
+  if (tid == 0) pre[nseg] = running;
+  __syncthreads();
+  const int total = imin(running, ev_cap);
+  constexpr int kB = 8;
+  int s = 0;
+  for (int j0 = tid; j0 < total; j0 += kB * nt) {
+    double v[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) {
+      const int j = imin(j0 + q * nt, total - 1);
+      while (j >= pre[s + 1]) ++s;                            // (a thread's elements ascend: the segment only moves forward)
+      v[q] = seg_events[(size_t)s * seg_cap + (j - pre[s])];
+    }
+#pragma unroll
+    for (int q = 0; q < kB; ++q) if (j0 + q * nt < total) events[j0 + q * nt] = v[q];
+  }
+  if (tid == 0) *ev_count = total;
 }
 
 // ---- interval F0s of one family and their interpolation onto frame times ----------

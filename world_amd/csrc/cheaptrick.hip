@@ -334,7 +334,7 @@ int ct_seg_stride(int fft_size) {
 size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size / 2 + 1; }   // window < fft_size, + bins
 
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
-  WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);    // 1024 threads: a 10 s utterance is two scans
   const dim3 grid(max_frames, p.b.n_utt);
   const size_t lds1 = ct_spectrum_lds_bytes(p.lg_fft), lds3 = ct_envelope_lds_bytes(p.lg_fft);
   const dim3 scan_grid((max_frames + WAVE - 1) / WAVE, p.b.n_utt);

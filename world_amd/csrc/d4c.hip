@@ -820,7 +820,7 @@ size_t d4c_max_draws_per_frame(int fs) {
 }
 
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
-  WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);
   // workgroup sizes follow the transform size (threads beyond N/16 idle through every radix-8 stage): for the
   // 2048-point internal FFT of fs <= 24 kHz, 64 x 1001 frames: lovetrain 0.53 -> 0.42 ms, groupdelay 3.77 -> 2.52,
   // band 0.97 -> 0.65
@@ -835,7 +835,7 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
     else devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<0>, love_grid, p.lg_love <= 11 ? 128 : 256, love_lds, stream, p);
 #endif
   }
-  WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);
   // one radix-8 butterfly per thread: 128 / 256 / 512 threads for the 2048- / 4096- / 8192-point internal FFT
   // (fs <= 24 kHz / <= 48 kHz / <= 96 kHz); the register arrays are sized per shape
   const dim3 grid(max_frames, p.b.n_utt);

@@ -83,7 +83,7 @@ __device__ __forceinline__ void dec_forward_block(const double *x, int n, int la
   const int cnt = imin(total, b0 + kDecSpan) - lo;
   {
     // kDecBatch loads in flight per thread (one load waited for per trip made staging the longest part of the kernel);
-    // dec_padded() without branches: every sample is x[src] or, in the reflected edges, 2 * end - x[src]
+    // the padded signal (see above) without branches: every sample is x[src] or, in the reflected edges, 2 * end - x[src]
     const int m = n + 2 * lag, nt = (int)blockDim.x;
     const double head = x[0], tail = x[n - 1];
     for (int k0 = threadIdx.x; k0 < cnt; k0 += kDecBatch * nt) {

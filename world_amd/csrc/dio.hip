@@ -164,10 +164,11 @@ __global__ void __launch_bounds__(kBpThreads) dio_band_events(DioParams p) {
   band_events_segment(job, seg);
 }
 __global__ void dio_compact_events(DioParams p) {
+  DYN_LDS(lds);
   const int bf = blockIdx.x, u = blockIdx.y;
   const size_t list = (size_t)u * p.nb * 4 + bf;
   compact_event_segments(p.seg_events + list * p.nseg * kSegCap, p.seg_count + list * p.nseg, p.nseg, kSegCap,
-                         p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list);
+                         p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list, lds);
 }
 
 // ---- candidates and scores (dio.cpp:441-572), one thread per (frame, channel, utt) ----
@@ -341,7 +342,7 @@ void launch_dio(const DioParams &p, int max_x_len, int max_y_len, int max_frames
   WH_BLOCKS(dio_nyquist_bins, dim3(B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(dio_band_quirk, dim3(p.nb, B), 64, 64 * sizeof(double), stream, p);
   WH_BLOCKS(dio_band_events, dim3(p.nseg, p.nb, B), kBpThreads, band_lds_bytes(p.max_ntap), stream, p);
-  WH_BLOCKS(dio_compact_events, dim3(p.nb * 4, B), 256, 0, stream, p);
+  WH_BLOCKS(dio_compact_events, dim3(p.nb * 4, B), 256, compact_lds_bytes(p.nseg), stream, p);
   WH_THREADS(dio_candidates, max_frames, p.nb, B, stream, p);
   WH_THREADS(dio_time_axis, max_frames, B, 1, stream, p);
   WH_THREADS(dio_step1, max_frames, B, 1, stream, p);

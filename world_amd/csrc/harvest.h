@@ -55,7 +55,7 @@ struct HarvestParams {
   double *cand_a, *score_a;  // [n_utt][fb_stride][maxc]
   double *cand_b, *score_b;  // [n_utt][fb_stride][maxc]
   int *nc;                 // [n_utt] candidates per frame (max over frames)
-  double *c0, *c1, *c2, *c3; // [n_utt][fb_stride(+600)] contour scratch
+  double *c0, *c2, *c3;      // [n_utt][fb_stride(+600)] contour scratch: base pick / step 4, step 2, step 3
   int *sec;                // [n_utt][6][sec_cap]: start, end, ext start, ext end, slice offset, slice origin
   int *sec_n;              // [n_utt][2]: number of sections, number kept by ExtendSub
   double *sec_sum;         // [n_utt][sec_cap] sum of a section's extended f0

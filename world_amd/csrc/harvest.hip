@@ -298,10 +298,11 @@ __global__ void __launch_bounds__(256, 3) hv_band_events_fft(HarvestParams p) {
 
 // concatenate the per-segment lists of one (family, band, utterance) in time order
 __global__ void hv_compact_events(HarvestParams p) {
+  DYN_LDS(lds);
   const int bf = blockIdx.x, u = blockIdx.y;        // bf = band * 4 + family
   const size_t list = (size_t)u * p.nch * 4 + bf;
   compact_event_segments(p.seg_events + list * p.nseg * p.seg_cap, p.seg_count + list * p.nseg, p.nseg, p.seg_cap,
-                         p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list);
+                         p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -750,7 +751,7 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
     WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
   }
   // one chunk per utterance: the kernel above appended straight into the final lists (seg_events == events)
-  if (!(p.fft_seg > 0 && p.nseg == 1)) WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, 0, stream, p);
+  if (!(p.fft_seg > 0 && p.nseg == 1)) WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, compact_lds_bytes(p.nseg), stream, p);
   WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawFrames - 1) / kRawFrames, p.nch, B), kRawFrames,
             8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);

@@ -5,14 +5,18 @@
 // Extend/ExtendF0/ExtendSub, MergeF0/MergeF0Sub), FixStep4 (:1000-1022), then
 // SmoothF0Contour (:1079-1113) and the hop subsampling of Harvest() (:1246-1251).
 //
-// The reference is one serial pass per utterance.  Here everything that is local
-// to a frame or to a voiced section runs in parallel -- one thread per frame for
-// the base pick / steps 1-2, one wavefront per voiced section for the candidate
-// tracking of step 3 (lanes = candidate slots, "nearest candidate, last wins" as
-// a (error, index) reduction), one thread per section for step 4 and for the
-// zero-phase smoother -- and only the short inherently ordered parts (section
-// selection with its running mean, the merge of overlapping sections) are walked
-// in order by a single wavefront per utterance.
+// The reference is one serial pass per utterance.  Here everything that is local to a frame or to a voiced section
+// runs in parallel, and the inherently ordered parts are kept short and staged in LDS.  Eight launches per batch:
+//   hc_base            one wavefront per frame, lanes over the candidate slots
+//   hc_step12          FixStep1 + FixStep2, a workgroup per tile of 256 frames (step 1 and its margin in LDS)
+//   hc_sections        the voiced runs of step 2's contour: one workgroup per utterance, flags as bit words, one scan
+//   hc_extend          a workgroup per section: two wavefronts track candidates forwards / backwards ("nearest
+//                      candidate, last wins" as ONE packed (distance, slot) minimum), all eight copy and sum
+//   hc_merge           a workgroup per utterance: section selection with the reference's running mean, the merge of
+//                      overlapping sections as a list of copy records, the contour written once at the end
+//   hc_sections_step4  sections of step 3's contour, FixStep4's gap bridging, sections of the patched contour
+//   hc_smooth          one wavefront per section: zero-phase Butterworth, in place in LDS
+//   hc_output          Harvest()'s hop subsampling
 #include "harvest.h"
 
 namespace world_hip {
@@ -222,25 +226,6 @@ __global__ void hc_sections_step4(HarvestParams p) {
 }
 
 // ---- FixStep3, part 1: Extend() per section (:791-878) --------------------------
-// nearest candidate of `ref` within `allowed`, ties -> the LAST one (SelectBestF0, :636-650)
-__device__ __forceinline__ double wave_nearest(double ref, const double *c, int nslot, double allowed) {
-  double best_e = allowed;
-  int best_i = -1;
-  for (int i = lane_id(); i < nslot; i += WAVE) {
-    double e = fabs(ref - c[i]) / ref;
-    if (e > best_e) continue;
-    best_e = e; best_i = i;
-  }
-#ifndef WORLD_EMU
-  for (int m = 32; m >= 1; m >>= 1) {
-    double oe = __shfl_xor(best_e, m, 64);
-    int oi = __shfl_xor(best_i, m, 64);
-    if (oe < best_e || (oe == best_e && oi > best_i)) { best_e = oe; best_i = oi; }
-  }
-#endif
-  return best_i < 0 ? 0.0 : c[best_i];
-}
-
 constexpr int kMaxSlots = 256;       // candidate slots per frame handled by the tracking lanes (maxc <= 256)
 constexpr int kExtReach = 100;       // frames a section may grow in each direction (:865)
 constexpr int kExtMargin = kExtReach + 1;

@@ -44,12 +44,23 @@ template <int NT = 0>
 __device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2 *global_tw) {
   const int quarter = 1 << (lg - 2);
   const double *dense = reinterpret_cast<const double *>(global_tw + kTwN) + quarter_table_offset(lg);   // tables.h
-  for (int i = wg_thread<NT>(); i <= quarter; i += wg_size<NT>()) q[i] = dense[i];
+  // everything the workgroup needs from the tables is requested before anything is waited for: four entries per
+  // thread and trip, and the two fine twiddles (one load per trip, then two more behind the barrier, were five trips
+  // to L2 in a row at the start of every workgroup)
+  const double2 f = global_tw[lg + 1 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 1) : 0];
+  const double2 f2 = global_tw[lg + 2 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 2) : 0];
+  constexpr int kB = 4;
+  const int tid = wg_thread<NT>(), nt = wg_size<NT>();
+  for (int i0 = tid; i0 <= quarter; i0 += kB * nt) {
+    double v[kB];
+#pragma unroll
+    for (int k = 0; k < kB; ++k) { const int i = i0 + k * nt; v[k] = dense[i < quarter ? i : quarter]; }
+#pragma unroll
+    for (int k = 0; k < kB; ++k) if (i0 + k * nt <= quarter) q[i0 + k * nt] = v[k];
+  }
   __syncthreads();
   TwLds t; t.q = q; t.lg = lg;
-  const double2 f = global_tw[lg + 1 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 1) : 0];
   t.fine_c = f.x; t.fine_s = f.y;
-  const double2 f2 = global_tw[lg + 2 <= kTwLog2 ? (size_t)1 << (kTwLog2 - lg - 2) : 0];
   t.fine2_c = f2.x; t.fine2_s = f2.y;
   return t;
 }

@@ -702,24 +702,62 @@ __global__ void hv_prune(HarvestParams p) {
   if (f0 >= nfb) return;
   const int nslot = p.nc[u] * 7;
   const int nrows = imin(kPruneFrames + 2, nfb - f0 + 1);
-  // stage rows f0-1 .. f0+kPruneFrames (coalesced); rows outside the utterance are never compared
-  for (int i = threadIdx.x; i < nrows * p.maxc; i += blockDim.x) {
-    const int r = i / p.maxc, j = i - r * p.maxc, f = f0 - 1 + r;
-    rows[i] = (f >= 0 && f < nfb && j < nslot) ? p.cand_b[((size_t)u * p.fb_stride + f) * p.maxc + j] : 0.0;
+  // stage rows f0-1 .. f0+kPruneFrames (coalesced, eight loads in flight per thread at clamped addresses: a load under
+  // a condition, stored to LDS in the same trip, made every trip wait for memory -- 14 trips a workgroup); rows
+  // outside the utterance are never compared
+  // Only the nslot slots in use are staged, as rows of nslot (the other maxc - nslot of a row are never written by
+  // hv_refine's tail and never compared).
+  const int nt = blockDim.x;
+  if (nslot == 0) return;                                  // no candidate anywhere in the utterance: nothing to prune
+  {
+    constexpr int kB = 8;
+    const int n = nrows * nslot;
+    for (int i0 = threadIdx.x; i0 < n; i0 += kB * nt) {
+      double v[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const int i = imin(i0 + q * nt, n - 1);
+        const int r = i / nslot, j = i - r * nslot, f = imax(0, imin(nfb - 1, f0 - 1 + r));
+        v[q] = p.cand_b[((size_t)u * p.fb_stride + f) * p.maxc + j];
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const int i = i0 + q * nt;
+        if (i < n) {
+          const int f = f0 - 1 + i / nslot;
+          rows[i] = (f >= 0 && f < nfb) ? v[q] : 0.0;
+        }
+      }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kPruneFrames * nslot; i += blockDim.x) {
-    const int r = i / nslot, j = i - r * nslot, frame = f0 + r;
-    if (frame >= nfb) break;
-    const size_t at = ((size_t)u * p.fb_stride + frame) * p.maxc + j;
-    double ref = rows[(r + 1) * p.maxc + j], sc = p.score_b[at];
-    if (frame >= 1 && frame < nfb - 1 && ref != 0) {
-      double e1 = nearest_error(ref, rows + (r + 2) * p.maxc, nslot);
-      double e2 = nearest_error(ref, rows + r * p.maxc, nslot);
-      if ((e1 < e2 ? e1 : e2) > 0.05) { ref = 0; sc = 0; }
+  {
+    constexpr int kB = 4;                                  // the scores of a thread's next slots are requested together
+    const int n = imin(kPruneFrames, nfb - f0) * nslot;    // slots of the tile's frames inside the utterance
+    for (int i0 = threadIdx.x; i0 < n; i0 += kB * nt) {
+      double scv[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const int i = imin(i0 + q * nt, n - 1);
+        const int r = i / nslot, j = i - r * nslot;
+        scv[q] = p.score_b[((size_t)u * p.fb_stride + f0 + r) * p.maxc + j];
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const int i = i0 + q * nt;
+        if (i >= n) break;
+        const int r = i / nslot, j = i - r * nslot, frame = f0 + r;
+        const size_t at = ((size_t)u * p.fb_stride + frame) * p.maxc + j;
+        double ref = rows[(r + 1) * nslot + j], sc = scv[q];
+        if (frame >= 1 && frame < nfb - 1 && ref != 0) {
+          double e1 = nearest_error(ref, rows + (r + 2) * nslot, nslot);
+          double e2 = nearest_error(ref, rows + r * nslot, nslot);
+          if ((e1 < e2 ? e1 : e2) > 0.05) { ref = 0; sc = 0; }
+        }
+        p.cand_a[at] = ref;
+        p.score_a[at] = sc;
+      }
     }
-    p.cand_a[at] = ref;
-    p.score_a[at] = sc;
   }
 }
 

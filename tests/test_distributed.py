@@ -115,6 +115,16 @@ def test_analyze_sharded_without_a_process_group():
     assert f0.shape == (2, int(nf.max())) and sp.shape == (2, int(nf.max()), 5) and torch.equal(ap, -sp)
 
 
+def test_analyze_sharded_refuses_a_dense_analysis_with_another_bin_count():
+    """every rank sizes its receive buffers from `bins`; an analysis that returns rows of another width must fail loudly
+    (on a multi-rank job the ranks that own no utterance of the chunk would otherwise wait in the all-gather for ever)"""
+    xs = [torch.rand(900, dtype=torch.float64)]
+    with pytest.raises(ValueError, match="bins"):
+        wd.analyze_sharded(xs, 16000, analyze=_fake_analyze, bins=7)       # _fake_analyze returns 5 bins
+    f0, sp, ap, nf = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze, bins=5).dense()
+    assert sp.shape[-1] == 5
+
+
 # ---- the real analysis on 2 ranks: the kernel sources compiled for the host (tests/emu) ----------------
 def _emu_analyze(x, fs, x_len=None, frame_period=5.0, **_):
     """WorldHip.analyze's contract on CPU tensors, computed by the emulated kernels (tests/emu/libworld_emu.so)

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r02", "bench_n1.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03", "bench_n1.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -50,6 +50,14 @@ def test_committed_line_carries_the_contract():
     for key in ("2", "3_share", "4"):
         leg = line["configs"][key]
         assert leg["timed_wall_s"] >= 2.0 and leg["value"] > 0 and leg["roofline"]["kernel"]
+    # round 3: twelve DIFFERENT utterances in flight, the reference's own test file as a leg, the whole configs[3] job on
+    # one GPU (the N = 1 anchor of the scaling curve), the job replayed as a HIP graph, the profile taken on these sources
+    assert p["distinct_utterances"] == p["slots"] == 12
+    assert line["configs"]["0"]["value"] > 0 and line["configs"]["0"]["golden"]["vuv_flips"] == 0
+    assert max(line["configs"]["0"]["golden"][k] for k in ("f0", "sp", "ap")) <= 1e-4
+    assert line["configs"]["3_full"]["value"] > 0 and "1024" in line["configs"]["3_full"]["workload"]
+    assert line["graph"]["replay_bit_identical_to_eager"] is True and line["graph"]["single_job_latency_ms"] > 0
+    assert line["roofline"]["traffic_stale"] is False and line["roofline"]["traffic"] > 0
     assert line["cpu_baseline"]["kind"] == "reference" and "-O1" in line["cpu_baseline"]["sample"]
     assert "-O3" in line["cpu_baseline_o3"]["sample"] and line["cpu_baseline_all_cores"]["cores"] >= 1
 

@@ -137,6 +137,26 @@ WORLD_HIP_API void WriteAperiodicity(const char *filename, int fs, int f0_length
 WORLD_HIP_API int ReadAperiodicity(const char *filename, double **aperiodicity);
 
 
+/* ---- behaviour of the drop-in symbols that the reference does not have to state -----------------
+ * Re-entrancy: like the reference (all state on the stack: src/cheaptrick.cpp:205-206, src/d4c.cpp:345-346) the
+ * symbols above may be called from several host threads at once.  Each call runs on one SLOT of a small pool (a
+ * library context on its own stream + its device / pinned buffers); WORLD_HIP_DROPIN_SLOTS (default 4) calls run side
+ * by side on device WORLD_HIP_DEVICE (default 0), further callers wait for a slot.
+ * Resident input: a slot keeps the last signal `x` it uploaded; StoneMask / CheapTrick / D4C (and a repeated Harvest /
+ * Dio) on the same pointer, length AND content (a 64-bit hash of every sample) skip the upload.
+ * WORLD_HIP_DROPIN_CACHE_X=0 turns that off.  Matrices move through pinned staging in chunks, copied to / from the
+ * caller's rows by the calling thread and WORLD_HIP_DROPIN_COPY_THREADS (default 3) helper threads.
+ * Errors: the reference API has no error channel and never fails; this library can (no GPU, out of device memory, a
+ * shape beyond world_hip_check_shape()).  There is NO CPU fallback.  A failing drop-in call reports through the handler
+ * installed here: `function` is the symbol's name, `message` the reason (also world_hip_last_error()).  If the handler
+ * returns, the drop-in call returns to its caller with its output buffers untouched; it may also longjmp or throw.
+ * With no handler (the default, handler = NULL) the reason is printed to stderr and the process aborts. */
+typedef void (*WorldHipErrorHandler)(const char *function, const char *message, void *user);
+WORLD_HIP_API void world_hip_set_error_handler(WorldHipErrorHandler handler, void *user);
+/* diagnostic counters of the drop-in layer: slots created, calls that found their signal resident / had to upload it */
+WORLD_HIP_API void world_hip_dropin_stats(unsigned long long *slots, unsigned long long *x_hits,
+                                          unsigned long long *x_misses);
+
 /* ------------------------------------------------------------------------- */
 /* Part 2: batched device-resident API                                        */
 /* ------------------------------------------------------------------------- */
@@ -243,10 +263,15 @@ WORLD_HIP_API int world_hip_analyze_batch(WorldHipContext *ctx, int n_utt, int f
                                           int f_stride, double *d_tpos, double *d_f0, double *d_spectrogram,
                                           double *d_aperiodicity);
 /* Harvest + CheapTrick + D4C of one batch written STRAIGHT into packed records: utterance u's frames occupy rows
- * first_row + sum_{v<u} n_frames[v] ... of d_block ([rows][cols] doubles, cols = 2 + 2 (fft_size/2 + 1) =
- * [tpos, f0, sp row, ap row]); n_frames[u] = GetSamplesForHarvest(fs, x_length[u], frame_period).  The stage kernels
- * store their rows at the records' stride, so no pack pass runs (world_hip_pack_results is for results that already
- * exist in the dense layout).  Same stream semantics as the *_batch calls. */
+ * first_row + sum_{v<u} n_frames[v] ... of d_block ([rows][cols] doubles); n_frames[u] = GetSamplesForHarvest(fs,
+ * x_length[u], frame_period).  `cols` names the record format (world_hip_record_columns):
+ *   wire 0, cols = 2 + 2 nb : [tpos, f0, sp f64[nb], ap f64[nb]]                       nb = fft_size/2 + 1
+ *   wire 1, cols = 2 + nb   : [tpos, f0, sp f32[nb], ap f32[nb]]  -- half the bytes for the multi-GPU exchange and the
+ *                             D2H copy; the values are the f64 results rounded once to float (6e-8 relative, the
+ *                             contract is 1e-4); tpos and f0 stay f64.
+ * The stage kernels store their rows at the records' stride, so no pack pass runs (world_hip_pack_results is for results
+ * that already exist in the dense layout).  Same stream semantics as the *_batch calls. */
+WORLD_HIP_API int world_hip_record_columns(int fft_size, int wire);
 WORLD_HIP_API int world_hip_analyze_packed(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
                                            const int *x_length, const HarvestOption *harvest_option,
                                            const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
@@ -283,7 +308,11 @@ WORLD_HIP_API int world_hip_check_shape(int fs, int cheaptrick_fft_size, char *w
 /* HIP graphs: the batched calls enqueued on ctx between _begin and _end are captured into ONE executable graph (bound to
  * the device buffers they were given) instead of being run; _launch replays it on the context's stream at the cost of one
  * host launch (a Harvest + CheapTrick + D4C job is ~45 kernel launches otherwise).  Every call shape must have run once
- * before capture (a captured call may not allocate, copy from the host or wait); an error inside a capture invalidates it. */
+ * before capture (a captured call may not allocate, copy from the host or wait); an error inside a capture invalidates it.
+ * A graph holds raw pointers into memory the CONTEXT owns (workspace arena, small per-call arrays, cached tables).  If a
+ * later eager call on the same context has to reallocate any of it (a larger batch, another option set or sampling
+ * rate), the graph is stale: world_hip_graph_launch then FAILS (world_hip_last_error: "stale graph") instead of
+ * replaying -- capture the job again.  Smaller or equal shapes never invalidate a graph. */
 WORLD_HIP_API int world_hip_graph_begin(WorldHipContext *ctx);
 WORLD_HIP_API int world_hip_graph_end(WorldHipContext *ctx, void **graph);
 WORLD_HIP_API int world_hip_graph_launch(WorldHipContext *ctx, void *graph);

@@ -1,0 +1,314 @@
+"""The drop-in layer's own behaviour (world_amd/csrc/dropin.inc): re-entrancy from host threads, the resident input
+signal, chunked transfers through pinned staging, the error handler, and the context's small-array slabs and graph
+generations.  CPU half: the host-compiled library (tests/emu); GPU half: libworld_hip.so through the C ABI.
+Reference behaviour these mirror: the reference is re-entrant and stateless (src/cheaptrick.cpp:205-206,
+src/d4c.cpp:345-346) and reads `x` afresh on every call."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU_DIR = os.path.join(HERE, "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libworld_emu.so")
+
+
+def _emu():
+    subprocess.run(["make", "-s", "-f", os.path.join(EMU_DIR, "Makefile")], check=True)
+    from world_amd.api import HostAPI
+    return HostAPI(EMU_LIB)
+
+
+def _signal(fs, seconds, seed):
+    from world_amd import synth
+    return np.ascontiguousarray(synth.utterance(seed, fs, seconds).numpy())
+
+
+def _analyse(H, x, fs):
+    tp, f0 = H.harvest(x, fs)
+    fft = H.cheaptrick_fft_size(fs)
+    return tp, f0, H.cheaptrick(x, fs, tp, f0, fft_size=fft), H.d4c(x, fs, tp, f0, fft)
+
+
+def _stats(lib):
+    lib.world_hip_dropin_stats.argtypes = [C.POINTER(C.c_ulonglong)] * 3
+    a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+    lib.world_hip_dropin_stats(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def _separate_rows(H, name, x, fs, tp, f0, fft, *extra):
+    """CheapTrick / D4C into rows that are SEPARATE allocations (test/test.cpp:148-151), not one dense block"""
+    from world_amd.api import CheapTrickOption, D4COption
+    nb = fft // 2 + 1
+    rows = [np.full(nb + 3, np.nan) for _ in range(len(f0))]          # + 3: rows are neither adjacent nor equally spaced
+    ptrs = (C.POINTER(C.c_double) * len(f0))(*[r.ctypes.data_as(C.POINTER(C.c_double)) for r in rows])
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    if name == "CheapTrick":
+        opt = CheapTrickOption(); H.lib.InitializeCheapTrickOption(fs, C.byref(opt)); opt.fft_size = fft
+        H.lib.CheapTrick(dp(x), len(x), fs, dp(tp), dp(f0), len(f0), C.byref(opt), ptrs)
+    else:
+        opt = D4COption(); H.lib.InitializeD4COption(C.byref(opt))
+        H.lib.D4C(dp(x), len(x), fs, dp(tp), dp(f0), len(f0), fft, C.byref(opt), ptrs)
+    assert all(np.isnan(r[nb:]).all() for r in rows)                    # nothing written beyond a row
+    return np.stack([r[:nb] for r in rows])
+
+
+def _check_threads(H, fs, seconds, n_threads, rounds):
+    xs = [_signal(fs, seconds, 10 + i) for i in range(n_threads)]
+    serial = [_analyse(H, x, fs) for x in xs]
+    out = [[None] * rounds for _ in range(n_threads)]
+    errors = []
+
+    def work(i):
+        try:
+            for r in range(rounds):
+                out[i][r] = _analyse(H, xs[i], fs)
+        except Exception as e:                                          # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    assert not errors, errors
+    for i in range(n_threads):
+        for r in range(rounds):
+            for a, b in zip(out[i][r], serial[i]):
+                assert np.array_equal(a, b), f"thread {i} round {r}"
+    return dt, xs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU: the host-compiled library
+# ---------------------------------------------------------------------------------------------------------
+def test_emulated_dropin_calls_from_four_host_threads_are_bit_identical():
+    H = _emu()
+    _check_threads(H, 16000, 0.25, 4, 2)
+    slots, hits, misses = _stats(H.lib)
+    assert 1 <= slots <= 4 and hits > 0
+
+
+def test_emulated_resident_signal_follows_an_in_place_edit():
+    """Harvest(x) -> edit ONE sample of x in place -> CheapTrick(x) must analyse the edited signal (the content hash
+    covers every sample), and an unchanged x must be found resident"""
+    H = _emu()
+    fs = 16000
+    x = _signal(fs, 0.3, 5)
+    tp, f0 = H.harvest(x, fs)
+    fft = H.cheaptrick_fft_size(fs)
+    _, h0, m0 = _stats(H.lib)
+    sp = H.cheaptrick(x, fs, tp, f0, fft_size=fft)
+    _, h1, m1 = _stats(H.lib)
+    assert h1 == h0 + 1 and m1 == m0                                    # same pointer, length, content: no upload
+    x[len(x) // 2] += 0.25                                              # one sample, in place
+    sp_edit = H.cheaptrick(x, fs, tp, f0, fft_size=fft)
+    _, h2, m2 = _stats(H.lib)
+    assert m2 == m1 + 1                                                 # uploaded again
+    fresh = H.cheaptrick(x.copy(), fs, tp, f0, fft_size=fft)            # another pointer: certainly uploaded
+    assert np.array_equal(sp_edit, fresh) and not np.array_equal(sp_edit, sp)
+
+
+def test_emulated_separate_rows_match_dense_rows():
+    H = _emu()
+    fs = 16000
+    x = _signal(fs, 0.4, 7)
+    tp, f0, sp, ap = _analyse(H, x, fs)
+    fft = H.cheaptrick_fft_size(fs)
+    assert np.array_equal(_separate_rows(H, "CheapTrick", x, fs, tp, f0, fft), sp)
+    assert np.array_equal(_separate_rows(H, "D4C", x, fs, tp, f0, fft), ap)
+
+
+HANDLER = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p, C.c_void_p)
+
+
+def _check_error_handler(H):
+    """a shape the GPU path refuses reaches the installed handler, the process survives, the outputs stay untouched,
+    and the library works afterwards"""
+    seen = []
+    cb = HANDLER(lambda fn, msg, user: seen.append((fn.decode(), msg.decode())))
+    H.lib.world_hip_set_error_handler.argtypes = [HANDLER, C.c_void_p]
+    H.lib.world_hip_set_error_handler(cb, None)
+    try:
+        fs = 16000
+        x = _signal(fs, 0.2, 3)
+        tp, f0 = H.harvest(x, fs)
+        from world_amd.api import CheapTrickOption
+        opt = CheapTrickOption(); H.lib.InitializeCheapTrickOption(fs, C.byref(opt))
+        opt.fft_size = 1000                                             # not a power of two: refused before any GPU work
+        sp = np.full((len(f0), 501), -7.0)
+        from world_amd.api import _rows, _p
+        H.lib.CheapTrick(_p(x), len(x), fs, _p(tp), _p(f0), len(f0), C.byref(opt), _rows(sp))
+        assert len(seen) == 1 and seen[0][0] == "CheapTrick" and "fft_size 1000" in seen[0][1]
+        assert np.all(sp == -7.0)
+        ap = np.full((len(f0), 513), -7.0)
+        from world_amd.api import D4COption
+        dopt = D4COption(); H.lib.InitializeD4COption(C.byref(dopt))
+        H.lib.D4C(_p(x), len(x), 8000, _p(tp), _p(f0), len(f0), 1024, C.byref(dopt), _rows(ap))   # fs below D4C's floor
+        assert len(seen) == 2 and seen[1][0] == "D4C" and "15.8 kHz" in seen[1][1]
+        assert np.all(ap == -7.0)
+        fft = H.cheaptrick_fft_size(fs)
+        assert np.isfinite(H.cheaptrick(x, fs, tp, f0, fft_size=fft)).all()   # the library still works
+        assert len(seen) == 2
+    finally:
+        H.lib.world_hip_set_error_handler(HANDLER(0), None)
+    return cb
+
+
+def test_emulated_error_handler_receives_shape_refusals():
+    _check_error_handler(_emu())
+
+
+def test_default_error_policy_prints_and_aborts():
+    """no handler installed: the reason on stderr, then abort() -- never a silent CPU result"""
+    _emu()
+    code = ("import sys, ctypes as C, numpy as np; sys.path.insert(0, %r)\n"
+            "from world_amd.api import HostAPI\n"
+            "H = HostAPI(%r)\n"
+            "x = np.zeros(4000); tp = np.zeros(41); f0 = np.zeros(41)\n"
+            "H.cheaptrick(x, 16000, tp, f0, fft_size=1000)\n"
+            "print('survived')\n" % (ROOT, EMU_LIB))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "survived" not in r.stdout
+    assert "libworld_hip: CheapTrick failed" in r.stderr and "fft_size 1000" in r.stderr
+
+
+def _slab_stress(lib_path, env_extra, out):
+    env = dict(os.environ, **env_extra)
+    subprocess.run([sys.executable, os.path.join(HERE, "slab_stress.py"), lib_path, out], check=True, env=env, timeout=1500)
+    return np.load(out)
+
+
+def test_emulated_small_array_slabs_chain_and_recycle(tmp_path):
+    """distinct length vectors beyond one slab must never invalidate pointers a call already holds.  The same
+    ragged batched calls with (a) the default 4 MB slab, (b) 1 KB slabs that chain after every few arrays, (c) a budget of
+    one byte, which drops the whole set at the start of every stage: identical results"""
+    _emu()
+    a = _slab_stress(EMU_LIB, {}, str(tmp_path / "a.npz"))
+    b = _slab_stress(EMU_LIB, {"WORLD_HIP_SMALL_SLAB": "1024"}, str(tmp_path / "b.npz"))
+    c = _slab_stress(EMU_LIB, {"WORLD_HIP_SMALL_SLAB": "512", "WORLD_HIP_SMALL_BUDGET": "1"}, str(tmp_path / "c.npz"))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    assert int(b["slabs"]) == int(a["slabs"])                          # (bookkeeping value only: same call count)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GPU: libworld_hip.so
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_concurrent_dropin_calls_from_host_threads():
+    """four host threads through Harvest + CheapTrick + D4C at once -- bit-identical to serial calls
+    and more than 1.5 x the aggregate throughput of one thread doing the same work"""
+    from world_amd.api import HostAPI
+    H = HostAPI()
+    fs, seconds, rounds = 48000, 4.0, 3
+    dt4, xs = _check_threads(H, fs, seconds, 4, rounds)                 # (also warms every slot up)
+    dt4, _ = _check_threads(H, fs, seconds, 4, rounds)
+    t0 = time.perf_counter()
+    for x in xs:
+        for _ in range(rounds):
+            _analyse(H, x, fs)
+    dt1 = time.perf_counter() - t0
+    slots, hits, _ = _stats(H.lib)
+    print(f"4 threads {dt4 * 1e3:.1f} ms, 1 thread {dt1 * 1e3:.1f} ms for the same {4 * rounds} jobs: {dt1 / dt4:.2f} x; "
+          f"{slots} slots, {hits} resident-signal hits")
+    assert slots >= 2 and hits > 0
+    assert dt1 / dt4 > 1.5
+
+
+@pytest.mark.gpu
+def test_resident_signal_follows_an_in_place_edit_on_the_gpu():
+    from world_amd.api import HostAPI
+    H = HostAPI()
+    fs = 48000
+    x = _signal(fs, 1.0, 5)
+    tp, f0 = H.harvest(x, fs)
+    fft = H.cheaptrick_fft_size(fs)
+    sp = H.cheaptrick(x, fs, tp, f0, fft_size=fft)
+    ap = H.d4c(x, fs, tp, f0, fft)
+    x[len(x) // 3] += 0.25
+    sp_edit, ap_edit = H.cheaptrick(x, fs, tp, f0, fft_size=fft), H.d4c(x, fs, tp, f0, fft)
+    x2 = x.copy()
+    assert np.array_equal(sp_edit, H.cheaptrick(x2, fs, tp, f0, fft_size=fft)) and not np.array_equal(sp_edit, sp)
+    assert np.array_equal(ap_edit, H.d4c(x2, fs, tp, f0, fft)) and not np.array_equal(ap_edit, ap)
+
+
+@pytest.mark.gpu
+def test_separate_rows_match_dense_rows_on_the_gpu(ref_oracle):
+    """2001 separately allocated rows (the reference's own calling convention) through the chunked, double-buffered
+    D2H and the helper threads == one dense matrix == the reference"""
+    from world_amd.api import HostAPI
+    from util import max_rel
+    H = HostAPI()
+    fs = 48000
+    x = _signal(fs, 10.0, 2)
+    tp, f0, sp, ap = _analyse(H, x, fs)
+    fft = H.cheaptrick_fft_size(fs)
+    assert np.array_equal(_separate_rows(H, "CheapTrick", x, fs, tp, f0, fft), sp)
+    assert np.array_equal(_separate_rows(H, "D4C", x, fs, tp, f0, fft), ap)
+    tp_r, f0_r = ref_oracle.harvest(x, fs)
+    assert np.array_equal(tp, tp_r) and np.array_equal(f0 > 0, f0_r > 0)
+    assert max_rel(sp, ref_oracle.cheaptrick(x, fs, tp_r, f0_r, fft_size=fft)) <= 1e-4
+    assert max_rel(ap, ref_oracle.d4c(x, fs, tp_r, f0_r, fft)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_error_handler_receives_shape_refusals_on_the_gpu():
+    from world_amd.api import HostAPI
+    _check_error_handler(HostAPI())
+
+
+@pytest.mark.gpu
+def test_small_array_slabs_chain_and_recycle_on_the_gpu(tmp_path):
+    from world_amd.api import LIB_PATH
+    a = _slab_stress(LIB_PATH, {}, str(tmp_path / "a.npz"))
+    b = _slab_stress(LIB_PATH, {"WORLD_HIP_SMALL_SLAB": "1024"}, str(tmp_path / "b.npz"))
+    c = _slab_stress(LIB_PATH, {"WORLD_HIP_SMALL_SLAB": "512", "WORLD_HIP_SMALL_BUDGET": "1"}, str(tmp_path / "c.npz"))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+
+
+@pytest.mark.gpu
+def test_stale_graph_is_refused_not_replayed():
+    """a captured job whose context later had to reallocate (a larger batch grows the arena) must not be
+    replayed into freed memory: graph_launch fails with "stale graph"; re-captured, it runs and is bit-identical"""
+    import torch
+    from world_amd import synth
+    from world_amd.api import WorldHip, cheaptrick_fft_size, frame_count
+    fs = 48000
+    nb = cheaptrick_fft_size(fs) // 2 + 1
+    wh = WorldHip()
+    x1 = synth.utterance(2, fs, 0.6)[None].cuda().contiguous()
+    b1 = torch.zeros((frame_count(fs, x1.shape[1], 5.0), 2 + 2 * nb), dtype=torch.float64, device="cuda")
+    xb = torch.stack([synth.utterance(i, fs, 1.5) for i in range(4)]).cuda().contiguous()
+    bb = torch.zeros((4 * frame_count(fs, xb.shape[1], 5.0), 2 + 2 * nb), dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        wh.analyze_packed(x1, fs, b1)
+        wh.analyze_packed(x1, fs, b1)
+        torch.cuda.synchronize()
+        ref = b1.clone()
+        g = wh.capture(lambda: wh.analyze_packed(x1, fs, b1))
+        b1.fill_(-3.0); g.launch(); torch.cuda.synchronize()
+        assert torch.equal(b1, ref)
+        wh.analyze_packed(x1, fs, b1)                       # the same shape again: nothing moves, the graph stays valid
+        g.launch(); torch.cuda.synchronize()
+        wh.analyze_packed(xb, fs, bb)                       # a larger job: the arena is regrown
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="stale graph"):
+            g.launch()
+        g.close()
+        wh.analyze_packed(x1, fs, b1)
+        g2 = wh.capture(lambda: wh.analyze_packed(x1, fs, b1))
+        b1.fill_(-3.0); g2.launch(); torch.cuda.synchronize()
+        assert torch.equal(b1, ref)
+        g2.close()

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -77,12 +78,32 @@ struct HarvestBands {            // cached per (fs, f0_floor, f0_ceil)
 // persistent slab and found again by content.  A call in steady state therefore does no host-to-device copy, touches no
 // staging buffer and waits for no event -- which is also what makes the batched calls capturable into a HIP graph
 // (round 2 staged them through a ring of pinned buffers guarded by events; hipErrorStreamCaptureInvalidated).
+// Slabs are CHAINED, never replaced under a call: a stage uploads several arrays before it launches, and a pointer it
+// already holds must stay valid whatever the later uploads do (a full 4 MB slab used to be freed and
+// reallocated between two uploads of one call).  The whole set is dropped only at the START of a stage (CallScope), with
+// the stream drained, once it holds more than kSmallBudget bytes -- a service fed ever-new length vectors then pays one
+// synchronisation per ~16 k distinct arrays instead of growing without bound.  Lookup is a hash of the content.
 struct SmallArrays {
   struct Entry { std::vector<char> bytes; char *dev; };
-  std::vector<Entry> entries;
-  char *slab = nullptr;
-  size_t cap = 0, used = 0;
+  struct Slab { char *base; size_t cap, used; };
+  std::vector<Slab> slabs;
+  std::unordered_multimap<uint64_t, Entry> entries;
+  size_t held = 0;               // bytes of all slabs
+  static uint64_t hash(const void *data, size_t bytes) {          // FNV-1a over the content and its length
+    uint64_t h = 1469598103934665603ull ^ bytes;
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+  }
 };
+static size_t small_slab() {                                      // WORLD_HIP_SMALL_SLAB: test hook (bytes per chained slab)
+  static const size_t v = [] { const char *e = getenv("WORLD_HIP_SMALL_SLAB"); return e ? std::max<size_t>(256, (size_t)atoll(e)) : (size_t(4) << 20); }();
+  return v;
+}
+static size_t small_budget() {                                    // WORLD_HIP_SMALL_BUDGET: test hook (bytes)
+  static const size_t v = [] { const char *e = getenv("WORLD_HIP_SMALL_BUDGET"); return e ? (size_t)atoll(e) : (size_t(64) << 20); }();
+  return v;
+}
 
 struct WorldHipContext {
   int device = 0;
@@ -106,6 +127,9 @@ struct WorldHipContext {
   hipStream_t xstream = nullptr;
   double *h_xin = nullptr, *d_xin = nullptr;
   size_t xin_cap = 0;            // doubles per half
+  // Bumped whenever memory a captured graph may have baked in is freed or replaced (arena, small-array slabs, d_pk, the
+  // cached filter / window / codec tables): world_hip_graph_launch refuses a graph of an older generation.
+  unsigned long long generation = 0;
   std::mutex lock;               // one call at a time per context
 };
 
@@ -114,7 +138,7 @@ namespace world_hip {
 static void ensure_arena(WorldHipContext *c, size_t bytes) {
   if (bytes <= c->arena.cap) return;
   devrt::sync(c->stream);
-  if (c->arena.base) devrt::dfree(c->arena.base);
+  if (c->arena.base) { devrt::dfree(c->arena.base); ++c->generation; }
   size_t cap = bytes + bytes / 8 + (1u << 20);
   c->arena.base = static_cast<char *>(devrt::dmalloc(cap));
   c->arena.cap = cap;
@@ -128,36 +152,52 @@ static const uint32_t *ensure_noise(WorldHipContext *c, size_t draws) {
   return noise_table_acquire(c->device, draws, c->tab.jump, c->stream);
 }
 
-// A small host array on the device: found by content in the context's slab, or appended to it (one H2D copy from a
-// host copy that lives as long as the entry).  The slab only ever grows by being replaced when full (stream drained first).
-struct CallScope {                       // kept as the marker of a call's upload section (nothing to acquire any more)
-  explicit CallScope(WorldHipContext *, size_t) {}
+// A small host array on the device: found by content in the context's slabs, or appended to them (one H2D copy from a
+// host copy that lives as long as the entry).  Nothing a call already holds a pointer to is ever freed by an upload.
+static void drop_small_arrays(WorldHipContext *c) {
+  SmallArrays &sa = c->small;
+  for (SmallArrays::Slab &sl : sa.slabs) devrt::dfree(sl.base);
+  sa.slabs.clear();
+  sa.entries.clear();
+  sa.held = 0;
+}
+// The start of a stage's upload section: the ONLY place the small arrays may be dropped -- no params struct of this
+// stage holds a pointer yet, and the kernels of earlier stages are waited for first.
+struct CallScope {
+  explicit CallScope(WorldHipContext *c, size_t) {
+    if (c->small.held > small_budget() && !devrt::is_capturing(c->stream)) {
+      devrt::sync(c->stream);
+      drop_small_arrays(c);
+      ++c->generation;
+    }
+  }
 };
 
 static char *small_array(WorldHipContext *c, const void *data, size_t bytes) {
   SmallArrays &sa = c->small;
-  for (const SmallArrays::Entry &e : sa.entries)
-    if (e.bytes.size() == bytes && memcmp(e.bytes.data(), data, bytes) == 0) return e.dev;
-  // a miss uploads (and may replace the slab): neither is possible while the stream is being captured into a graph
+  const uint64_t h = SmallArrays::hash(data, bytes);
+  auto range = sa.entries.equal_range(h);
+  for (auto it = range.first; it != range.second; ++it)
+    if (it->second.bytes.size() == bytes && memcmp(it->second.bytes.data(), data, bytes) == 0) return it->second.dev;
+  // a miss uploads (and may allocate): neither is possible while the stream is being captured into a graph
   if (devrt::is_capturing(c->stream)) fail("a call shape that was never run before cannot be captured: run it once first");
   const size_t padded = (bytes + 255) & ~size_t(255);
-  if (sa.used + padded > sa.cap) {
-    // full (or first use): a fresh slab; nobody may still be reading the old entries
-    devrt::sync(c->stream);
-    if (sa.slab) devrt::dfree(sa.slab);
-    sa.entries.clear();
-    sa.cap = std::max<size_t>(size_t(4) << 20, 16 * padded);
-    sa.slab = static_cast<char *>(devrt::dmalloc(sa.cap));
-    sa.used = 0;
+  if (sa.slabs.empty() || sa.slabs.back().used + padded > sa.slabs.back().cap) {
+    SmallArrays::Slab sl;                                          // chain a fresh slab; the old ones stay valid
+    sl.cap = std::max(small_slab(), padded);
+    sl.base = static_cast<char *>(devrt::dmalloc(sl.cap));
+    sl.used = 0;
+    sa.slabs.push_back(sl);
+    sa.held += sl.cap;
   }
+  SmallArrays::Slab &sl = sa.slabs.back();
   SmallArrays::Entry e;
   e.bytes.assign(static_cast<const char *>(data), static_cast<const char *>(data) + bytes);
-  e.dev = sa.slab + sa.used;
-  sa.used += padded;
-  sa.entries.push_back(std::move(e));
-  const SmallArrays::Entry &kept = sa.entries.back();
-  devrt::h2d(kept.dev, kept.bytes.data(), bytes, c->stream);      // the source outlives the copy
-  return kept.dev;
+  e.dev = sl.base + sl.used;
+  sl.used += padded;
+  auto kept = sa.entries.emplace(h, std::move(e));
+  devrt::h2d(kept->second.dev, kept->second.bytes.data(), bytes, c->stream);   // the source outlives the copy (node-based map)
+  return kept->second.dev;
 }
 
 template <class T> static T *upload(WorldHipContext *c, const std::vector<T> &v) {
@@ -190,8 +230,16 @@ static void check_batch(int n_utt, int fs, const void *d_x, int x_stride, const 
 struct RowLayout {
   const int *rows = nullptr;     // host, [n_utt]
   size_t stride = 0;             // 0: bins
+  size_t col_bytes = 0;          // bytes from a record's start to this stage's row (the stage's output pointer = records' base)
+  int f32 = 0;                   // 1: rows stored as float (narrow wire format)
   double *rec = nullptr;         // D4C only: records' base for the (tpos, f0) head of every record
 };
+// Doubles per packed record.  wire 0: [tpos, f0, sp f64[nb], ap f64[nb]]; wire 1: [tpos, f0, sp f32[nb], ap f32[nb]] -- half
+// the bytes on the xGMI links and in the D2H copy, 6e-8 relative (the contract is 1e-4): 16 + 8 nb bytes = 2 + nb doubles.
+static int record_cols(int fft_size, int wire) {
+  const int nb = fft_size / 2 + 1;
+  return wire == 1 ? 2 + nb : 2 + 2 * nb;
+}
 
 static size_t cheaptrick_arena_bytes(int n_utt, int f_stride, int fft_size) {
   return pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 4 * pad256(sizeof(int) * n_utt) +
@@ -228,6 +276,7 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
   p.tpos = d_tpos; p.f0 = d_f0; p.spectrogram = d_sp;
   p.out_row = lay.rows ? upload(c, std::vector<int>(lay.rows, lay.rows + n_utt)) : nullptr;
   p.out_stride = lay.stride ? lay.stride : (size_t)(opt->fft_size / 2 + 1);
+  p.out_col_bytes = lay.col_bytes; p.out_f32 = lay.f32;
   p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
   p.seg = c->arena.take<double>((size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * seg_stride);
   p.seg_stride = seg_stride;
@@ -267,7 +316,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
       w[i] = 0.355768 - 0.487396 * cos(2.0 * kPi * t) + 0.144232 * cos(4.0 * kPi * t) - 0.012604 * cos(6.0 * kPi * t);
     }
     devrt::sync(c->stream);
-    if (c->d_nuttall) devrt::dfree(c->d_nuttall);
+    if (c->d_nuttall) { devrt::dfree(c->d_nuttall); ++c->generation; }
     c->d_nuttall = static_cast<double *>(devrt::dmalloc(sizeof(double) * wl));
     devrt::h2d(c->d_nuttall, w.data(), sizeof(double) * wl, c->stream);
     devrt::sync(c->stream);
@@ -283,6 +332,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.tpos = d_tpos; p.f0 = d_f0; p.aperiodicity = d_ap;
   p.out_row = lay.rows ? upload(c, std::vector<int>(lay.rows, lay.rows + n_utt)) : nullptr;
   p.out_stride = lay.stride ? lay.stride : (size_t)(fft_size / 2 + 1);
+  p.out_col_bytes = lay.col_bytes; p.out_f32 = lay.f32;
   p.rec = lay.rec;
   p.ap0 = c->arena.take<double>(fr);
   p.offsets1 = c->arena.take<unsigned>(fr);
@@ -329,6 +379,7 @@ static void prepare_bands(WorldHipContext *c, int fs, double f0_floor, double f0
     }
   }
   devrt::sync(c->stream);
+  ++c->generation;
   if (hb.d_band_f0) { devrt::dfree(hb.d_band_f0); devrt::dfree(hb.d_taps); devrt::dfree(hb.d_half); devrt::dfree(hb.d_off); }
   hb.d_band_f0 = static_cast<double *>(devrt::dmalloc(sizeof(double) * nch));
   hb.d_taps = static_cast<double *>(devrt::dmalloc(sizeof(double) * taps.size()));
@@ -546,6 +597,7 @@ static void prepare_dio_bands(WorldHipContext *c, DioBands &db, int fs, const Di
   for (int i = 0; i < n; ++i) lowcut[i] = -lowcut[i] / sum;
   lowcut[cut] += 1.0;
   devrt::sync(c->stream);
+  ++c->generation;
   if (db.d_band_f0) {
     devrt::dfree(db.d_band_f0); devrt::dfree(db.d_taps); devrt::dfree(db.d_lowcut); devrt::dfree(db.d_hal);
     devrt::dfree(db.d_off);
@@ -835,7 +887,7 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
     }
     for (int i = 0; i < fft_size / 2; ++i) { rem[i] /= dc; rem[fft_size - i - 1] = rem[i]; }
     devrt::sync(c->stream);
-    if (c->d_dc_remover) devrt::dfree(c->d_dc_remover);
+    if (c->d_dc_remover) { devrt::dfree(c->d_dc_remover); ++c->generation; }
     c->d_dc_remover = static_cast<double *>(devrt::dmalloc(sizeof(double) * fft_size));
     devrt::h2d(c->d_dc_remover, rem.data(), sizeof(double) * fft_size, c->stream);
     devrt::sync(c->stream);
@@ -947,8 +999,13 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
                                long long first_row, double *d_block, int cols) {
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   const int nb = copt->fft_size / 2 + 1;
-  if (cols != 2 + 2 * nb) fail("analyze_packed: %d columns, fft_size %d needs %d", cols, copt->fft_size, 2 + 2 * nb);
+  // the record width names the wire format: 2 + 2 nb doubles = f64 spectra, 2 + nb doubles = f32 spectra
+  const int wire = cols == record_cols(copt->fft_size, 1) ? 1 : 0;
+  if (cols != record_cols(copt->fft_size, wire))
+    fail("analyze_packed: %d columns, fft_size %d needs %d (f64 records) or %d (f32 spectra)", cols, copt->fft_size,
+         record_cols(copt->fft_size, 0), record_cols(copt->fft_size, 1));
   if (!d_block) fail("analyze_packed: null block");
+  if (first_row < 0) fail("analyze_packed: negative first_row");
   std::vector<int> nf(n_utt), rows(n_utt);
   long long row = first_row;
   int f_stride = 1;
@@ -963,7 +1020,7 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
   const size_t fr = (size_t)n_utt * f_stride;
   if (c->pk_cap < 2 * fr) {
     devrt::sync(c->stream);
-    if (c->d_pk) devrt::dfree(c->d_pk);
+    if (c->d_pk) { devrt::dfree(c->d_pk); ++c->generation; }
     c->pk_cap = 2 * fr + fr / 4;
     c->d_pk = static_cast<double *>(devrt::dmalloc(sizeof(double) * c->pk_cap));
   }
@@ -971,9 +1028,12 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
   run_harvest(c, n_utt, fs, d_x, x_stride, x_length, hopt, f_stride, d_tpos, d_f0);
   RowLayout lay_sp, lay_ap;
   lay_sp.rows = lay_ap.rows = rows.data(); lay_sp.stride = lay_ap.stride = (size_t)cols;
+  lay_sp.f32 = lay_ap.f32 = wire == 1;
+  const size_t elem = wire == 1 ? sizeof(float) : sizeof(double);
+  lay_sp.col_bytes = 2 * sizeof(double); lay_ap.col_bytes = 2 * sizeof(double) + elem * nb;
   lay_ap.rec = d_block;
-  run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, dopt, d_block + 2,
-                      d_block + 2 + nb, lay_sp, lay_ap);
+  run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, dopt, d_block,
+                      d_block, lay_sp, lay_ap);
 }
 
 // ---------------------------------------------------------------------------
@@ -1106,7 +1166,7 @@ void world_hip_destroy(WorldHipContext *c) {
     free_codec_tables(c);
     if (c->d_dc_remover) devrt::dfree(c->d_dc_remover);
     if (c->d_synth_need) devrt::dfree(c->d_synth_need);
-    if (c->small.slab) devrt::dfree(c->small.slab);
+    drop_small_arrays(c);
     HarvestBands &hb = c->bands;
     if (hb.d_band_f0) { devrt::dfree(hb.d_band_f0); devrt::dfree(hb.d_taps); devrt::dfree(hb.d_half); devrt::dfree(hb.d_off); }
     if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
@@ -1241,6 +1301,11 @@ int world_hip_analyze_batch(WorldHipContext *c, int n_utt, int fs, const double 
   });
 }
 
+int world_hip_record_columns(int fft_size, int wire) {
+  if (fft_size < 2 || (wire != 0 && wire != 1)) return -1;
+  return record_cols(fft_size, wire);
+}
+
 int world_hip_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
                              const HarvestOption *harvest_option, const CheapTrickOption *cheaptrick_option,
                              const D4COption *d4c_option, long long first_row, double *d_block, int cols) {
@@ -1254,23 +1319,40 @@ int world_hip_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double
 // Harvest + CheapTrick + D4C job is ~45 launches -- becomes ONE replayable graph bound to the buffers it was captured with.
 // The shapes must have run once before (workspace, tables and the small per-call arrays are then resident and a call
 // neither allocates nor copies nor waits); a replay costs the host one launch.
+// A graph bakes in raw device pointers to memory the context owns (arena, small-array slabs, d_pk, cached tables).  The
+// handle remembers the context's generation at capture; a later eager call that had to free or regrow any of that memory
+// bumps the generation, and a replay of the stale graph is REFUSED instead of reading freed memory.
+struct GraphHandle {
+  void *exec;
+  WorldHipContext *ctx;
+  unsigned long long generation;
+};
 int world_hip_graph_begin(WorldHipContext *c) {
   return guarded(c, [&] { devrt::graph_begin(c->stream); });
 }
 int world_hip_graph_end(WorldHipContext *c, void **graph) {
   return guarded(c, [&] {
     if (!graph) fail("null graph handle");
-    *graph = devrt::graph_end(c->stream);
+    *graph = nullptr;
+    void *exec = devrt::graph_end(c->stream);
+    *graph = new GraphHandle{exec, c, c->generation};
   });
 }
 int world_hip_graph_launch(WorldHipContext *c, void *graph) {
   return guarded(c, [&] {
     if (!graph) fail("null graph");
-    devrt::graph_launch(graph, c->stream);
+    const GraphHandle *g = static_cast<const GraphHandle *>(graph);
+    if (g->ctx != c) fail("graph_launch: the graph was captured on another context");
+    if (g->generation != c->generation)
+      fail("graph_launch: stale graph -- the context reallocated memory the graph points into since it was captured "
+           "(a larger batch, a new option set or shape ran eagerly); capture it again");
+    devrt::graph_launch(g->exec, c->stream);
   });
 }
 int world_hip_graph_destroy(void *graph) {
-  try { devrt::graph_destroy(graph); return 0; } catch (const std::exception &e) { g_last_error = e.what(); return 1; }
+  if (!graph) return 0;
+  GraphHandle *g = static_cast<GraphHandle *>(graph);
+  try { devrt::graph_destroy(g->exec); delete g; return 0; } catch (const std::exception &e) { delete g; g_last_error = e.what(); return 1; }
 }
 
 // 0: every stage of the analysis path supports (fs, cheaptrick_fft_size); 1: it does not, and why (<= cap bytes) says which
@@ -1381,6 +1463,25 @@ int world_hip_allgather_blocks(int n_dev, WorldHipContext *const *ctxs, const do
   }
 }
 
+// Sub-batch sizes of a device's share of n utterances (world_amd/distributed.py: chunk_sizes states the same schedule):
+// full sub-batches of sb, and the LAST one tapered into halves (sb/2, sb/4, sb/4) -- sub-batch k's exchange runs under the
+// analysis of k + 1, so only the last exchange is exposed, and tapering shrinks it from 1/4 of a 128-utterance share to
+// 1/16.  Tails of fewer than 8 utterances stay whole (smaller batches stop filling the chip).
+static std::vector<int> chunk_sizes(int n, int sb) {
+  std::vector<int> out;
+  sb = std::max(1, sb);
+  while (n > sb) { out.push_back(sb); n -= sb; }
+  if (n >= 8 && !getenv("WORLD_HIP_NO_TAPER")) {
+    const int a = (n + 1) / 2, b = (n - a + 1) / 2, c = n - a - b;
+    out.push_back(a);
+    if (b > 0) out.push_back(b);
+    if (c > 0) out.push_back(c);
+  } else if (n > 0) {
+    out.push_back(n);
+  }
+  return out;
+}
+
 // One PROCESS, n_dev GPUs ("one host thread + stream per GPU"): the C/C++ counterpart of
 // world_amd/distributed.py.  Utterances (host memory) are partitioned longest-first over the contexts' devices; a host
 // thread per device uploads its share in sub-batches (pinned double buffer), analyses each straight into packed records
@@ -1396,7 +1497,9 @@ int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *ctxs, int n_utt
   try {
     if (n_dev <= 0 || !ctxs || n_utt < 0 || !x_length || !hopt || !copt || !dopt || !d_blocks || !where) fail("bad arguments");
     if (n_utt > 0 && !x) fail("null input");
-    if (cols != 2 + 2 * (copt->fft_size / 2 + 1)) fail("analyze_sharded: %d columns do not fit fft_size %d", cols, copt->fft_size);
+    if (cols != record_cols(copt->fft_size, 0) && cols != record_cols(copt->fft_size, 1))
+      fail("analyze_sharded: %d columns do not fit fft_size %d (%d for f64 records, %d for f32 spectra)", cols, copt->fft_size,
+           record_cols(copt->fft_size, 0), record_cols(copt->fft_size, 1));
     for (int d = 0; d < n_dev; ++d) {
       if (!ctxs[d] || !d_blocks[d]) fail("bad device entry %d", d);
       for (int e = 0; e < d; ++e) {
@@ -1426,8 +1529,10 @@ int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *ctxs, int n_utt
     long long row = 0;
     for (int r = 0; r < n_dev; ++r) {
       std::sort(part[r].begin(), part[r].end());
-      for (size_t lo = 0; lo < part[r].size(); lo += sb) {
-        Chunk c{r, (int)lo, (int)std::min(part[r].size(), lo + sb), row, 0, 0};
+      size_t lo = 0;
+      for (int take : chunk_sizes((int)part[r].size(), sb)) {
+        Chunk c{r, (int)lo, (int)(lo + take), row, 0, 0};
+        lo += take;
         for (int j = c.lo; j < c.hi; ++j) {
           const int i = part[r][j], nf = frame_count(fs, x_length[i], hopt->frame_period);
           where[3 * i] = r; where[3 * i + 1] = row; where[3 * i + 2] = nf;

@@ -311,8 +311,14 @@ __global__ void __launch_bounds__(256, 4) ct_envelope(CtParams p) {
   WH_STAMP(0, 8);
   block_irfft<kCtMaxLr, LGN>(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   WH_STAMP(0, 9);
-  double *out = p.spectrogram + (p.out_row ? (size_t)p.out_row[u] + f : fi) * p.out_stride;
-  block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = v; });
+  char *out_at = reinterpret_cast<char *>(p.spectrogram + (p.out_row ? (size_t)p.out_row[u] + f : fi) * p.out_stride) + p.out_col_bytes;
+  if (p.out_f32) {
+    float *out = reinterpret_cast<float *>(out_at);
+    block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = static_cast<float>(v); });
+  } else {
+    double *out = reinterpret_cast<double *>(out_at);
+    block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = v; });
+  }
   WH_STAMP(0, 10);
 }
 

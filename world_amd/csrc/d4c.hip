@@ -770,11 +770,14 @@ __global__ void d4c_finish(D4cParams p) {
   const int tid = threadIdx.x, nt = blockDim.x, fs = p.b.fs;
   const int nb_out = p.fft_out / 2 + 1;
   const size_t orow = p.out_row ? (size_t)p.out_row[u] + f : fi;
-  double *row = p.aperiodicity + orow * p.out_stride;
+  char *row_at = reinterpret_cast<char *>(p.aperiodicity + orow * p.out_stride) + p.out_col_bytes;
+  double *row = reinterpret_cast<double *>(row_at);
+  float *row32 = reinterpret_cast<float *>(row_at);                    // the narrow wire format (p.out_f32)
   const double f0 = p.f0[fi];
   if (p.rec && tid == 0) { double *r = p.rec + orow * p.out_stride; r[0] = p.tpos[fi]; r[1] = f0; }   // the record's head
   if (f0 == 0 || p.ap0[fi] <= p.threshold) {                          // d4c.cpp:323-328,386
-    for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny;
+    if (p.out_f32) { for (int i = tid; i < nb_out; i += nt) row32[i] = static_cast<float>(1.0 - kTiny); }
+    else { for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny; }
     return;
   }
   // the bands' coarse aperiodicity in dB from the sums d4c_frame left (d4c.cpp:221-224, 314-316), once per frame
@@ -802,7 +805,8 @@ __global__ void d4c_finish(D4cParams p) {
     double x1 = k <= p.nap ? k * 3000.0 : fs / 2.0;
     double s = (xi - x0) / (x1 - x0);
     double y = cval(k - 1) + s * (cval(k) - cval(k - 1));
-    row[i] = exp10(y / 20.0);                           // the reference: pow(10.0, y / 20.0) -- same value to an ulp or two, a third of the instructions
+    const double v = exp10(y / 20.0);                   // the reference: pow(10.0, y / 20.0) -- same value to an ulp or two, a third of the instructions
+    if (p.out_f32) row32[i] = static_cast<float>(v); else row[i] = v;
   }
 }
 

@@ -122,22 +122,23 @@ void peer_copy(void *dst, int dst_device, const void *src, int src_device, size_
 void enable_peer_access(int device, int peer) {
   if (device == peer) return;
   // once per pair and process: the query, the device switch and the enable are host calls that a path advertised as
-  // host-wait-free should not repeat on every exchange
+  // host-wait-free should not repeat on every exchange.  A pair is recorded only after a DEFINITIVE answer
+  // (enabled, already enabled, or the hardware says no); a transient failure is retried by the next exchange instead of
+  // condemning the pair to staged copies for the life of the process, and the lock is held across the enable so that a
+  // second thread cannot run ahead of a pair that is still being enabled.
   static std::mutex lock;
   static std::map<std::pair<int, int>, bool> done;
-  {
-    std::lock_guard<std::mutex> g(lock);
-    if (done.count({device, peer})) return;
-    done[{device, peer}] = true;
-  }
+  std::lock_guard<std::mutex> g(lock);
+  if (done.count({device, peer})) return;
   int can = 0;
-  if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can) return;
+  if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess) { (void)hipGetLastError(); return; }   // transient: ask again
+  if (!can) { done[{device, peer}] = false; return; }
   int before = 0;
   check(hipGetDevice(&before), "hipGetDevice");
   check(hipSetDevice(device), "hipSetDevice");
   const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
-  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-  else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+  if (e != hipSuccess) (void)hipGetLastError();
+  if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) done[{device, peer}] = true;
   check(hipSetDevice(before), "hipSetDevice");
 }
 

@@ -9,9 +9,11 @@ struct CtParams {
   BatchView b;
   const double *tpos;    // [n_utt][f_stride]
   const double *f0;      // [n_utt][f_stride]
-  double *spectrogram;   // [n_utt][f_stride][fft/2+1], or rows of packed records (out_row / out_stride)
+  double *spectrogram;   // [n_utt][f_stride][fft/2+1], or the base of packed records (out_row / out_stride / out_col_bytes)
   const int *out_row;    // nullptr: row of frame (u, f) = u f_stride + f; else out_row[u] + f (records back to back)
   size_t out_stride;     // doubles between consecutive rows (fft/2+1 for the dense layout)
+  size_t out_col_bytes;  // bytes from a row's start to this stage's first value (0 for the dense layout)
+  int out_f32;           // 1: the row's values are stored as float (the narrow wire format of the multi-GPU exchange)
   unsigned *offsets;     // [n_utt][f_stride] stream position of each frame's first draw
   double *seg;           // [n_utt][ceil(f_stride / WAVE)][seg_stride][WAVE] LinearSmoothing's mirrored segment / prefix sums
   int seg_stride;
@@ -26,9 +28,11 @@ struct D4cParams {
   BatchView b;
   const double *tpos;     // [n_utt][f_stride]
   const double *f0;       // [n_utt][f_stride]
-  double *aperiodicity;   // [n_utt][f_stride][fft_out/2+1], or rows of packed records (out_row / out_stride)
+  double *aperiodicity;   // [n_utt][f_stride][fft_out/2+1], or the base of packed records (out_row / out_stride / out_col_bytes)
   const int *out_row;     // as CtParams
   size_t out_stride;
+  size_t out_col_bytes;
+  int out_f32;
   double *rec;            // packed records' base (column 0 = tpos, 1 = f0), written by d4c_finish; nullptr: dense output
   double *ap0;            // [n_utt][f_stride]  LoveTrain result
   double *coarse;         // [n_utt][f_stride][16] coarse aperiodicity (dB) per band, slot 1 + band

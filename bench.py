@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--job-utterances", type=int, default=1024, help="N > 1: utterances of the configs[3] job")
     ap.add_argument("--sub-batch", type=int, default=32,
                     help="configs[3] job (N > 1, and the N = 1 anchor configs['3_full']): utterances per batched call = per all-gather")
+    ap.add_argument("--wire", choices=["f64", "f32"], default="f64",
+                    help="configs[3] job: record format of the exchange (f32 = the spectra rounded once to float by the stage "
+                         "kernels: half the bytes on the links; default f64 = bit-identical to a lone analysis)")
     ap.add_argument("--streams", type=int, default=12,
                     help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
                          "stream with its own workspace; 1 = strictly one after the other)")
@@ -330,13 +333,13 @@ def main():
 
         def step():
             last[0] = wd.analyze_sharded(xs, FS, lengths=lengths, packer=wh, sub_batch=args.sub_batch,
-                                         gather=not args.no_gather, timings=phases)
+                                         gather=not args.no_gather, timings=phases, wire=args.wire)
 
         for _ in range(max(1, args.warmup)):
             step()
         phases.update(compute_ms=0.0, exchange_ms=0.0, exchange_exposed_ms=0.0, steps=0)
         est = estimate(step, lambda: None, 1)
-        phases.update(compute_ms=0.0, exchange_ms=0.0, exchange_exposed_ms=0.0, steps=0)
+        phases.update(compute_ms=0.0, exchange_ms=0.0, exchange_exposed_ms=0.0, steps=0, gathered_bytes=0, last_chunk_bytes=0)
         dt, repeats = timed_region(step, lambda: None, args.steps, est)
         frames_per_step = sum(frame_count(FS, n, FRAME_PERIOD) for n in lengths)
         nsteps = args.steps * repeats
@@ -352,13 +355,34 @@ def main():
                 tp1, f01, sp1, ap1, nf1 = wh.analyze(synth.utterance(i, FS, sec, device=dev).unsqueeze(0), FS)
                 tp, f0, sp, ap = res.utterance(i)
                 k = int(nf1[0])
+                sp_want, ap_want = (sp1[0, :k], ap1[0, :k]) if args.wire == "f64" else \
+                    (sp1[0, :k].to(torch.float32), ap1[0, :k].to(torch.float32))      # f32 wire: the f64 result rounded once
                 same = same and tp.shape[0] == k and torch.equal(tp, tp1[0, :k]) and torch.equal(f0, f01[0, :k]) and \
-                    torch.equal(sp, sp1[0, :k]) and torch.equal(ap, ap1[0, :k])
+                    torch.equal(sp, sp_want) and torch.equal(ap, ap_want)
                 checked.append(i)
             ok = torch.tensor([1 if same else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             parity = {"utterances_checked_on_rank0": checked, "every_rank_bit_identical_to_lone_analysis": bool(ok.item()),
                       "randn_table_intact": bool(wh.verify_tables())}
+        # The all-gather by itself: blocking in-place all-gathers of the job's largest sub-batch buffer, HIP events around
+        # them -- the rate RCCL achieves on this node when nothing else runs, beside the rate the overlap NEEDS
+        # (bytes a rank receives per step / the step's time) and the bytes of the one exchange the overlap cannot hide.
+        gather_gbs = None
+        if not args.no_gather:
+            buf = max(last[0].blocks, key=lambda b: b.numel())
+            recv = (world - 1) * buf[0].numel() * 8
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2):
+                wd._gather_in_place(buf, rank, None, False)
+            torch.cuda.synchronize(); barrier()
+            e0.record()
+            for _ in range(5):
+                wd._gather_in_place(buf, rank, None, False)
+            e1.record(); torch.cuda.synchronize()
+            tg = torch.tensor([e0.elapsed_time(e1) / 5], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gather_gbs = {"allgather_gbs_per_rank": recv / (float(tg.item()) * 1e-3) / 1e9, "bytes_received_per_rank": recv,
+                          "ms": float(tg.item()), "what": "blocking in-place all_gather_into_tensor of the largest sub-batch buffer, nothing else running"}
         # roofline of the dominant kernel of ONE batched call of this rank's share (rank 0; HIP events per kernel)
         roofline = None
         if rank == 0 and mine:
@@ -384,10 +408,18 @@ def main():
                            "frames_per_step": frames_per_step, "utterances_per_gpu": len(mine),
                            "parallelism": f"utterance-sharded x{world}" + (
                                ", no collective" if args.no_gather else
-                               f", one in-place RCCL all-gather of packed [frames][{2 + 2 * nb}] f64 records per sub-batch, overlapped with the next sub-batch's analysis "
-                               f"({frames_per_step * (2 + 2 * nb) * 8 / 1e9:.1f} GB reassembled on every rank)")},
+                               f", one in-place RCCL all-gather of packed [frames][{wd.WIRE_COLS[args.wire](nb)}] records ({args.wire} spectra) per sub-batch "
+                               f"(sizes {wd.chunk_sizes(len(mine), args.sub_batch)}: the last, exposed one is tapered), overlapped with the next sub-batch's analysis "
+                               f"({frames_per_step * wd.WIRE_COLS[args.wire](nb) * 8 / 1e9:.1f} GB reassembled on every rank)")},
                 "phases": {"compute_ms_per_step_max_over_ranks": float(ph_max[0]),
                            "exchange_exposed_ms_per_step_max_over_ranks": float(ph_max[1]),
+                           "allgather_gbs_per_rank": None if gather_gbs is None else gather_gbs["allgather_gbs_per_rank"],
+                           "allgather_standalone": gather_gbs,
+                           "allgather_gbs_per_rank_needed_to_hide": None if args.no_gather else
+                               phases.get("gathered_bytes", 0) / max(1, phases["steps"]) / (dt / nsteps) / 1e9,
+                           "exposed_last_chunk_bytes_per_step": None if args.no_gather else
+                               phases.get("last_chunk_bytes", 0) // max(1, phases["steps"]),
+                           "wire": args.wire,
                            "note": "chunk k's all-gather runs while chunk k+1 is analysed; exposed = device time the compute stream "
                                    "waited for all-gathers after its last analysis (HIP events), compute = the rest of the step"},
                 "parity_in_run": parity, "roofline": roofline, "cpu_baseline": None}))
@@ -514,7 +546,7 @@ def main():
         phases = {}
 
         def step():
-            return wd.analyze_sharded(xs_job, FS, lengths=lengths, packer=whj, sub_batch=args.sub_batch, timings=phases)
+            return wd.analyze_sharded(xs_job, FS, lengths=lengths, packer=whj, sub_batch=args.sub_batch, timings=phases, wire=args.wire)
         res = step()
         phases.clear()
         torch.cuda.synchronize()
@@ -526,22 +558,31 @@ def main():
         torch.cuda.synchronize()
         dtj = time.perf_counter() - t1
         frames = sum(res.n_frames)
-        # the job checks itself: three utterances against lone analyses (bit-identical: batched == single)
+        # the job checks itself: one utterance of EVERY sub-batch (so both lanes and every chunk size, the tapered tail
+        # included; at a different position in each) against a lone analysis -- bit-identical: batched == single
+        by_chunk = {}
+        for i, w in res.where.items():
+            by_chunk.setdefault(w[0], []).append(i)
+        picks = [sorted(v)[(7 * k + 3) % len(v)] for k, v in sorted(by_chunk.items())]
         same = True
-        for i in (0, n_job // 2 + 1, n_job - 1):
+        for i in picks:
             tp1, f01, sp1, ap1, nf1 = whj.analyze(xs_job[i].unsqueeze(0), FS)
             tp, f0, sp, ap = res.utterance(i)
             k = int(nf1[0])
+            sp_want, ap_want = (sp1[0, :k], ap1[0, :k]) if args.wire == "f64" else \
+                (sp1[0, :k].to(torch.float32), ap1[0, :k].to(torch.float32))
             same = same and tp.shape[0] == k and torch.equal(tp, tp1[0, :k]) and torch.equal(f0, f01[0, :k]) and \
-                torch.equal(sp, sp1[0, :k]) and torch.equal(ap, ap1[0, :k])
+                torch.equal(sp, sp_want) and torch.equal(ap, ap_want)
         leg = {"workload": f"configs[3] full job on one GPU: {n_job} x (48 kHz, {sec:g} s), Harvest+CheapTrick+D4C, sub-batches of "
-                           f"{args.sub_batch} written straight into packed [frames][2052] records (no pack pass, no collective)",
+                           f"{args.sub_batch} (tapered tail: {wd.chunk_sizes(n_job, args.sub_batch)[-3:]}) written straight into packed "
+                           f"[frames][{wd.WIRE_COLS[args.wire](FFT_SIZE // 2 + 1)}] records ({args.wire} spectra; no pack pass, no collective)",
                "value": frames * steps / dtj, "unit": "frames/s", "frames_per_step": frames, "steps": steps,
                "ms_per_step": dtj / steps * 1e3, "timed_wall_s": dtj,
                "phases": {"compute_ms_per_step": phases.get("compute_ms", 0.0) / max(1, phases.get("steps", 1)),
                           "exchange_exposed_ms_per_step": phases.get("exchange_exposed_ms", 0.0) / max(1, phases.get("steps", 1))},
-               "utterances_bit_identical_to_lone_analysis": bool(same),
-               "result_bytes": frames * (2 + 2 * (FFT_SIZE // 2 + 1)) * 8, "workspace_bytes": whj.workspace_bytes()}
+               "utterances_bit_identical_to_lone_analysis": bool(same), "utterances_checked": len(picks),
+               "sub_batches": len(by_chunk),
+               "result_bytes": frames * wd.WIRE_COLS[args.wire](FFT_SIZE // 2 + 1) * 8, "workspace_bytes": whj.workspace_bytes()}
         whj.close()
         wd._buffers.clear()
         wd._lanes.clear()
@@ -733,8 +774,37 @@ def main():
         frames_h = sum(host_job() for _ in range(5))
         dt_h = time.perf_counter() - t1
         host_to_host = {"workload": "Harvest() + CheapTrick() + D4C() on host pointers (libworld_hip.so drop-in symbols), "
-                                    "one utterance at a time, PCIe and per-stage synchronisation included",
+                                    "one utterance at a time, PCIe and per-stage synchronisation included; the ctypes "
+                                    "binding allocates fresh numpy outputs every call, as round 3's line did",
                         "ms_per_utterance": dt_h / 5 * 1e3, "frames_per_s": frames_h / dt_h}
+        # the same with four host threads (the drop-in layer is re-entrant since round 4: a slot per caller)
+        import threading
+        xs_h = [xs_k.cpu().numpy()[0, :n].copy() for xs_k in x_slots[:4]]
+
+        def host_thread(xh):
+            for _ in range(3):
+                tp, f0 = H.harvest(xh, FS, frame_period=FRAME_PERIOD)
+                H.cheaptrick(xh, FS, tp, f0, fft_size=FFT_SIZE)
+                H.d4c(xh, FS, tp, f0, FFT_SIZE)
+        for warm in range(2):
+            th = [threading.Thread(target=host_thread, args=(xh,)) for xh in xs_h]
+            t1 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt_t = time.perf_counter() - t1
+        host_to_host["four_threads_ms_per_utterance"] = dt_t / (3 * len(xs_h)) * 1e3
+        host_to_host["four_threads_frames_per_s"] = 3 * len(xs_h) * nf / dt_t
+        # cold start, in a fresh process (tools/first_call.py)
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py"), str(args.seconds)],
+                               capture_output=True, text=True, timeout=600)
+            cold = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-500:]}
+        except Exception as e:                                          # noqa: BLE001
+            cold = {"error": repr(e)}
+        host_to_host["cold_start"] = cold
 
     workspace = sum(w.workspace_bytes() for w in whs)
     table_bytes = wh.noise_table_bytes()
@@ -792,6 +862,8 @@ def main():
         "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(
             kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "configs": configs, "graph": graph_leg, "codec": codec, "synthesis": synthesis, "host_to_host": host_to_host,
+        "first_call_ms": None if not host_to_host else host_to_host.get("cold_start", {}).get("first_call_ms"),
+        "randn_table_first_build_ms": None if not host_to_host else host_to_host.get("cold_start", {}).get("randn_table_build_ms"),
         "workspace_bytes": workspace, "randn_table_bytes": table_bytes, "csrc_hash": csrc_hash(),
     }
     print(json.dumps(out))

@@ -188,6 +188,10 @@ WORLD_HIP_API unsigned long long world_hip_workspace_bytes(WorldHipContext *ctx)
  * generations); verify() reduces the live table again and compares (0 = intact; synchronises). */
 WORLD_HIP_API unsigned long long world_hip_noise_table_bytes(WorldHipContext *ctx);
 WORLD_HIP_API int world_hip_verify_tables(WorldHipContext *ctx);
+/* cold-start accounting: host wall-clock milliseconds this process has spent building + verifying the device's tables
+ * (all generations), and how many generations were built.  The host statement is stepped by up to
+ * WORLD_HIP_TABLE_THREADS (default min(16, cores)) threads, each range's jump-table seed confirmed sequentially. */
+WORLD_HIP_API double world_hip_noise_table_build_ms(WorldHipContext *ctx, int *builds);
 
 /* Per-kernel timing with HIP events on the launch stream (process-wide switch).
  * collect() waits for the recorded kernels and returns "kernel_name ms\n" lines. */
@@ -300,9 +304,10 @@ WORLD_HIP_API int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *c
                                             long long rows_capacity, int cols, long long *where);
 
 /* Shape limits of the GPU path (the reference has none): 0 = StoneMask, CheapTrick(cheaptrick_fft_size) and D4C all run at
- * this fs; 1 = one of them does not, `why` names the stage and the limit (fs <= 96 kHz for D4C and for CheapTrick's default
- * fft_size, fs >= 15.8 kHz for D4C, fs <= 180 kHz for StoneMask).  Pure host arithmetic.  The drop-in symbols make the
- * same check before any GPU work and abort with that message -- the reference API has no error channel. */
+ * this fs; 1 = one of them does not, `why` names the stage and the limit (fs <= 96 kHz for D4C, CheapTrick fft_size <=
+ * 8192 -- its default up to fs = 192 kHz --, fs >= 15.8 kHz for D4C, fs <= 180 kHz for StoneMask).  Pure host
+ * arithmetic.  The drop-in symbols make the same check before any GPU work and report through the error handler
+ * (world_hip_set_error_handler; by default: message + abort -- the reference API has no error channel). */
 WORLD_HIP_API int world_hip_check_shape(int fs, int cheaptrick_fft_size, char *why, int why_capacity);
 
 /* HIP graphs: the batched calls enqueued on ctx between _begin and _end are captured into ONE executable graph (bound to

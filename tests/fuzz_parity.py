@@ -18,7 +18,10 @@ def run(seed=0, n_cases=40, hip=None, orc=None, verbose=True):
     failures = []
     t0 = time.time()
     for case in range(n_cases):
-        fs = int(rng.choice([16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000]))
+        # 11.025 kHz: Harvest's decimation ratio is 1 there (round(11025 / 8000); 12 kHz already rounds to 2): the longest
+        # filters of the bank at the full rate.  D4C needs fs >= 15.8 kHz (the reference reads out of bounds below), so
+        # D4C and what consumes its output are skipped at that rate
+        fs = int(rng.choice([11025, 16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000]))
         dur = float(rng.uniform(0.03, 0.25)) if rng.random() < 0.2 else float(rng.uniform(0.25, 1.2))
         kind = rng.choice(['vowel', 'utt', 'noise', 'mix', 'gappy', 'quiet', 'dc', 'clip', 'impulses'])
         seed_c = int(rng.integers(1, 10**6))
@@ -38,7 +41,9 @@ def run(seed=0, n_cases=40, hip=None, orc=None, verbose=True):
             elif kind == 'clip': x = np.clip(x * float(rng.uniform(2, 10)), -1, 32767 / 32768)
         x = np.clip(x, -1, 32767 / 32768)
         msg = []
-        hopt = dict(f0_floor=float(rng.choice([40.0, 50.0, 71.0, 90.0])), f0_ceil=float(rng.choice([500.0, 800.0, 1200.0])),
+        # floor 30 Hz: filters too long for the overlap-save block at the decimated rate -> the direct-form filter bank
+        # (harvest.hip: hv_band_events), which the floors above 35 Hz never reach
+        hopt = dict(f0_floor=float(rng.choice([30.0, 40.0, 50.0, 71.0, 90.0])), f0_ceil=float(rng.choice([500.0, 800.0, 1200.0])),
                     frame_period=float(rng.choice([1.0, 2.5, 5.0, 10.0, 15.0])))
         tp_o, f0_o = orc.harvest(x, fs, **hopt)
         tp, f0 = hip.harvest(x, fs, **hopt)
@@ -65,27 +70,31 @@ def run(seed=0, n_cases=40, hip=None, orc=None, verbose=True):
         sp = hip.cheaptrick(x, fs, tp_o, f0_o, q1=q1, f0_floor=ct_floor, fft_size=fft)
         e = max_rel(sp, sp_o)
         if e > 1e-6: msg.append(f'cheaptrick rel={e:.1e}')
-        thr = float(rng.choice([0.85, 0.85, 0.5, 0.0]))
-        ap_o, ap = orc.d4c(x, fs, tp_o, f0_o, fft, threshold=thr), hip.d4c(x, fs, tp_o, f0_o, fft, threshold=thr)
-        e = max_rel(ap, ap_o)
-        if e > 1e-5: msg.append(f'd4c rel={e:.1e}')
-        y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
-        e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
-        if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
-        # parameter modification as in test.cpp:221-240: shifted F0, other output length
-        f0m = f0_o * float(rng.choice([0.5, 0.8, 1.5, 2.0])); ylen = int(len(x) * float(rng.uniform(0.5, 1.0))) + 1   # beyond the parameters the reference extrapolates f0 and overruns its buffers
-        y_o, y = orc.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen), hip.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen)
-        e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
-        if e > 1e-7: msg.append(f'synthesis(modified) peak-rel={e:.1e}')
-        nd = int(rng.choice([1, 24, 60])); 
-        e = float(np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, nd) - orc.code_spectral_envelope(sp_o, fs, fft, nd))))
-        if e > 1e-9: msg.append(f'mcep abs={e:.1e}')
-        e = float(np.max(np.abs(hip.code_aperiodicity(ap_o, fs, fft) - orc.code_aperiodicity(ap_o, fs, fft))))
-        if e > 1e-9: msg.append(f'bap abs={e:.1e}')
+        if fs >= 15800:
+            thr = float(rng.choice([0.85, 0.85, 0.5, 0.0]))
+            ap_o, ap = orc.d4c(x, fs, tp_o, f0_o, fft, threshold=thr), hip.d4c(x, fs, tp_o, f0_o, fft, threshold=thr)
+            e = max_rel(ap, ap_o)
+            if e > 1e-5: msg.append(f'd4c rel={e:.1e}')
+            y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
+            e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
+            if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
+            # parameter modification as in test.cpp:221-240: shifted F0, other output length
+            f0m = f0_o * float(rng.choice([0.5, 0.8, 1.5, 2.0])); ylen = int(len(x) * float(rng.uniform(0.5, 1.0))) + 1   # beyond the parameters the reference extrapolates f0 and overruns its buffers
+            y_o, y = orc.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen), hip.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen)
+            e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
+            if e > 1e-7: msg.append(f'synthesis(modified) peak-rel={e:.1e}')
+            nd = int(rng.choice([1, 24, 60])); 
+            e = float(np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, nd) - orc.code_spectral_envelope(sp_o, fs, fft, nd))))
+            if e > 1e-9: msg.append(f'mcep abs={e:.1e}')
+            e = float(np.max(np.abs(hip.code_aperiodicity(ap_o, fs, fft) - orc.code_aperiodicity(ap_o, fs, fft))))
+            if e > 1e-9: msg.append(f'bap abs={e:.1e}')
         if msg:
             bad += 1
             if os.path.isdir('gpurun_out'):       # keep the inputs of a diverging case for replay
                 np.savez(f'gpurun_out/fuzz_case_{case}.npz', x=x, fs=fs, hopt=repr(hopt), dopt=repr(dopt))
+            # (round 4: this append had gone missing in round 2 -- the suite's slice of this sweep then passed whatever
+            # it found; tests/test_bench_contract.py::test_sweeps_report_their_failures keeps that from recurring)
+            failures.append(f'case {case}: fs={fs} dur={dur:.2f} kind={kind} hopt={hopt}: ' + '; '.join(msg))
             if verbose: print(failures[-1], flush=True)
     if verbose: print(f'{n_cases} cases, {bad} with divergences, {time.time() - t0:.0f} s')
     return failures

@@ -78,3 +78,29 @@ def test_a_profile_of_other_sources_is_reported_stale(tmp_path, monkeypatch):
     t["csrc_hash"] = "f" * 16
     (fake / "pmc_traffic.json").write_text(json.dumps(t))
     assert bench.traffic_stale("1") is False and bench.traffic_stale("9") is None
+
+
+def test_sweeps_report_their_failures(port_oracle):
+    """tests/fuzz_parity.py is the checker behind the suite's randomised slices: a backend that is wrong must come back
+    as a non-empty failure list (round 2 lost the `failures.append`, and the slice passed whatever it found)"""
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import fuzz_parity
+
+    class Wrong:
+        """the oracle itself, with Harvest's F0 off by 1e-3"""
+        def __init__(self, o):
+            self.o = o
+
+        def __getattr__(self, name):
+            return getattr(self.o, name)
+
+        def harvest(self, x, fs, **kw):
+            tp, f0 = self.o.harvest(x, fs, **kw)
+            return tp, f0 * (1.0 + 1e-3)
+
+    assert fuzz_parity.run(seed=3, n_cases=2, hip=port_oracle, orc=port_oracle, verbose=False) == []
+    bad = fuzz_parity.run(seed=3, n_cases=2, hip=Wrong(port_oracle), orc=port_oracle, verbose=False)
+    assert bad and all("harvest" in b for b in bad)

@@ -179,3 +179,95 @@ def test_two_ranks_run_the_real_analysis_and_exchange_packed_blocks(tmp_path):
     port = 29700 + os.getpid() % 200
     mp.spawn(_emu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"emu{r}.npy") for r in range(world))
+
+
+def test_chunk_sizes_taper_the_last_sub_batch():
+    """only the last chunk's all-gather is exposed: a 128-utterance share in sub-batches of 32 is cut 32, 32, 32, 16, 8, 8"""
+    assert wd.chunk_sizes(128, 32) == [32, 32, 32, 16, 8, 8]
+    assert wd.chunk_sizes(128, 32, taper=False) == [32, 32, 32, 32]
+    assert wd.chunk_sizes(40, 32) == [32, 4, 2, 2]
+    assert wd.chunk_sizes(37, 32) == [32, 5]                      # tails of fewer than 8 stay whole
+    assert wd.chunk_sizes(5, 32) == [5] and wd.chunk_sizes(0, 32) == []
+    for n in range(0, 200):
+        for sb in (1, 3, 8, 32):
+            s = wd.chunk_sizes(n, sb)
+            assert sum(s) == n and all(0 < v <= sb for v in s)
+    parts = [list(range(0, 24)), list(range(24, 33))]             # ranks with shares of 24 and 9
+    ch = wd.chunks_of(parts, 8)
+    assert [len(c[0]) for c in ch] == [8, 8, 4, 2, 2] and [len(c[1]) for c in ch] == [8, 1, 0, 0, 0]
+    assert sorted(i for c in ch for p in c for i in p) == list(range(33))
+
+
+# ---- the packed analysis (the stage kernels write the records) on 2 ranks, both wire formats -----------
+def _emu_packed(wire_cols):
+    """WorldHip.analyze_packed's contract on CPU tensors: world_hip_analyze_packed of the host-compiled library"""
+    import ctypes as C
+    import subprocess
+    from world_amd.api import (CheapTrickOption, D4COption, HarvestOption, cheaptrick_fft_size, frame_count, load_library)
+    emu_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    subprocess.run(["make", "-s", "-f", os.path.join(emu_dir, "Makefile")], check=True)
+    L = load_library(os.path.join(emu_dir, "libworld_emu.so"))
+    ctx = L.world_hip_create(0, None)
+
+    def run(x, fs, block, first_row=0, x_len=None, frame_period=5.0, **_):
+        fft = cheaptrick_fft_size(fs)
+        assert block.shape[-1] == wire_cols(fft // 2 + 1) and block.is_contiguous() and x.is_contiguous()
+        xl = np.ascontiguousarray(x_len, dtype=np.int32)
+        h, c, d = HarvestOption(71.0, 800.0, frame_period), CheapTrickOption(-0.15, 71.0, fft), D4COption(0.85)
+        rc = L.world_hip_analyze_packed(ctx, x.shape[0], fs, x.data_ptr(), x.shape[1], xl.ctypes.data_as(C.POINTER(C.c_int)),
+                                        C.byref(h), C.byref(c), C.byref(d), first_row, block.data_ptr(), block.shape[-1])
+        assert rc == 0, L.world_hip_last_error().decode()
+        return [frame_count(fs, int(n), frame_period) for n in xl]
+    return run
+
+
+def _packed_worker(rank, world, port, tmp, wire):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from world_amd import synth
+        fs = 16000
+        lengths = [4000, 2600, 3300, 2000]
+        xs = [synth.utterance(i, fs, n / fs) for i, n in enumerate(lengths)]
+        res = wd.analyze_sharded(xs, fs, analyze_packed=_emu_packed(wd.WIRE_COLS[wire]), sub_batch=1, wire=wire)
+        assert res.wire == wire
+        for i, n in enumerate(lengths):
+            tp_i, f0_i, sp_i, ap_i, nf_i = _emu_analyze(xs[i][None], fs, x_len=[n])
+            tp, f0, sp, ap = res.utterance(i)
+            assert torch.equal(tp, tp_i[0]) and torch.equal(f0, f0_i[0])          # the record's head stays float64
+            if wire == "f64":
+                assert torch.equal(sp, sp_i[0]) and torch.equal(ap, ap_i[0])
+            else:                                                              # the f64 results rounded ONCE to float32
+                assert sp.dtype == torch.float32 and ap.dtype == torch.float32
+                assert torch.equal(sp, sp_i[0].to(torch.float32)) and torch.equal(ap, ap_i[0].to(torch.float32))
+        f0_d, sp_d, ap_d, _ = res.dense()
+        assert sp_d.dtype == torch.float64 and float(sp_d[0, :res.n_frames[0]].min()) > 0      # dense(): float64 again
+        np.save(os.path.join(tmp, f"packed_{wire}_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("wire", ["f64", "f32"])
+def test_two_ranks_exchange_records_written_by_the_stage_kernels(tmp_path, wire):
+    """the path bench.py --gpus N runs (analyze_packed -> in-place all-gather), both wire formats, on 2 gloo ranks with
+    the host-compiled kernels: every utterance on every rank equals a lone analysis (f32: rounded once to float)"""
+    world = 2
+    port = 29300 + (os.getpid() + (17 if wire == "f32" else 0)) % 180
+    mp.spawn(_packed_worker, args=(world, port, str(tmp_path), wire), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"packed_{wire}_{r}.npy") for r in range(world))
+
+
+def test_own_buffers_survive_the_next_call():
+    """the default result views a per-shape cache that the next call overwrites; own_buffers=True gives a
+    result that stays valid while the next step runs"""
+    xs = [torch.rand(900, dtype=torch.float64), torch.rand(300, dtype=torch.float64)]
+    ys = [x + 5.0 for x in xs]
+    kept = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze, bins=5, own_buffers=True)
+    snap = kept.utterance(0)[1].clone()
+    nxt = wd.analyze_sharded(ys, 16000, analyze=_fake_analyze, bins=5, own_buffers=True)
+    assert torch.equal(kept.utterance(0)[1], snap) and not torch.equal(nxt.utterance(0)[1], snap)
+    a = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze, bins=5)
+    b = wd.analyze_sharded(ys, 16000, analyze=_fake_analyze, bins=5)          # same shape: the cached buffers are reused
+    assert a.blocks[0].data_ptr() == b.blocks[0].data_ptr()

@@ -312,3 +312,29 @@ def test_stale_graph_is_refused_not_replayed():
         b1.fill_(-3.0); g2.launch(); torch.cuda.synchronize()
         assert torch.equal(b1, ref)
         g2.close()
+
+
+def _check_cheaptrick_8192(H, oracle, cases):
+    from util import max_rel
+    from world_amd import synth
+    for fs, seconds, floor in cases:
+        x = synth.vowel(fs, seconds, seed=31, base_f0=120.0).numpy()
+        tp, f0 = oracle.harvest(x, fs)
+        fft = H.cheaptrick_fft_size(fs, floor)
+        assert fft == 8192
+        sp = H.cheaptrick(x, fs, tp, f0, f0_floor=floor, fft_size=fft)
+        sp_o = oracle.cheaptrick(x, fs, tp, f0, f0_floor=floor, fft_size=fft)
+        assert sp.shape == sp_o.shape == (len(f0), 4097)
+        assert max_rel(sp, sp_o) <= 1e-6, (fs, floor, max_rel(sp, sp_o))
+
+
+def test_emulated_cheaptrick_fft_size_8192(port_oracle):
+    """the reference takes any power of two (src/cheaptrick.cpp:200-229); fft_size 8192 -- f0 floors below
+    35 Hz at 48 kHz, default options above 96 kHz -- used to be refused"""
+    _check_cheaptrick_8192(_emu(), port_oracle, [(48000, 0.12, 30.0)])
+
+
+@pytest.mark.gpu
+def test_cheaptrick_fft_size_8192_on_the_gpu(ref_oracle):
+    from world_amd.api import HostAPI
+    _check_cheaptrick_8192(HostAPI(), ref_oracle, [(48000, 0.6, 30.0), (96000, 0.4, 40.0), (192000, 0.25, 71.0)])

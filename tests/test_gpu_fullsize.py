@@ -298,3 +298,14 @@ def test_bench_multi_rank_path_on_one_gpu():
     p = line["parity_in_run"]
     assert p["every_rank_bit_identical_to_lone_analysis"] and p["randn_table_intact"], p
     assert line["phases"]["compute_ms_per_step_max_over_ranks"] > 0 and line["roofline"]["kernel"]
+
+
+@pytest.mark.parametrize("wire", ["f64", "f32"])
+def test_rccl_collective_path_executes_with_a_world_of_one(wire):
+    """the RCCL path had never executed.  torch.distributed backend "nccl" (= RCCL), world_size 1: the
+    communicator initialises and every sub-batch's in-place all_gather_into_tensor (input aliasing out[rank]) runs on
+    the lanes' streams; every utterance's records are bit-identical to a lone analysis (f32 wire: rounded once)."""
+    port = 29200 + (os.getpid() + (31 if wire == "f32" else 0)) % 250
+    r = subprocess.run([sys.executable, os.path.join(HERE, "nccl_single_rank.py"), wire, str(port)], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "nccl single rank ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -630,3 +630,32 @@ def test_merge_routes_agree_on_the_gpu(tmp_path):
     for k in A.files:
         assert np.array_equal(A[k], B[k]), k
         assert (A[k] > 0).any()
+
+
+@pytest.mark.gpu
+def test_direct_form_filter_bank_matches_golden_and_reference(tmp_path, ref_oracle):
+    """Harvest's direct-form filter bank (harvest.hip: hv_band_events -- taken when a filter is too long for
+    the overlap-save block, i.e. floors below ~35 Hz, or when WORLD_HIP_HARVEST_FIR=1 forces it) had no test of its own.
+    (a) forced on the golden fixtures: the same F0 as the reference's (reference src/harvest.cpp:99-148);
+    (b) f0_floor = 30 Hz, where it is the route taken by itself, against the reference on 48 kHz and 16 kHz speech."""
+    import subprocess
+    import sys
+    from util import assert_f0_close, load_golden
+    out = str(tmp_path / "fir.npz")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fir_route.py"), out],
+                       env=dict(os.environ, WORLD_HIP_HARVEST_FIR="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    for name in ("vaiueo2d_harvest", "vowel48k_harvest"):
+        g = load_golden(name)
+        assert np.array_equal(got[name + "_tp"], g["tp"])
+        assert_f0_close(got[name + "_f0"], g["f0"], 1e-6, name + " (direct-form filter bank)")
+    from world_amd import synth
+    from world_amd.api import HostAPI
+    H = HostAPI()
+    for fs, seconds, seed, base in ((48000, 1.5, 21, 95.0), (16000, 1.2, 22, 62.0), (11025, 1.0, 23, 110.0)):
+        x = synth.vowel(fs, seconds, seed=seed, base_f0=base).numpy()
+        tp_r, f0_r = ref_oracle.harvest(x, fs, f0_floor=30.0)
+        tp, f0 = H.harvest(x, fs, f0_floor=30.0)
+        assert np.array_equal(tp, tp_r) and (f0_r > 0).sum() > 20
+        assert_f0_close(f0, f0_r, 1e-6, f"f0_floor 30 at {fs} Hz")

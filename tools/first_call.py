@@ -1,0 +1,50 @@
+"""Cold start of the drop-in path, measured in a FRESH process (bench.py runs this as a subprocess): the first
+Harvest() + CheapTrick() + D4C() of a 10 s, 48 kHz utterance on host pointers -- HIP runtime start-up, code-object
+load, context + tables, the randn table's first build and its verification against the host statement, workspace
+allocation -- against the same calls repeated.  Prints one JSON object."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np                                                    # noqa: E402
+
+from world_amd import synth                                           # noqa: E402
+from world_amd.api import HostAPI, load_library                       # noqa: E402
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+fs = 48000
+x = np.ascontiguousarray(synth.vowel(fs, seconds, seed=12345).numpy())
+t_load = time.perf_counter()
+H = HostAPI()
+L = load_library()
+L.world_hip_noise_table_build_ms.restype = C.c_double
+L.world_hip_noise_table_build_ms.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+t_lib = time.perf_counter()
+
+
+def job():
+    t0 = time.perf_counter()
+    tp, f0 = H.harvest(x, fs)
+    t1 = time.perf_counter()
+    sp = H.cheaptrick(x, fs, tp, f0, fft_size=2048)
+    t2 = time.perf_counter()
+    ap = H.d4c(x, fs, tp, f0, 2048)
+    t3 = time.perf_counter()
+    return [(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3]
+
+
+first = job()
+ctx = L.world_hip_create(0, None)
+builds = C.c_int()
+table_ms = L.world_hip_noise_table_build_ms(ctx, C.byref(builds))
+later = [job() for _ in range(3)]
+L.world_hip_destroy(ctx)
+print(json.dumps({"seconds": seconds, "library_load_ms": (t_lib - t_load) * 1e3,
+                  "first_call_ms": sum(first), "first_call_stages_ms": first,
+                  "randn_table_build_ms": table_ms, "randn_table_builds": builds.value,
+                  "steady_call_ms": min(sum(j) for j in later),
+                  "table_threads": os.environ.get("WORLD_HIP_TABLE_THREADS", "default: min(16, cores)")}))

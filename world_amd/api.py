@@ -90,6 +90,7 @@ def load_library(path=LIB_PATH):
                                               C.POINTER(HarvestOption), C.POINTER(CheapTrickOption), C.POINTER(D4COption),
                                               C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
     lib.world_hip_check_shape.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    lib.world_hip_record_columns.argtypes = [C.c_int, C.c_int]
     lib.world_hip_analyze_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(HarvestOption),
                                             C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, vp, vp, vp, vp]
     lib.world_hip_graph_begin.argtypes = [vp]
@@ -577,12 +578,15 @@ class WorldHip:
         inside a HIP graph capture; returns a Graph whose launch() replays all of it with one host call."""
         ctx = self._context()
         self._check(self.lib.world_hip_graph_begin(ctx), "graph_begin")
+        g = C.c_void_p()
         try:
             fn()
-        finally:
-            g = C.c_void_p()
-            rc = self.lib.world_hip_graph_end(ctx, C.byref(g))
-        self._check(rc, "graph_end")
+        except BaseException:
+            # the capture must be ended whatever fn() did; a graph it still produced is destroyed, not leaked (ADVICE r03)
+            if self.lib.world_hip_graph_end(ctx, C.byref(g)) == 0 and g:
+                self.lib.world_hip_graph_destroy(g)
+            raise
+        self._check(self.lib.world_hip_graph_end(ctx, C.byref(g)), "graph_end")
         return Graph(self, ctx, g)
 
     def analyze_packed(self, x, fs, block, first_row=0, x_len=None, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
@@ -594,12 +598,13 @@ class WorldHip:
         fft_size = cheaptrick_fft_size(fs, 71.0)
         nb = fft_size // 2 + 1
         nf = [frame_count(fs, int(n), frame_period) for n in xl]
-        assert block.dtype == t.float64 and block.is_contiguous() and block.shape[-1] == 2 + 2 * nb and block.device == x.device
-        assert first_row + sum(nf) <= block.shape[0]
+        cols = block.shape[-1]                       # 2 + 2 nb: f64 records; 2 + nb: the spectra as float32 (narrow wire)
+        assert block.dtype == t.float64 and block.is_contiguous() and cols in (2 + 2 * nb, 2 + nb) and block.device == x.device
+        assert first_row >= 0 and first_row + sum(nf) <= block.shape[0]
         hopt, copt, dopt = HarvestOption(f0_floor, f0_ceil, frame_period), CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
         self._check(self.lib.world_hip_analyze_packed(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
                                                       C.byref(hopt), C.byref(copt), C.byref(dopt), first_row,
-                                                      block.data_ptr(), 2 + 2 * nb), "analyze_packed")
+                                                      block.data_ptr(), cols), "analyze_packed")
         return nf
 
     def pack_results(self, tpos, f0, sp, ap, n_frames, block, first_row=0):
@@ -753,14 +758,15 @@ class WorldHip:
 
 
 def analyze_sharded_c(lib, ctxs, xs, fs, block_ptrs, rows_capacity, sub_batch=32, frame_period=5.0, f0_floor=71.0,
-                      f0_ceil=800.0, q1=-0.15, threshold=0.85):
+                      f0_ceil=800.0, q1=-0.15, threshold=0.85, wire=0):
     """world_hip_analyze_sharded (include/world_hip.h): ONE process, several contexts (normally one per GPU), the job's
     utterances as host arrays.  ctxs: library contexts; xs: list of 1-D float64 numpy arrays; block_ptrs: one device
-    pointer per context to rows_capacity x (2 + 2 (fft/2+1)) doubles.  Returns where [n_utt, 3] = (context index, first
-    row, n_frames): every block then holds ALL records at those rows."""
+    pointer per context to rows_capacity x world_hip_record_columns(fft, wire) doubles (wire 0: f64 records, 1: the
+    spectra as float32).  Returns where [n_utt, 3] = (context index, first row, n_frames): every block then holds ALL
+    records at those rows."""
     n = len(xs)
     fft_size = cheaptrick_fft_size(fs, 71.0)
-    cols = 2 + 2 * (fft_size // 2 + 1)
+    cols = lib.world_hip_record_columns(fft_size, wire)
     xs = [np.ascontiguousarray(x, dtype=np.float64) for x in xs]
     vp = C.c_void_p
     xp = (vp * max(1, n))(*[x.ctypes.data for x in xs])

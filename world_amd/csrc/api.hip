@@ -260,7 +260,7 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
                            const RowLayout &lay = RowLayout()) {
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   const int lg = ilog2_exact(opt->fft_size);
-  if (lg < 7 || lg > 12) fail("CheapTrick fft_size %d unsupported (128..4096: one frame must fit LDS)", opt->fft_size);
+  if (lg < 7 || lg > 13) fail("CheapTrick fft_size %d unsupported (128..8192: one frame must fit LDS)", opt->fft_size);
   int max_frames = 0;
   for (int u = 0; u < n_utt; ++u) {
     if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
@@ -1054,8 +1054,8 @@ static std::string shape_limit(int what, int fs, int fft_size) {
   if (what & 2) {
     int lg = 0;
     while ((1 << lg) < fft_size) ++lg;
-    if ((1 << lg) != fft_size || lg < 7 || lg > 12) {
-      snprintf(msg, sizeof msg, "CheapTrick: fft_size %d unsupported (a power of two, 128..4096: one frame must fit LDS; fs <= 96 kHz at the default f0 floor)", fft_size);
+    if ((1 << lg) != fft_size || lg < 7 || lg > 13) {
+      snprintf(msg, sizeof msg, "CheapTrick: fft_size %d unsupported (a power of two, 128..8192: one frame must fit LDS; fs <= 192 kHz at the default f0 floor)", fft_size);
       return msg;
     }
   }
@@ -1220,6 +1220,12 @@ unsigned long long world_hip_workspace_bytes(WorldHipContext *c) {
 
 // the device's shared randn table (live + superseded generations), see rng.h
 unsigned long long world_hip_noise_table_bytes(WorldHipContext *c) { return c ? noise_table_bytes(c->device) : 0; }
+
+// wall-clock milliseconds this process has spent building + verifying the device's randn tables (cold-start cost)
+double world_hip_noise_table_build_ms(WorldHipContext *c, int *builds) {
+  if (!c) { if (builds) *builds = 0; return 0.0; }
+  return noise_table_build_ms(c->device, builds);
+}
 
 // re-reduce the live randn table on the device and compare it with the host's sums (diagnostic; synchronises)
 int world_hip_verify_tables(WorldHipContext *c) {

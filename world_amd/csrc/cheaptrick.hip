@@ -89,8 +89,11 @@ __device__ __forceinline__ size_t ct_seg_elem(int i) { return (size_t)(i >> 1) *
 // ---- stage 1: window -> r2c -> |X|^2 -> DC correction -> mirrored segment of LinearSmoothing, to HBM ----------
 // PER: samples of the window a thread owns (fft_size / threads); LGN: log2(fft_size) when it is a compile-time
 // constant of the instantiation (static FFT stages), 0 = taken from p.lg_fft.
-template <int PER, int LGN>
-__global__ void __launch_bounds__(256, 4) ct_spectrum(CtParams p) {
+// TB: the largest workgroup the instantiation is launched with (512 for the 8192-point transform: one frame then owns
+// 107 KB of LDS, one workgroup per CU -- the shape exists so that f0 floors below 35 Hz at 48 kHz and sampling rates
+// above 96 kHz run at all, not to be fast)
+template <int PER, int LGN, int TB = 256>
+__global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_spectrum(CtParams p) {
   DYN_LDS(lds);
   const int lgn = LGN > 0 ? LGN : p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
@@ -241,8 +244,8 @@ __global__ void __launch_bounds__(WAVE) ct_scan(CtParams p) {
 }
 
 // ---- stage 3: rectangular smoothing from the prefix sums -> log -> cepstrum -> lifter -> exp, to HBM -----------
-template <int LGN>
-__global__ void __launch_bounds__(256, 4) ct_envelope(CtParams p) {
+template <int LGN, int TB = 256>
+__global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_envelope(CtParams p) {
   DYN_LDS(lds);
   const int lgn = LGN > 0 ? LGN : p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
@@ -345,7 +348,7 @@ void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
   const size_t lds1 = ct_spectrum_lds_bytes(p.lg_fft), lds3 = ct_envelope_lds_bytes(p.lg_fft);
   const dim3 scan_grid((max_frames + WAVE - 1) / WAVE, p.b.n_utt);
 #ifdef WORLD_EMU
-  devrt::launch_blocks("ct_spectrum", ct_spectrum<4096, 0>, grid, 256, lds1, stream, p);
+  devrt::launch_blocks("ct_spectrum", ct_spectrum<8192, 0>, grid, 256, lds1, stream, p);
   WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
   devrt::launch_blocks("ct_envelope", ct_envelope<0>, grid, 256, lds3, stream, p);
 #else
@@ -364,6 +367,10 @@ void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
     devrt::launch_blocks("ct_spectrum", ct_spectrum<16, 12>, grid, 256, lds1, stream, p);
     WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
     devrt::launch_blocks("ct_envelope", ct_envelope<12>, grid, 256, lds3, stream, p);
+  } else if (p.lg_fft == 13) {
+    devrt::launch_blocks("ct_spectrum", ct_spectrum<16, 0, 512>, grid, 512, lds1, stream, p);
+    WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
+    devrt::launch_blocks("ct_envelope", ct_envelope<0, 512>, grid, 512, lds3, stream, p);
   } else {
     devrt::launch_blocks("ct_spectrum", ct_spectrum<8, 0>, grid, 128, lds1, stream, p);
     WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);

@@ -97,5 +97,7 @@ const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jum
 // re-reduce the live table on `stream` and compare with the host's sums (diagnostic; synchronises); throws on mismatch
 void noise_table_verify(int device, hipStream_t stream);
 size_t noise_table_bytes(int device);              // live + superseded tables
+// host wall time spent building + verifying this device's tables so far (every generation), and how many were built
+double noise_table_build_ms(int device, int *builds);
 
 }  // namespace world_hip

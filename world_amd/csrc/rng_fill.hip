@@ -4,11 +4,13 @@
 // against a sequential host statement of the generator before anybody may read it.
 #include "rng.h"
 
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace world_hip {
@@ -87,6 +89,8 @@ struct DeviceNoise {
   HostGen gen;
   size_t host_pos = 0;
   std::vector<unsigned long long> host_sums;
+  double build_ms = 0.0;                           // wall time spent building + verifying tables (all generations)
+  int builds = 0;
 };
 
 // g_noise_lock guards the map and the reference counts only; a device's table is grown, verified and re-verified under
@@ -108,19 +112,97 @@ DeviceEntry *find_entry(int device) {
   return it == g_noise.end() ? nullptr : it->second.get();
 }
 
-void host_extend(DeviceNoise &d, size_t upto) {
-  while (d.host_pos < upto) {
-    const size_t n = upto - d.host_pos < kNoiseChunk ? upto - d.host_pos : kNoiseChunk;
+// The host's jump tables (tables.cpp), built once per process: they only SEED the helper threads below, and every
+// seed is then confirmed by sequential stepping, so the check stays independent of them.
+const uint4 *host_jump_tables() {
+  static const std::vector<uint4> *tab = [] {
+    auto *v = new std::vector<uint4>((size_t)kJumpLevels * kJumpStride);
+    build_jump_tables(v->data());
+    return v;
+  }();
+  return tab->data();
+}
+HostGen host_jump(size_t calls) {                    // the generator after `calls` draws from the seed, by the tables
+  const uint4 *jump = host_jump_tables();
+  HostGen g;
+  uint32_t in[4] = {g.x, g.y, g.z, g.w};
+  for (int level = 0; calls != 0; ++level, calls >>= 1) {
+    if (!(calls & 1u)) continue;
+    const uint4 *tab = jump + (size_t)level * kJumpStride;
+    uint32_t out[4] = {0, 0, 0, 0};
+    for (int wd = 0; wd < 4; ++wd)
+      for (int n = 0; n < 8; ++n) {
+        const uint4 e = tab[(wd * 8 + n) * 16 + ((in[wd] >> (4 * n)) & 15u)];
+        out[0] ^= e.x; out[1] ^= e.y; out[2] ^= e.z; out[3] ^= e.w;
+      }
+    for (int k = 0; k < 4; ++k) in[k] = out[k];
+  }
+  g.x = in[0]; g.y = in[1]; g.z = in[2]; g.w = in[3];
+  return g;
+}
+
+// sums of the chunks that cover draws [pos, upto) (pos a multiple of kNoiseChunk), stepping `g` sequentially
+void host_chunks(HostGen &g, size_t pos, size_t upto, unsigned long long *sums) {
+  while (pos < upto) {
+    const size_t n = upto - pos < kNoiseChunk ? upto - pos : kNoiseChunk;
     unsigned long long s1 = 0, s2 = 0;
     for (size_t i = 0; i < n; ++i) {
-      const unsigned long long w = d.gen.word();
+      const unsigned long long w = g.word();
       s1 += w;
       s2 += w * (unsigned long long)(i + 1);
     }
-    d.host_sums.push_back(s1);
-    d.host_sums.push_back(s2);
-    d.host_pos += n;
+    *sums++ = s1;
+    *sums++ = s2;
+    pos += n;
   }
+}
+
+// The host statement of the stream up to draw `upto`.  Stepping is sequential by nature (12 ns per draw: 0.4 s for the
+// 32 M draws of a 10 s utterance -- round 3's whole cold start, 500 x a steady-state call), so the new draws are cut into
+// T contiguous ranges stepped side by side: range 0 continues the generator where the last statement stopped, range k is
+// SEEDED by the jump tables -- and then every seed is confirmed, not trusted: range k - 1's generator, stepped
+// sequentially to its end, must arrive at exactly the state range k started from.  By induction from the true seed the
+// whole statement is the sequential generator's; the jump tables cannot make a wrong table pass.
+void host_extend(DeviceNoise &d, size_t upto) {
+  if (d.host_pos >= upto) return;
+  const size_t first_chunk = d.host_pos / kNoiseChunk;
+  const size_t chunks = (upto - d.host_pos + kNoiseChunk - 1) / kNoiseChunk;
+  d.host_sums.resize(2 * (first_chunk + chunks));
+  static const int max_threads = [] {
+    const char *e = getenv("WORLD_HIP_TABLE_THREADS");
+    const int hw = (int)std::thread::hardware_concurrency();
+    return e ? std::max(1, atoi(e)) : std::max(1, std::min(16, hw > 0 ? hw : 1));
+  }();
+  const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_threads, chunks / 4));   // >= 4 chunks (3 ms) a thread
+  if (T == 1 || d.host_pos % kNoiseChunk != 0) {
+    host_chunks(d.gen, d.host_pos, upto, d.host_sums.data() + 2 * first_chunk);
+    d.host_pos = upto;
+    return;
+  }
+  std::vector<size_t> lo(T + 1);
+  for (int k = 0; k <= T; ++k) lo[k] = d.host_pos + (chunks * k / T) * kNoiseChunk;
+  lo[T] = upto;
+  std::vector<HostGen> start(T), end(T);
+  start[0] = d.gen;
+  for (int k = 1; k < T; ++k) start[k] = host_jump(lo[k]);
+  auto work = [&](int k) {
+    HostGen g = start[k];
+    host_chunks(g, lo[k], lo[k + 1], d.host_sums.data() + 2 * (lo[k] / kNoiseChunk));
+    end[k] = g;
+  };
+  std::vector<std::thread> threads;
+  int spawned = 0;
+  for (int k = 1; k < T; ++k) {
+    try { threads.emplace_back(work, k); ++spawned; } catch (...) { break; }
+  }
+  work(0);
+  for (std::thread &t : threads) t.join();
+  for (int k = spawned + 1; k < T; ++k) work(k);     // threads that could not be started: their ranges on this one
+  for (int k = 0; k + 1 < T; ++k)
+    if (end[k].x != start[k + 1].x || end[k].y != start[k + 1].y || end[k].z != start[k + 1].z || end[k].w != start[k + 1].w)
+      throw std::runtime_error("randn host statement: the jump-table seed of a verification range disagrees with the sequential generator");
+  d.gen = end[T - 1];
+  d.host_pos = upto;
 }
 
 // reduce `table[0, len)` on the device and compare every chunk with the host's sums
@@ -182,6 +264,7 @@ const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jum
   if (cap < ((size_t)1 << 22)) cap = (size_t)1 << 22;
   cap = (cap + kNoiseChunk - 1) / kNoiseChunk * kNoiseChunk;
   if (cap > kNoiseMaxDraws) cap = kNoiseMaxDraws;
+  const auto t_build = std::chrono::steady_clock::now();
   uint32_t *fresh = static_cast<uint32_t *>(devrt::dmalloc(sizeof(uint32_t) * cap));
   try {
     // every word comes from the fill kernel (nothing is copied over from the shorter table) ...
@@ -201,6 +284,8 @@ const uint32_t *noise_table_acquire(int device, size_t draws, const uint4 *d_jum
   }
   d.live = fresh;
   d.len = cap;
+  d.build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
+  d.builds += 1;
   return d.live;
 }
 
@@ -210,6 +295,15 @@ void noise_table_verify(int device, hipStream_t stream) {
   std::lock_guard<std::mutex> g(e->lock);
   if (!e->d.live) return;
   check_table(e->d, e->d.live, e->d.len, stream, "re-check of the live table");
+}
+
+double noise_table_build_ms(int device, int *builds) {
+  DeviceEntry *e = find_entry(device);
+  if (builds) *builds = 0;
+  if (!e) return 0.0;
+  std::lock_guard<std::mutex> g(e->lock);
+  if (builds) *builds = e->d.builds;
+  return e->d.build_ms;
 }
 
 size_t noise_table_bytes(int device) {

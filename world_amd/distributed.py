@@ -37,12 +37,36 @@ def partition(lengths, world_size):
     return parts
 
 
-def chunks_of(parts, sub_batch):
-    """parts[r] cut into runs of <= sub_batch utterances: chunks[k][r] = rank r's utterances of chunk k
-    (every rank has the same number of chunks; late ones may be empty on some ranks)"""
+def chunk_sizes(n, sub_batch, taper=True):
+    """Sub-batch sizes for a share of n utterances: full sub-batches, and the LAST one tapered into halves
+    (sb/2, sb/4, sb/4).  Chunk k's all-gather runs under chunk k + 1's analysis, so only the last chunk's exchange is
+    exposed: tapering shrinks it from 1/4 of a 128-utterance share (32, 32, 32, 32) to 1/16 (32, 32, 32, 16, 8, 8).
+    Tails of fewer than 8 utterances stay whole -- smaller batches stop filling the chip.  (api.hip: chunk_sizes is the
+    same schedule for the C driver.)"""
     sb = max(1, int(sub_batch))
-    n = max((len(p) + sb - 1) // sb for p in parts) if parts else 0
-    return [[p[k * sb:(k + 1) * sb] for p in parts] for k in range(n)]
+    out = []
+    while n > sb:
+        out.append(sb)
+        n -= sb
+    if taper and n >= 8:
+        a = (n + 1) // 2
+        b = (n - a + 1) // 2
+        out += [v for v in (a, b, n - a - b) if v > 0]
+    elif n > 0:
+        out.append(n)
+    return out
+
+
+def chunks_of(parts, sub_batch, taper=True):
+    """parts[r] cut into sub-batches (chunk_sizes of the LARGEST share, the same cuts on every rank):
+    chunks[k][r] = rank r's utterances of chunk k (every rank has the same number of chunks; late ones may be
+    short or empty on ranks with a smaller share)"""
+    n = max((len(p) for p in parts), default=0)
+    cuts, lo = [], 0
+    for size in chunk_sizes(n, sub_batch, taper):
+        cuts.append((lo, lo + size))
+        lo += size
+    return [[p[a:b] for p in parts] for a, b in cuts]
 
 
 def _gather_in_place(out, rank, group, async_op):
@@ -78,24 +102,37 @@ def wait_all(works):
             w.wait()
 
 
+WIRE_COLS = {"f64": lambda nb: 2 + 2 * nb, "f32": lambda nb: 2 + nb}
+
+
+def record_views(rec, nb, wire="f64"):
+    """(tpos, f0, sp, ap) views of packed records rec [n, cols] (float64 storage).  wire "f64": cols = 2 + 2 nb, all
+    doubles; wire "f32": cols = 2 + nb doubles = 16 + 8 nb bytes, the spectra stored as float32 (include/world_hip.h:
+    world_hip_analyze_packed) -- sp / ap come back as float32 views of the same memory."""
+    if wire == "f64":
+        return rec[:, 0], rec[:, 1], rec[:, 2:2 + nb], rec[:, 2 + nb:2 + 2 * nb]
+    assert wire == "f32" and rec.shape[-1] == 2 + nb
+    f32 = rec.view(torch.float32)                      # [n, 2 cols]: float j of a record = bytes 4 j ..
+    return rec[:, 0], rec[:, 1], f32[:, 4:4 + nb], f32[:, 4 + nb:4 + 2 * nb]
+
+
 class ShardedResult:
     """Every utterance's analysis on this rank, as views into the gathered chunk buffers (nothing is copied again).
 
-    blocks  list over chunks of [world][rows_k][2 + 2 nb] float64
+    blocks  list over chunks of [world][rows_k][cols] float64 (cols by wire format: WIRE_COLS)
     where   {utterance index: (chunk, rank, first record, n_frames)}
     """
 
-    def __init__(self, blocks, where, n_frames, nb):
-        self.blocks, self.where, self.n_frames, self.nb = blocks, where, n_frames, nb
+    def __init__(self, blocks, where, n_frames, nb, wire="f64"):
+        self.blocks, self.where, self.n_frames, self.nb, self.wire = blocks, where, n_frames, nb, wire
 
     def __len__(self):
         return len(self.n_frames)
 
     def utterance(self, i):
-        """(tpos [n], f0 [n], sp [n, nb], ap [n, nb]) of utterance i: views, no copy"""
+        """(tpos [n], f0 [n], sp [n, nb], ap [n, nb]) of utterance i: views, no copy (sp / ap float32 on the f32 wire)"""
         k, r, first, n = self.where[i]
-        rec = self.blocks[k][r, first:first + n]
-        return rec[:, 0], rec[:, 1], rec[:, 2:2 + self.nb], rec[:, 2 + self.nb:2 + 2 * self.nb]
+        return record_views(self.blocks[k][r, first:first + n], self.nb, self.wire)
 
     def dense(self):
         """(f0 [n_utt, F], sp [n_utt, F, nb], ap [n_utt, F, nb], n_frames) padded to the longest utterance
@@ -109,7 +146,7 @@ class ShardedResult:
             if i in self.where:
                 _, f, s, a = self.utterance(i)
                 k = f.shape[0]
-                f0[i, :k], sp[i, :k], ap[i, :k] = f, s, a
+                f0[i, :k], sp[i, :k], ap[i, :k] = f, s.to(torch.float64), a.to(torch.float64)
         return f0, sp, ap, torch.tensor(self.n_frames, dtype=torch.int32)
 
 
@@ -139,9 +176,10 @@ def _default_lanes(packer=None):
     """two (stream, analyze_packed) lanes per device and process: the caller's analyser (or the default one) and a second
     library context, each bound to its own stream"""
     device = torch.cuda.current_device()
-    key = (device, id(packer))
+    wh = packer or _default_analyzer()                 # a WorldHip keeps one library context per stream it is used on
+    # keyed by the analyser ITSELF (kept alive by the entry): an id() can name another object after garbage collection
+    key = (device, wh)
     if key not in _lanes:
-        wh = packer or _default_analyzer()             # a WorldHip keeps one library context per stream it is used on
         _lanes[key] = [(torch.cuda.Stream(device=device), wh.analyze_packed), (torch.cuda.Stream(device=device), wh.analyze_packed)]
     return _lanes[key]
 
@@ -166,7 +204,8 @@ def _store_records(packer, tpos, f0, sp, ap, nf, block):
 
 
 def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, lengths=None, sub_batch=32, gather=True,
-                    timings=None, packer=None, bins=None, analyze_packed=None, lanes=None, **options):
+                    timings=None, packer=None, bins=None, analyze_packed=None, lanes=None, wire="f64", taper=True,
+                    own_buffers=False, exchange_single_rank=False, **options):
     """The whole multi-GPU recipe in one call (BASELINE configs[3]).
 
     x_list   every utterance of the job as a 1-D float64 tensor: a list (the same on every rank), or -- with
@@ -182,9 +221,18 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
              32-utterance chunk's time with the chip nearly idle) overlaps the wide kernels of the next chunk.  Default on a
              GPU: two lanes, each with its own library context.
     bins     spectrogram bins per frame (default: fft/2+1 of fs)
+    wire     record format on the links: "f64" (default; [tpos, f0, sp[nb], ap[nb]] doubles) or "f32" (the spectra
+             rounded once to float32 by the stage kernels: half the bytes, 6e-8 relative -- the contract is 1e-4)
+    taper    cut the last sub-batch into halves so that the one exposed exchange is small (chunk_sizes)
+    exchange_single_rank  run the all-gathers even in a process group of ONE rank (a functional check of the collective
+             path -- RCCL, the aliased in-place all_gather_into_tensor -- on a 1-GPU box; never needed for results)
+    own_buffers  True: the result owns freshly allocated receive buffers (a caller that keeps step N's result while step
+             N + 1 runs); False (default): the buffers are cached per job shape and the NEXT call with the same shape
+             overwrites them -- a 16.8 GB set is not reallocated every step
     timings  optional dict, accumulates: "compute_ms" (host wall clock of the analysis calls, device synchronised at the
              end), "exchange_exposed_ms" (device time the compute stream spent waiting for all-gathers after its last
-             analysis: what the overlap did NOT hide), "exchange_ms" (= exposed), "steps"
+             analysis: what the overlap did NOT hide), "exchange_ms" (= exposed), "steps", "gathered_bytes" (bytes this
+             rank RECEIVED from the other ranks), "last_chunk_bytes" (those of the final, exposed all-gather)
     Returns a ShardedResult covering ALL utterances on every rank (gather=False: this rank's only).  Its views point into
     receive buffers that the next call for the same job shape reuses (a 16.8 GB set is not reallocated every step).
     """
@@ -197,10 +245,14 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
     n_utt = len(lengths)
     n_frames = [frame_count(fs, n, frame_period) for n in lengths]
     nb = bins or cheaptrick_fft_size(fs) // 2 + 1
-    cols = 2 + 2 * nb
+    if wire not in WIRE_COLS:
+        raise ValueError(f"wire format {wire!r}: expected one of {sorted(WIRE_COLS)}")
+    if wire != "f64" and analyze is not None:
+        raise ValueError("the narrow wire formats are written by the stage kernels: they need analyze_packed, not analyze")
+    cols = WIRE_COLS[wire](nb)
     device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     if n_utt == 0:
-        return ShardedResult([], {}, [], nb)
+        return ShardedResult([], {}, [], nb, wire)
     if analyze is None and analyze_packed is None:
         analyze_packed = (packer or _default_analyzer()).analyze_packed
         if lanes is None and device.type == "cuda":
@@ -208,7 +260,7 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
     if lanes is not None and not lanes:
         lanes = None
     parts = partition(lengths, world)
-    chunks = chunks_of(parts, sub_batch)
+    chunks = chunks_of(parts, sub_batch, taper)
     rows = [[sum(n_frames[i] for i in c[r]) for r in range(world)] for c in chunks]
     rows_k = [max(r) for r in rows]
     where = {}
@@ -218,13 +270,15 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
             for i in c[r]:
                 where[i] = (k, r, row, n_frames[i])
                 row += n_frames[i]
-    exchange = world > 1 and gather
+    exchange = gather and (world > 1 or (on and exchange_single_rank))
     key = (str(device), world if exchange else 1, tuple(rows_k), cols)
-    bufs = _buffers.get(key)
+    bufs = None if own_buffers else _buffers.get(key)
     if bufs is None:
-        _buffers.clear()                           # one job shape at a time: a 16.8 GB set is not kept beside the next one
+        if not own_buffers:
+            _buffers.clear()                       # one job shape at a time: a 16.8 GB set is not kept beside the next one
         bufs = [torch.zeros((key[1], max(1, rk), cols), dtype=torch.float64, device=device) for rk in rows_k]
-        _buffers[key] = bufs
+        if not own_buffers:
+            _buffers[key] = bufs
     me = rank if exchange else 0
     cuda = device.type == "cuda"
     if timings is not None and cuda:
@@ -277,7 +331,11 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
         timings["exchange_exposed_ms"] = timings.get("exchange_exposed_ms", 0.0) + exposed
         timings["exchange_ms"] = timings.get("exchange_ms", 0.0) + exposed
         timings["steps"] = timings.get("steps", 0) + 1
+        if exchange:
+            per_chunk = [(world - 1) * max(1, rk) * cols * 8 for rk in rows_k]
+            timings["gathered_bytes"] = timings.get("gathered_bytes", 0) + sum(per_chunk)
+            timings["last_chunk_bytes"] = timings.get("last_chunk_bytes", 0) + per_chunk[-1]
     if world > 1 and not gather:                  # this rank's utterances only
         local = {i: (w[0], 0, w[2], w[3]) for i, w in where.items() if w[1] == rank}
-        return ShardedResult(bufs, local, n_frames, nb)
-    return ShardedResult(bufs, where, n_frames, nb)
+        return ShardedResult(bufs, local, n_frames, nb, wire)
+    return ShardedResult(bufs, where, n_frames, nb, wire)

@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libworld_hip.so")
+# WORLD_HIP_LIB: another build of the library (tools/ab.py times variants built with other flags side by side)
+LIB_PATH = os.environ.get("WORLD_HIP_LIB") or os.path.join(HERE, "libworld_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -140,11 +141,12 @@ def _p(a):
 
 
 def _rows(a):
-    """double** view over a dense 2-D array (the reference's row-pointer ABI)."""
-    ptrs = (_dp * a.shape[0])()
-    base, stride = a.ctypes.data, a.strides[0]
-    for i in range(a.shape[0]):
-        ptrs[i] = C.cast(base + i * stride, _dp)
+    """double** view over a dense 2-D array (the reference's row-pointer ABI).  The row addresses are computed by numpy
+    and handed over as one pointer array (a Python loop over 2001 rows cost the caller milliseconds per call); the array
+    object keeps itself alive on the ctypes pointer."""
+    addr = (a.ctypes.data + a.strides[0] * np.arange(a.shape[0], dtype=np.uintp)).astype(np.uintp)
+    ptrs = addr.ctypes.data_as(C.POINTER(_dp))
+    ptrs._keep = addr
     return ptrs
 
 

@@ -65,18 +65,23 @@ def build(force=False, verbose=False):
 
 
 def build_examples():
-    """examples/batch_analysis.cpp: the device-resident C API from plain C++ (hipcc, host code only)."""
+    """examples/batch_analysis.cpp: the device-resident C API from plain C++ (hipcc, host code only);
+    examples/dropin_bench.cpp: the drop-in symbols timed from a plain C++ caller (g++: it knows nothing of HIP)."""
     root = os.path.dirname(HERE)
-    src, exe = os.path.join(root, "examples", "batch_analysis.cpp"), os.path.join(root, "examples", "batch_analysis")
-    if not os.path.exists(src):
-        return None
-    newest = max(os.path.getmtime(src), os.path.getmtime(LIB), os.path.getmtime(os.path.join(root, "include", "world_hip.h")))
-    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
-        r = subprocess.run([hipcc(), "-O1", "-I", os.path.join(root, "include"), src, "-L", HERE, "-lworld_hip",
-                            "-Wl,-rpath,$ORIGIN/../world_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed on the example:\n" + r.stdout + r.stderr)
-    return exe
+    inc = os.path.join(root, "include")
+    out = None
+    for name, cmd in (("batch_analysis", [hipcc(), "-O1"]), ("dropin_bench", ["g++", "-O2", "-std=c++17", "-pthread"])):
+        src, exe = os.path.join(root, "examples", name + ".cpp"), os.path.join(root, "examples", name)
+        if not os.path.exists(src):
+            continue
+        newest = max(os.path.getmtime(src), os.path.getmtime(LIB), os.path.getmtime(os.path.join(inc, "world_hip.h")))
+        if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
+            r = subprocess.run([*cmd, "-I", inc, src, "-L", HERE, "-lworld_hip", "-Wl,-rpath,$ORIGIN/../world_amd",
+                                "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"building examples/{name} failed:\n" + r.stdout + r.stderr)
+        out = out or exe
+    return out
 
 
 if __name__ == "__main__":

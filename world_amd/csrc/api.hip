@@ -399,15 +399,29 @@ static void prepare_bands(WorldHipContext *c, int fs, double f0_floor, double f0
     launch_band_spectra(hb.d_taps, hb.d_off, hb.d_half, nch, hb.d_spec, c->tab, c->stream);
     devrt::sync(c->stream);
   }
-  // GetMainWindow's angle step for every window half length hv_refine can meet (harvest.cpp:446-456):
-  // cos/sin of pi*d and of pi*WAVE*d with d = 2/(2hw+1), so the kernel needs one sincospi per rebuild
+  // GetMainWindow's angles for every window half length hv_refine can meet (harvest.cpp:446-456), d = 2/(2hw+1):
+  //   [hw][6]        sin/cos(pi d), sin/cos(pi WAVE d), 2 / window length in seconds, pi d
+  //   then [hw][WAVE] (sin, cos)(pi (lane - hw - 1) d): a lane's FIRST sample of the window when the frame centre falls on
+  //                  a whole sample (it does at 8 kHz: the decimated rate of 16 / 32 / 48 / 96 kHz input); the kernel turns
+  //                  it by the residual angle for other rates.  One 16-byte load replaces a division and a sincospi per
+  //                  window rebuild (70 of its ~190 instructions).
   const int hw_max = static_cast<int>(1.5 * afs / f0_floor + 1.0) + 2;
-  std::vector<double> wt((size_t)(hw_max + 1) * 4);
+  const size_t head = (size_t)(hw_max + 1) * 6;
+  std::vector<double> wt(head + (size_t)(hw_max + 1) * WAVE * 2);
+  const long double pi_l = 3.14159265358979323846264338327950288L;
   for (int hw = 0; hw <= hw_max; ++hw) {
     const double wlen_t = (2.0 * hw + 1.0) / afs;
     const double d = (1.0 / afs) * (2.0 / wlen_t);
-    wt[4 * hw + 0] = sin(kPi * d); wt[4 * hw + 1] = cos(kPi * d);
-    wt[4 * hw + 2] = sin(kPi * (WAVE * d)); wt[4 * hw + 3] = cos(kPi * (WAVE * d));
+    wt[6 * hw + 0] = sin(kPi * d); wt[6 * hw + 1] = cos(kPi * d);
+    wt[6 * hw + 2] = sin(kPi * (WAVE * d)); wt[6 * hw + 3] = cos(kPi * (WAVE * d));
+    wt[6 * hw + 4] = 2.0 / ((2.0 * hw + 1.0) * (1.0 / afs));           // the kernel's two_over_t, same operations
+    wt[6 * hw + 5] = kPi * d;
+    const long double dl = 2.0L / (2.0L * hw + 1.0L);
+    for (int lane = 0; lane < WAVE; ++lane) {
+      const long double a = pi_l * (lane - hw - 1) * dl;
+      wt[head + ((size_t)hw * WAVE + lane) * 2 + 0] = (double)sinl(a);
+      wt[head + ((size_t)hw * WAVE + lane) * 2 + 1] = (double)cosl(a);
+    }
   }
   if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
   hb.d_win_tab = static_cast<double *>(devrt::dmalloc(sizeof(double) * wt.size()));
@@ -507,7 +521,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.nyq = c->arena.take<double>(B * p.nyq_slices * 4);
   p.quirk = c->arena.take<double>(B * p.nch * 4);
   p.band_f0 = hb.d_band_f0; p.band_half = hb.d_half; p.band_off = hb.d_off; p.band_taps = hb.d_taps;
-  p.win_tab = hb.d_win_tab;
+  p.win_tab = hb.d_win_tab; p.win_lane = hb.d_win_tab + (size_t)hb.win_tab_len * 6;
   p.fwd = c->arena.take<double>(B * p.m_stride);
   p.y = c->arena.take<double>(B * p.y_stride);
   p.events = c->arena.take<double>(B * p.nch * 4 * p.ev_cap);

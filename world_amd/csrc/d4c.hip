@@ -219,6 +219,148 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
   *total = s_all;
 }
 
+#ifndef WORLD_EMU
+// ---------------------------------------------------------------------------
+// The same selection for the frame kernel's shape, written for INSTRUCTION COUNT: d4c_frame is bound by VALU issue
+// (three resident workgroups share every SIMD), and the general routine above spent as many VALU instructions per band
+// as the band's transform (~620: 64-bit key arithmetic with a `q < mine` predicate on every key, two 256-bin passes,
+// three block sums, five barriers).  Here:
+//   * unowned slots hold key 0 and everything is ranked FROM THE TOP (the K = n - m largest are what is excluded), so
+//     padding can never be selected and no per-key ownership test exists;
+//   * passes work on the keys' HIGH WORDS (32-bit compares and shifts; the low words only matter if two of the K
+//     largest keys agree to 2^-20 -- then the general routine runs);
+//   * the first pass maps [floor, top] of the candidates LINEARLY onto 1024 bins (bin = (hi - floor) >> s: all of the
+//     resolution lies where the candidates are, whatever power-of-two boundary they straddle) with a 64-bin coarse
+//     level beside it, so locating the K-th largest is one LDS word per lane, a DPP scan, a ballot, 16 fine bins
+//     scanned by DPP inside a row, a ballot;
+//   * once the threshold's bin holds ONE key the answer needs no threshold VALUE: the m smallest are exactly the keys
+//     below that bin's lower edge -- one 32-bit compare and one masked add per key, two block sums, one barrier.
+// Typical band: 3 barriers, ~200 VALU instructions.  A bin with several keys gets one 256-bin pass over its own range;
+// whatever is still ambiguous after that (or a spectrum whose thread maxima all share a high word) goes to the general
+// routine -- same result, every thread of the block takes the same path.
+// key[0 .. kKeys-2): owned by every thread; key[kKeys-2]: thread 0 only (the merge's unpaired bin), 0 elsewhere;
+// key[kKeys-1]: 0.  hist: 1344 ints of LDS.  K: how many of the largest keys are EXCLUDED from *partial.
+template <int NT, int kKeys>
+__device__ __forceinline__ void block_excluding_largest(const unsigned long long (&key)[kKeys], int K, int *hist, double *scratch,
+                                                        double *partial, double *total, bool trace_me = false) {
+  (void)trace_me;
+  constexpr int kFull = kKeys - 2, nw = NT / WAVE;
+  static_assert(NT % WAVE == 0 && nw <= 16, "whole wavefronts");
+  const int tid = wg_thread<NT>(), lane = lane_id(), wv = wave_in_block();
+  int hk[kFull];
+#pragma unroll
+  for (int q = 0; q < kFull; ++q) hk[q] = (int)(key[q] >> 32);            // non-negative doubles: the high words order like the keys
+  const int hx = (int)(key[kFull] >> 32);                                 // 0 except on thread 0
+  int hm = hx;
+#pragma unroll
+  for (int q = 0; q < kFull; ++q) hm = hk[q] > hm ? hk[q] : hm;
+  // [0, 1024) fine bins | [1024, 1088) coarse bins (16 fine each) | [1088, 1344) the second pass's bins
+  for (int i = tid; i < 336; i += NT) reinterpret_cast<int4 *>(hist)[i] = make_int4(0, 0, 0, 0);
+  // Every thread's largest key is a candidate, and there are NT >= K threads: the K-th largest key is >= the smallest of
+  // the threads' maxima (`floor`), so keys below it are below the threshold whatever their rank.
+  const int wmin = -wave_max_int(-hm), wmax = wave_max_int(hm);
+  int *hs = reinterpret_cast<int *>(scratch + 48);                        // doubles 48..63: nobody else's scratch
+  if (lane == 0) { hs[wv] = wmin; hs[16 + wv] = wmax; }
+  __syncthreads();                                                        // also: the bins are zero before anybody counts
+  int fl = hs[0], tp = hs[16];
+#pragma unroll
+  for (int w = 1; w < nw; ++w) { fl = hs[w] < fl ? hs[w] : fl; tp = hs[16 + w] > tp ? hs[16 + w] : tp; }
+  fl = __builtin_amdgcn_readfirstlane(fl); tp = __builtin_amdgcn_readfirstlane(tp);
+  WH_STAMP(0, 3);
+  bool fast = NT >= K && tp > fl;
+  int t_low = 0;                                                          // keys with a high word below this are the m smallest
+  if (fast) {
+    const unsigned range = (unsigned)(tp - fl);
+    const int bits = 32 - __builtin_clz(range), s0 = bits > 10 ? bits - 10 : 0;      // (tp - fl) >> s0 < 1024
+    auto count0 = [&](int h) __attribute__((always_inline)) {
+      const unsigned b = (unsigned)(h - fl) >> s0;                        // below the floor: wraps to >= 2^31 >> 21 = 1024
+      if (b < 1024u) { atomicAdd(&hist[b], 1); atomicAdd(&hist[1024 + (b >> 4)], 1); }
+    };
+#pragma unroll
+    for (int q = 0; q < kFull; ++q) count0(hk[q]);
+    if (tid == 0) count0(hx);
+    __syncthreads();
+    // coarse level: lane l holds coarse bin l; `above` = candidates in bins above it
+    const int cc = hist[1024 + lane];
+    const int inc = wave_incl_scan_int(cc);
+    const int above_l = __builtin_amdgcn_readlane(inc, 63) - inc;
+    const unsigned long long sel = __ballot(above_l < K && K <= above_l + cc);      // exactly one lane
+    const int ls = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(sel));
+    const int above_c = __builtin_amdgcn_readlane(above_l, ls);
+    // fine level: the 16 bins of coarse bin ls, one per lane of a row; u = candidates in this bin and above
+    int u = hist[16 * ls + (lane & 15)];
+    u += __builtin_amdgcn_update_dpp(0, u, 0x101, 0xf, 0xf, true);        // row_shl 1, 2, 4, 8: suffix sums inside the row
+    u += __builtin_amdgcn_update_dpp(0, u, 0x102, 0xf, 0xf, true);
+    u += __builtin_amdgcn_update_dpp(0, u, 0x104, 0xf, 0xf, true);
+    u += __builtin_amdgcn_update_dpp(0, u, 0x108, 0xf, 0xf, true);
+    u += above_c;
+    const unsigned ge = (unsigned)(__ballot(u >= K) & 0xFFFFull);        // lanes 0 .. is of the first row (u falls with the lane)
+    const int is = __builtin_amdgcn_readfirstlane(31 - __builtin_clz(ge));
+    const int u_is = __builtin_amdgcn_readlane(u, is);
+    const int above0 = is == 15 ? above_c : __builtin_amdgcn_readlane(u, (is + 1) & 15);
+    int bucket = u_is - above0;
+    t_low = fl + ((16 * ls + is) << s0);
+    WH_STAMP(0, 4);
+    if (bucket != 1) {
+      if (s0 == 0) {
+        fast = false;                                                     // several of the largest keys share a high word
+      } else {
+        // second pass over the keys of that bin: its range of 2^s0 high words on 256 bins
+        const int K1 = K - above0, s1 = s0 > 8 ? s0 - 8 : 0;
+        int *h1 = hist + 1088;
+        auto count1 = [&](int h) __attribute__((always_inline)) {
+          const unsigned d = (unsigned)(h - t_low);
+          if (d < (1u << s0)) atomicAdd(&h1[d >> s1], 1);
+        };
+#pragma unroll
+        for (int q = 0; q < kFull; ++q) count1(hk[q]);
+        if (tid == 0) count1(hx);
+        __syncthreads();
+        const int4 c4 = *reinterpret_cast<const int4 *>(h1 + 4 * lane);
+        const int local = (c4.x + c4.y) + (c4.z + c4.w);
+        const int inc1 = wave_incl_scan_int(local);
+        const int ab1 = __builtin_amdgcn_readlane(inc1, 63) - inc1;
+        const unsigned long long sel1 = __ballot(ab1 < K1 && K1 <= ab1 + local);
+        const int l1 = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(sel1));
+        int a = __builtin_amdgcn_readlane(ab1, l1);
+        const int c3 = __builtin_amdgcn_readlane(c4.w, l1), c2 = __builtin_amdgcn_readlane(c4.z, l1),
+                  c1 = __builtin_amdgcn_readlane(c4.y, l1), c0 = __builtin_amdgcn_readlane(c4.x, l1);
+        int j;                                                            // scalar walk from the top bin of the lane's four
+        if (a + c3 >= K1) { j = 3; bucket = c3; }
+        else if ((a += c3) + c2 >= K1) { j = 2; bucket = c2; }
+        else if ((a += c2) + c1 >= K1) { j = 1; bucket = c1; }
+        else { j = 0; bucket = c0; }
+        t_low += (4 * l1 + j) << s1;
+        if (bucket != 1) fast = false;
+        WH_STAMP(0, 5);
+      }
+    }
+  }
+  if (!fast) {
+    __syncthreads();                                                      // nobody is still reading the bins
+    // the general routine: every slot counts as a key (the zeros are the smallest and add nothing)
+    block_smallest_sum<NT>(key, kKeys, NT * kKeys, NT * kKeys - K, hist, scratch, partial, total, trace_me);
+    return;
+  }
+  double s_lt = 0.0, s_all = 0.0;
+#pragma unroll
+  for (int q = 0; q < kFull; ++q) {
+    const double x = __longlong_as_double((long long)key[q]);
+    s_all += x;
+    s_lt += hk[q] < t_low ? x : 0.0;
+  }
+  if (tid == 0) {
+    const double x = __longlong_as_double((long long)key[kFull]);
+    s_all += x;
+    s_lt += hx < t_low ? x : 0.0;
+  }
+  WH_STAMP(0, 8);
+  block_sum2<NT, false>(s_lt, s_all, scratch);                             // doubles 0..35: last read before this band's passes
+  *partial = s_lt;
+  *total = s_all;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // D4CGeneralBody for one selected frame in ONE workgroup (d4c.cpp:90-225, 291-316):
 //   GetStaticCentroid -> GetSmoothedPowerSpectrum -> GetStaticGroupDelay -> GetCoarseAperiodicity.
@@ -395,6 +537,13 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
 #else
 #define D4C_SCHED_FENCE() do { } while (0)
 #endif
+// value of the key slots a thread does not own: the general selection skips them by count (`mine`), the frame kernel's
+// own ranks from the top and needs them to be the smallest
+#if defined(WORLD_EMU) || defined(D4C_OLD_SELECT)
+#define D4C_KEY_PAD (~0ull)
+#else
+#define D4C_KEY_PAD 0ull
+#endif
 #ifndef D4C_TW_LEVEL
 #define D4C_TW_LEVEL 2      // the twiddle table in LDS is this many levels coarser than the N-point merge asks for
 #endif
@@ -480,8 +629,18 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     __syncthreads();
     for_own([&](int slot, int k) { if (k <= upper) Zr[k] = S[slot]; });
     __syncthreads();
+    // interp1Q at k fs / N on the axis cf0 - j fs / N: position cf0 N / fs - k -- the SAME fraction for every bin, and
+    // the knot index a constant minus k (the per-bin subtract / scale / convert / clamp of the general routine was a
+    // quarter of this pass's instructions; the weights agree to the rounding of the position, ~1e-13)
+    const double pos0 = (0.0 - cf0) * inv_dx;
+    const int b0 = static_cast<int>(pos0);
+    const double fr0 = pos0 - b0;
     for_own([&](int slot, int k) {
-      if (k < nrep) S[slot] = keep(S[slot] + interp_uniform_rcp(cf0, inv_dx, Zr, upper + 1, static_cast<double>(k) * fs * inv_n));
+      if (k < nrep) {
+        const int b = b0 - k;                                // 1 <= b <= upper - 1 for k < nrep = upper - 1 ... b0 = upper - 2
+        const double y0 = Zr[b], y1 = Zr[b + 1 <= upper ? b + 1 : upper];
+        S[slot] = keep(S[slot] + (y0 + (y1 - y0) * fr0));
+      }
     });
     __syncthreads();
   };
@@ -500,13 +659,21 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     block_scan_incl_double<T>(Zr, seg_len, scratch);
     const double origin_axis = -(bnd - 0.5) * fs / N;
     const double inv_step = static_cast<double>(N) / fs, inv_width = 1.0 / width;
+    // interp1Q of the prefix sums at k fs / N -+ width / 2: on the segment's axis that is position k + c_lo and k + c_hi
+    // with c_lo = bnd - 0.5 - r / 2, c_hi = c_lo + r (r = width N / fs) -- the fractions are the same for EVERY bin and
+    // the knot indices are k plus a constant.  The general routine recomputed position, index, fraction and an end clamp
+    // per bin and edge (24 VALU instructions per bin; 6 here); the weights agree to the rounding of the position
+    // (~1e-13), and k + floor(c_hi) + 1 <= H + 1.5 r + 2 < seg_len - 1: no clamp can ever apply.
+    const double c_lo = (0.0 - width / 2.0 - origin_axis) * inv_step, c_hi = (width / 2.0 - origin_axis) * inv_step;
+    const int i_lo = static_cast<int>(c_lo), i_hi = static_cast<int>(c_hi);
+    const double f_lo = c_lo - i_lo, f_hi = c_hi - i_hi;
+    const double *z_lo = Zr + i_lo, *z_hi = Zr + i_hi;
     for_out([&](int slot, int k) {
-      double fa = static_cast<double>(k) * inv_n * fs - width / 2.0;
-      const double lo = interp_uniform_rcp(origin_axis, inv_step, Zr, seg_len, fa);
-      fa += width;
-      const double hi = interp_uniform_rcp(origin_axis, inv_step, Zr, seg_len, fa);
+      const double l0 = z_lo[k], l1 = z_lo[k + 1], h0 = z_hi[k], h1 = z_hi[k + 1];
+      const double lo = l0 + (l1 - l0) * f_lo, hi = h0 + (h1 - h0) * f_hi;
       out[slot] = keep((hi - lo) * inv_width);
     });
+    (void)seg_len;
   };
 
   // The frame's three windows -- two Blackman for the centroid, one Hanning for the power spectrum -- share their
@@ -745,14 +912,19 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     if (band == 0) WH_STAMP(32, 16);
     unsigned long long key[kBins];
 #pragma unroll
-    for (int e = 0; e < kBins; ++e) key[e] = ~0ull;
+    for (int e = 0; e < kBins; ++e) key[e] = D4C_KEY_PAD;
     rfft_merge_items_rot<kItems, T>(Z, lgn, plan, tw, wb, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
       key[2 * m] = (unsigned long long)__double_as_longlong(ar * ar + ai * ai);
       if (paired) key[2 * m + 1] = (unsigned long long)__double_as_longlong(br * br + bi * bi);
     });
     if (band == 0) WH_STAMP(32, 17);
     double part, tot;
+#if defined(WORLD_EMU) || defined(D4C_OLD_SELECT)
     block_smallest_sum<T>(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
+#else
+    (void)mine;
+    block_excluding_largest<T>(key, bnd + 1, hist, scratch, &part, &tot, trace_me);   // the bnd + 1 largest of the H + 1 bins
+#endif
     // the band's two sums; d4c_finish turns them into dB (d4c.cpp:221-224, 314-316) -- a division and a log10 on
     // one lane here would stand between this band's select and the next band's first barrier
     if (tid == 0) { p.coarse[fi * 16 + 1 + band] = part; p.coarse[fi * 16 + 9 + band] = tot; }

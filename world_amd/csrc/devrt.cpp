@@ -38,6 +38,8 @@ struct Timed {
 };
 }  // namespace
 void host_trace_add(const char *name, double us) {
+  static std::mutex lock;                         // drop-in calls come from several host threads
+  std::lock_guard<std::mutex> g(lock);
   auto &e = g_trace.acc[name];
   e.first += us; e.second += 1;
 }

@@ -37,7 +37,8 @@ struct HarvestParams {
   double *nyq;             // [n_utt][nyq_slices][4]: partial sums of Y[N/2], Re/Im Y[N/2-1] (mean-free signal), 2/N
   int nyq_slices;          // slices of 4096 samples per utterance slot
   double *quirk;           // [n_utt][nch][4] per-band constants of the mirror-store term (bandfilter.h)
-  const double *win_tab;   // [hw][4] = sin/cos(pi d), sin/cos(pi WAVE d), d = 2/(2hw+1): refinement window steps
+  const double *win_tab;   // [hw][6] = sin/cos(pi d), sin/cos(pi WAVE d), 2 / window length, pi d; d = 2/(2hw+1): refinement window steps
+  const double *win_lane;  // [hw][WAVE][2] = (sin, cos)(pi (lane - hw - 1) d): a lane's first window sample at a whole-sample frame centre
   Tables tab;
   // ---- workspace (device) ----
   double *fwd;             // [n_utt][m_stride] forward-filtered padded signal

@@ -447,6 +447,13 @@ __global__ void hv_refine(HarvestParams p) {
   const int cap = p.refine_cap;
   double *yc = reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * 3 * cap;
   cplx *yw = reinterpret_cast<cplx *>(yc + cap);    // signal around the frame | (y*main window, y*diff window) pairs
+#ifndef WORLD_EMU
+  // the deferred tail's inputs: [slot m][harmonic h] = (are, aim, dre, dim, bin index), written by the lanes (h, g == m)
+  // when slot m's sums are complete, read back by the same lanes once per track (round 3 kept them in registers behind
+  // a dozen selects per candidate)
+  constexpr int kKbufDoubles = 7 * 8 * 6;
+  double *kbuf = reinterpret_cast<double *>(lds) + (size_t)waves_per_block() * 3 * cap + (size_t)wave_in_block() * kKbufDoubles;
+#endif
   const int nfb = p.nfb[u], nc = p.nc[u];
   const double *src = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
   double *dst_f0 = p.cand_b + ((size_t)u * p.fb_stride + frame) * p.maxc;
@@ -514,7 +521,9 @@ __global__ void hv_refine(HarvestParams p) {
   for (int j = 0; j < nc; ++j) {
     double k_are[kM][kIter], k_aim[kM][kIter], k_dre[kM][kIter], k_dim[kM][kIter], k_f0[kM];
     int k_idx[kM][kIter], k_lgn[kM];
+#ifdef WORLD_EMU
     for (int q = 0; q < kM; ++q) k_f0[q] = 0.0;
+#endif
 #ifndef WORLD_EMU
     // The seven slots of the track are set up side by side, slot m on lane m -- one load of the seven source
     // frames, the divisions and roundings once per track -- and handed to the wavefront as scalars (v_readlane):
@@ -536,7 +545,6 @@ __global__ void hv_refine(HarvestParams p) {
       const int hw = cm.hw, lgN = cm.lgN, first = cm.first, nh = cm.nh;
 #endif
       const int blen = 2 * hw + 1;
-      const double wlen_t = (2.0 * hw + 1.0) * inv_fs;
       const int N = 1 << lgN;
       const bool same_window = hw == c_hw && first == c_first;
       if (!same_window) {
@@ -544,16 +552,27 @@ __global__ void hv_refine(HarvestParams p) {
         // Blackman main window (harvest.cpp:446-456) and its central difference
         // (GetDiffWindow, :462-468).  w[i+1]-w[i-1] follows from the angle-addition
         // identities, so no neighbour values are exchanged.
-        const double two_over_t = 2.0 / wlen_t;
-        // sin/cos of one sample's and of WAVE samples' angle step: host table indexed by hw
-        const double *wt = p.win_tab + 4 * hw;
+        // sin/cos of one sample's and of WAVE samples' angle step, 2 / window length, pi d: host table indexed by hw
+        const double *wt = p.win_tab + 6 * hw;
         const double sd = wt[0], cd = wt[1], sD = wt[2], cD = wt[3];
         const double s2d = 2.0 * sd * cd, c2d = 2.0 * cd * cd - 1.0;
         wave_sync();                                             // the previous candidate's reads are done
-        // a lane's samples are WAVE apart: one sincospi for its first sample, then a rotation
-        // by WAVE * delta per further sample
+        // A lane's samples are WAVE apart: sin / cos of its first sample's angle, then a rotation by WAVE * delta per
+        // further sample.  The first angle is pi ((first + lane - 1) / fs - pos) (2 / window length)
+        //   = pi (lane - hw - 1) d  +  pi r d,   r = first + hw - pos fs   (|r| <= 0.501: GetBaseIndex's rounding),
+        // the first term from the host's table (exact to half an ulp), the second a rotation by an angle below 0.12 rad
+        // whose sine and cosine are short series (r vanishes where a millisecond is a whole number of samples: 8 kHz).
+        // (round 3: a division and a sincospi per rebuild, 70 of its ~190 instructions)
         double sa, ca;
-        sincospi((((first + lane) - 1.0) * inv_fs - pos) * two_over_t, &sa, &ca);
+        {
+          const double2 t0 = reinterpret_cast<const double2 *>(p.win_lane)[(size_t)hw * WAVE + lane];
+          const double rho = ((first + hw) - pos * fs) * wt[5];
+          const double x2 = rho * rho;
+          const double sr = rho * fma(x2, fma(x2, fma(x2, fma(x2, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+          const double cr = fma(x2, fma(x2, fma(x2, fma(x2, fma(x2, -1.0 / 3628800.0, 1.0 / 40320.0), -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+          sa = fma(t0.x, cr, t0.y * sr);
+          ca = fma(t0.y, cr, -(t0.x * sr));
+        }
         for (int i = lane; i < blen; i += WAVE) {
           const double c2a = 2.0 * ca * ca - 1.0, s2a = 2.0 * sa * ca;
           const double w = 0.42 + 0.5 * ca + 0.08 * c2a;
@@ -623,16 +642,38 @@ __global__ void hv_refine(HarvestParams p) {
 #endif
         c_idx[hi] = h < nh ? idx : -1;
         c_are[hi] = are; c_aim[hi] = aim; c_dre[hi] = dre; c_dim[hi] = dim;
+#ifndef WORLD_EMU
+        if (g == m) {                                          // m < 7 < G: the lanes that finish slot m in the tail
+          double2 *kb = reinterpret_cast<double2 *>(kbuf + (m * 8 + hl) * 6);
+          kb[0] = make_double2(are, aim); kb[1] = make_double2(dre, dim);
+          reinterpret_cast<int *>(kb + 2)[0] = idx;
+        }
+#else
         if (m % G == g) {
           const int q = m / G;
           k_are[q][hi] = are; k_aim[q][hi] = aim; k_dre[q][hi] = dre; k_dim[q][hi] = dim;
           k_idx[q][hi] = idx; k_lgn[q] = lgN; k_f0[q] = f0c;
         }
+#endif
       }
       WH_ACC_END(2);
       WH_ACC_COUNT(4);
     }
     WH_ACC_BEGIN;
+#ifndef WORLD_EMU
+    // slot m = g of this track: its candidate comes from lane m's set-up (one shuffle each), its sums from the wave's
+    // buffer (slots without a candidate keep stale sums there: f0c says so)
+    wave_sync();
+    {
+      const int src = g < 7 ? g : 7;
+      k_f0[0] = __shfl(mine.f0c, src, 64);
+      k_lgn[0] = __shfl(mine.lgN, src, 64);
+      const double2 *kb = reinterpret_cast<const double2 *>(kbuf + ((g < 7 ? g : 6) * 8 + hl) * 6);   // (g == 7: no slot; f0c = 0)
+      const double2 v0 = kb[0], v1 = kb[1];
+      k_are[0][0] = v0.x; k_aim[0][0] = v0.y; k_dre[0][0] = v1.x; k_dim[0][0] = v1.y;
+      k_idx[0][0] = reinterpret_cast<const int *>(kb + 2)[0];
+    }
+#endif
     // deferred tail: lane (h, g) finishes harmonic h of slot m = g (+ q*G)
     for (int q = 0; q < kM; ++q) {
       const int m = q * G + g;
@@ -793,7 +834,7 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawFrames - 1) / kRawFrames, p.nch, B), kRawFrames,
             8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
-  WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
+  WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap + 7 * 8 * 6 * sizeof(double), stream, p);
   WH_BLOCKS(hv_prune, dim3((max_fb + kPruneFrames - 1) / kPruneFrames, B), 256,
             sizeof(double) * (size_t)(kPruneFrames + 2) * p.maxc, stream, p);
   launch_harvest_contour(p, max_fb, max_frames, stream);

@@ -37,6 +37,8 @@ for unit, name, base, n in (("d4c", "d4c_frame select (last band)", 0, 10), ("d4
             print(f"  stamp {k:2d}: +{t[k] - prev}")
             prev = t[k]
 
+t = stamps("d4c")
+print("d4c_frame band selections since the library was loaded: one pass", t[100], "two passes", t[101], "general routine", t[102])
 t = stamps("hv")[:8]
 print("hv_refine (one wave, frame 5000): cache fill", t[0], "window rebuilds", t[1], "DFT+reduce", t[2], "tails", t[3],
       "refined candidates", t[4])

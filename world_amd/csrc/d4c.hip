@@ -268,6 +268,7 @@ __device__ __forceinline__ void block_excluding_largest(const unsigned long long
   fl = __builtin_amdgcn_readfirstlane(fl); tp = __builtin_amdgcn_readfirstlane(tp);
   WH_STAMP(0, 3);
   bool fast = NT >= K && tp > fl;
+  bool t_low_two = false; (void)t_low_two;                                // (statistics of the WH_TRACE build)
   int t_low = 0;                                                          // keys with a high word below this are the m smallest
   if (fast) {
     const unsigned range = (unsigned)(tp - fl);
@@ -331,11 +332,16 @@ __device__ __forceinline__ void block_excluding_largest(const unsigned long long
         else if ((a += c2) + c1 >= K1) { j = 1; bucket = c1; }
         else { j = 0; bucket = c0; }
         t_low += (4 * l1 + j) << s1;
+        t_low_two = true;
         if (bucket != 1) fast = false;
         WH_STAMP(0, 5);
       }
     }
   }
+#ifdef WH_TRACE
+  // development aid: how the bands of a launch were decided (tools/trace.py): [100] one pass, [101] two, [102] general routine
+  if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&wh_trace[!fast ? 102 : (t_low_two ? 101 : 100)]), 1ull);
+#endif
   if (!fast) {
     __syncthreads();                                                      // nobody is still reading the bins
     // the general routine: every slot counts as a key (the zeros are the smallest and add nothing)
@@ -695,6 +701,22 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       }
     }
   };
+  // the same walk with the slot known at compile time: sample H + tid + k T belongs to the thread's element k
+  auto hi_samples = [&](const D4cWin &w, double coef, auto body) __attribute__((always_inline)) {
+    if (w.wlen > H) {
+      D4cWinRot rot = rot0;                                            // H / T steps on: sample H + tid
+#pragma unroll 1
+      for (int i = tid; i < H; i += nt) d4c_win_next(w, rot);
+#pragma unroll
+      for (int k = 0; k < kLo; ++k) {
+        const int i = H + tid + k * nt;
+        if (i < w.wlen) {
+          const D4cSample sm = d4c_sample(w, i, rot);
+          body(k, i, sm.v - sm.w * coef);
+        }
+      }
+    }
+  };
   auto balanced = [&](const D4cWin &w, double (&ulo)[kLo]) __attribute__((always_inline)) {
     double wlo[kLo];
     double s1 = 0.0, s2 = 0.0;
@@ -731,6 +753,24 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     return coef;
   };
 
+#ifndef WORLD_EMU
+  // A transform whose inputs the thread already holds: element tid + r T of the N/2-point buffer is the thread's own
+  // sample r (kLo = 8 = the radix), so the FIRST stage runs from registers -- no input pass through LDS (eight 16-byte
+  // stores at ~13 cycles each, the LDS's slowest instruction, eight loads and a barrier per transform; the band
+  // transforms below always worked this way).
+  static_assert(kLo == 8 && T * 8 * 2 == NMAX, "one radix-8 butterfly per thread");
+  auto cfft_from_registers = [&](cplx (&a)[8]) __attribute__((always_inline)) {
+    constexpr int sh = lgn - 1 - 3;
+    dft_reg<true, 3>(a);
+    mul_powers<3>(a, twiddle(tw, tid, lgn - 1, -1));
+    const int s0 = swz(tid);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Z[s0 ^ swz(k << sh)] = a[k];
+    DifStages<lgn - 1, 3, lgn - 1 - 3, T>::run(Z, tw);
+    __syncthreads();
+  };
+#endif
+
   // ---- GetStaticCentroid (d4c.cpp:90-143) -------------------------------------
   // The centroid of the two positions is summed in LDS (`park`, natural bin order: a thread only ever touches its
   // own pairs): nothing but the window's samples waits in registers through the transforms.
@@ -744,25 +784,44 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     WH_STAMP(32, 1 + 4 * c);
     // even half: e[n] = z[n] + z[n + H], z[n] = u[n] (1 + i (n + 1)); the previous readers of Z are behind a barrier
     double pw = 0.0;
+#ifndef WORLD_EMU
+    {
+      // the butterfly's eight inputs are the thread's own: e[tid + j T] from sample j (and, for a window longer than N/2,
+      // from its upper sample j as well)
+      cplx a[8];
 #pragma unroll
-    for (int j = 0; j < kLo; ++j) {
-      const int n = tid + j * nt;
-      if (n < H) {
-        cplx e; e.re = ulo[j]; e.im = ulo[j] * (n + 1.0);
-        Z[swz(n)] = e;
+      for (int j = 0; j < 8; ++j) {
+        a[j].re = ulo[j]; a[j].im = ulo[j] * (tid + j * nt + 1.0);
         pw += ulo[j] * ulo[j];
       }
+      hi_samples(w, coef, [&](int k, int i, double uh) { a[k].re += uh; a[k].im += uh * (i + 1.0); pw += uh * uh; });
+      // |w x|^2 (d4c.cpp:104-107) is needed after the transform only: the waves' partial sums cross in scratch (doubles
+      // 40..47) behind the transform's own barriers
+      pw = wave_sum(pw);
+      if (lane_id() == 0) scratch[40 + wave_in_block()] = pw;
+      cfft_from_registers(a);
     }
-    for_hi(w, coef, [&](int i, double uh) {
-      cplx &e = Z[swz(i - H)];                                         // this thread's own slot
-      e.re += uh; e.im += uh * (i + 1.0);
-      pw += uh * uh;
-    });
-    // |w x|^2 (d4c.cpp:104-107) is needed after the transform only: the waves' partial sums cross in scratch (doubles
-    // 40..47) behind the transform's own barriers
-    pw = wave_sum(pw);
-    if (lane_id() == 0) scratch[40 + wave_in_block()] = pw;
-    cfft();
+#else
+    {
+#pragma unroll
+      for (int j = 0; j < kLo; ++j) {
+        const int n = tid + j * nt;
+        if (n < H) {
+          cplx e; e.re = ulo[j]; e.im = ulo[j] * (n + 1.0);
+          Z[swz(n)] = e;
+          pw += ulo[j] * ulo[j];
+        }
+      }
+      for_hi(w, coef, [&](int i, double uh) {
+        cplx &e = Z[swz(i - H)];                                       // this thread's own slot
+        e.re += uh; e.im += uh * (i + 1.0);
+        pw += uh * uh;
+      });
+      pw = wave_sum(pw);
+      if (lane_id() == 0) scratch[40 + wave_in_block()] = pw;
+      cfft();
+    }
+#endif
     pw = 0.0;
     for (int wv = 0; wv < wg_waves<T>(); ++wv) pw += scratch[40 + wv];
     const double half_inv_pw = 0.5 / pw;                               // and the 1/2 of Im(P Q)/2
@@ -779,23 +838,38 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     __syncthreads();
     D4C_FRESH_TID();
     // odd half: o[n] = (z[n] - z[n + H]) W_N^n
+#ifndef WORLD_EMU
+    {
+      cplx a[8];
 #pragma unroll
-    for (int j = 0; j < kLo; ++j) {
-      const int n = tid + j * nt;
-      if (n < H) {
-        cplx zl; zl.re = ulo[j]; zl.im = ulo[j] * (n + 1.0);
-        const cplx wn = kRot ? mul_w16_fwd(wb, j) : twiddle(tw, n, lgn, -1);
-        Z[swz(n)] = cmul(zl, wn);
-      }
+      for (int j = 0; j < 8; ++j) { a[j].re = ulo[j]; a[j].im = ulo[j] * (tid + j * nt + 1.0); }
+      hi_samples(w, coef, [&](int k, int i, double uh) { a[k].re -= uh; a[k].im -= uh * (i + 1.0); });
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = cmul(a[j], kRot ? mul_w16_fwd(wb, j) : twiddle(tw, tid + j * nt, lgn, -1));
+      WH_STAMP(32, 3 + 4 * c);
+      cfft_from_registers(a);
     }
-    for_hi(w, coef, [&](int i, double uh) {
-      cplx zh; zh.re = uh; zh.im = uh * (i + 1.0);
-      const cplx d = cmul(zh, twiddle(tw, i - H, lgn, -1));
-      cplx &o = Z[swz(i - H)];
-      o.re -= d.re; o.im -= d.im;
-    });
-    WH_STAMP(32, 3 + 4 * c);
-    cfft();
+#else
+    {
+#pragma unroll
+      for (int j = 0; j < kLo; ++j) {
+        const int n = tid + j * nt;
+        if (n < H) {
+          cplx zl; zl.re = ulo[j]; zl.im = ulo[j] * (n + 1.0);
+          const cplx wn = kRot ? mul_w16_fwd(wb, j) : twiddle(tw, n, lgn, -1);
+          Z[swz(n)] = cmul(zl, wn);
+        }
+      }
+      for_hi(w, coef, [&](int i, double uh) {
+        cplx zh; zh.re = uh; zh.im = uh * (i + 1.0);
+        const cplx d = cmul(zh, twiddle(tw, i - H, lgn, -1));
+        cplx &o = Z[swz(i - H)];
+        o.re -= d.re; o.im -= d.im;
+      });
+      WH_STAMP(32, 3 + 4 * c);
+      cfft();
+    }
+#endif
 #pragma unroll
     for (int m = 0; m < kItems; ++m) {
       const int it = tid + m * nt;

@@ -447,13 +447,8 @@ __global__ void hv_refine(HarvestParams p) {
   const int cap = p.refine_cap;
   double *yc = reinterpret_cast<double *>(lds) + (size_t)wave_in_block() * 3 * cap;
   cplx *yw = reinterpret_cast<cplx *>(yc + cap);    // signal around the frame | (y*main window, y*diff window) pairs
-#ifndef WORLD_EMU
-  // the deferred tail's inputs: [slot m][harmonic h] = (are, aim, dre, dim, bin index), written by the lanes (h, g == m)
-  // when slot m's sums are complete, read back by the same lanes once per track (round 3 kept them in registers behind
-  // a dozen selects per candidate)
-  constexpr int kKbufDoubles = 7 * 8 * 6;
-  double *kbuf = reinterpret_cast<double *>(lds) + (size_t)waves_per_block() * 3 * cap + (size_t)wave_in_block() * kKbufDoubles;
-#endif
+  // (Round 4 tried handing the tail its per-slot sums through 2.7 KB of LDS per wavefront instead of a dozen selects per
+  // candidate: the extra LDS took the kernel from four workgroups per CU to three -- 6.7 -> 7.4 ms per 128 utterances.)
   const int nfb = p.nfb[u], nc = p.nc[u];
   const double *src = p.cand_a + (size_t)u * p.fb_stride * p.maxc;
   double *dst_f0 = p.cand_b + ((size_t)u * p.fb_stride + frame) * p.maxc;
@@ -521,16 +516,19 @@ __global__ void hv_refine(HarvestParams p) {
   for (int j = 0; j < nc; ++j) {
     double k_are[kM][kIter], k_aim[kM][kIter], k_dre[kM][kIter], k_dim[kM][kIter], k_f0[kM];
     int k_idx[kM][kIter], k_lgn[kM];
-#ifdef WORLD_EMU
     for (int q = 0; q < kM; ++q) k_f0[q] = 0.0;
-#endif
 #ifndef WORLD_EMU
     // The seven slots of the track are set up side by side, slot m on lane m -- one load of the seven source
     // frames, the divisions and roundings once per track -- and handed to the wavefront as scalars (v_readlane):
     // done per slot by all 64 lanes they were a sixth of the kernel's instructions and seven dependent loads.
     const Cand mine = cand_of(j, lane < 7 ? lane : 7);
 #endif
-    for (int m = 0; m < 7; ++m) {
+    // The slots are visited in TIME order -- frames f-3, f-2, f-1, f, f+1, f+2, f+3 = slots 3, 2, 1, 0, 4, 5, 6 -- so that
+    // F0, and with it the window length, moves monotonically through the track: every distinct window is built once
+    // (in slot order the walk came back from f-3 to f+1 and rebuilt windows it had already had: ~1.5 of a track's ~4.5
+    // rebuilds).  What a slot computes does not depend on the order.
+    for (int mi = 0; mi < 7; ++mi) {
+      const int m = mi < 4 ? 3 - mi : mi;
 #ifndef WORLD_EMU
       const double f0c = readlane_f64(mine.f0c, m);
       if (!(f0c > 0.0)) continue;
@@ -642,38 +640,16 @@ __global__ void hv_refine(HarvestParams p) {
 #endif
         c_idx[hi] = h < nh ? idx : -1;
         c_are[hi] = are; c_aim[hi] = aim; c_dre[hi] = dre; c_dim[hi] = dim;
-#ifndef WORLD_EMU
-        if (g == m) {                                          // m < 7 < G: the lanes that finish slot m in the tail
-          double2 *kb = reinterpret_cast<double2 *>(kbuf + (m * 8 + hl) * 6);
-          kb[0] = make_double2(are, aim); kb[1] = make_double2(dre, dim);
-          reinterpret_cast<int *>(kb + 2)[0] = idx;
-        }
-#else
         if (m % G == g) {
           const int q = m / G;
           k_are[q][hi] = are; k_aim[q][hi] = aim; k_dre[q][hi] = dre; k_dim[q][hi] = dim;
           k_idx[q][hi] = idx; k_lgn[q] = lgN; k_f0[q] = f0c;
         }
-#endif
       }
       WH_ACC_END(2);
       WH_ACC_COUNT(4);
     }
     WH_ACC_BEGIN;
-#ifndef WORLD_EMU
-    // slot m = g of this track: its candidate comes from lane m's set-up (one shuffle each), its sums from the wave's
-    // buffer (slots without a candidate keep stale sums there: f0c says so)
-    wave_sync();
-    {
-      const int src = g < 7 ? g : 7;
-      k_f0[0] = __shfl(mine.f0c, src, 64);
-      k_lgn[0] = __shfl(mine.lgN, src, 64);
-      const double2 *kb = reinterpret_cast<const double2 *>(kbuf + ((g < 7 ? g : 6) * 8 + hl) * 6);   // (g == 7: no slot; f0c = 0)
-      const double2 v0 = kb[0], v1 = kb[1];
-      k_are[0][0] = v0.x; k_aim[0][0] = v0.y; k_dre[0][0] = v1.x; k_dim[0][0] = v1.y;
-      k_idx[0][0] = reinterpret_cast<const int *>(kb + 2)[0];
-    }
-#endif
     // deferred tail: lane (h, g) finishes harmonic h of slot m = g (+ q*G)
     for (int q = 0; q < kM; ++q) {
       const int m = q * G + g;
@@ -834,7 +810,7 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawFrames - 1) / kRawFrames, p.nch, B), kRawFrames,
             8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
-  WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap + 7 * 8 * 6 * sizeof(double), stream, p);
+  WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
   WH_BLOCKS(hv_prune, dim3((max_fb + kPruneFrames - 1) / kPruneFrames, B), 256,
             sizeof(double) * (size_t)(kPruneFrames + 2) * p.maxc, stream, p);
   launch_harvest_contour(p, max_fb, max_frames, stream);

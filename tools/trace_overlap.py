@@ -26,7 +26,16 @@ def main():
     for f in files:
         for r in csv.DictReader(open(f)):
             try:
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")))
+                def dims(prefix):
+                    if prefix in r:
+                        return max(1, int(r[prefix] or 1))
+                    v = 1
+                    for ax in ("_X", "_Y", "_Z"):
+                        v *= max(1, int(r.get(prefix + ax, 1) or 1))
+                    return v
+                wg, grid = dims("Workgroup_Size"), dims("Grid_Size")
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?"),
+                             max(1, grid // wg)))
             except (KeyError, ValueError):
                 continue
     rows = [r for r in rows if not r[2].startswith(("rng_", "hv_band_spectra"))]          # set-up kernels of the first call
@@ -38,7 +47,7 @@ def main():
     span = t1 - t0
     out = []
     per = defaultdict(lambda: [0, 0])
-    for s, e, k, q in rows:
+    for s, e, k, q, _ in rows:
         per[k][0] += 1
         per[k][1] += e - s
     busy = sum(v[1] for v in per.values())
@@ -48,21 +57,27 @@ def main():
     for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         out.append(f"{k:46s} {c:7d} {t / 1e6:9.3f} {t / c / 1e3:8.2f} {100.0 * t / busy:6.2f}")
     # residency histogram by sweeping the start / end events
-    ev = sorted([(s, 1) for s, e, _, _ in rows] + [(e, -1) for s, e, _, _ in rows])
-    level, last, hist, gaps = 0, t0, defaultdict(int), []
-    for t, dlt in ev:
+    ev = sorted([(s, 1, w) for s, e, _, _, w in rows] + [(e, -1, -w) for s, e, _, _, w in rows])
+    level, width, last, hist, gaps, narrow = 0, 0, t0, defaultdict(int), [], defaultdict(int)
+    for t, dlt, dw in ev:
         if t > last:
             hist[level] += t - last
             if level == 0 and t - last > 2000:
                 gaps.append(t - last)
+            # workgroups the resident kernels were launched with, against the 256 CUs: < 256 means that not even one
+            # workgroup per CU exists among everything resident -- the chip is mostly idle whatever the kernel count says
+            narrow["< 64" if width < 64 else "64-255" if width < 256 else "256-1023" if width < 1024 else ">= 1024"] += t - last
         last = t
         level += dlt
+        width += dw
     buckets = {"0": hist[0], "1": hist[1], "2-3": hist[2] + hist[3], "4-7": sum(hist[i] for i in range(4, 8)),
                ">=8": sum(v for i, v in hist.items() if i >= 8)}
     out.append("fraction of the span with N kernels resident: " + ", ".join(f"{k}: {100.0 * v / span:.1f} %" for k, v in buckets.items()))
+    out.append("fraction of the span by the total number of workgroups the resident kernels were launched with: "
+               + ", ".join(f"{k}: {100.0 * narrow[k] / span:.1f} %" for k in ("< 64", "64-255", "256-1023", ">= 1024")))
     out.append(f"gaps with nothing resident longer than 2 us: {len(gaps)}, {sum(gaps) / 1e3:.1f} us in all ({100.0 * sum(gaps) / span:.2f} % of the span)")
     qs = defaultdict(int)
-    for _, _, _, q in rows:
+    for _, _, _, q, _ in rows:
         qs[q] += 1
     out.append(f"hardware queues used: {len(qs)}; launches per queue min / max: {min(qs.values())} / {max(qs.values())}")
     text = "\n".join(out)

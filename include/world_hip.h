@@ -280,6 +280,29 @@ WORLD_HIP_API int world_hip_analyze_packed(WorldHipContext *ctx, int n_utt, int 
                                            const int *x_length, const HarvestOption *harvest_option,
                                            const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
                                            long long first_row, double *d_block, int cols);
+/* Frame ranges (frame-level sharding of ONE long utterance -- CheapTrick / D4C only, F0 broadcast; the
+ * reference's frames are independent given F0: src/cheaptrick.cpp:207-216, src/d4c.cpp:378-400).  The stages' rows of
+ * frames [frame_lo, frame_hi) of every utterance of the batch; the positions in the reference's randn() stream are those of
+ * a whole-utterance call (the offset scans, and D4C's LoveTrain pass on which its second scan depends, always cover every
+ * frame), so a range's rows are BIT-IDENTICAL to the same rows of the full call.
+ *   _spectral_packed_range: CheapTrick + D4C given tpos / f0 ([n_utt][f_stride], device) straight into packed records (same
+ *       formats as world_hip_analyze_packed): utterance u's range starts at row first_row + sum over v < u of v's frames in range;
+ *   _cheaptrick_batch_range / _d4c_batch_range: one stage into the dense arrays of the *_batch calls (rows outside the range
+ *       untouched).  reuse_offsets != 0: the previous call on this context had the same shape and inputs and only the range
+ *       differs -- its offsets / LoveTrain results are still in the workspace and are not recomputed. */
+WORLD_HIP_API int world_hip_spectral_packed_range(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
+                                                  const int *x_length, const int *n_frames, int f_stride,
+                                                  const double *d_tpos, const double *d_f0,
+                                                  const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
+                                                  int frame_lo, int frame_hi, long long first_row, double *d_block, int cols);
+WORLD_HIP_API int world_hip_cheaptrick_batch_range(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
+                                                   const int *x_length, const int *n_frames, int f_stride,
+                                                   const double *d_tpos, const double *d_f0, const CheapTrickOption *option,
+                                                   int frame_lo, int frame_hi, int reuse_offsets, double *d_spectrogram);
+WORLD_HIP_API int world_hip_d4c_batch_range(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
+                                            const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
+                                            const double *d_f0, int fft_size, const D4COption *option, int frame_lo,
+                                            int frame_hi, int reuse_offsets, double *d_aperiodicity);
 WORLD_HIP_API int world_hip_pack_results(WorldHipContext *ctx, int n_utt, const int *n_frames, int f_stride,
                                          int bins, const double *d_tpos, const double *d_f0,
                                          const double *d_spectrogram, const double *d_aperiodicity,

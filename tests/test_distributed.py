@@ -271,3 +271,81 @@ def test_own_buffers_survive_the_next_call():
     a = wd.analyze_sharded(xs, 16000, analyze=_fake_analyze, bins=5)
     b = wd.analyze_sharded(ys, 16000, analyze=_fake_analyze, bins=5)          # same shape: the cached buffers are reused
     assert a.blocks[0].data_ptr() == b.blocks[0].data_ptr()
+
+
+# ---- frame-level sharding of ONE long utterance (last sentence) -----------------------------------
+def _emu_range_backend(fs):
+    """harvest / spectral_range of analyze_long_sharded on CPU tensors: the host-compiled library's batched entry points"""
+    import ctypes as C
+    import subprocess
+    from world_amd.api import (CheapTrickOption, D4COption, HarvestOption, cheaptrick_fft_size, frame_count, load_library)
+    emu_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    subprocess.run(["make", "-s", "-f", os.path.join(emu_dir, "Makefile")], check=True)
+    L = load_library(os.path.join(emu_dir, "libworld_emu.so"))
+    ctx = L.world_hip_create(0, None)
+    fft = cheaptrick_fft_size(fs)
+    ip = C.POINTER(C.c_int)
+
+    def harvest(xb):
+        n = xb.shape[1]
+        nf = frame_count(fs, n, 5.0)
+        tp, f0 = torch.zeros((1, nf), dtype=torch.float64), torch.zeros((1, nf), dtype=torch.float64)
+        xl = np.array([n], dtype=np.int32)
+        h = HarvestOption(71.0, 800.0, 5.0)
+        assert L.world_hip_harvest_batch(ctx, 1, fs, xb.data_ptr(), n, xl.ctypes.data_as(ip), C.byref(h), nf, tp.data_ptr(), f0.data_ptr()) == 0
+        return tp, f0
+
+    def spectral_range(xb, tp, f0, block, lo, hi):
+        n, nf = xb.shape[1], tp.shape[1]
+        xl, nfa = np.array([n], dtype=np.int32), np.array([nf], dtype=np.int32)
+        c, d = CheapTrickOption(-0.15, 71.0, fft), D4COption(0.85)
+        rc = L.world_hip_spectral_packed_range(ctx, 1, fs, xb.data_ptr(), n, xl.ctypes.data_as(ip), nfa.ctypes.data_as(ip), nf,
+                                               tp.data_ptr(), f0.data_ptr(), C.byref(c), C.byref(d), lo, hi, 0, block.data_ptr(),
+                                               block.shape[-1])
+        assert rc == 0, L.world_hip_last_error().decode()
+    return harvest, spectral_range
+
+
+def test_frame_ranges_cover_the_utterance():
+    assert wd.frame_ranges(1001, 1) == [(0, 1001)]
+    assert wd.frame_ranges(1001, 4) == [(0, 256), (256, 512), (512, 768), (768, 1001)]
+    assert wd.frame_ranges(100, 8)[0] == (0, 64) and wd.frame_ranges(100, 8)[1] == (64, 100) and wd.frame_ranges(100, 8)[2] == (100, 100)
+    for nf in (1, 63, 64, 65, 2001, 48001):
+        for w in (1, 2, 3, 8):
+            r = wd.frame_ranges(nf, w)
+            assert r[0][0] == 0 and r[-1][1] == nf and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def _long_worker(rank, world, port, tmp, wire):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from world_amd import synth
+        fs = 16000
+        x = synth.utterance(4, fs, 0.9)                                  # 181 frames: ranges 0-128 and 128-181
+        harvest, spectral_range = _emu_range_backend(fs)
+        tp, f0, sp, ap = wd.analyze_long_sharded(x, fs, wire=wire, harvest=harvest, spectral_range=spectral_range, sub_frames=64)
+        tp_i, f0_i, sp_i, ap_i, nf_i = _emu_analyze(x[None], fs, x_len=[x.numel()])
+        k = int(nf_i[0])
+        assert tp.shape[0] == k == sp.shape[0] == ap.shape[0]
+        assert torch.equal(tp, tp_i[0]) and torch.equal(f0, f0_i[0])
+        if wire == "f64":
+            assert torch.equal(sp, sp_i[0]) and torch.equal(ap, ap_i[0])
+        else:
+            assert torch.equal(sp, sp_i[0].to(torch.float32)) and torch.equal(ap, ap_i[0].to(torch.float32))
+        np.save(os.path.join(tmp, f"long_{wire}_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("wire", ["f64", "f32"])
+def test_two_ranks_share_the_frames_of_one_utterance(tmp_path, wire):
+    """every rank runs Harvest, rank r the spectral stages of its frame range only (sub-ranges of 64 frames, records
+    written by the host-compiled stage kernels, all-gathered): bit-identical to analysing the utterance alone -- the
+    randn() stream positions of a range are those of the whole utterance"""
+    world = 2
+    port = 29100 + (os.getpid() + (13 if wire == "f32" else 0)) % 90
+    mp.spawn(_long_worker, args=(world, port, str(tmp_path), wire), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"long_{wire}_{r}.npy") for r in range(world))

@@ -345,3 +345,108 @@ def test_emulated_cheaptrick_fft_size_8192(port_oracle):
 def test_cheaptrick_fft_size_8192_on_the_gpu(ref_oracle):
     from world_amd.api import HostAPI
     _check_cheaptrick_8192(HostAPI(), ref_oracle, [(48000, 0.6, 30.0), (96000, 0.4, 40.0), (192000, 0.25, 71.0)])
+
+
+def _check_frame_ranges(lib_path, device):
+    """the stages' rows of a frame range == the same rows of the whole call, bit for bit (dense and packed, both wire
+    formats; with and without reusing the offsets of the previous call)"""
+    from world_amd import synth
+    from world_amd.api import CheapTrickOption, D4COption, HarvestOption, cheaptrick_fft_size, frame_count, load_library
+    L = load_library(lib_path)
+    fs = 16000
+    fft = cheaptrick_fft_size(fs)
+    nb = fft // 2 + 1
+    xs = [synth.utterance(6, fs, 0.9).numpy(), synth.utterance(9, fs, 0.55).numpy()]
+    B, Lmax = 2, max(len(x) for x in xs)
+    xh = np.zeros((B, Lmax)); [xh[i].__setitem__(slice(0, len(x)), x) for i, x in enumerate(xs)]
+    xl = np.array([len(x) for x in xs], dtype=np.int32)
+    nf = np.array([frame_count(fs, int(n), 5.0) for n in xl], dtype=np.int32)
+    F = int(nf.max())
+    if device:
+        import torch
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        host = lambda t: t.cpu().numpy()
+        ptr = lambda t: t.data_ptr()
+        sync = torch.cuda.synchronize
+    else:
+        up = lambda a: np.ascontiguousarray(a).copy()
+        host = lambda a: a
+        ptr = lambda a: a.ctypes.data
+        sync = lambda: None
+    ip = C.POINTER(C.c_int)
+    ctx = L.world_hip_create(0, None)
+    try:
+        x = up(xh)
+        tp, f0 = up(np.zeros((B, F))), up(np.zeros((B, F)))
+        h, c, d = HarvestOption(71.0, 800.0, 5.0), CheapTrickOption(-0.15, 71.0, fft), D4COption(0.85)
+        args = (ctx, B, fs, ptr(x), Lmax, xl.ctypes.data_as(ip))
+        assert L.world_hip_harvest_batch(*args, C.byref(h), F, ptr(tp), ptr(f0)) == 0
+        sp, ap = up(np.full((B, F, nb), -1.0)), up(np.full((B, F, nb), -1.0))
+        assert L.world_hip_cheaptrick_batch(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), C.byref(c), ptr(sp)) == 0
+        assert L.world_hip_d4c_batch(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), fft, C.byref(d), ptr(ap)) == 0
+        sync()
+        sp_full, ap_full = host(sp).copy(), host(ap).copy()
+        # dense rows, three ranges, the second and third reusing the first call's offsets / LoveTrain pass
+        sp2, ap2 = up(np.full((B, F, nb), -1.0)), up(np.full((B, F, nb), -1.0))
+        cuts = [(64, 128), (0, 64), (128, 1 << 30)]
+        for i, (lo, hi) in enumerate(cuts):
+            assert L.world_hip_cheaptrick_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), C.byref(c), lo, hi, int(i > 0), ptr(sp2)) == 0
+        for i, (lo, hi) in enumerate(cuts):
+            assert L.world_hip_d4c_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), fft, C.byref(d), lo, hi, int(i > 0), ptr(ap2)) == 0
+        sync()
+        assert np.array_equal(host(sp2), sp_full) and np.array_equal(host(ap2), ap_full)
+        # packed records of a range that cuts through both utterances
+        lo, hi = 70, 150
+        rows = int(sum(min(hi, n) - min(lo, n) for n in nf))
+        for wire in (0, 1):
+            cols = L.world_hip_record_columns(fft, wire)
+            block = up(np.full((rows + 2, cols), np.nan))
+            rc = L.world_hip_spectral_packed_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), C.byref(c), C.byref(d), lo, hi,
+                                                   1, ptr(block), cols)
+            assert rc == 0, L.world_hip_last_error().decode()
+            sync()
+            rec = host(block)
+            assert np.isnan(rec[0]).all() and np.isnan(rec[rows + 1]).all()          # nothing outside [first_row, first_row + rows)
+            row = 1
+            tph, f0h = host(tp), host(f0)
+            for u in range(B):
+                a, b = min(lo, int(nf[u])), min(hi, int(nf[u]))
+                r = rec[row:row + b - a]
+                assert np.array_equal(r[:, 0], tph[u, a:b]) and np.array_equal(r[:, 1], f0h[u, a:b])
+                if wire == 0:
+                    assert np.array_equal(r[:, 2:2 + nb], sp_full[u, a:b]) and np.array_equal(r[:, 2 + nb:], ap_full[u, a:b])
+                else:
+                    f32 = np.ascontiguousarray(r[:, 2:]).view(np.float32)
+                    assert np.array_equal(f32[:, :nb], sp_full[u, a:b].astype(np.float32))
+                    assert np.array_equal(f32[:, nb:2 * nb], ap_full[u, a:b].astype(np.float32))
+                row += b - a
+            assert row == 1 + rows
+    finally:
+        L.world_hip_destroy(ctx)
+
+
+def test_emulated_frame_ranges_are_bit_identical_to_the_whole_call():
+    _emu()
+    _check_frame_ranges(EMU_LIB, device=False)
+
+
+@pytest.mark.gpu
+def test_frame_ranges_are_bit_identical_to_the_whole_call_on_the_gpu():
+    from world_amd.api import LIB_PATH
+    _check_frame_ranges(LIB_PATH, device=True)
+
+
+@pytest.mark.gpu
+def test_long_utterance_frames_sharded_on_one_gpu():
+    """world_amd.distributed.analyze_long_sharded without a process group (one rank owns every frame; sub-ranges of 512
+    frames): a 12 s utterance, bit-identical to WorldHip.analyze"""
+    import torch
+    from world_amd import distributed as wd, synth
+    from world_amd.api import WorldHip
+    fs = 48000
+    x = torch.cat([synth.utterance(40 + i, fs, 4.0) for i in range(3)]).cuda()
+    tp, f0, sp, ap = wd.analyze_long_sharded(x, fs, sub_frames=512)
+    tp1, f01, sp1, ap1, nf1 = WorldHip().analyze(x[None].contiguous(), fs)
+    k = int(nf1[0])
+    assert tp.shape[0] == k and torch.equal(tp, tp1[0, :k]) and torch.equal(f0, f01[0, :k])
+    assert torch.equal(sp, sp1[0, :k]) and torch.equal(ap, ap1[0, :k])

@@ -92,6 +92,13 @@ def load_library(path=LIB_PATH):
                                               C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
     lib.world_hip_check_shape.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
     lib.world_hip_record_columns.argtypes = [C.c_int, C.c_int]
+    lib.world_hip_spectral_packed_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp,
+                                                    C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, C.c_int,
+                                                    C.c_longlong, vp, C.c_int]
+    lib.world_hip_cheaptrick_batch_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp,
+                                                     C.POINTER(CheapTrickOption), C.c_int, C.c_int, C.c_int, vp]
+    lib.world_hip_d4c_batch_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp, C.c_int,
+                                              C.POINTER(D4COption), C.c_int, C.c_int, C.c_int, vp]
     lib.world_hip_analyze_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(HarvestOption),
                                             C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, vp, vp, vp, vp]
     lib.world_hip_graph_begin.argtypes = [vp]
@@ -608,6 +615,29 @@ class WorldHip:
                                                       C.byref(hopt), C.byref(copt), C.byref(dopt), first_row,
                                                       block.data_ptr(), cols), "analyze_packed")
         return nf
+
+    def spectral_packed_range(self, x, fs, tpos, f0, n_frames, block, frame_lo, frame_hi, first_row=0, x_len=None, q1=-0.15,
+                              threshold=0.85):
+        """CheapTrick + D4C of frames [frame_lo, frame_hi) of every utterance, given F0, straight into packed records
+        (include/world_hip.h: world_hip_spectral_packed_range): bit-identical to the same rows of a whole-utterance call.
+        Returns the number of records written."""
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        fft_size = cheaptrick_fft_size(fs, 71.0)
+        nb = fft_size // 2 + 1
+        nf = np.ascontiguousarray(n_frames, dtype=np.int32)
+        F = tpos.shape[1]
+        cols = block.shape[-1]
+        rows = int(sum(min(frame_hi, int(n)) - min(frame_lo, int(n)) for n in nf))
+        assert block.dtype == t.float64 and block.is_contiguous() and cols in (2 + 2 * nb, 2 + nb) and block.device == x.device
+        assert tpos.is_contiguous() and f0.is_contiguous() and tpos.shape == f0.shape == (B, F)
+        assert 0 <= frame_lo <= frame_hi and first_row >= 0 and first_row + rows <= block.shape[0]
+        copt, dopt = CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
+        self._check(self.lib.world_hip_spectral_packed_range(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
+                                                             nf.ctypes.data_as(_ip), F, tpos.data_ptr(), f0.data_ptr(),
+                                                             C.byref(copt), C.byref(dopt), frame_lo, frame_hi, first_row,
+                                                             block.data_ptr(), cols), "spectral_packed_range")
+        return rows
 
     def pack_results(self, tpos, f0, sp, ap, n_frames, block, first_row=0):
         """valid frames of a batched analysis -> records [tpos, f0, sp row, ap row] in block[first_row:] (device)"""

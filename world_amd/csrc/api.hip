@@ -233,6 +233,10 @@ struct RowLayout {
   size_t col_bytes = 0;          // bytes from a record's start to this stage's row (the stage's output pointer = records' base)
   int f32 = 0;                   // 1: rows stored as float (narrow wire format)
   double *rec = nullptr;         // D4C only: records' base for the (tpos, f0) head of every record
+  // frames [frame_lo, frame_hi) of every utterance only (stream positions as in a whole-utterance call); skip_prepare:
+  // the offsets (and D4C's LoveTrain pass) of the previous call with the same shape are still in the workspace
+  int frame_lo = 0, frame_hi = 0x7FFFFFFF;
+  bool skip_prepare = false;
 };
 // Doubles per packed record.  wire 0: [tpos, f0, sp f64[nb], ap f64[nb]]; wire 1: [tpos, f0, sp f32[nb], ap f32[nb]] -- half
 // the bytes on the xGMI links and in the D2H copy, 6e-8 relative (the contract is 1e-4): 16 + 8 nb bytes = 2 + nb doubles.
@@ -285,6 +289,8 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
   p.q1 = opt->q1;
   p.f0_floor = 3.0 * fs / (opt->fft_size - 3.0);                       // cheaptrick.cpp:196-198
   p.lg_fft = lg;
+  if (lay.frame_lo < 0 || lay.frame_hi < lay.frame_lo) fail("bad frame range [%d, %d)", lay.frame_lo, lay.frame_hi);
+  p.frame_lo = lay.frame_lo; p.frame_hi = lay.frame_hi; p.skip_prepare = lay.skip_prepare ? 1 : 0;
   launch_cheaptrick(p, max_frames, c->stream);
 }
 
@@ -348,6 +354,8 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.lg_d4c = ilog2_exact(fft_d4c);
   p.nap = nap;
   p.wl = wl;
+  if (lay.frame_lo < 0 || lay.frame_hi < lay.frame_lo) fail("bad frame range [%d, %d)", lay.frame_lo, lay.frame_hi);
+  p.frame_lo = lay.frame_lo; p.frame_hi = lay.frame_hi; p.skip_prepare = lay.skip_prepare ? 1 : 0;
   launch_d4c(p, max_frames, c->stream);
 }
 
@@ -1051,6 +1059,44 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
 }
 
 // ---------------------------------------------------------------------------
+// CheapTrick + D4C of the frames [frame_lo, frame_hi) of every utterance, given F0, straight into packed records
+// (include/world_hip.h: world_hip_spectral_packed_range): the unit of frame-level sharding ("CheapTrick /
+// D4C only, F0 broadcast") and of the drop-in calls' download that overlaps the kernels.
+// ---------------------------------------------------------------------------
+static void run_spectral_packed_range(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                                      const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0,
+                                      const CheapTrickOption *copt, const D4COption *dopt, int frame_lo, int frame_hi,
+                                      long long first_row, double *d_block, int cols) {
+  check_batch(n_utt, fs, d_x, x_stride, x_length);
+  if (!n_frames || !d_tpos || !d_f0 || !d_block) fail("null buffer");
+  if (frame_lo < 0 || frame_hi < frame_lo || first_row < 0) fail("bad frame range [%d, %d) or first row", frame_lo, frame_hi);
+  const int nb = copt->fft_size / 2 + 1;
+  const int wire = cols == record_cols(copt->fft_size, 1) ? 1 : 0;
+  if (cols != record_cols(copt->fft_size, wire))
+    fail("spectral_packed_range: %d columns, fft_size %d needs %d (f64 records) or %d (f32 spectra)", cols, copt->fft_size,
+         record_cols(copt->fft_size, 0), record_cols(copt->fft_size, 1));
+  // utterance u's frame f goes to row rows[u] + f: its range's first frame lands where the previous utterance's range ended
+  std::vector<int> rows(n_utt);
+  long long row = first_row;
+  for (int u = 0; u < n_utt; ++u) {
+    if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
+    const int lo = std::min(frame_lo, n_frames[u]), hi = std::min(frame_hi, n_frames[u]);
+    if (row - lo < -0x7FFFFFFFll || row + (hi - lo) > 0x7FFFFFFFll) fail("block exceeds 2^31 records");
+    rows[u] = static_cast<int>(row - lo);
+    row += hi - lo;
+  }
+  RowLayout lay_sp, lay_ap;
+  lay_sp.rows = lay_ap.rows = rows.data(); lay_sp.stride = lay_ap.stride = (size_t)cols;
+  lay_sp.f32 = lay_ap.f32 = wire == 1;
+  const size_t elem = wire == 1 ? sizeof(float) : sizeof(double);
+  lay_sp.col_bytes = 2 * sizeof(double); lay_ap.col_bytes = 2 * sizeof(double) + elem * nb;
+  lay_ap.rec = d_block;
+  lay_sp.frame_lo = lay_ap.frame_lo = frame_lo; lay_sp.frame_hi = lay_ap.frame_hi = frame_hi;
+  run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt, dopt, d_block, d_block,
+                      lay_sp, lay_ap);
+}
+
+// ---------------------------------------------------------------------------
 // Shape limits of the GPU path (the reference has none: it allocates whatever fs asks for).  One function states them,
 // the stages and world_hip_check_shape ask it, and the drop-in entries ask it BEFORE any upload or launch.
 // what: bit 0 StoneMask, bit 1 CheapTrick (needs fft_size), bit 2 D4C.  Returns nullptr or the reason.
@@ -1332,6 +1378,37 @@ int world_hip_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double
   return guarded(c, [&] {
     run_analyze_packed(c, n_utt, fs, d_x, x_stride, x_length, harvest_option, cheaptrick_option, d4c_option, first_row,
                        d_block, cols);
+  });
+}
+
+int world_hip_spectral_packed_range(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                                     const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0,
+                                     const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option, int frame_lo,
+                                     int frame_hi, long long first_row, double *d_block, int cols) {
+  return guarded(c, [&] {
+    run_spectral_packed_range(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, cheaptrick_option,
+                              d4c_option, frame_lo, frame_hi, first_row, d_block, cols);
+  });
+}
+
+// one stage, one frame range, dense rows (the rows of frames outside the range are not touched)
+int world_hip_cheaptrick_batch_range(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride,
+                                     const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
+                                     const double *d_f0, const CheapTrickOption *option, int frame_lo, int frame_hi,
+                                     int reuse_offsets, double *d_sp) {
+  return guarded(c, [&] {
+    RowLayout lay;
+    lay.frame_lo = frame_lo; lay.frame_hi = frame_hi; lay.skip_prepare = reuse_offsets != 0;
+    run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, option, d_sp, true, lay);
+  });
+}
+int world_hip_d4c_batch_range(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                              const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0, int fft_size,
+                              const D4COption *option, int frame_lo, int frame_hi, int reuse_offsets, double *d_ap) {
+  return guarded(c, [&] {
+    RowLayout lay;
+    lay.frame_lo = frame_lo; lay.frame_hi = frame_hi; lay.skip_prepare = reuse_offsets != 0;
+    run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, true, lay);
   });
 }
 

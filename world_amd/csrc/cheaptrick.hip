@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_spectrum(CtParams p)
   DYN_LDS(lds);
   const int lgn = LGN > 0 ? LGN : p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
-  const int u = blockIdx.y, f = xcd_grouped(blockIdx.x, gridDim.x);
-  if (f >= p.b.n_frames[u]) return;
+  const int u = blockIdx.y, f = p.frame_lo + xcd_grouped(blockIdx.x, gridDim.x);
+  if (f >= p.b.n_frames[u] || f >= p.frame_hi) return;
   const bool trace_me = f == 1000; (void)trace_me;
   WH_STAMP(0, 0);
   // LDS (doubles): Z: N | P: nb+1 | scratch: 64 | quarter-wave table of the inner N/2-point transform
@@ -211,9 +211,9 @@ constexpr int kScanDepth = 5;      // batches in flight per lane: enough rows re
 // nobody reads), so the loop has no per-element bounds -- no divergent branch, no waiting for all loads at
 // every step.
 __global__ void __launch_bounds__(WAVE) ct_scan(CtParams p) {
-  const int u = blockIdx.y, f = (int)(blockIdx.x * WAVE) + lane_id();
+  const int u = blockIdx.y, f = p.frame_lo + (int)(blockIdx.x * WAVE) + lane_id();
   const int N = 1 << p.lg_fft;
-  const bool active = f < p.b.n_frames[u];
+  const bool active = f < p.b.n_frames[u] && f < p.frame_hi;
   const size_t fi = (size_t)u * p.b.f_stride + (active ? f : 0);
   const int len = active ? ct_smooth_shape(ct_effective_f0(p.f0[fi], p.f0_floor), N, p.b.fs).seg_len : 0;
   const int max_len = wave_max_int(len);
@@ -249,8 +249,8 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_envelope(CtParams p)
   DYN_LDS(lds);
   const int lgn = LGN > 0 ? LGN : p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
-  const int u = blockIdx.y, f = xcd_grouped(blockIdx.x, gridDim.x);
-  if (f >= p.b.n_frames[u]) return;
+  const int u = blockIdx.y, f = p.frame_lo + xcd_grouped(blockIdx.x, gridDim.x);
+  if (f >= p.b.n_frames[u] || f >= p.frame_hi) return;
   const bool trace_me = f == 1000; (void)trace_me;
   WH_STAMP(0, 6);
   // LDS (doubles): seg / Z overlaid (the segment is dead once the transforms start): ct_seg_cap | P: nb+1 |
@@ -342,8 +342,10 @@ int ct_seg_stride(int fft_size) {
 
 size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size / 2 + 1; }   // window < fft_size, + bins
 
-void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream) {
-  WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);    // 1024 threads: a 10 s utterance is two scans
+void launch_cheaptrick(const CtParams &p, int max_frames_all, hipStream_t stream) {
+  if (!p.skip_prepare) WH_BLOCKS(ct_prepare, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);    // 1024 threads: a 10 s utterance is two scans
+  const int max_frames = imin(max_frames_all, p.frame_hi) - p.frame_lo;          // frames of the range
+  if (max_frames <= 0) return;
   const dim3 grid(max_frames, p.b.n_utt);
   const size_t lds1 = ct_spectrum_lds_bytes(p.lg_fft), lds3 = ct_envelope_lds_bytes(p.lg_fft);
   const dim3 scan_grid((max_frames + WAVE - 1) / WAVE, p.b.n_utt);

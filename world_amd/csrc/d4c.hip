@@ -568,8 +568,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   constexpr int kItems = D4cShape<NMAX, T>::kItems, kBins = D4cShape<NMAX, T>::kBins, kLo = D4cShape<NMAX, T>::kLo;
   constexpr bool kRot = T * 16 == NMAX;                                // twiddles by constant rotation (fft.h)
   DYN_LDS(lds);
-  const int u = blockIdx.y, f = blockIdx.x;
-  if (f >= p.b.n_frames[u]) return;
+  const int u = blockIdx.y, f = p.frame_lo + blockIdx.x;
+  if (f >= p.b.n_frames[u] || f >= p.frame_hi) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
   int tid = wg_thread<T>();
   constexpr int nt = T;                                                // launch_d4c launches exactly T threads
@@ -701,6 +701,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       }
     }
   };
+#ifndef WORLD_EMU
   // the same walk with the slot known at compile time: sample H + tid + k T belongs to the thread's element k
   auto hi_samples = [&](const D4cWin &w, double coef, auto body) __attribute__((always_inline)) {
     if (w.wlen > H) {
@@ -717,6 +718,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       }
     }
   };
+#endif
   auto balanced = [&](const D4cWin &w, double (&ulo)[kLo]) __attribute__((always_inline)) {
     double wlo[kLo];
     double s1 = 0.0, s2 = 0.0;
@@ -1010,8 +1012,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
 // ---------------------------------------------------------------------------
 // Stage C: GetAperiodicity (d4c.cpp:323-338) -- every frame's output row.
 __global__ void d4c_finish(D4cParams p) {
-  const int u = blockIdx.y, f = blockIdx.x;
-  if (f >= p.b.n_frames[u]) return;
+  const int u = blockIdx.y, f = p.frame_lo + blockIdx.x;
+  if (f >= p.b.n_frames[u] || f >= p.frame_hi) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const int tid = threadIdx.x, nt = blockDim.x, fs = p.b.fs;
   const int nb_out = p.fft_out / 2 + 1;
@@ -1070,6 +1072,7 @@ size_t d4c_max_draws_per_frame(int fs) {
 }
 
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
+  if (!p.skip_prepare) {
   WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);
   // workgroup sizes follow the transform size (threads beyond N/16 idle through every radix-8 stage): for the
   // 2048-point internal FFT of fs <= 24 kHz, 64 x 1001 frames: lovetrain 0.53 -> 0.42 ms, groupdelay 3.77 -> 2.52,
@@ -1086,9 +1089,12 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
 #endif
   }
   WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);
+  }
   // one radix-8 butterfly per thread: 128 / 256 / 512 threads for the 2048- / 4096- / 8192-point internal FFT
   // (fs <= 24 kHz / <= 48 kHz / <= 96 kHz); the register arrays are sized per shape
-  const dim3 grid(max_frames, p.b.n_utt);
+  const int range_frames = imin(max_frames, p.frame_hi) - p.frame_lo;     // frames of the range
+  if (range_frames <= 0) return;
+  const dim3 grid(range_frames, p.b.n_utt);
   const size_t lds = d4c_frame_lds_bytes(p.lg_d4c);
 #ifdef WORLD_EMU
   devrt::launch_blocks("d4c_frame", d4c_frame<8192, 1>, grid, 1, lds, stream, p);
@@ -1097,7 +1103,7 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   else if (p.lg_d4c == 12) devrt::launch_blocks("d4c_frame", d4c_frame<4096, 256>, grid, 256, lds, stream, p);
   else devrt::launch_blocks("d4c_frame", d4c_frame<8192, 512>, grid, 512, lds, stream, p);
 #endif
-  WH_BLOCKS(d4c_finish, dim3(max_frames, p.b.n_utt), 256, 8 * sizeof(double), stream, p);
+  WH_BLOCKS(d4c_finish, dim3(range_frames, p.b.n_utt), 256, 8 * sizeof(double), stream, p);
 }
 
 }  // namespace world_hip

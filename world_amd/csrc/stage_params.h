@@ -22,6 +22,10 @@ struct CtParams {
   double q1;
   double f0_floor;       // GetF0FloorForCheapTrick()
   int lg_fft;            // log2(fft_size)
+  // Frame range of the frame kernels: rows of frames [frame_lo, frame_hi) only (the stream positions are those of the
+  // whole utterance: ct_prepare always covers every frame).  0 / INT_MAX = all.
+  int frame_lo, frame_hi;
+  int skip_prepare;      // 1: the offsets of an earlier call with the same shape are still in the workspace
 };
 
 struct D4cParams {
@@ -48,6 +52,10 @@ struct D4cParams {
   int lg_d4c;             // log2 of fft_size_d4c
   int nap;                // number_of_aperiodicities
   int wl;                 // Nuttall window length
+  // Frame range of d4c_frame / d4c_finish (LoveTrain and the two offset scans always cover every frame: the second
+  // pass's stream positions depend on every earlier frame's LoveTrain result).  0 / INT_MAX = all.
+  int frame_lo, frame_hi;
+  int skip_prepare;       // 1: LoveTrain + offsets of an earlier call with the same shape are still in the workspace
 };
 
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream);

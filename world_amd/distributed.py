@@ -339,3 +339,77 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
         local = {i: (w[0], 0, w[2], w[3]) for i, w in where.items() if w[1] == rank}
         return ShardedResult(bufs, local, n_frames, nb, wire)
     return ShardedResult(bufs, where, n_frames, nb, wire)
+
+
+def frame_ranges(n_frames, world, align=64):
+    """[lo, hi) of every rank's share of one utterance's frames: contiguous, equal to within `align` frames (a multiple of
+    the wavefront: CheapTrick's serial prefix sums walk 64 frames side by side), empty for ranks beyond the end"""
+    per = -(-n_frames // world)
+    per = -(-per // align) * align
+    return [(min(n_frames, r * per), min(n_frames, (r + 1) * per)) for r in range(world)]
+
+
+def analyze_long_sharded(x, fs, group=None, frame_period=5.0, wire="f64", harvest=None, spectral_range=None, sub_frames=4096,
+                         timings=None, **options):
+    """Frame-level sharding of ONE long utterance (last sentence): Harvest needs the whole utterance and is
+    cheap next to the spectral stages (a tenth of their time), so EVERY rank runs it (identical F0 on every rank, nothing
+    to broadcast); CheapTrick and D4C are independent per frame given F0 (reference src/cheaptrick.cpp:207-216,
+    src/d4c.cpp:378-400), so rank r analyses frames frame_ranges()[r] only -- in sub-ranges of `sub_frames`, written by the
+    stage kernels as packed records straight into its slice of the sub-range's receive buffer and all-gathered in place
+    while the next sub-range is analysed.  The positions in the reference's randn() stream are those of the whole
+    utterance, so the reassembled result is BIT-IDENTICAL to a lone analysis (f32 wire: rounded once).
+
+    x        1-D float64 tensor, the same on every rank
+    harvest / spectral_range  (tests on CPU) replacements for WorldHip.harvest / WorldHip.spectral_packed_range
+    Returns (tpos [n], f0 [n], sp [n, nb], ap [n, nb]) -- sp / ap gathered from all ranks (one copy out of the receive
+    buffers: the ranks' ranges are concatenated)."""
+    from .api import cheaptrick_fft_size, frame_count
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    if wire not in WIRE_COLS:
+        raise ValueError(f"wire format {wire!r}: expected one of {sorted(WIRE_COLS)}")
+    n = int(x.numel())
+    nf = frame_count(fs, n, frame_period)
+    nb = cheaptrick_fft_size(fs) // 2 + 1
+    cols = WIRE_COLS[wire](nb)
+    cuda = x.is_cuda
+    if harvest is None or spectral_range is None:
+        wh = _default_analyzer()
+        harvest = harvest or (lambda xb: wh.harvest(xb, fs, frame_period=frame_period, **{k: v for k, v in options.items() if k in ("f0_floor", "f0_ceil")}))
+        spectral_range = spectral_range or (lambda xb, tp, f0, block, lo, hi: wh.spectral_packed_range(
+            xb, fs, tp, f0, [nf], block, lo, hi, **{k: v for k, v in options.items() if k in ("q1", "threshold")}))
+    if timings is not None and cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    xb = x.reshape(1, -1).contiguous()
+    tpos, f0 = harvest(xb)[:2]                                   # [1, nf] each, on every rank
+    ranges = frame_ranges(nf, world)
+    lo, hi = ranges[rank]
+    span = max(h - l for l, h in ranges)
+    cuts = [(a, min(span, a + sub_frames)) for a in range(0, span, sub_frames)] or [(0, 0)]
+    bufs = [torch.zeros((world, max(1, b - a), cols), dtype=torch.float64, device=x.device) for a, b in cuts]
+    works = []
+    for k, (a, b) in enumerate(cuts):
+        l, h = min(hi, lo + a), min(hi, lo + b)
+        if h > l:
+            spectral_range(xb, tpos, f0, bufs[k][rank], l, h)
+        if world > 1:
+            works.append(_gather_in_place(bufs[k], rank, group, True))
+    wait_all(works)
+    sp_parts, ap_parts = [], []
+    for r, (l, h) in enumerate(ranges):
+        for k, (a, b) in enumerate(cuts):
+            m = min(h, l + b) - min(h, l + a)
+            if m > 0:
+                _, _, s, p = record_views(bufs[k][r, :m], nb, wire)
+                sp_parts.append(s)
+                ap_parts.append(p)
+    sp = torch.cat(sp_parts) if sp_parts else torch.zeros((0, nb), dtype=torch.float64, device=x.device)
+    ap = torch.cat(ap_parts) if ap_parts else torch.zeros((0, nb), dtype=torch.float64, device=x.device)
+    if timings is not None:
+        if cuda:
+            torch.cuda.synchronize()
+        timings["ms"] = timings.get("ms", 0.0) + (time.perf_counter() - t0) * 1e3
+        timings["steps"] = timings.get("steps", 0) + 1
+    return tpos[0, :nf], f0[0, :nf], sp, ap

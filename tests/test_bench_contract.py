@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r03", "bench_n1.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04", "bench_n1.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -60,6 +60,16 @@ def test_committed_line_carries_the_contract():
     assert line["roofline"]["traffic_stale"] is False and line["roofline"]["traffic"] > 0
     assert line["cpu_baseline"]["kind"] == "reference" and "-O1" in line["cpu_baseline"]["sample"]
     assert "-O3" in line["cpu_baseline_o3"]["sample"] and line["cpu_baseline_all_cores"]["cores"] >= 1
+    # round 4: the drop-in path timed from a C++ caller (and re-entrant: four threads beat one), the cold start apart,
+    # the full configs[3] job bit-checked once per sub-batch, the tapered schedule in the leg's description
+    h = line["host_to_host"]
+    assert h["measured_by"].startswith("examples/dropin_bench.cpp") and h["c_caller"]["all_results_identical"] is True
+    assert h["ms_per_utterance"] == h["c_caller"]["separate_rows_ms"] <= 2.3
+    assert h["c_caller"]["separate_rows_ms"] / h["c_caller"]["threads_ms_per_utterance"] > 1.5
+    assert line["first_call_ms"] == h["cold_start"]["first_call_ms"] > 0 and line["randn_table_first_build_ms"] <= 50.0
+    full = line["configs"]["3_full"]
+    assert full["utterances_bit_identical_to_lone_analysis"] is True and full["utterances_checked"] >= 32
+    assert full["utterances_checked"] == full["sub_batches"] and "tapered" in full["workload"]
 
 
 def test_a_profile_of_other_sources_is_reported_stale(tmp_path, monkeypatch):

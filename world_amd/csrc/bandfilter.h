@@ -498,7 +498,10 @@ struct IntervalRange {       // per family, in LDS
   int c_first, c_last;       // counts at t_first / t_last
   int j_lo, m;               // staged intervals [j_lo, j_lo + m)
 };
-constexpr int kIntervalCap = 384;   // staged intervals per family (a 0.256 s run holds <= ~340 at 1.3 kHz): 24.6 KB, 6 workgroups per CU
+#ifndef HV_INTERVAL_CAP
+#define HV_INTERVAL_CAP 384
+#endif
+constexpr int kIntervalCap = HV_INTERVAL_CAP;   // staged intervals per family (a 0.256 s run holds <= ~340 at 1.3 kHz): 24.6 KB, 6 workgroups per CU
 
 __device__ __forceinline__ void interval_range_ends(const double *e, int n_int, double fs, double t, bool last,
                                                     IntervalRange *r) {

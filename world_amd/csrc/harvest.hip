@@ -308,7 +308,11 @@ __global__ void hv_compact_events(HarvestParams p) {
 // ---------------------------------------------------------------------------
 // interp1 of the interval F0s onto the 1 ms grid + gating (harvest.cpp:240-293);
 // one workgroup per run of kRawFrames frames of one (band, utt), one thread per frame.
-constexpr int kRawFrames = 256;
+constexpr int kRawFrames = 256;                       // threads of a workgroup
+#ifndef HV_RAW_RUN
+#define HV_RAW_RUN 256
+#endif
+constexpr int kRawRun = HV_RAW_RUN;                    // frames of a workgroup's run (the eight end-point searches are per run)
 __device__ __forceinline__ double hv_gate(const HarvestParams &p, int band, double v0, double v1, double v2, double v3) {
   double c = (v0 + v1 + v2 + v3) / 4.0;
   const double fb = p.band_f0[band];
@@ -318,7 +322,7 @@ __device__ __forceinline__ double hv_gate(const HarvestParams &p, int band, doub
 __global__ void __launch_bounds__(kRawFrames) hv_raw_candidates(HarvestParams p) {
   DYN_LDS(lds);
   const int band = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
-  const int f_begin = blockIdx.x * kRawFrames, f_end = imin(f_begin + kRawFrames, p.nfb[u]);
+  const int f_begin = blockIdx.x * kRawRun, f_end = imin(f_begin + kRawRun, p.nfb[u]);
   if (f_begin >= f_end) return;
   const int *cnt = p.ev_count + (u * p.nch + band) * 4;
   const double *ev = p.events + ((size_t)(u * p.nch + band) * 4) * p.ev_cap;
@@ -807,7 +811,7 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   }
   // one chunk per utterance: the kernel above appended straight into the final lists (seg_events == events)
   if (!(p.fft_seg > 0 && p.nseg == 1)) WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, compact_lds_bytes(p.nseg), stream, p);
-  WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawFrames - 1) / kRawFrames, p.nch, B), kRawFrames,
+  WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawRun - 1) / kRawRun, p.nch, B), kRawFrames,
             8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
   WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);

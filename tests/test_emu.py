@@ -220,3 +220,43 @@ def test_merge_routes_agree(tmp_path):
     for k in A.files:
         assert np.array_equal(A[k], B[k]), k
         assert (A[k] > 0).any()
+
+
+def test_emulated_c_driver_tapers_and_narrows_the_exchange(emu):
+    """world_hip_analyze_sharded with a share long enough to be tapered (32 utterances on two contexts, sub-batches of 8:
+    every context runs 8 and then a tail of 8 cut into 4, 2, 2 -- api.hip: chunk_sizes, the schedule world_amd.distributed
+    states for the RCCL path) and with the narrow wire format (records of 2 + nb doubles, the spectra as float32): both
+    blocks complete and identical, every utterance equal to a lone analysis rounded once to float"""
+    import ctypes as C
+    from world_amd import distributed as wd, synth
+    from world_amd.api import analyze_sharded_c, cheaptrick_fft_size, load_library
+    L = load_library(os.path.join(EMU_DIR, "libworld_emu.so"))
+    fs = 16000
+    lengths = [1700 + 37 * i for i in range(32)]
+    xs = [synth.utterance(i, fs, n / fs).numpy() for i, n in enumerate(lengths)]
+    fft = cheaptrick_fft_size(fs)
+    nb = fft // 2 + 1
+    cols = L.world_hip_record_columns(fft, 1)
+    assert cols == 2 + nb and L.world_hip_record_columns(fft, 0) == 2 + 2 * nb and L.world_hip_record_columns(fft, 7) == -1
+    ctxs = [L.world_hip_create(0, None) for _ in range(2)]
+    try:
+        rows = sum(emu.frame_count(fs, n, 5.0) for n in lengths)
+        blocks = [np.full((rows + 1, cols), np.nan) for _ in ctxs]
+        where = analyze_sharded_c(L, ctxs, xs, fs, [b.ctypes.data for b in blocks], rows + 1, sub_batch=8, wire=1)
+        assert sorted(set(where[:, 0])) == [0, 1]
+        assert np.array_equal(blocks[0][:rows], blocks[1][:rows])
+        shares = [int((where[:, 0] == d).sum()) for d in (0, 1)]
+        assert shares == [16, 16] and wd.chunk_sizes(16, 8) == [8, 4, 2, 2]   # a full sub-batch, then the tail in halves
+        for i in (0, 5, 11, 17, 26, 31):
+            x = xs[i]
+            tp, f0 = emu.harvest(x, fs)
+            sp = emu.cheaptrick(x, fs, tp, f0, fft_size=fft)
+            ap = emu.d4c(x, fs, tp, f0, fft)
+            dev, first, n = (int(v) for v in where[i])
+            rec = blocks[1 - dev][first:first + n]
+            assert np.array_equal(rec[:, 0], tp) and np.array_equal(rec[:, 1], f0)
+            f32 = np.ascontiguousarray(rec[:, 2:]).view(np.float32)
+            assert np.array_equal(f32[:, :nb], sp.astype(np.float32)) and np.array_equal(f32[:, nb:2 * nb], ap.astype(np.float32))
+    finally:
+        for c in ctxs:
+            L.world_hip_destroy(c)

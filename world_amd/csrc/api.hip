@@ -246,8 +246,8 @@ static int record_cols(int fft_size, int wire) {
 }
 
 static size_t cheaptrick_arena_bytes(int n_utt, int f_stride, int fft_size) {
-  return pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 4 * pad256(sizeof(int) * n_utt) +
-         pad256(sizeof(double) * (size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * ct_seg_stride(fft_size));
+  (void)fft_size;       // the frame kernel keeps everything between x and the spectrogram in LDS: no per-frame scratch
+  return pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 4 * pad256(sizeof(int) * n_utt);
 }
 static size_t d4c_arena_bytes(int n_utt, int f_stride) {
   const size_t fr = (size_t)n_utt * f_stride;
@@ -270,7 +270,6 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
     if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
     max_frames = std::max(max_frames, n_frames[u]);
   }
-  const int seg_stride = ct_seg_stride(opt->fft_size);
   if (own_arena) { ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, opt->fft_size)); c->arena.reset(); }
   CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
   CtParams p;
@@ -282,8 +281,6 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
   p.out_stride = lay.stride ? lay.stride : (size_t)(opt->fft_size / 2 + 1);
   p.out_col_bytes = lay.col_bytes; p.out_f32 = lay.f32;
   p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
-  p.seg = c->arena.take<double>((size_t)n_utt * ((f_stride + WAVE - 1) / WAVE * WAVE) * seg_stride);
-  p.seg_stride = seg_stride;
   p.noise = ensure_noise(c, (size_t)max_frames * ct_max_draws_per_frame(opt->fft_size));
   p.tab = c->tab;
   p.q1 = opt->q1;

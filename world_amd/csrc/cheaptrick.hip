@@ -7,19 +7,14 @@
 //
 //   ct_prepare : per utterance, prefix-sum of randn() calls consumed per frame
 //                -> each frame's xorshift128 state by GF(2) jump-ahead.
-//   ct_spectrum: one workgroup per (frame, utterance): F0-adaptive window + noise ->
-//                r2c FFT -> |X|^2 -> DC correction -> the mirrored segment whose
-//                prefix sum LinearSmoothing needs, to the frame's scratch row.
-//   ct_scan    : that prefix sum, SERIAL and in FP64 order (its rounding is visible
-//                in low-energy bins) -- one LANE per frame, 64 chains
-//                per wavefront.
-//   ct_envelope: one workgroup per frame: rectangular smoothing -> +|randn|*eps ->
-//                log -> r2c FFT (cepstrum) -> lifter -> c2r FFT -> exp -> HBM.
+//   ct_frame   : one workgroup per (frame, utterance): F0-adaptive window + noise -> r2c FFT -> |X|^2 -> DC
+//                correction -> the mirrored segment of LinearSmoothing and its prefix sum, SERIAL and in FP64
+//                order (its rounding is visible in low-energy bins), walked by one lane in LDS
+//                while the other wavefronts prepare the per-bin noise terms -> rectangular smoothing ->
+//                +|randn|*eps -> log -> r2c FFT (cepstrum) -> lifter -> c2r FFT -> exp -> HBM.
 //
-// HBM traffic per frame: the window's samples of x (L2-resident: adjacent
-// frames overlap ~97%), the smoothing segment's round trip through its scratch
-// row (~1200 doubles written, scanned in place, read: Infinity-Cache resident)
-// and one row of the spectrogram written once.
+// HBM traffic per frame: the window's samples of x (L2-resident: adjacent frames overlap ~97%), the frame's draws
+// from the noise table (4 bytes each: window length + one per bin) and one row of the spectrogram written once.
 #include "stage_params.h"
 #include "trace.h"
 WH_TRACE_DEFINE(ct)
@@ -30,11 +25,11 @@ __device__ __forceinline__ double ct_effective_f0(double f0, double floor_f0) {
   return f0 <= floor_f0 ? kDefaultF0 : f0;              // cheaptrick.cpp:218
 }
 
-// doubles reserved for Z and the smoothing work area that overlays it (even)
+// doubles reserved for Z and the smoothing work area that overlays it: a whole number of the prefix sum's rows of 16
 __host__ __device__ __forceinline__ int ct_seg_cap(int N) {
   const int need = N / 2 + 1 + 2 * (N / 3 + 2) + 1;
   const int cap = need > N ? need : N;
-  return cap + (cap & 1);
+  return (cap + 15) / 16 * 16;
 }
 
 // ---------------------------------------------------------------------------
@@ -75,38 +70,133 @@ __device__ __forceinline__ CtSmooth ct_smooth_shape(double cf0, int N, int fs) {
   return s;
 }
 
-// Layout of the smoothing segments in HBM: frames in groups of WAVE, PAIRS of consecutive elements of the
-// group's frames side by side -- [utterance][frame / WAVE][i / 2][frame % WAVE][i % 2] -- so that ct_scan, one
-// lane per frame, moves 1 KB of contiguous memory per instruction (16 bytes per lane).  Row-per-frame, a lane's
-// access is its own cache line, 64 lines per instruction: measured 74 us for the scan.  The frame kernels pay
-// with 8-byte accesses 1 KB apart; they have the waves to hide it.
-__device__ __forceinline__ double *ct_seg_at(const CtParams &p, int u, int f) {
-  const size_t groups = (size_t)(p.b.f_stride + WAVE - 1) / WAVE;
-  return p.seg + (((size_t)u * groups + f / WAVE) * p.seg_stride) * WAVE + (size_t)(f % WAVE) * 2;
+// ---- LinearSmoothing's prefix sum (common.cpp:85-86), SERIAL and in FP64 order -------------------------------------
+// `hi - lo` of the smoothing cancels up to 12 digits where the envelope sits at the noise floor, so any other summation
+// order moves those bins by 1e-4 (tests/test_gpu_parity.py::test_hard_inputs_vs_oracle): the chain of
+// seg_len dependent additions is walked by ONE lane, in LDS.  What makes it affordable is that nothing else sits on
+// the chain: pairs of values arrive by 16-byte LDS reads a batch ahead of the additions and leave by 16-byte writes
+// behind them, so a step costs the latency of one FP64 add (rounds 1-3 took other routes: the whole workgroup waiting
+// on a lane that read, added and wrote element by element -- 40 k cycles a frame; then a kernel of its own, one lane
+// per frame and 64 chains per wavefront, which needed every frame's segment written to HBM, read, written and read
+// again: 7.6 GB per 128 utterances for a stage whose inputs and outputs are 2.4 GB).
+constexpr int kScanPairs = 8;         // pairs per batch: 16 chained additions between one group of reads and writes
+__device__ __forceinline__ void ct_serial_prefix_sum(double *seg, int seg_len, int cap) {
+  double2 *s2 = reinterpret_cast<double2 *>(seg);
+  const int pairs = (seg_len + 1) >> 1, last = cap / 2 - 1;            // (an odd length drags one value of scratch along)
+  double2 cur[kScanPairs], nxt[kScanPairs];
+#pragma unroll
+  for (int q = 0; q < kScanPairs; ++q) cur[q] = s2[imin(q, last)];
+  double acc = 0.0;                   // 0 + seg[0] == seg[0]: the first element passes through unchanged, as in the reference
+  for (int j0 = 0; j0 < pairs; j0 += kScanPairs) {
+#pragma unroll
+    for (int q = 0; q < kScanPairs; ++q) nxt[q] = s2[imin(j0 + kScanPairs + q, last)];
+#pragma unroll
+    for (int q = 0; q < kScanPairs; ++q) {                             // strictly left to right
+      acc = cur[q].x + acc; cur[q].x = acc;
+      acc = cur[q].y + acc; cur[q].y = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < kScanPairs; ++q) if (j0 + q < pairs) s2[j0 + q] = cur[q];
+#pragma unroll
+    for (int q = 0; q < kScanPairs; ++q) cur[q] = nxt[q];
+  }
 }
-__device__ __forceinline__ size_t ct_seg_elem(int i) { return (size_t)(i >> 1) * (2 * WAVE) + (i & 1); }   // offset of element i
 
-// ---- stage 1: window -> r2c -> |X|^2 -> DC correction -> mirrored segment of LinearSmoothing, to HBM ----------
+#ifndef WORLD_EMU
+// The same chain walked by the lanes of a wavefront, immune to the latency of a loaded LDS: lane k (of the first 16)
+// holds element k of a row of 16, the running sum lives in all 16, and step l adds lane l's value to it in the lanes
+// >= l only -- so when the row is done lane k is left with the sum up to ITS element; one 128-byte read and one write
+// per row, rows requested six ahead, no memory on the chain.  A step is ONE vector instruction: v_fmac_f64 with the
+// DPP control row_newbcast:l, which hands every lane of a 16-lane row lane l's operand (the one DPP form CDNA's FP64
+// ALU takes, and only in the VOP2 encoding: v_add_f64 has none) -- acc = v * 1.0 + acc, one rounding of the exact
+// v + acc, i.e. the addition -- under an EXEC mask the scalar unit rewrites in its shadow.  Measured per frame, in a CU whose other fifteen
+// wavefronts are busy with transforms: 52 k cycles for the single-lane walk above (every batch of 16 values waited
+// ~750 cycles for its turn in the LDS pipe), 35 k for this scheme with v_readlane pairs feeding a plain v_add_f64
+// (three vector instructions a step, each queueing behind the other wavefronts' FP64 work).
+// One row: on entry lane 15 holds the sum so far (the last element of the previous row; 0 before the first), which a
+// DPP move hands to the 16 lanes first.  (The s_nop pairs are the wait states a DPP read of a freshly written VGPR asks
+// for; inside an asm block nobody inserts them for us.)
+__device__ __forceinline__ double ct_row_prefix_sum(double v, double acc, double one) {
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %[saved], exec\n s_mov_b64 exec, 0xffff\n s_nop 1\n"
+      "v_mov_b64_dpp %[acc], %[acc] row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xfffe\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xfffc\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xfff8\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xfff0\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xffe0\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xffc0\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xff80\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xff00\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xfe00\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xfc00\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xf800\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xf000\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xe000\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0xc000\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, 0x8000\n v_fmac_f64_dpp %[acc], %[v], %[one] row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
+      "s_mov_b64 exec, %[saved]\n"
+      : [acc] "+v"(acc), [saved] "=&s"(saved)
+      : [v] "v"(v), [one] "v"(one));
+  return acc;
+}
+constexpr int kScanRow = 16;          // the width of a DPP row
+constexpr int kScanAhead = 4;         // rows in flight: 64 elements' worth of additions covers a trip through a busy LDS pipe
+__device__ __forceinline__ void ct_wave_prefix_sum(double *seg, int seg_len) {
+  const int lane = lane_id(), k = lane & (kScanRow - 1);         // (lanes 16.. mirror the first 16's reads and idle)
+  const bool mine = lane < kScanRow;
+  const int rows = (seg_len + kScanRow - 1) / kScanRow;           // rows * 16 <= ct_seg_cap: the last row's tail is scratch
+  double *at = seg + k;
+  double ring[kScanAhead];
+  // (rows beyond the segment are read, never added: they lie in the frame's LDS -- the segment's spare room, then P)
+#pragma unroll
+  for (int q = 0; q < kScanAhead; ++q) ring[q] = at[q * kScanRow];
+  double acc = 0.0;                   // 0 + seg[0] == seg[0]: the first element passes through unchanged, as in the reference
+  const double one = 1.0;
+  for (int r0 = 0; r0 < rows; r0 += kScanAhead) {
+#pragma unroll
+    for (int q = 0; q < kScanAhead; ++q) {             // (whole groups of rows: a branch per row cost more register moves
+      const double v = ring[q];                          // than the few rows of scratch a group may add past the segment)
+      ring[q] = at[(q + kScanAhead) * kScanRow];
+      acc = ct_row_prefix_sum(v, acc, one);            // strictly left to right
+      if (mine && r0 + q < rows) at[q * kScanRow] = acc;
+    }
+    at += kScanAhead * kScanRow;
+  }
+}
+#endif
+
+// ---- one workgroup per frame: window -> r2c -> |X|^2 -> DC correction -> LinearSmoothing -> log -> cepstrum -> lifter
+// -> exp, from x to the spectrogram row without touching HBM in between ---------------------------------------------------
 // PER: samples of the window a thread owns (fft_size / threads); LGN: log2(fft_size) when it is a compile-time
 // constant of the instantiation (static FFT stages), 0 = taken from p.lg_fft.
 // TB: the largest workgroup the instantiation is launched with (512 for the 8192-point transform: one frame then owns
 // 107 KB of LDS, one workgroup per CU -- the shape exists so that f0 floors below 35 Hz at 48 kHz and sampling rates
 // above 96 kHz run at all, not to be fast)
 template <int PER, int LGN, int TB = 256>
-__global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_spectrum(CtParams p) {
+// (the 4096-point frame owns 59 KB of LDS: two workgroups per CU whatever the registers, so it may have 256 of them --
+// its 48 window values per thread spilled at the 128 of four workgroups per CU)
+__global__ void __launch_bounds__(TB, TB <= 256 ? (LGN == 12 ? 2 : 4) : 1) ct_frame(CtParams p) {
   DYN_LDS(lds);
   const int lgn = LGN > 0 ? LGN : p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
   const int u = blockIdx.y, f = p.frame_lo + xcd_grouped(blockIdx.x, gridDim.x);
   if (f >= p.b.n_frames[u] || f >= p.frame_hi) return;
-  const bool trace_me = f == 1000; (void)trace_me;
+  const bool trace_me = f == WH_TRACE_FRAME && u == WH_TRACE_UTT; (void)trace_me;
   WH_STAMP(0, 0);
-  // LDS (doubles): Z: N | P: nb+1 | scratch: 64 | quarter-wave table of the inner N/2-point transform
+  // LDS (doubles): Z / the smoothing segment, overlaid (the transforms' buffer is dead while the segment lives and
+  // the other way round): ct_seg_cap | P: nb+1 | scratch: 64 | quarter-wave table of the inner N/2-point transform
   cplx *Z = reinterpret_cast<cplx *>(lds);
-  double *Zr = reinterpret_cast<double *>(lds);
-  double *P = Zr + N;
+  double *Zr = reinterpret_cast<double *>(lds), *seg = Zr;
+  const int cap = ct_seg_cap(N);
+  double *P = Zr + cap;
   double *scratch = P + (nb + 1) + ((nb + 1) & 1);
   const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
+#ifdef CT_LIFTER_TABLE
+  double *lift = scratch + 64 + twiddle_lds_doubles(lgn - 1);
+#endif
 
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
@@ -128,34 +218,36 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_spectrum(CtParams p)
   // from the noise stream.  cos(pi position f0) advances by a fixed angle from one of the thread's
   // samples to the next (they are nt apart): one sincospi pair per thread, then rotations.
   const double win_scale = 1.0 / 1.5 / fs * cf0;        // position * f0 = (i - hw) / 1.5 / fs * f0
-  double wv[PER], av[PER], nv[PER];
-  double s_ww = 0.0, s_a = 0.0, s_n = 0.0, s_w = 0.0;
   {
-    double rc, rs, dc, ds;
-    sincospi(win_scale * (tid - hw), &rs, &rc);
-    sincospi(win_scale * nt, &ds, &dc);
+    double wv[PER], av[PER], nv[PER];
+    double s_ww = 0.0, s_a = 0.0, s_n = 0.0, s_w = 0.0;
+    {
+      double rc, rs, dc, ds;
+      sincospi(win_scale * (tid - hw), &rs, &rc);
+      sincospi(win_scale * nt, &ds, &dc);
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i = tid + q * nt;
+        wv[q] = 0.0; av[q] = 0.0; nv[q] = 0.0;
+        if (i < wlen) {
+          const double w = 0.5 * rc + 0.5;                   // cos(pi * position * f0), cheaptrick.cpp:101-102
+          const double a = x[imin(x_len - 1, imax(0, origin + i - hw))] * w, n = randn_value(noise[i]) * kTiny;
+          wv[q] = w; av[q] = a; nv[q] = n;
+          s_ww += w * w; s_a += a; s_n += n; s_w += w;
+        }
+        const double t = rc * dc - rs * ds;
+        rs = rs * dc + rc * ds;
+        rc = t;
+      }
+    }
+    block_sum4(s_ww, s_a, s_n, s_w, scratch);
+    const double c = 1.0 / sqrt(s_ww);
+    const double cc = c * ((c * s_a + s_n) / (c * s_w));
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = tid + q * nt;
-      wv[q] = 0.0; av[q] = 0.0; nv[q] = 0.0;
-      if (i < wlen) {
-        const double w = 0.5 * rc + 0.5;                   // cos(pi * position * f0), cheaptrick.cpp:101-102
-        const double a = x[imin(x_len - 1, imax(0, origin + i - hw))] * w, n = randn_value(noise[i]) * kTiny;
-        wv[q] = w; av[q] = a; nv[q] = n;
-        s_ww += w * w; s_a += a; s_n += n; s_w += w;
-      }
-      const double t = rc * dc - rs * ds;
-      rs = rs * dc + rc * ds;
-      rc = t;
+      if (i < N) rfft_in(Z, i) = i < wlen ? av[q] * c + nv[q] - wv[q] * cc : 0.0;
     }
-  }
-  block_sum4(s_ww, s_a, s_n, s_w, scratch);
-  const double c = 1.0 / sqrt(s_ww);
-  const double cc = c * ((c * s_a + s_n) / (c * s_w));
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const int i = tid + q * nt;
-    if (i < N) rfft_in(Z, i) = i < wlen ? av[q] * c + nv[q] - wv[q] * cc : 0.0;
   }
 
   WH_STAMP(0, 2);
@@ -178,11 +270,10 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_spectrum(CtParams p)
   }
 
   WH_STAMP(0, 4);
-  // ---- LinearSmoothing (common.cpp:27-111), width = 2/3 f0: the mirrored, scaled segment whose prefix sum
-  // the reference walks serially goes to this frame's row in HBM (ct_scan)
+  // ---- LinearSmoothing (common.cpp:27-111), width = 2/3 f0: the mirrored, scaled segment whose prefix sum the
+  // reference walks serially, in LDS
   const CtSmooth sm = ct_smooth_shape(cf0, N, fs);
   const double inv_n = 1.0 / N;
-  double *row = ct_seg_at(p, u, f);
   block_map<4, double>(sm.seg_len,
     [&](int i) {
       double m;
@@ -191,84 +282,75 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_spectrum(CtParams p)
       else m = P[half - (i - (half + sm.bnd))];
       return m * fs * inv_n;                           // == m * fs / N: N is a power of two
     },
-    [&](int i, double v) { row[ct_seg_elem(i)] = v; });
+    [&](int i, double v) { seg[i] = v; });
+  __syncthreads();
   WH_STAMP(0, 5);
-}
-
-// ---- stage 2: the order-sensitive prefix sums, one LANE per frame ---------------------------------------------
-// The cumulative sum of LinearSmoothing (common.cpp:85-86) must round exactly as the reference's left-to-right
-// loop does: `hi - lo` below cancels up to 12 digits where the envelope sits at the noise floor, so any other
-// summation order moves those bins by 1e-4 (tests/test_gpu_parity.py::test_hard_inputs_vs_oracle).
-// A chain of dependent FP64 adds costs the same whatever the other lanes do, so the chains of 64 frames run
-// side by side in one wavefront: 1200 steps for 64 frames instead of 1200 steps per frame with 255 threads of a
-// workgroup waiting at a barrier (round 1: 40k of a frame's 135k cycles).  Rows are read in batches of 8 values
-// per lane, the next batch in flight while the current one is added up.
-constexpr int kScanBatch = 16;     // values per lane and batch (8 loads of 16 bytes)
-constexpr int kScanDepth = 5;      // batches in flight per lane: enough rows requested ahead to cover a trip to HBM
-                                   // (40 loads + a batch of stores stay below the 63 the vmcnt counter can tell apart)
-// A frame's row holds seg_stride values although its segment is shorter: every lane walks to the longest
-// segment of its wavefront, rounded up to whole rings (what lies beyond a frame's own length is scratch that
-// nobody reads), so the loop has no per-element bounds -- no divergent branch, no waiting for all loads at
-// every step.
-__global__ void __launch_bounds__(WAVE) ct_scan(CtParams p) {
-  const int u = blockIdx.y, f = p.frame_lo + (int)(blockIdx.x * WAVE) + lane_id();
-  const int N = 1 << p.lg_fft;
-  const bool active = f < p.b.n_frames[u] && f < p.frame_hi;
-  const size_t fi = (size_t)u * p.b.f_stride + (active ? f : 0);
-  const int len = active ? ct_smooth_shape(ct_effective_f0(p.f0[fi], p.f0_floor), N, p.b.fs).seg_len : 0;
-  const int max_len = wave_max_int(len);
-  if (!active) return;
-  double2 *row = reinterpret_cast<double2 *>(ct_seg_at(p, u, f));      // pair j of this frame: row[j * WAVE]
-  constexpr int kPairs = kScanBatch / 2;
-  double2 buf[kScanDepth][kPairs];
+  // Thread 0 walks the chain; the wavefronts it does not belong to meanwhile prepare what the rest of the frame needs
+  // and the chain does not touch: AddInfinitesimalNoise's per-bin terms -- the draws continue the frame's stream after
+  // the window's (cheaptrick.cpp:147-151) -- into P, whose power spectrum is dead, and the lifter of
+  // SmoothingWithRecovery.  (One wavefront -- the emulator's one thread, a 64-thread launch -- does both in turn.)
+  {
+    const int waves = waves_per_block();
+    constexpr int scan_wave = 0;        // (rotating the chain over the wavefronts, i.e. the SIMDs, by frame: 5.26 ms against 5.06)
+    const int helpers = waves > 1 ? nt - WAVE : nt;
+    const bool helper = waves == 1 || wave_in_block() != scan_wave;
+#if !defined(WORLD_EMU) && !defined(CT_LANE_SCAN)
+    if (wave_in_block() == scan_wave) {
+#ifndef CT_NO_PRIO
+      __builtin_amdgcn_s_setprio(3);
+#endif
+      ct_wave_prefix_sum(seg, sm.seg_len);
+#ifndef CT_NO_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+#else
+    if (tid == scan_wave * WAVE) {
+#if !defined(WORLD_EMU) && !defined(CT_NO_PRIO)
+      // A chain of dependent additions advances one issue slot at a time: among the four wavefronts of its SIMD, all busy
+      // with other frames' transforms, it got every fourth slot or so (measured: 6.05 ms per 128 utterances against the
+      // 4.18 of the three kernels this one replaces).  Issue priority for the chain's duration costs the others one
+      // slot in two for ~10 k cycles and gives the frame its latency back.
+      __builtin_amdgcn_s_setprio(3);
+#endif
+      ct_serial_prefix_sum(seg, sm.seg_len, cap);
+#if !defined(WORLD_EMU) && !defined(CT_NO_PRIO)
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+#endif
+    if (helper) {
+      const int ht = (waves > 1 && wave_in_block() > scan_wave) ? tid - WAVE : tid;
+      constexpr int kB = 6;                                  // draws requested together
+      for (int i0 = ht; i0 <= half; i0 += kB * helpers) {
+        uint32_t d[kB];
 #pragma unroll
-  for (int d = 0; d < kScanDepth; ++d)
+        for (int q = 0; q < kB; ++q) d[q] = noise[wlen + imin(i0 + q * helpers, half)];
 #pragma unroll
-    for (int q = 0; q < kPairs; ++q) buf[d][q] = row[(size_t)(d * kPairs + q) * WAVE];
-  double acc = 0.0;                   // 0 + seg[0] == seg[0]: the first element passes through unchanged, as in the reference
-  for (int i0 = 0; i0 < max_len; i0 += kScanDepth * kScanBatch) {
-#pragma unroll
-    for (int d = 0; d < kScanDepth; ++d) {
-      double2 *at = row + (size_t)(i0 / 2 + d * kPairs) * WAVE;
-#pragma unroll
-      for (int q = 0; q < kPairs; ++q) {                               // strictly left to right
-        acc = buf[d][q].x + acc; buf[d][q].x = acc;
-        acc = buf[d][q].y + acc; buf[d][q].y = acc;
+        for (int q = 0; q < kB; ++q) if (i0 + q * helpers <= half) P[i0 + q * helpers] = fabs(randn_value(d[q])) * kEps;
       }
-#pragma unroll
-      for (int q = 0; q < kPairs; ++q) at[(size_t)q * WAVE] = buf[d][q];
-#pragma unroll
-      for (int q = 0; q < kPairs; ++q) buf[d][q] = at[(size_t)(kScanDepth * kPairs + q) * WAVE];
+#ifdef CT_LIFTER_TABLE
+      // sin(pi f0 q) / (pi f0 q) and (1 - 2 q1) + 2 q1 cos(2 pi f0 q) at quefrency q = k / fs; with a = f0 k / fs both
+      // come from ONE sinpi: cos(2 pi a) = 1 - 2 sin^2(pi a)
+      const double q1 = p.q1, f0_over_fs = cf0 / fs;
+      for (int k = ht; k <= half; k += helpers) {
+        double sl, cl;
+        if (k == 0) {
+          sl = 1.0;
+          cl = (1.0 - 2.0 * q1) + 2.0 * q1;
+        } else {
+          const double a = static_cast<double>(k) * f0_over_fs;
+          const double sp = sinpi(a);
+          sl = sp / (kPi * a);
+          cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * sp * sp);
+        }
+        lift[k] = sl * cl;
+      }
+#endif
     }
   }
-}
-
-// ---- stage 3: rectangular smoothing from the prefix sums -> log -> cepstrum -> lifter -> exp, to HBM -----------
-template <int LGN, int TB = 256>
-__global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_envelope(CtParams p) {
-  DYN_LDS(lds);
-  const int lgn = LGN > 0 ? LGN : p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
-  const int fs = p.b.fs;
-  const int u = blockIdx.y, f = p.frame_lo + xcd_grouped(blockIdx.x, gridDim.x);
-  if (f >= p.b.n_frames[u] || f >= p.frame_hi) return;
-  const bool trace_me = f == 1000; (void)trace_me;
-  WH_STAMP(0, 6);
-  // LDS (doubles): seg / Z overlaid (the segment is dead once the transforms start): ct_seg_cap | P: nb+1 |
-  // scratch: 64 | quarter-wave table of the inner N/2-point transform
-  cplx *Z = reinterpret_cast<cplx *>(lds);
-  double *seg = reinterpret_cast<double *>(lds);
-  double *P = seg + ct_seg_cap(N);
-  double *scratch = P + (nb + 1) + ((nb + 1) & 1);
-  const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
-  const size_t fi = (size_t)u * p.b.f_stride + f;
-  const double cf0 = ct_effective_f0(p.f0[fi], p.f0_floor);
-  const int wlen = 2 * mround(1.5 * fs / cf0) + 1;
-  const uint32_t *noise = p.noise + p.offsets[fi];
-  const CtSmooth sm = ct_smooth_shape(cf0, N, fs);
-  const double inv_n = 1.0 / N;
-  const double *row = ct_seg_at(p, u, f);
-  block_map<8, double>(sm.seg_len, [&](int i) { return row[ct_seg_elem(i)]; }, [&](int i, double v) { seg[i] = v; });
   __syncthreads();
+  WH_STAMP(0, 6);
   {
     const double origin_axis = -(sm.bnd - 0.5) * fs / N;
     const double step = static_cast<double>(fs) / N;
@@ -282,23 +364,26 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_envelope(CtParams p)
         fa += sm.width;
         double hi = interp_uniform(origin_axis, step, seg, sm.seg_len, fa);
         double smoothed = (hi - lo) / sm.width;
-        // AddInfinitesimalNoise: the per-bin draws continue the frame's stream after the
-        // window draws (cheaptrick.cpp:147-151); then the log of SmoothingWithRecovery (:39-42)
-        return log(smoothed + fabs(randn_value(noise[wlen + i])) * kEps);
+        return log(smoothed + P[i]);                   // the log of SmoothingWithRecovery (cheaptrick.cpp:39-42)
       },
       [&](int i, double lg) { P[i] = lg; });
+    __syncthreads();                                   // the transforms below overwrite the segment
   }
 
   WH_STAMP(0, 7);
   // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
   // the symmetric extension of the log spectrum is read by the first FFT stage directly from P.
-  // Lifters: sin(pi f0 q) / (pi f0 q) and (1 - 2 q1) + 2 q1 cos(2 pi f0 q) at quefrency q = k / fs; with
-  // a = f0 k / fs both come from ONE sinpi: cos(2 pi a) = 1 - 2 sin^2(pi a).
   const double q1 = p.q1, f0_over_fs = cf0 / fs;
+  (void)q1; (void)f0_over_fs;
   auto mirrored = [&](int i) { return i <= half ? P[i] : P[N - i]; };
   block_rfft_from<kCtMaxLr, LGN>(Z, lgn, tw, [&](int n) { cplx v; v.re = mirrored(2 * n); v.im = mirrored(2 * n + 1); return v; },
                   [&](int k, double re, double im) {
     (void)im;
+#ifdef CT_LIFTER_TABLE
+    P[k] = re * lift[k] * inv_n;
+#else
+    // Lifters: sin(pi f0 q) / (pi f0 q) and (1 - 2 q1) + 2 q1 cos(2 pi f0 q) at quefrency q = k / fs; with
+    // a = f0 k / fs both come from ONE sinpi: cos(2 pi a) = 1 - 2 sin^2(pi a).
     double sl, cl;
     if (k == 0) {
       sl = 1.0;
@@ -310,6 +395,7 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_envelope(CtParams p)
       cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * sp * sp);
     }
     P[k] = re * sl * cl * inv_n;                        // == .. / N: N is a power of two
+#endif
   });
   WH_STAMP(0, 8);
   block_irfft<kCtMaxLr, LGN>(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
@@ -326,18 +412,13 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? 4 : 1) ct_envelope(CtParams p)
 }
 
 // ---------------------------------------------------------------------------
-size_t ct_spectrum_lds_bytes(int lg_fft) {
+size_t ct_frame_lds_bytes(int lg_fft) {
   int N = 1 << lg_fft, nb = N / 2 + 1;
-  return sizeof(double) * (size_t)(N + nb + 1 + ((nb + 1) & 1) + 64 + N / 8 + 2);
-}
-size_t ct_envelope_lds_bytes(int lg_fft) {
-  int N = 1 << lg_fft, nb = N / 2 + 1;
-  return sizeof(double) * (size_t)(ct_seg_cap(N) + nb + 1 + ((nb + 1) & 1) + 64 + N / 8 + 2);
-}
-// room for the longest segment rounded up to whole rings of ct_scan, plus the ring it prefetches beyond
-int ct_seg_stride(int fft_size) {
-  const int ring = kScanDepth * kScanBatch;
-  return ((ct_seg_cap(fft_size) + ring - 1) / ring + 1) * ring;
+  size_t doubles = (size_t)(ct_seg_cap(N) + nb + 1 + ((nb + 1) & 1) + 64 + N / 8 + 2);
+#ifdef CT_LIFTER_TABLE
+  doubles += nb + 1;
+#endif
+  return sizeof(double) * doubles;
 }
 
 size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size / 2 + 1; }   // window < fft_size, + bins
@@ -347,37 +428,18 @@ void launch_cheaptrick(const CtParams &p, int max_frames_all, hipStream_t stream
   const int max_frames = imin(max_frames_all, p.frame_hi) - p.frame_lo;          // frames of the range
   if (max_frames <= 0) return;
   const dim3 grid(max_frames, p.b.n_utt);
-  const size_t lds1 = ct_spectrum_lds_bytes(p.lg_fft), lds3 = ct_envelope_lds_bytes(p.lg_fft);
-  const dim3 scan_grid((max_frames + WAVE - 1) / WAVE, p.b.n_utt);
+  const size_t lds = ct_frame_lds_bytes(p.lg_fft);
 #ifdef WORLD_EMU
-  devrt::launch_blocks("ct_spectrum", ct_spectrum<8192, 0>, grid, 256, lds1, stream, p);
-  WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
-  devrt::launch_blocks("ct_envelope", ct_envelope<0>, grid, 256, lds3, stream, p);
+  devrt::launch_blocks("ct_frame", ct_frame<8192, 0>, grid, 256, lds, stream, p);
 #else
   // Workgroup size follows the transform: fft_size 1024 (fs <= 24 kHz) runs with 128 threads (64 butterflies per
   // radix-8 stage; measured 1.33 ms for 64 x 1001 frames against 1.60 with 256 threads and 1.49 with 64), 2048 and
   // 4096 with 256.  The three sizes the sampling rates of speech lead to get compile-time plans.
-  if (p.lg_fft == 10) {
-    devrt::launch_blocks("ct_spectrum", ct_spectrum<8, 10>, grid, 128, lds1, stream, p);
-    WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
-    devrt::launch_blocks("ct_envelope", ct_envelope<10>, grid, 128, lds3, stream, p);
-  } else if (p.lg_fft == 11) {
-    devrt::launch_blocks("ct_spectrum", ct_spectrum<8, 11>, grid, 256, lds1, stream, p);
-    WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
-    devrt::launch_blocks("ct_envelope", ct_envelope<11>, grid, 256, lds3, stream, p);
-  } else if (p.lg_fft == 12) {
-    devrt::launch_blocks("ct_spectrum", ct_spectrum<16, 12>, grid, 256, lds1, stream, p);
-    WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
-    devrt::launch_blocks("ct_envelope", ct_envelope<12>, grid, 256, lds3, stream, p);
-  } else if (p.lg_fft == 13) {
-    devrt::launch_blocks("ct_spectrum", ct_spectrum<16, 0, 512>, grid, 512, lds1, stream, p);
-    WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
-    devrt::launch_blocks("ct_envelope", ct_envelope<0, 512>, grid, 512, lds3, stream, p);
-  } else {
-    devrt::launch_blocks("ct_spectrum", ct_spectrum<8, 0>, grid, 128, lds1, stream, p);
-    WH_BLOCKS(ct_scan, scan_grid, WAVE, 0, stream, p);
-    devrt::launch_blocks("ct_envelope", ct_envelope<0>, grid, 128, lds3, stream, p);
-  }
+  if (p.lg_fft == 10) devrt::launch_blocks("ct_frame", ct_frame<8, 10>, grid, 128, lds, stream, p);
+  else if (p.lg_fft == 11) devrt::launch_blocks("ct_frame", ct_frame<8, 11>, grid, 256, lds, stream, p);
+  else if (p.lg_fft == 12) devrt::launch_blocks("ct_frame", ct_frame<16, 12>, grid, 256, lds, stream, p);
+  else if (p.lg_fft == 13) devrt::launch_blocks("ct_frame", ct_frame<16, 0, 512>, grid, 512, lds, stream, p);
+  else devrt::launch_blocks("ct_frame", ct_frame<8, 0>, grid, 128, lds, stream, p);
 #endif
 }
 

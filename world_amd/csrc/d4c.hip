@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   constexpr int nt = T;                                                // launch_d4c launches exactly T threads
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
-  const bool trace_me = f == 1000; (void)trace_me;
+  const bool trace_me = f == WH_TRACE_FRAME && u == WH_TRACE_UTT; (void)trace_me;
   WH_STAMP(32, 0);
   // On the GPU the transform length is the shape's (launch_d4c picks the instantiation), so the plan, every
   // stage's radix and stride and the digit reversal of the merge steps are compile-time constants.

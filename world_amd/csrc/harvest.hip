@@ -321,8 +321,13 @@ __device__ __forceinline__ double hv_gate(const HarvestParams &p, int band, doub
 }
 __global__ void __launch_bounds__(kRawFrames) hv_raw_candidates(HarvestParams p) {
   DYN_LDS(lds);
-  const int band = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
-  const int f_begin = blockIdx.x * kRawRun, f_end = imin(f_begin + kRawRun, p.nfb[u]);
+  // Bands are the fastest grid dimension, padded to a multiple of the eight XCDs: workgroups go to the XCDs round robin,
+  // so every run of one band's lists is served by the same L2 and a list crosses the fabric once.  (Runs fastest, the
+  // 20 runs of a list were spread over all eight L2s, each fetching the list's head and tail for the proportional
+  // guess and its neighbours' boundary intervals: 3.4 x the lists' size in fetches.)
+  const int band = blockIdx.x, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+  if (band >= p.nch) return;
+  const int f_begin = blockIdx.y * kRawRun, f_end = imin(f_begin + kRawRun, p.nfb[u]);
   if (f_begin >= f_end) return;
   const int *cnt = p.ev_count + (u * p.nch + band) * 4;
   const double *ev = p.events + ((size_t)(u * p.nch + band) * 4) * p.ev_cap;
@@ -433,7 +438,11 @@ __global__ void hv_detect(HarvestParams p) {
     fetch(va, j0 + 2 * kBatch);
     walk(vb, j0 + kBatch);
   }
-  for (int j = cnt; j < p.maxc; ++j) out[j] = 0.0;
+  // Empty slots up to the most a frame can hold: voiced runs are >= 10 bands long and a band apart, bands 0 and nch - 1
+  // never voiced -- at most (nch - 1) / 11 of them.  (Nobody reads a slot beyond the utterance's largest count, p.nc; the
+  // rows are maxc = 7 x that wide for hv_refine's overlapped set, and zeroing all of it was 7/8 of this kernel's stores.)
+  const int zcap = imin(p.maxc, (p.nch + 10) / 11 + 1);
+  for (int j = cnt; j < zcap; ++j) out[j] = 0.0;
   if (cnt > 0) atomicMax(p.nc + u, cnt);
 }
 
@@ -811,7 +820,7 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   }
   // one chunk per utterance: the kernel above appended straight into the final lists (seg_events == events)
   if (!(p.fft_seg > 0 && p.nseg == 1)) WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, compact_lds_bytes(p.nseg), stream, p);
-  WH_BLOCKS(hv_raw_candidates, dim3((max_fb + kRawRun - 1) / kRawRun, p.nch, B), kRawFrames,
+  WH_BLOCKS(hv_raw_candidates, dim3((p.nch + 7) / 8 * 8, (max_fb + kRawRun - 1) / kRawRun, B), kRawFrames,
             8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
   WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);

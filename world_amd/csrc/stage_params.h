@@ -15,8 +15,6 @@ struct CtParams {
   size_t out_col_bytes;  // bytes from a row's start to this stage's first value (0 for the dense layout)
   int out_f32;           // 1: the row's values are stored as float (the narrow wire format of the multi-GPU exchange)
   unsigned *offsets;     // [n_utt][f_stride] stream position of each frame's first draw
-  double *seg;           // [n_utt][ceil(f_stride / WAVE)][seg_stride][WAVE] LinearSmoothing's mirrored segment / prefix sums
-  int seg_stride;
   const uint32_t *noise; // randn_value(noise[k]) = k-th randn() of the stream (context-wide table)
   Tables tab;
   double q1;
@@ -61,7 +59,6 @@ struct D4cParams {
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream);
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
 size_t ct_max_draws_per_frame(int fft_size);
-int ct_seg_stride(int fft_size);
 size_t d4c_max_draws_per_frame(int fs);
 
 }  // namespace world_hip

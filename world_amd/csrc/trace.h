@@ -3,6 +3,14 @@
 // are read back through world_hip_trace_read_<unit>() (tools/trace.py prints the deltas).
 // In-situ phase latencies are what rocprofv3's per-kernel totals cannot show.
 #pragma once
+// which workgroup of the frame kernels stamps: frame WH_TRACE_FRAME of utterance WH_TRACE_UTT (tools/trace.py: a lone 10 s
+// utterance; tools/trace_batch.py: the middle of a 64 x 5 s batch, every CU loaded with other frames' workgroups)
+#ifndef WH_TRACE_FRAME
+#define WH_TRACE_FRAME 1000
+#endif
+#ifndef WH_TRACE_UTT
+#define WH_TRACE_UTT 0
+#endif
 #if defined(WH_TRACE) && !defined(WORLD_EMU)
 namespace world_hip { static __device__ long long wh_trace[128]; }   // one per translation unit
 #define WH_TRACE_DEFINE(unit)                                                                        \

@@ -88,6 +88,22 @@ def test_matches_oracle_on_fresh_signals(hip, oracle, fs, seconds, kind):
     assert max_rel(hip.d4c(x, fs, tp_o, f0_o, fft), oracle.d4c(x, fs, tp_o, f0_o, fft)) <= RTOL
 
 
+def test_harvest_ceiling_above_the_staged_interval_capacity(hip, oracle):
+    """f0_ceil 1600 Hz: the upper bands' event lists hold ~450 intervals per 0.256 s run of hv_raw_candidates, more than
+    the 288 a workgroup stages in LDS (bandfilter.h: kIntervalCap) -- those runs interpolate straight from the lists;
+    a tone gliding from 1.0 to 1.3 kHz makes the bands in question voiced."""
+    fs = 48000
+    t = np.arange(int(0.9 * fs)) / fs
+    ph = 2 * np.pi * np.cumsum(1000.0 + 300.0 * t / 0.9) / fs
+    x = 0.4 * np.sin(ph) + 0.2 * np.sin(2 * ph) + 0.1 * np.sin(3 * ph) + 0.001 * np.random.default_rng(5).standard_normal(len(t))
+    for opt in (dict(f0_ceil=1600.0), dict(f0_floor=60.0, f0_ceil=2000.0, frame_period=2.0)):
+        tp_o, f0_o = oracle.harvest(x, fs, **opt)
+        tp, f0 = hip.harvest(x, fs, **opt)
+        assert np.array_equal(tp, tp_o)
+        assert_f0_close(f0, f0_o)
+        assert (f0_o > 900.0).any()                        # the high bands did produce candidates
+
+
 def test_edge_cases(hip, oracle):
     """tiny / ragged / silent / clipped inputs and unusual options"""
     from world_amd import synth

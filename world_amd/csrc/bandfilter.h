@@ -499,9 +499,14 @@ struct IntervalRange {       // per family, in LDS
   int j_lo, m;               // staged intervals [j_lo, j_lo + m)
 };
 #ifndef HV_INTERVAL_CAP
-#define HV_INTERVAL_CAP 384
+#define HV_INTERVAL_CAP 288
 #endif
-constexpr int kIntervalCap = HV_INTERVAL_CAP;   // staged intervals per family (a 0.256 s run holds <= ~340 at 1.3 kHz): 24.6 KB, 6 workgroups per CU
+// staged intervals per family: a 0.256 s run holds 225 + margins at the default ceiling's 880 Hz (a run with more takes
+// the unstaged route: same result, tests/test_gpu_parity.py::test_harvest_ceiling_above_the_staged_interval_capacity).
+// 18.4 KB: eight workgroups per CU -- the kernel is a chain of four trips to memory, so its time is the number of
+// workgroups a CU can keep waiting at once (384 intervals, six workgroups: 1.99 ms per 128 utterances; 288 with the 64
+// registers of eight: 1.76)
+constexpr int kIntervalCap = HV_INTERVAL_CAP;
 
 __device__ __forceinline__ void interval_range_ends(const double *e, int n_int, double fs, double t, bool last,
                                                     IntervalRange *r) {

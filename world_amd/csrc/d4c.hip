@@ -240,8 +240,12 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 // routine -- same result, every thread of the block takes the same path.
 // key[0 .. kKeys-2): owned by every thread; key[kKeys-2]: thread 0 only (the merge's unpaired bin), 0 elsewhere;
 // key[kKeys-1]: 0.  hist: 1344 ints of LDS.  K: how many of the largest keys are EXCLUDED from *partial.
+// Returns true when *partial / *total are the BLOCK's sums (the general routine ran), false when they are the calling
+// wavefront's share of them: the caller adds the wavefronts' shares up whenever it next crosses a barrier anyway (the
+// block sum here -- LDS, barrier, LDS -- was a quarter of the routine's time in a CU whose LDS pipe is busy with other
+// workgroups' transforms: every dependent trip through it costs ~750 cycles there).
 template <int NT, int kKeys>
-__device__ __forceinline__ void block_excluding_largest(const unsigned long long (&key)[kKeys], int K, int *hist, double *scratch,
+__device__ __forceinline__ bool block_excluding_largest(const unsigned long long (&key)[kKeys], int K, int *hist, double *scratch,
                                                         double *partial, double *total, bool trace_me = false) {
   (void)trace_me;
   constexpr int kFull = kKeys - 2, nw = NT / WAVE;
@@ -346,7 +350,7 @@ __device__ __forceinline__ void block_excluding_largest(const unsigned long long
     __syncthreads();                                                      // nobody is still reading the bins
     // the general routine: every slot counts as a key (the zeros are the smallest and add nothing)
     block_smallest_sum<NT>(key, kKeys, NT * kKeys, NT * kKeys - K, hist, scratch, partial, total, trace_me);
-    return;
+    return true;
   }
   double s_lt = 0.0, s_all = 0.0;
 #pragma unroll
@@ -361,9 +365,9 @@ __device__ __forceinline__ void block_excluding_largest(const unsigned long long
     s_lt += hx < t_low ? x : 0.0;
   }
   WH_STAMP(0, 8);
-  block_sum2<NT, false>(s_lt, s_all, scratch);                             // doubles 0..35: last read before this band's passes
-  *partial = s_lt;
-  *total = s_all;
+  *partial = wave_sum(s_lt);
+  *total = wave_sum(s_all);
+  return false;
 }
 #endif
 
@@ -938,6 +942,10 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   int mine = 0;
   for_nat([&](int, int) { ++mine; });
   int *hist = reinterpret_cast<int *>(Zr);
+#ifndef WORLD_EMU
+  constexpr int kWaves = T / WAVE;
+  double *band_sums = park + (H + 2);                   // [band][partial, total][wavefront]: d4c_frame_lds_bytes
+#endif
   // the Nuttall taps of the thread's own slice element: the same for every band
   const double nut0 = 2 * tid < wl ? p.nuttall[2 * tid] : 0.0, nut1 = 2 * tid + 1 < wl ? p.nuttall[2 * tid + 1] : 0.0;
   for (int band = 0; band < p.nap; ++band) {
@@ -997,15 +1005,32 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     double part, tot;
 #if defined(WORLD_EMU) || defined(D4C_OLD_SELECT)
     block_smallest_sum<T>(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
-#else
-    (void)mine;
-    block_excluding_largest<T>(key, bnd + 1, hist, scratch, &part, &tot, trace_me);   // the bnd + 1 largest of the H + 1 bins
-#endif
     // the band's two sums; d4c_finish turns them into dB (d4c.cpp:221-224, 314-316) -- a division and a log10 on
     // one lane here would stand between this band's select and the next band's first barrier
     if (tid == 0) { p.coarse[fi * 16 + 1 + band] = part; p.coarse[fi * 16 + 9 + band] = tot; }
+#else
+    (void)mine;
+    // the bnd + 1 largest of the H + 1 bins excluded; each wavefront parks its share of the band's two sums
+    const bool whole = block_excluding_largest<T>(key, bnd + 1, hist, scratch, &part, &tot, trace_me);
+    if (lane_id() == 0) {
+      const int wv = wave_in_block();
+      band_sums[(2 * band) * kWaves + wv] = whole && wv > 0 ? 0.0 : part;
+      band_sums[(2 * band + 1) * kWaves + wv] = whole && wv > 0 ? 0.0 : tot;
+    }
+#endif
     if (band == 0) WH_STAMP(32, 18);
   }
+#ifndef WORLD_EMU
+  __syncthreads();
+  if (tid < 2 * p.nap) {                                  // thread b: band b's partial sum, thread nap + b: its total
+    const int band = tid < p.nap ? tid : tid - p.nap, which = tid < p.nap ? 0 : 1;
+    const double *w = band_sums + (2 * band + which) * kWaves;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) t += w[k];           // wavefront order, from zero: the block sum's own order
+    p.coarse[fi * 16 + (which ? 9 : 1) + band] = t;
+  }
+#endif
   WH_STAMP(32, 19);
 }
 
@@ -1061,9 +1086,10 @@ __global__ void d4c_finish(D4cParams p) {
 // ---------------------------------------------------------------------------
 size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) + 64 + (1 << lg) / 8 + 2); }
 // Z (N doubles) | scratch (64) | quarter-wave table of the N/2-point complex transform | the group delay (N/2 + 2; N <= 4096 only)
+// | the wavefronts' shares of the bands' sums (8 bands x 2 x N / 1024 wavefronts)
 size_t d4c_frame_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(N + 64 + twiddle_lds_doubles(lg - D4C_TW_LEVEL) + N / 2 + 2);
+  return sizeof(double) * (size_t)(N + 64 + twiddle_lds_doubles(lg - D4C_TW_LEVEL) + N / 2 + 2 + 16 * std::max(1, N / 1024));
 }
 int d4c_frame_threads(int lg) { return (1 << lg) / 16; }   // one radix-8 butterfly per thread and stage
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz

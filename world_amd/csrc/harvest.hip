@@ -319,7 +319,10 @@ __device__ __forceinline__ double hv_gate(const HarvestParams &p, int band, doub
   if (c > fb * 1.1 || c < fb * 0.9 || c > p.f0_ceil || c < p.f0_floor) c = 0.0;
   return c;
 }
-__global__ void __launch_bounds__(kRawFrames) hv_raw_candidates(HarvestParams p) {
+#ifndef HV_RAW_MIN_WG
+#define HV_RAW_MIN_WG 8                                // workgroups per CU the register allocation leaves room for (bandfilter.h: kIntervalCap)
+#endif
+__global__ void __launch_bounds__(kRawFrames, HV_RAW_MIN_WG) hv_raw_candidates(HarvestParams p) {
   DYN_LDS(lds);
   // Bands are the fastest grid dimension, padded to a multiple of the eight XCDs: workgroups go to the XCDs round robin,
   // so every run of one band's lists is served by the same L2 and a list crosses the fabric once.  (Runs fastest, the

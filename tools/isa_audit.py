@@ -6,7 +6,8 @@ round 3 the most lone-job latency:
      lane-varying condition (`cond ? p[i] : 0`: the value is waited for where the branch rejoins), a prefetch under `if`
      (the wait-count bookkeeping gives up at the join), a loop `dst[i] = f(src[i])` the compiler may not reorder;
   2. innermost loops that wait for a load they issued in the same trip with at most three loads in flight (harmless for
-     short trip counts -- twiddle tables -- and a trip to memory per iteration otherwise).
+     short trip counts -- twiddle tables -- and a trip to memory per iteration otherwise);
+  3. the same for LDS: innermost loops that wait for the one or two ds_reads of the trip (waiting_lds_loops).
 
     python tools/isa_audit.py [unit ...]        # default: every .hip under world_amd/csrc
 """
@@ -77,6 +78,35 @@ def waiting_loops(lines):
     return found
 
 
+def waiting_lds_loops(lines):
+    """innermost loops that read LDS and wait for it (lgkmcnt(0)) every trip with at most two reads in flight: a trip
+    through the LDS pipe per iteration -- ~100 cycles on an idle CU, ~750 in one whose other workgroups run transforms
+    (tools/trace_batch.py).  Round 4 found hv_band_events_fft's mirror-store loop this way (10.5 k of a block's 47 k cycles)."""
+    found, kern = [], None
+    for n, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            kern = m.group(1)
+        m = re.match(r"^(\.LBB\d+_\d+):.*Inner Loop Header", l)
+        if not m:
+            continue
+        lab, end = m.group(1), None
+        for k in range(n + 1, min(n + 4000, len(lines))):
+            if re.search(r"s_c?branch\w*\s+" + re.escape(lab) + r"\b", lines[k]):
+                end = k
+                break
+            if re.match(r"^_Z\w+:", lines[k]):
+                break
+        if end is None:
+            continue
+        body = lines[n:end + 1]
+        reads = sum(1 for b in body if re.search(r"\bds_read", b))
+        waits = sum(1 for b in body if re.search(r"s_waitcnt.*lgkmcnt\(0\)", b))
+        if reads and waits and reads <= 2:
+            found.append((kern, lab, len(body), reads))
+    return found
+
+
 def main():
     units = sys.argv[1:] or sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(SRC, "*.hip")))
     with tempfile.TemporaryDirectory() as tmp:
@@ -86,6 +116,8 @@ def main():
                 print(f"{unit:18s} {demangle(kern):88s} chained load-wait pairs: {run}")
             for kern, lab, size, loads in waiting_loops(lines):
                 print(f"{unit:18s} {demangle(kern):88s} loop {lab} ({size} instructions) waits for its {loads} load(s) every trip")
+            for kern, lab, size, reads in waiting_lds_loops(lines):
+                print(f"{unit:18s} {demangle(kern):88s} loop {lab} ({size} instructions) waits for its {reads} LDS read(s) every trip")
 
 
 if __name__ == "__main__":

@@ -48,3 +48,11 @@ for k in range(1, 20):
         prev = t[k]
 t = stamps("d4c")[0:10]
 print("  select (last band) stamps:", [t[k] - t[0] for k in range(1, 10) if t[k]])
+t = stamps("hv")[:8]
+print("hv_refine (one wavefront, utterance / 1 ms frame of the build): cache fill", t[0], "window rebuilds", t[1], "DFT+reduce", t[2],
+      "tails", t[3], "refined candidates", t[4])
+t = stamps("hv")[24:31]
+print("hv_band_events_fft (band 20, first block): twiddle table", t[1] - t[0], "H to registers", t[2] - t[1],
+      "X * H + pre-twiddle", t[3] - t[2], "c2r stages", t[4] - t[3], "mirror-store term", t[5] - t[4], "events", t[6] - t[5])
+t = stamps("hv")[32:35]
+print("   its events phase (summed over the chunk's blocks): sample reads + masks", t[0], "block scan", t[1], "edge times + stores", t[2])

@@ -172,13 +172,13 @@ __device__ __forceinline__ void ct_wave_prefix_sum(double *seg, int seg_len) {
 // -> exp, from x to the spectrogram row without touching HBM in between ---------------------------------------------------
 // PER: samples of the window a thread owns (fft_size / threads); LGN: log2(fft_size) when it is a compile-time
 // constant of the instantiation (static FFT stages), 0 = taken from p.lg_fft.
-// TB: the largest workgroup the instantiation is launched with (512 for the 8192-point transform: one frame then owns
-// 107 KB of LDS, one workgroup per CU -- the shape exists so that f0 floors below 35 Hz at 48 kHz and sampling rates
-// above 96 kHz run at all, not to be fast)
-template <int PER, int LGN, int TB = 256>
+// TB: the threads the instantiation is launched with (0: read from the launch -- the emulator's one thread).  512 for
+// the 8192-point transform: one frame then owns 118 KB of LDS, one workgroup per CU -- the shape exists so that f0 floors
+// below 35 Hz at 48 kHz and sampling rates above 96 kHz run at all, not to be fast.
+template <int PER, int LGN, int TB>
 // (the 4096-point frame owns 59 KB of LDS: two workgroups per CU whatever the registers, so it may have 256 of them --
 // its 48 window values per thread spilled at the 128 of four workgroups per CU)
-__global__ void __launch_bounds__(TB, TB <= 256 ? (LGN == 12 ? 2 : 4) : 1) ct_frame(CtParams p) {
+__global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 2 : 4) ct_frame(CtParams p) {   // (threads, waves per SIMD)
   DYN_LDS(lds);
   const int lgn = LGN > 0 ? LGN : p.lg_fft, N = 1 << lgn, half = N / 2, nb = half + 1;
   const int fs = p.b.fs;
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? (LGN == 12 ? 2 : 4) : 1) ct_fr
   const double pos = p.tpos[fi];
   const double cf0 = ct_effective_f0(p.f0[fi], p.f0_floor);
   const uint32_t *noise = p.noise + p.offsets[fi];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = wg_thread<TB>(), nt = wg_size<TB>();
 
   WH_STAMP(0, 1);
   // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) -------------------------
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? (LGN == 12 ? 2 : 4) : 1) ct_fr
         rc = t;
       }
     }
-    block_sum4(s_ww, s_a, s_n, s_w, scratch);
+    block_sum4<TB>(s_ww, s_a, s_n, s_w, scratch);
     const double c = 1.0 / sqrt(s_ww);
     const double cc = c * ((c * s_a + s_n) / (c * s_w));
 #pragma unroll
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(TB, TB <= 256 ? (LGN == 12 ? 2 : 4) : 1) ct_fr
   // the window's (cheaptrick.cpp:147-151) -- into P, whose power spectrum is dead, and the lifter of
   // SmoothingWithRecovery.  (One wavefront -- the emulator's one thread, a 64-thread launch -- does both in turn.)
   {
-    const int waves = waves_per_block();
+    const int waves = wg_waves<TB>();
     constexpr int scan_wave = 0;        // (rotating the chain over the wavefronts, i.e. the SIMDs, by frame: 5.26 ms against 5.06)
     const int helpers = waves > 1 ? nt - WAVE : nt;
     const bool helper = waves == 1 || wave_in_block() != scan_wave;
@@ -430,16 +430,16 @@ void launch_cheaptrick(const CtParams &p, int max_frames_all, hipStream_t stream
   const dim3 grid(max_frames, p.b.n_utt);
   const size_t lds = ct_frame_lds_bytes(p.lg_fft);
 #ifdef WORLD_EMU
-  devrt::launch_blocks("ct_frame", ct_frame<8192, 0>, grid, 256, lds, stream, p);
+  devrt::launch_blocks("ct_frame", ct_frame<8192, 0, 0>, grid, 256, lds, stream, p);
 #else
   // Workgroup size follows the transform: fft_size 1024 (fs <= 24 kHz) runs with 128 threads (64 butterflies per
   // radix-8 stage; measured 1.33 ms for 64 x 1001 frames against 1.60 with 256 threads and 1.49 with 64), 2048 and
   // 4096 with 256.  The three sizes the sampling rates of speech lead to get compile-time plans.
-  if (p.lg_fft == 10) devrt::launch_blocks("ct_frame", ct_frame<8, 10>, grid, 128, lds, stream, p);
-  else if (p.lg_fft == 11) devrt::launch_blocks("ct_frame", ct_frame<8, 11>, grid, 256, lds, stream, p);
-  else if (p.lg_fft == 12) devrt::launch_blocks("ct_frame", ct_frame<16, 12>, grid, 256, lds, stream, p);
+  if (p.lg_fft == 10) devrt::launch_blocks("ct_frame", ct_frame<8, 10, 128>, grid, 128, lds, stream, p);
+  else if (p.lg_fft == 11) devrt::launch_blocks("ct_frame", ct_frame<8, 11, 256>, grid, 256, lds, stream, p);
+  else if (p.lg_fft == 12) devrt::launch_blocks("ct_frame", ct_frame<16, 12, 256>, grid, 256, lds, stream, p);
   else if (p.lg_fft == 13) devrt::launch_blocks("ct_frame", ct_frame<16, 0, 512>, grid, 512, lds, stream, p);
-  else devrt::launch_blocks("ct_frame", ct_frame<8, 0>, grid, 128, lds, stream, p);
+  else devrt::launch_blocks("ct_frame", ct_frame<8, 0, 128>, grid, 128, lds, stream, p);
 #endif
 }
 

@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
     }
     block_rfft<3, LGN>(Z, lgn, tw, band_power);
   }
-  block_sum2(lo, hi, scratch);
+  block_sum2<LGN == 11 ? 128 : LGN == 12 ? 256 : 0>(lo, hi, scratch);   // (launch_d4c's workgroup sizes: the wavefronts' shares are read together)
   if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
 }
 

@@ -214,8 +214,13 @@ template <int NT> __device__ __forceinline__ int wg_size() {
   if constexpr (NT > 0) return NT; else return (int)blockDim.x;
 }
 template <int NT> __device__ __forceinline__ int wg_thread() {
-  const int t = (int)threadIdx.x;
+  int t = (int)threadIdx.x;
 #ifndef WORLD_EMU
+#ifdef WH_FRESH_TID
+  // a unit's choice (harvest.hip): an opaque copy per call, so that what a stage derives from the thread index (LDS
+  // addresses, butterfly numbers) is recomputed where it is used instead of living in registers across a kernel's outer loop
+  if constexpr (NT > 0) asm volatile("" : "+v"(t));
+#endif
   if constexpr (NT > 0) __builtin_assume(t >= 0 && t < NT);
 #endif
   return t;

@@ -267,6 +267,9 @@ template <int NT, int WR> struct BflyMap {
     if constexpr (WR >= 0) return 1 << WR; else return 0;
   }
 };
+// butterflies of one thread whose inputs are read together (dif_stage, dit_stage): the 2^WR of a wave-region stage, a
+// pair for other small radices, one for the radix-8 / 16 stages (16 .. 32 registers of operands each)
+template <int LR, int WR> __host__ __device__ constexpr int fft_gather() { return LR > 2 ? 1 : (WR >= 0 ? (1 << WR) : 2); }
 template <int LR, int NT = 0, int WR = -1> __device__ __forceinline__ void dif_stage(cplx *z, int lg, int lev, const TwLds &tw) {
   constexpr int R = 1 << LR;
   const int sh = lev - LR, q = 1 << sh, nbf = 1 << (lg - LR);
@@ -274,6 +277,37 @@ template <int LR, int NT = 0, int WR = -1> __device__ __forceinline__ void dif_s
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = swz(r << sh);
   const int b_end = WR >= 0 ? BflyMap<NT, WR>::first() + (64 << (WR >= 0 ? WR : 0)) : nbf;
+  // Small butterflies come several to a thread (the remainder stage of a plan: 2 radix-4 or 4 radix-2 per thread): their
+  // inputs are ALL read before any output is stored.  Written one butterfly after the other, the second one's reads
+  // wait behind the first one's stores -- the compiler cannot know they do not alias -- and a stage is two or four
+  // trips through the LDS pipe instead of one: ~750 cycles each in a CU whose other workgroups run their transforms
+  // (tools/trace_batch.py; tools/isa_audit.py lists such loops).
+  constexpr int kGather = fft_gather<LR, WR>();
+  if constexpr (kGather > 1) {
+    const int step = BflyMap<NT, WR>::step();
+    for (int b0 = BflyMap<NT, WR>::first(); b0 < b_end; b0 += kGather * step) {
+      cplx a[kGather][R];
+      int s0[kGather], j[kGather];
+#pragma unroll
+      for (int t = 0; t < kGather; ++t) {
+        const int b = b0 + t * step < b_end ? b0 + t * step : b0;       // (a missing butterfly re-reads the first: never stored)
+        j[t] = b & (q - 1);
+        s0[t] = swz(((b >> sh) << lev) + j[t]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[t][r] = z[s0[t] ^ c[r]];
+      }
+#pragma unroll
+      for (int t = 0; t < kGather; ++t) {
+        dft_reg<true, LR>(a[t]);
+        if (q > 1) mul_powers<LR>(a[t], twiddle(tw, j[t], lev, -1));
+        if (b0 + t * step < b_end) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) z[s0[t] ^ c[k]] = a[t][k];
+        }
+      }
+    }
+    return;
+  }
   for (int b = BflyMap<NT, WR>::first(); b < b_end; b += BflyMap<NT, WR>::step()) {
     const int j = b & (q - 1);
     const int s0 = swz(((b >> sh) << lev) + j);      // bits [sh, lev) of the base index are clear
@@ -347,6 +381,33 @@ __device__ __forceinline__ void dit_stage(cplx *z, int lg, int done, const TwLds
 #pragma unroll
   for (int r = 0; r < R; ++r) c[r] = swz(r << done);
   const int b_end = WR >= 0 ? BflyMap<NT, WR>::first() + (64 << (WR >= 0 ? WR : 0)) : nbf;
+  constexpr int kGather = fft_gather<LR, WR>();        // dif_stage: a thread's small butterflies are read together
+  if constexpr (kGather > 1) {
+    const int step = BflyMap<NT, WR>::step();
+    for (int b0 = BflyMap<NT, WR>::first(); b0 < b_end; b0 += kGather * step) {
+      cplx a[kGather][R];
+      int s0[kGather], j[kGather], base[kGather];
+#pragma unroll
+      for (int t = 0; t < kGather; ++t) {
+        const int b = b0 + t * step < b_end ? b0 + t * step : b0;
+        j[t] = b & (q - 1);
+        base[t] = ((b >> done) << L) + j[t];
+        s0[t] = swz(base[t]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[t][r] = z[s0[t] ^ c[r]];
+      }
+#pragma unroll
+      for (int t = 0; t < kGather; ++t) {
+        if (q > 1) mul_powers<LR>(a[t], twiddle(tw, j[t], L, +1));
+        dft_reg<false, LR>(a[t]);
+        if (b0 + t * step < b_end) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) z[s0[t] ^ c[k]] = epi(base[t] + (k << done), a[t][k]);
+        }
+      }
+    }
+    return;
+  }
   for (int b = BflyMap<NT, WR>::first(); b < b_end; b += BflyMap<NT, WR>::step()) {
     const int j = b & (q - 1);
     const int base = ((b >> done) << L) + j;         // bits [done, L) of the base index are clear
@@ -558,8 +619,7 @@ __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan
   // bin k = h/2.  Every bin in [0, h] is emitted exactly once, <= 2 ceil((h/2+1)/T) per thread.
   const int top_bit = plan.rl(plan.ns - 1) - 1;
   struct Pair { int k; double ar, ai, br, bi; };      // bins k and h-k (k = 0: DC and Nyquist; k = h/2: a only)
-  block_map<2, Pair>(q + 1,
-    [&](int it) {
+  auto item = [&](int it) {
       Pair r;
       if (it < q) {
         const int pos = ((it >> top_bit) << (top_bit + 1)) | (it & ((1 << top_bit) - 1));
@@ -582,11 +642,19 @@ __device__ __forceinline__ void rfft_merge(cplx *z, int lgn, const FftPlan &plan
         r.k = q; r.ar = za.re; r.ai = -za.im; r.br = 0.0; r.bi = 0.0;
       }
       return r;
-    },
-    [&](int, Pair r) {
+    };
+  auto out = [&](int, Pair r) {
       emit(r.k, r.ar, r.ai);
       if (r.k != q) emit(h - r.k, r.br, r.bi);
-    });
+    };
+  // The q paired items divide evenly among the threads; item q, the odd one out, is read by the LAST thread before
+  // anybody stores (as item q + 1 of the loop it was a trip of its own for thread 0 -- a read waiting behind the first
+  // trip's stores -- with the whole workgroup at the closing barrier meanwhile).
+  const bool odd_one = (int)threadIdx.x == (int)blockDim.x - 1;
+  Pair last;
+  if (odd_one) last = item(q);
+  block_map<2, Pair>(q, item, out);
+  if (odd_one) out(q, last);
   __syncthreads();
 }
 
@@ -676,8 +744,7 @@ __device__ __forceinline__ void irfft_pretwiddle(cplx *z, int lgn, const FftPlan
   // conj(X[h-k]), t = w_k (X[k] - conj(X[h-k])):  Z[k] = s + i t  and  Z[h-k] = conj(s - i t).
   const int q = h >> 1, top_bit = plan.rl(plan.ns - 1) - 1;
   struct Pair { int slot, mslot; cplx r, rm; };
-  block_map<2, Pair>(q + 1,
-    [&](int it) {
+  auto item = [&](int it) {
       Pair o;
       o.mslot = -1;
       if (it < q) {
@@ -701,11 +768,16 @@ __device__ __forceinline__ void irfft_pretwiddle(cplx *z, int lgn, const FftPlan
         o.r.re = 2.0 * x.re; o.r.im = -2.0 * x.im;
       }
       return o;
-    },
-    [&](int, Pair o) {
+    };
+  auto out = [&](int, Pair o) {
       z[o.slot] = o.r;
       if (o.mslot >= 0) z[o.mslot] = o.rm;
-    });
+    };
+  const bool odd_one = (int)threadIdx.x == (int)blockDim.x - 1;     // item q beside the q paired ones: rfft_merge
+  Pair last;
+  if (odd_one) last = item(q);
+  block_map<2, Pair>(q, item, out);
+  if (odd_one) out(q, last);
 }
 // The pre-twiddle for callers whose spectrum lives in GLOBAL memory: items in natural bin order (item it = tid + m T
 // owns bins it and h - it, like rfft_merge_items), so that a wavefront's spec(k) calls touch consecutive addresses.

@@ -18,6 +18,15 @@
 //    FFTs of 128..2048 points per candidate, harvest.cpp:541-584) only ever reads
 //    <= 6 harmonic bins of each spectrum, so it is done as 6-bin DFTs over the
 //    un-padded window: one wavefront per frame, lanes = (harmonic, sample phase).
+// devrt.h: in this unit wg_thread<NT>() hands out opaque copies of the thread index, so that what a transform stage
+// derives from it (LDS addresses, butterfly numbers) is recomputed where it is used.  Hoisted out of
+// hv_band_events_fft's loop over blocks those were ~35 registers; the kernel sat at its 168 with four of them in
+// scratch, reloaded -- a trip to memory each -- at the top of two phases of every block.  134 registers, no scratch,
+// 3 % more vector instructions; the unit's kernels together: 29.5 -> 29.15 ms per 128 utterances.  (d4c.hip keeps the
+// plain index: d4c_frame's 13 % more instructions cost more than its one spilled register.)
+#ifndef HV_PLAIN_TID
+#define WH_FRESH_TID
+#endif
 #include "bandfilter.h"
 #include "decimate.h"
 #include "harvest.h"
@@ -193,7 +202,10 @@ __global__ void __launch_bounds__(256) hv_block_spectra(HarvestParams p) {
 // twiddle table, the merge twiddles and the mirror-store constants are set up once, and the crossings of block after
 // block are APPENDED to the chunk's lists: with one chunk per utterance (batches) those are the final lists and
 // hv_compact_events does not run at all.
-__global__ void __launch_bounds__(256, 3) hv_band_events_fft(HarvestParams p) {
+#ifndef HV_FFT_MIN_WAVES
+#define HV_FFT_MIN_WAVES 4      // 128 registers (two in scratch) and 35 KB of LDS: four workgroups per CU -- 3.79 -> 3.47 ms per 128 utterances against three
+#endif
+__global__ void __launch_bounds__(256, HV_FFT_MIN_WAVES) hv_band_events_fft(HarvestParams p) {
   DYN_LDS(lds);
   const int band = blockIdx.x, chunk = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
   const int n = p.y_len[u];
@@ -205,7 +217,7 @@ __global__ void __launch_bounds__(256, 3) hv_band_events_fft(HarvestParams p) {
     return;
   }
   const int blk1 = imin(blk0 + p.chunk_blocks, (n + p.fft_seg - 1) / p.fft_seg);
-  const bool trace_me = blockIdx.x == 20 && blockIdx.y == 0; (void)trace_me;
+  const bool trace_me = blockIdx.x == 20 && blockIdx.y == 0 && u == WH_TRACE_UTT; (void)trace_me;
   WH_STAMP(24, 0);
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *scratch = reinterpret_cast<double *>(lds) + kBandFft;
@@ -277,6 +289,10 @@ __global__ void __launch_bounds__(256, 3) hv_band_events_fft(HarvestParams p) {
       double sn = sn0, cs = cs0;
       { const double c2 = cs0 * cb - sn0 * sb; sn0 = sn0 * cb + cs0 * sb; cs0 = c2; }     // the next block's phase
       const double sign = (n0 & 1) ? -1.0 : 1.0;
+      // (Round 4 fetched the thread's samples eight at a time before updating any -- written `Z[k] += term` the loop is a
+      // read, a wait and a write per sample -- and measured it slower, 3.80 -> 3.97 ms per 128 utterances: the kernel sits
+      // at its 168 registers, the batch spilled 25 more SGPRs, and what the loop waits for is not the LDS read but the
+      // reload of two spilled registers from scratch.)
       for (int k = tid, j = 0; k < len + 2; k += nt, ++j) {
         const double flip = ((nt & 1) && (j & 1)) ? -sign : sign;     // (-1)^(n0 + j nt)
         rfft_in(Z, k + at0) += flip * (qc * cs + qs * sn + q0);
@@ -477,7 +493,7 @@ __global__ void hv_refine(HarvestParams p) {
   // Every window of this frame is centred on `pos`, so the samples any of them can touch
   // (clamped at the signal ends like GetBaseIndex's safe_index, harvest.cpp:434-441) are
   // fetched from HBM once and kept in LDS.
-  const bool trace_me = frame == 5000; (void)trace_me;
+  const bool trace_me = frame == 5 * WH_TRACE_FRAME && u == WH_TRACE_UTT; (void)trace_me;   // (the 1 ms grid)
   WH_ACC_DECL;
   WH_ACC_BEGIN;
   const int origin = mround(pos * fs) - cap / 2;

@@ -20,7 +20,7 @@ def test_committed_profile_feeds_the_bench_line():
     frames = line["config"]["frames_per_step"]
     assert frames == 2001 and line["config"]["workload"].startswith("configs[1]")
     kernels = {k: {"avg_ms": v, "launches_per_step": 1, "ms_per_step": v} for k, v in line["kernels_ms_per_step"].items()}
-    for dominant in ("d4c_frame", "hv_refine", "hv_band_events_fft", "ct_envelope", "ct_spectrum"):
+    for dominant in ("d4c_frame", "hv_refine", "hv_band_events_fft", "ct_frame"):
         traffic = bench.measured_traffic(dominant, frames)
         assert isinstance(traffic, int) and traffic > 1_000_000, dominant          # bytes per launch
         flops, per_frame = bench.measured_fp64(kernels, frames)

@@ -73,12 +73,12 @@ __device__ __forceinline__ CtSmooth ct_smooth_shape(double cf0, int N, int fs) {
 // ---- LinearSmoothing's prefix sum (common.cpp:85-86), SERIAL and in FP64 order -------------------------------------
 // `hi - lo` of the smoothing cancels up to 12 digits where the envelope sits at the noise floor, so any other summation
 // order moves those bins by 1e-4 (tests/test_gpu_parity.py::test_hard_inputs_vs_oracle): the chain of
-// seg_len dependent additions is walked by ONE lane, in LDS.  What makes it affordable is that nothing else sits on
-// the chain: pairs of values arrive by 16-byte LDS reads a batch ahead of the additions and leave by 16-byte writes
-// behind them, so a step costs the latency of one FP64 add (rounds 1-3 took other routes: the whole workgroup waiting
-// on a lane that read, added and wrote element by element -- 40 k cycles a frame; then a kernel of its own, one lane
-// per frame and 64 chains per wavefront, which needed every frame's segment written to HBM, read, written and read
-// again: 7.6 GB per 128 utterances for a stage whose inputs and outputs are 2.4 GB).
+// seg_len dependent additions is walked in LDS, by one wavefront of the frame's workgroup.  (Rounds 1-3 took other
+// routes: the whole workgroup waiting on a lane that read, added and wrote element by element -- 40 k cycles a frame;
+// then a kernel of its own, one lane per frame and 64 chains per wavefront, which needed every frame's segment written
+// to HBM, read, written and read again: 7.6 GB per 128 utterances for a stage whose inputs and outputs are 2.4 GB.)
+// This is the plain form -- one thread, pairs of values read a batch ahead of the additions -- that the host-compiled
+// test build runs; on the GPU it measured 52 k cycles a frame (below) and the DPP row further down replaced it.
 constexpr int kScanPairs = 8;         // pairs per batch: 16 chained additions between one group of reads and writes
 __device__ __forceinline__ void ct_serial_prefix_sum(double *seg, int seg_len, int cap) {
   double2 *s2 = reinterpret_cast<double2 *>(seg);
@@ -194,9 +194,6 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
   double *P = Zr + cap;
   double *scratch = P + (nb + 1) + ((nb + 1) & 1);
   const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
-#ifdef CT_LIFTER_TABLE
-  double *lift = scratch + 64 + twiddle_lds_doubles(lgn - 1);
-#endif
 
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
@@ -285,39 +282,26 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
     [&](int i, double v) { seg[i] = v; });
   __syncthreads();
   WH_STAMP(0, 5);
-  // Thread 0 walks the chain; the wavefronts it does not belong to meanwhile prepare what the rest of the frame needs
+  // Wavefront 0 walks the chain; the others meanwhile prepare what the rest of the frame needs
   // and the chain does not touch: AddInfinitesimalNoise's per-bin terms -- the draws continue the frame's stream after
-  // the window's (cheaptrick.cpp:147-151) -- into P, whose power spectrum is dead, and the lifter of
-  // SmoothingWithRecovery.  (One wavefront -- the emulator's one thread, a 64-thread launch -- does both in turn.)
+  // the window's (cheaptrick.cpp:147-151) -- into P, whose power spectrum is dead.  (One wavefront -- the emulator's
+  // one thread -- does both in turn.)
   {
     const int waves = wg_waves<TB>();
     constexpr int scan_wave = 0;        // (rotating the chain over the wavefronts, i.e. the SIMDs, by frame: 5.26 ms against 5.06)
     const int helpers = waves > 1 ? nt - WAVE : nt;
     const bool helper = waves == 1 || wave_in_block() != scan_wave;
-#if !defined(WORLD_EMU) && !defined(CT_LANE_SCAN)
+#ifndef WORLD_EMU
     if (wave_in_block() == scan_wave) {
-#ifndef CT_NO_PRIO
+      // A chain of dependent additions advances one issue slot at a time; among the wavefronts of its SIMD, all busy with
+      // other frames' transforms, it got every fourth slot or so.  Issue priority for the chain's duration gives the
+      // frame its latency back (5.53 -> 5.26 ms per 128 utterances when the chain was still a single lane).
       __builtin_amdgcn_s_setprio(3);
-#endif
       ct_wave_prefix_sum(seg, sm.seg_len);
-#ifndef CT_NO_PRIO
       __builtin_amdgcn_s_setprio(0);
-#endif
     }
 #else
-    if (tid == scan_wave * WAVE) {
-#if !defined(WORLD_EMU) && !defined(CT_NO_PRIO)
-      // A chain of dependent additions advances one issue slot at a time: among the four wavefronts of its SIMD, all busy
-      // with other frames' transforms, it got every fourth slot or so (measured: 6.05 ms per 128 utterances against the
-      // 4.18 of the three kernels this one replaces).  Issue priority for the chain's duration costs the others one
-      // slot in two for ~10 k cycles and gives the frame its latency back.
-      __builtin_amdgcn_s_setprio(3);
-#endif
-      ct_serial_prefix_sum(seg, sm.seg_len, cap);
-#if !defined(WORLD_EMU) && !defined(CT_NO_PRIO)
-      __builtin_amdgcn_s_setprio(0);
-#endif
-    }
+    if (tid == 0) ct_serial_prefix_sum(seg, sm.seg_len, cap);
 #endif
     if (helper) {
       const int ht = (waves > 1 && wave_in_block() > scan_wave) ? tid - WAVE : tid;
@@ -329,24 +313,6 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
 #pragma unroll
         for (int q = 0; q < kB; ++q) if (i0 + q * helpers <= half) P[i0 + q * helpers] = fabs(randn_value(d[q])) * kEps;
       }
-#ifdef CT_LIFTER_TABLE
-      // sin(pi f0 q) / (pi f0 q) and (1 - 2 q1) + 2 q1 cos(2 pi f0 q) at quefrency q = k / fs; with a = f0 k / fs both
-      // come from ONE sinpi: cos(2 pi a) = 1 - 2 sin^2(pi a)
-      const double q1 = p.q1, f0_over_fs = cf0 / fs;
-      for (int k = ht; k <= half; k += helpers) {
-        double sl, cl;
-        if (k == 0) {
-          sl = 1.0;
-          cl = (1.0 - 2.0 * q1) + 2.0 * q1;
-        } else {
-          const double a = static_cast<double>(k) * f0_over_fs;
-          const double sp = sinpi(a);
-          sl = sp / (kPi * a);
-          cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * sp * sp);
-        }
-        lift[k] = sl * cl;
-      }
-#endif
     }
   }
   __syncthreads();
@@ -374,14 +340,10 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
   // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) -------------------------
   // the symmetric extension of the log spectrum is read by the first FFT stage directly from P.
   const double q1 = p.q1, f0_over_fs = cf0 / fs;
-  (void)q1; (void)f0_over_fs;
   auto mirrored = [&](int i) { return i <= half ? P[i] : P[N - i]; };
   block_rfft_from<kCtMaxLr, LGN>(Z, lgn, tw, [&](int n) { cplx v; v.re = mirrored(2 * n); v.im = mirrored(2 * n + 1); return v; },
                   [&](int k, double re, double im) {
     (void)im;
-#ifdef CT_LIFTER_TABLE
-    P[k] = re * lift[k] * inv_n;
-#else
     // Lifters: sin(pi f0 q) / (pi f0 q) and (1 - 2 q1) + 2 q1 cos(2 pi f0 q) at quefrency q = k / fs; with
     // a = f0 k / fs both come from ONE sinpi: cos(2 pi a) = 1 - 2 sin^2(pi a).
     double sl, cl;
@@ -395,7 +357,6 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
       cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * sp * sp);
     }
     P[k] = re * sl * cl * inv_n;                        // == .. / N: N is a power of two
-#endif
   });
   WH_STAMP(0, 8);
   block_irfft<kCtMaxLr, LGN>(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
@@ -414,11 +375,7 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
 // ---------------------------------------------------------------------------
 size_t ct_frame_lds_bytes(int lg_fft) {
   int N = 1 << lg_fft, nb = N / 2 + 1;
-  size_t doubles = (size_t)(ct_seg_cap(N) + nb + 1 + ((nb + 1) & 1) + 64 + N / 8 + 2);
-#ifdef CT_LIFTER_TABLE
-  doubles += nb + 1;
-#endif
-  return sizeof(double) * doubles;
+  return sizeof(double) * (size_t)(ct_seg_cap(N) + nb + 1 + ((nb + 1) & 1) + 64 + N / 8 + 2);
 }
 
 size_t ct_max_draws_per_frame(int fft_size) { return (size_t)fft_size + fft_size / 2 + 1; }   // window < fft_size, + bins

@@ -83,6 +83,21 @@ def test_emulated_ragged_and_tiny_inputs(emu, port_oracle):
         assert np.allclose(emu.d4c(x, fs, tp, f0_o, fft), port_oracle.d4c(x, fs, tp_o, f0_o, fft), rtol=1e-7, atol=0)
 
 
+def test_emulated_cheaptrick_f0_up_to_nyquist(emu, port_oracle):
+    """the smoothing segment at its longest (F0 towards fs / 2 fills ct_seg_cap): the host-compiled frame kernel against
+    the oracle; tests/test_gpu_parity.py::test_cheaptrick_f0_up_to_nyquist is the same on the GPU's DPP-row prefix sum"""
+    from world_amd import synth
+    from util import max_rel
+    for fs, fft in ((48000, 2048), (16000, 1024)):
+        x = synth.utterance(11, fs, 0.25).numpy()
+        nf = int(1000.0 * len(x) / fs / 5.0) + 1
+        tp = np.arange(nf) * 0.005
+        f0 = np.linspace(0.30 * fs, 0.4999 * fs, nf)
+        f0[::7] = 0.0
+        f0[3::11] = 900.0
+        assert max_rel(emu.cheaptrick(x, fs, tp, f0, fft_size=fft), port_oracle.cheaptrick(x, fs, tp, f0, fft_size=fft)) <= 1e-6, (fs, fft)
+
+
 def test_emulated_silence_and_dc(emu, port_oracle):
     """exact zeros: the spectrum is then entirely determined by the RNG stream"""
     fs = 16000

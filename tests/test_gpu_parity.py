@@ -349,6 +349,23 @@ def test_stages_fed_with_arbitrary_f0_tracks(hip, oracle):
         assert np.max(np.abs(y - y_o)) <= 1e-6 * max(np.max(np.abs(y_o)), 1e-9), what
 
 
+def test_cheaptrick_f0_up_to_nyquist(hip, oracle):
+    """CheapTrick takes any F0 the caller hands it.  Its smoothing segment grows with F0 (N/2 + 2 (2/3 f0 N / fs + 1) + 1
+    values): towards fs/2 it fills the frame kernel's LDS region to the last of its rows of 16 -- the far end of the
+    DPP-row prefix sum, where a miscounted row would write into the next array (cheaptrick.hip: ct_seg_cap)."""
+    from world_amd import synth
+    for fs, fft in ((48000, 2048), (16000, 1024), (48000, 4096)):
+        x = synth.utterance(11, fs, 0.25).numpy()
+        nf = int(1000.0 * len(x) / fs / 5.0) + 1
+        tp = np.arange(nf) * 0.005
+        f0 = np.linspace(0.30 * fs, 0.4999 * fs, nf)           # segments of 1.4 .. 1.67 x fft_size / 2 ... the capacity
+        f0[::7] = 0.0
+        f0[3::11] = 900.0
+        sp_o = oracle.cheaptrick(x, fs, tp, f0, fft_size=fft)
+        sp = hip.cheaptrick(x, fs, tp, f0, fft_size=fft)
+        assert np.all(np.isfinite(sp)) and max_rel(sp, sp_o) <= RTOL, (fs, fft)
+
+
 def test_fft_size_4096_paths(hip, oracle):
     """f0_floor 40 at 48 kHz makes CheapTrick pick fft_size 4096 (cheaptrick.cpp:191-194): the largest
     transforms CheapTrick, D4C's output rows, the coders and Synthesis handle"""

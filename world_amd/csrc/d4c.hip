@@ -1002,6 +1002,12 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       if (paired) key[2 * m + 1] = (unsigned long long)__double_as_longlong(br * br + bi * bi);
     });
     if (band == 0) WH_STAMP(32, 17);
+    // The select's histograms alias the head of the transform buffer and are zeroed as its first step: every wavefront
+    // must have finished READING the transform (the merge above keeps its bins in registers and has no closing barrier)
+    // before any of them starts.  (Until the end of round 4 this barrier was missing: a wavefront done with its merge
+    // could have zeroed slots a slower one had not read yet -- never observed, the reads enter the LDS queue within a
+    // few hundred cycles of the transform's barrier and the zeroing follows ~2 000 cycles of arithmetic later.)
+    __syncthreads();
     double part, tot;
 #if defined(WORLD_EMU) || defined(D4C_OLD_SELECT)
     block_smallest_sum<T>(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);

@@ -66,8 +66,8 @@ def main():
             build(name, flags)
         return
     names = sys.argv[2:] or ["tree"] + sorted(f[len("libworld_hip_"):-3] for f in os.listdir(VAR_DIR) if f.endswith(".so"))
-    show = ("d4c_frame", "hv_refine", "hv_band_events_fft", "ct_frame", "ct_envelope", "ct_spectrum", "ct_scan", "hv_raw_candidates",
-            "hv_detect", "d4c_lovetrain")
+    show = ("d4c_frame", "hv_refine", "hv_band_events_fft", "ct_frame", "hv_raw_candidates", "hv_detect", "d4c_lovetrain",
+            "ct_envelope", "ct_spectrum", "ct_scan")        # (the last three: variants built from trees before round 4's second half)
     for rnd in range(2):
         for name in names:
             d = bench(name, ["--no-configs", "--no-cpu-baseline", "--min-wall=1.5"])

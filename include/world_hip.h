@@ -288,13 +288,21 @@ WORLD_HIP_API int world_hip_analyze_packed(WorldHipContext *ctx, int n_utt, int 
  *   _spectral_packed_range: CheapTrick + D4C given tpos / f0 ([n_utt][f_stride], device) straight into packed records (same
  *       formats as world_hip_analyze_packed): utterance u's range starts at row first_row + sum over v < u of v's frames in range;
  *   _cheaptrick_batch_range / _d4c_batch_range: one stage into the dense arrays of the *_batch calls (rows outside the range
- *       untouched).  reuse_offsets != 0: the previous call on this context had the same shape and inputs and only the range
- *       differs -- its offsets / LoveTrain results are still in the workspace and are not recomputed. */
+ *       untouched).
+ * reuse_offsets != 0 (all three): an earlier call of the stage on this context had the same shape, buffers and options and
+ * only the range differs -- its offsets / LoveTrain results are still in the workspace and are not recomputed (LoveTrain
+ * over all frames is a seventh of a whole analysis: a rank that walks its frames in S sub-ranges would repeat it S times).
+ * CheapTrick's and D4C's prepared arrays occupy disjoint parts of the workspace, so ranges of the two stages may
+ * alternate.  The context remembers what the arrays were prepared FOR (shape, the x / tpos / f0 pointers, lengths, options,
+ * the workspace's identity); a call that asks for reuse without matching -- another stage (Harvest, DIO, StoneMask, a coder,
+ * Synthesis) ran in between, a different shape, a regrown workspace -- fails with a message instead of reading whatever
+ * lies there (the CONTENT of the caller's f0 / x buffers is the caller's promise: the library compares pointers). */
 WORLD_HIP_API int world_hip_spectral_packed_range(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
                                                   const int *x_length, const int *n_frames, int f_stride,
                                                   const double *d_tpos, const double *d_f0,
                                                   const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
-                                                  int frame_lo, int frame_hi, long long first_row, double *d_block, int cols);
+                                                  int frame_lo, int frame_hi, int reuse_offsets, long long first_row,
+                                                  double *d_block, int cols);
 WORLD_HIP_API int world_hip_cheaptrick_batch_range(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
                                                    const int *x_length, const int *n_frames, int f_stride,
                                                    const double *d_tpos, const double *d_f0, const CheapTrickOption *option,

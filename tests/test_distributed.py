@@ -295,13 +295,13 @@ def _emu_range_backend(fs):
         assert L.world_hip_harvest_batch(ctx, 1, fs, xb.data_ptr(), n, xl.ctypes.data_as(ip), C.byref(h), nf, tp.data_ptr(), f0.data_ptr()) == 0
         return tp, f0
 
-    def spectral_range(xb, tp, f0, block, lo, hi):
+    def spectral_range(xb, tp, f0, block, lo, hi, reuse=False):
         n, nf = xb.shape[1], tp.shape[1]
         xl, nfa = np.array([n], dtype=np.int32), np.array([nf], dtype=np.int32)
         c, d = CheapTrickOption(-0.15, 71.0, fft), D4COption(0.85)
         rc = L.world_hip_spectral_packed_range(ctx, 1, fs, xb.data_ptr(), n, xl.ctypes.data_as(ip), nfa.ctypes.data_as(ip), nf,
-                                               tp.data_ptr(), f0.data_ptr(), C.byref(c), C.byref(d), lo, hi, 0, block.data_ptr(),
-                                               block.shape[-1])
+                                               tp.data_ptr(), f0.data_ptr(), C.byref(c), C.byref(d), lo, hi, 1 if reuse else 0,
+                                               0, block.data_ptr(), block.shape[-1])
         assert rc == 0, L.world_hip_last_error().decode()
     return harvest, spectral_range
 

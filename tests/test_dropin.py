@@ -402,7 +402,7 @@ def _check_frame_ranges(lib_path, device):
             cols = L.world_hip_record_columns(fft, wire)
             block = up(np.full((rows + 2, cols), np.nan))
             rc = L.world_hip_spectral_packed_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), C.byref(c), C.byref(d), lo, hi,
-                                                   1, ptr(block), cols)
+                                                   0, 1, ptr(block), cols)
             assert rc == 0, L.world_hip_last_error().decode()
             sync()
             rec = host(block)
@@ -421,6 +421,45 @@ def _check_frame_ranges(lib_path, device):
                     assert np.array_equal(f32[:, nb:2 * nb], ap_full[u, a:b].astype(np.float32))
                 row += b - a
             assert row == 1 + rows
+        # ranges of the two stages ALTERNATING while reusing: their prepared arrays occupy disjoint workspace
+        sp3, ap3 = up(np.full((B, F, nb), -1.0)), up(np.full((B, F, nb), -1.0))
+        for i, (lo, hi) in enumerate(cuts):
+            assert L.world_hip_cheaptrick_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), C.byref(c), lo, hi, int(i > 0), ptr(sp3)) == 0
+            assert L.world_hip_d4c_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), fft, C.byref(d), lo, hi, int(i > 0), ptr(ap3)) == 0
+        sync()
+        assert np.array_equal(host(sp3), sp_full) and np.array_equal(host(ap3), ap_full)
+        # ... and packed sub-ranges reusing what the first one prepared (what a rank of analyze_long_sharded does)
+        cols = L.world_hip_record_columns(fft, 0)
+        tot = int(nf.sum())
+        block = up(np.full((tot, cols), np.nan))
+        row = 0
+        for i, (lo, hi) in enumerate(sorted(cuts)):
+            rc = L.world_hip_spectral_packed_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), C.byref(c), C.byref(d), lo, hi,
+                                                   int(i > 0), row, ptr(block), cols)
+            assert rc == 0, L.world_hip_last_error().decode()
+            row += int(sum(min(hi, n) - min(lo, n) for n in nf))
+        sync()
+        rec, row = host(block), 0
+        for lo, hi in sorted(cuts):
+            for u in range(B):
+                a, b = min(lo, int(nf[u])), min(hi, int(nf[u]))
+                assert np.array_equal(rec[row:row + b - a, 2:2 + nb], sp_full[u, a:b])
+                assert np.array_equal(rec[row:row + b - a, 2 + nb:], ap_full[u, a:b])
+                row += b - a
+        # reuse is CHECKED, not trusted: another stage in between, other buffers or another option -> an error, not garbage
+        def refused(rc):
+            return rc != 0 and b"reuse_offsets" in L.world_hip_last_error()
+        assert L.world_hip_harvest_batch(*args, C.byref(h), F, ptr(tp), ptr(f0)) == 0            # overwrites the workspace
+        assert refused(L.world_hip_cheaptrick_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), C.byref(c), 0, 8, 1, ptr(sp3)))
+        assert refused(L.world_hip_d4c_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), fft, C.byref(d), 0, 8, 1, ptr(ap3)))
+        assert L.world_hip_d4c_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), fft, C.byref(d), 0, 8, 0, ptr(ap3)) == 0
+        f0_other = up(host(f0).copy())
+        assert refused(L.world_hip_d4c_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0_other), fft, C.byref(d), 8, 16, 1, ptr(ap3)))
+        d_other = D4COption(0.5)
+        assert refused(L.world_hip_d4c_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), fft, C.byref(d_other), 8, 16, 1, ptr(ap3)))
+        assert L.world_hip_d4c_batch_range(*args, nf.ctypes.data_as(ip), F, ptr(tp), ptr(f0), fft, C.byref(d), 8, 16, 1, ptr(ap3)) == 0
+        sync()
+        assert np.array_equal(host(ap3)[:, :16], ap_full[:, :16])
     finally:
         L.world_hip_destroy(ctx)
 

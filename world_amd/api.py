@@ -94,7 +94,7 @@ def load_library(path=LIB_PATH):
     lib.world_hip_record_columns.argtypes = [C.c_int, C.c_int]
     lib.world_hip_spectral_packed_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp,
                                                     C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, C.c_int,
-                                                    C.c_longlong, vp, C.c_int]
+                                                    C.c_int, C.c_longlong, vp, C.c_int]
     lib.world_hip_cheaptrick_batch_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp,
                                                      C.POINTER(CheapTrickOption), C.c_int, C.c_int, C.c_int, vp]
     lib.world_hip_d4c_batch_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp, C.c_int,
@@ -617,9 +617,11 @@ class WorldHip:
         return nf
 
     def spectral_packed_range(self, x, fs, tpos, f0, n_frames, block, frame_lo, frame_hi, first_row=0, x_len=None, q1=-0.15,
-                              threshold=0.85):
+                              threshold=0.85, reuse_offsets=False):
         """CheapTrick + D4C of frames [frame_lo, frame_hi) of every utterance, given F0, straight into packed records
         (include/world_hip.h: world_hip_spectral_packed_range): bit-identical to the same rows of a whole-utterance call.
+        reuse_offsets: an earlier call on this context had the same inputs and only another range -- its offset scans and
+        LoveTrain pass are reused (the library checks that they are still there and were made for these buffers).
         Returns the number of records written."""
         t = self.torch
         B, L, xl = self._prep(x, x_len)
@@ -635,8 +637,9 @@ class WorldHip:
         copt, dopt = CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
         self._check(self.lib.world_hip_spectral_packed_range(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
                                                              nf.ctypes.data_as(_ip), F, tpos.data_ptr(), f0.data_ptr(),
-                                                             C.byref(copt), C.byref(dopt), frame_lo, frame_hi, first_row,
-                                                             block.data_ptr(), cols), "spectral_packed_range")
+                                                             C.byref(copt), C.byref(dopt), frame_lo, frame_hi,
+                                                             1 if reuse_offsets else 0, first_row, block.data_ptr(), cols),
+                    "spectral_packed_range")
         return rows
 
     def pack_results(self, tpos, f0, sp, ap, n_frames, block, first_row=0):
@@ -758,8 +761,11 @@ class WorldHip:
                            fft_size // 2 + 1)
 
     def analyze(self, x, fs, x_len=None, f0_method="harvest", frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
-                q1=-0.15, threshold=0.85, sp_out=None, ap_out=None):
-        """The north-star pipeline: F0 (Harvest, or DIO+StoneMask) -> CheapTrick -> D4C."""
+                q1=-0.15, threshold=0.85, sp_out=None, ap_out=None, tpos_out=None, f0_out=None):
+        """The north-star pipeline: F0 (Harvest, or DIO+StoneMask) -> CheapTrick -> D4C.
+        sp_out / ap_out / tpos_out / f0_out (Harvest route): caller-owned result buffers of the right shape, reused from
+        call to call -- the library writes every frame below an utterance's count and nothing else, so what lies beyond
+        (the padding of a ragged batch) is the caller's."""
         if f0_method == "harvest":
             # one library call: Harvest, then CheapTrick beside D4C on two streams of the context
             t = self.torch
@@ -768,10 +774,15 @@ class WorldHip:
             nb = fft_size // 2 + 1
             nf = np.array([frame_count(fs, int(n), frame_period) for n in xl], dtype=np.int32)
             F = int(nf.max())
-            tpos = t.zeros((B, F), dtype=t.float64, device=x.device)
-            f0 = t.zeros((B, F), dtype=t.float64, device=x.device)
-            sp = sp_out if sp_out is not None else t.zeros((B, F, nb), dtype=t.float64, device=x.device)
-            ap = ap_out if ap_out is not None else t.zeros((B, F, nb), dtype=t.float64, device=x.device)
+            # Fresh buffers are zero-filled only where a ragged batch leaves padding behind the shorter utterances'
+            # frames: every frame below nf[u] is written by the stages (hc_output; ct_frame / d4c_finish write whole rows),
+            # and a fill is a launch of its own per array and job (round 4's kernel trace: two per job for tpos / f0).
+            new = t.zeros if int(nf.min()) < F else t.empty
+            tpos = tpos_out if tpos_out is not None else new((B, F), dtype=t.float64, device=x.device)
+            f0 = f0_out if f0_out is not None else new((B, F), dtype=t.float64, device=x.device)
+            assert tpos.shape == (B, F) and f0.shape == (B, F) and tpos.is_contiguous() and f0.is_contiguous()
+            sp = sp_out if sp_out is not None else new((B, F, nb), dtype=t.float64, device=x.device)
+            ap = ap_out if ap_out is not None else new((B, F, nb), dtype=t.float64, device=x.device)
             assert sp.shape == (B, F, nb) and ap.shape == (B, F, nb) and sp.is_contiguous() and ap.is_contiguous()
             hopt, copt, dopt = HarvestOption(f0_floor, f0_ceil, frame_period), CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
             self._check(self.lib.world_hip_analyze_batch(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),

@@ -49,6 +49,7 @@ struct Arena {
   char *base = nullptr;
   size_t cap = 0, used = 0;
   void reset() { used = 0; }
+  void skip_to(size_t offset) { used = (offset + 255) & ~size_t(255); }
   template <class T> T *take(size_t count) {
     size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
     if (used + bytes > cap) fail("workspace arena overflow (%zu + %zu > %zu)", used, bytes, cap);
@@ -130,6 +131,24 @@ struct WorldHipContext {
   // Bumped whenever memory a captured graph may have baked in is freed or replaced (arena, small-array slabs, d_pk, the
   // cached filter / window / codec tables): world_hip_graph_launch refuses a graph of an older generation.
   unsigned long long generation = 0;
+  // What the offset scans (and D4C's LoveTrain pass) still lying in the workspace were computed FOR: a later call may
+  // ask to reuse them (`reuse_offsets`, the frame-range entries) and gets them only if its own inputs say the same thing
+  // and nothing has touched that part of the arena since (the flag used to be trusted blindly).
+  struct PrepToken {
+    bool valid = false;
+    int n_utt = 0, fs = 0, f_stride = 0, x_stride = 0, fft = 0;
+    const void *x = nullptr, *f0 = nullptr, *tpos = nullptr, *arena_base = nullptr;
+    double opt = 0.0;              // CheapTrick: its F0 floor; D4C: the threshold
+    uint64_t lengths_hash = 0;     // x_length and n_frames
+    size_t lo = 0, hi = 0;         // the arena bytes the prepared arrays occupy
+    unsigned long long generation = 0;
+    bool same_inputs(const PrepToken &o) const {
+      return n_utt == o.n_utt && fs == o.fs && f_stride == o.f_stride && x_stride == o.x_stride && fft == o.fft && x == o.x &&
+             f0 == o.f0 && tpos == o.tpos && arena_base == o.arena_base && opt == o.opt && lengths_hash == o.lengths_hash &&
+             lo == o.lo && hi == o.hi && generation == o.generation;
+    }
+  };
+  PrepToken prep_ct, prep_d4c;
   std::mutex lock;               // one call at a time per context
 };
 
@@ -251,17 +270,50 @@ static size_t cheaptrick_arena_bytes(int n_utt, int f_stride, int fft_size) {
 }
 static size_t d4c_arena_bytes(int n_utt, int f_stride) {
   const size_t fr = (size_t)n_utt * f_stride;
-  return 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 5 * pad256(sizeof(int) * n_utt) +
+  return 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 6 * pad256(sizeof(int) * n_utt) + 512 +
          pad256(sizeof(double) * fr * 16);
+}
+
+// ---------------------------------------------------------------------------
+// The spectral stages' workspace.  CheapTrick's arrays sit at the bottom of the arena, D4C's behind them (a D4C call by
+// itself skips CheapTrick's part for its own shape): the two never overlap, so the offset scans of both -- and D4C's
+// LoveTrain pass -- survive the other stage's calls, one prepare kernel can serve both (run_spectral_stages), and frame
+// ranges of the two stages can alternate while reusing them.  Any other stage's arena_reset() voids them.
+// ---------------------------------------------------------------------------
+static void arena_reset(WorldHipContext *c) {
+  c->arena.reset();
+  c->prep_ct.valid = c->prep_d4c.valid = false;
+}
+static uint64_t lengths_hash(const int *x_length, const int *n_frames, int n_utt) {
+  const uint64_t a = SmallArrays::hash(x_length, sizeof(int) * n_utt), b = SmallArrays::hash(n_frames, sizeof(int) * n_utt);
+  return a * 0x9E3779B97F4A7C15ull ^ b;
+}
+// Claims [lo, hi) of the arena for `mine`; with `reuse` the claim must equal what is there (else: a clear error instead
+// of kernels reading garbage offsets).  The other stage's prepared arrays are void if the claim runs into them.
+static void claim_prepared(WorldHipContext *c, WorldHipContext::PrepToken &mine, WorldHipContext::PrepToken &other,
+                           WorldHipContext::PrepToken want, bool reuse, const char *stage) {
+  want.arena_base = c->arena.base; want.generation = c->generation;
+  if (reuse) {
+    if (!mine.valid)
+      fail("%s: reuse_offsets, but this context holds no prepared offsets (another stage, another shape or a regrown "
+           "workspace since the call that prepared them)", stage);
+    if (!mine.same_inputs(want))
+      fail("%s: reuse_offsets, but the prepared offsets belong to other inputs (shape, buffers or options differ from the "
+           "call that prepared them)", stage);
+    return;
+  }
+  if (other.valid && want.lo < other.hi && other.lo < want.hi) other.valid = false;
+  mine = want;
+  mine.valid = true;
 }
 
 // ---------------------------------------------------------------------------
 // CheapTrick
 // ---------------------------------------------------------------------------
-static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride,
-                           const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
-                           const double *d_f0, const CheapTrickOption *opt, double *d_sp, bool own_arena,
-                           const RowLayout &lay = RowLayout()) {
+static CtParams setup_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride,
+                                 const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
+                                 const double *d_f0, const CheapTrickOption *opt, double *d_sp, const RowLayout &lay,
+                                 int *max_frames_out) {
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   const int lg = ilog2_exact(opt->fft_size);
   if (lg < 7 || lg > 13) fail("CheapTrick fft_size %d unsupported (128..8192: one frame must fit LDS)", opt->fft_size);
@@ -270,8 +322,7 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
     if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
     max_frames = std::max(max_frames, n_frames[u]);
   }
-  if (own_arena) { ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, opt->fft_size)); c->arena.reset(); }
-  CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
+  *max_frames_out = max_frames;
   CtParams p;
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, std::vector<int>(x_length, x_length + n_utt));
@@ -280,23 +331,42 @@ static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *
   p.out_row = lay.rows ? upload(c, std::vector<int>(lay.rows, lay.rows + n_utt)) : nullptr;
   p.out_stride = lay.stride ? lay.stride : (size_t)(opt->fft_size / 2 + 1);
   p.out_col_bytes = lay.col_bytes; p.out_f32 = lay.f32;
+  p.f0_floor = 3.0 * fs / (opt->fft_size - 3.0);                       // cheaptrick.cpp:196-198
+  c->arena.skip_to(0);
   p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
+  {
+    WorldHipContext::PrepToken t;
+    t.n_utt = n_utt; t.fs = fs; t.f_stride = f_stride; t.x_stride = x_stride; t.fft = opt->fft_size;
+    t.x = d_x; t.f0 = d_f0; t.tpos = d_tpos; t.opt = p.f0_floor; t.lengths_hash = lengths_hash(x_length, n_frames, n_utt);
+    t.lo = 0; t.hi = c->arena.used;
+    claim_prepared(c, c->prep_ct, c->prep_d4c, t, lay.skip_prepare, "CheapTrick");
+  }
   p.noise = ensure_noise(c, (size_t)max_frames * ct_max_draws_per_frame(opt->fft_size));
   p.tab = c->tab;
   p.q1 = opt->q1;
-  p.f0_floor = 3.0 * fs / (opt->fft_size - 3.0);                       // cheaptrick.cpp:196-198
   p.lg_fft = lg;
   if (lay.frame_lo < 0 || lay.frame_hi < lay.frame_lo) fail("bad frame range [%d, %d)", lay.frame_lo, lay.frame_hi);
   p.frame_lo = lay.frame_lo; p.frame_hi = lay.frame_hi; p.skip_prepare = lay.skip_prepare ? 1 : 0;
+  return p;
+}
+static void run_cheaptrick(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride,
+                           const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
+                           const double *d_f0, const CheapTrickOption *opt, double *d_sp,
+                           const RowLayout &lay = RowLayout()) {
+  ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, opt->fft_size));
+  CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
+  int max_frames = 0;
+  const CtParams p = setup_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, opt, d_sp, lay,
+                                      &max_frames);
   launch_cheaptrick(p, max_frames, c->stream);
 }
 
 // ---------------------------------------------------------------------------
 // D4C
 // ---------------------------------------------------------------------------
-static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
-                    const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0, int fft_size,
-                    const D4COption *opt, double *d_ap, bool own_arena, const RowLayout &lay = RowLayout()) {
+static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                           const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0, int fft_size,
+                           const D4COption *opt, double *d_ap, const RowLayout &lay, int *max_frames_out) {
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   ilog2_exact(fft_size);
   int max_frames = 0;
@@ -304,6 +374,7 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     if (n_frames[u] < 0 || n_frames[u] > f_stride) fail("n_frames[%d] outside [0, f_stride]", u);
     max_frames = std::max(max_frames, n_frames[u]);
   }
+  *max_frames_out = max_frames;
   // d4c.cpp:350-363 and :264-265
   const int fft_d4c = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(4.0 * fs / kFloorF0D4C + 1) / kLog2)));
   const int fft_love = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(3.0 * fs / 40.0 + 1) / kLog2)));
@@ -326,8 +397,6 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
     c->nuttall_len = wl;
   }
   size_t fr = (size_t)n_utt * f_stride;
-  if (own_arena) { ensure_arena(c, d4c_arena_bytes(n_utt, f_stride)); c->arena.reset(); }
-  CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
   D4cParams p;
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, std::vector<int>(x_length, x_length + n_utt));
@@ -337,11 +406,21 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.out_stride = lay.stride ? lay.stride : (size_t)(fft_size / 2 + 1);
   p.out_col_bytes = lay.col_bytes; p.out_f32 = lay.f32;
   p.rec = lay.rec;
+  c->arena.skip_to(cheaptrick_arena_bytes(n_utt, f_stride, fft_size));      // behind CheapTrick's part for this shape
+  const size_t region_lo = c->arena.used;
   p.ap0 = c->arena.take<double>(fr);
   p.offsets1 = c->arena.take<unsigned>(fr);
   p.offsets2 = c->arena.take<unsigned>(fr);
   p.draws1 = c->arena.take<unsigned>(n_utt);
+  p.love_ticket = c->arena.take<int>(n_utt);
   p.coarse = c->arena.take<double>(fr * 16);
+  {
+    WorldHipContext::PrepToken t;
+    t.n_utt = n_utt; t.fs = fs; t.f_stride = f_stride; t.x_stride = x_stride; t.fft = fft_size;
+    t.x = d_x; t.f0 = d_f0; t.tpos = d_tpos; t.opt = opt->threshold; t.lengths_hash = lengths_hash(x_length, n_frames, n_utt);
+    t.lo = region_lo; t.hi = c->arena.used;
+    claim_prepared(c, c->prep_d4c, c->prep_ct, t, lay.skip_prepare, "D4C");
+  }
   p.noise = ensure_noise(c, (size_t)max_frames * d4c_max_draws_per_frame(fs));
   p.nuttall = c->d_nuttall;
   p.tab = c->tab;
@@ -352,7 +431,18 @@ static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.nap = nap;
   p.wl = wl;
   if (lay.frame_lo < 0 || lay.frame_hi < lay.frame_lo) fail("bad frame range [%d, %d)", lay.frame_lo, lay.frame_hi);
-  p.frame_lo = lay.frame_lo; p.frame_hi = lay.frame_hi; p.skip_prepare = lay.skip_prepare ? 1 : 0;
+  p.frame_lo = lay.frame_lo; p.frame_hi = lay.frame_hi;
+  p.skip_prepare = lay.skip_prepare ? kD4cSkipScan | kD4cSkipLoveTrain : 0;
+  return p;
+}
+static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                    const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0, int fft_size,
+                    const D4COption *opt, double *d_ap, const RowLayout &lay = RowLayout()) {
+  ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, fft_size) + d4c_arena_bytes(n_utt, f_stride));
+  CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
+  int max_frames = 0;
+  const D4cParams p = setup_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, opt, d_ap,
+                                lay, &max_frames);
   launch_d4c(p, max_frames, c->stream);
 }
 
@@ -496,6 +586,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   const size_t cand_elems = B * p.fb_stride * p.maxc;
   size_t need = 0;
   need += 5 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * ((max_y + 4095) / 4096) * 4) +
+          pad256(sizeof(double) * B * ((max_y + 4095) / 4096 + (max_x + 2 * p.lag + 2 * kDecPad) / kDecSpan + 1)) +
           pad256(sizeof(double) * B * p.nch * 4);
   need += pad256(sizeof(double) * B * p.m_stride);
   need += pad256(sizeof(double) * B * p.y_stride);
@@ -513,7 +604,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   need += pad256(sizeof(int) * B * 6 * p.sec_cap) + pad256(sizeof(int) * B * 2) + pad256(sizeof(double) * B * p.sec_cap);
   need += pad256(sizeof(double) * B * p.ext_cap);
   ensure_arena(c, need);
-  c->arena.reset();
+  arena_reset(c);
   CallScope scope(c, 5 * sizeof(int) * n_utt + 512);
 
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
@@ -524,6 +615,9 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.ref_fft = upload(c, rfft);
   p.nyq_slices = (max_y + 4095) / 4096;                                // kMeanSlice of harvest.hip
   p.nyq = c->arena.take<double>(B * p.nyq_slices * 4);
+  // launch_harvest's grids: spans of the decimation sweeps (harvest.hip), or the 4096-sample slices at ratio 1
+  p.mean_parts = p.ratio == 1 ? p.nyq_slices : (max_x + 2 * p.lag + 2 * kDecPad + kDecSpan - 1) / kDecSpan;
+  p.mean_part = c->arena.take<double>(B * p.mean_parts);
   p.quirk = c->arena.take<double>(B * p.nch * 4);
   p.band_f0 = hb.d_band_f0; p.band_half = hb.d_half; p.band_off = hb.d_off; p.band_taps = hb.d_taps;
   p.win_tab = hb.d_win_tab; p.win_lane = hb.d_win_tab + (size_t)hb.win_tab_len * 6;
@@ -677,7 +771,7 @@ static void run_dio(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   need += pad256(sizeof(double) * B * p.nb * 4 * p.ev_cap) + pad256(sizeof(int) * B * p.nb * 4);
   need += 2 * pad256(sizeof(double) * B * p.nb * f_stride) + 2 * pad256(sizeof(double) * B * f_stride);
   ensure_arena(c, need);
-  c->arena.reset();
+  arena_reset(c);
   CallScope scope(c, 4 * sizeof(int) * n_utt + 512);
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, xl);
@@ -718,7 +812,7 @@ static void run_stonemask(WorldHipContext *c, int n_utt, int fs, const double *d
     fail("StoneMask: fs=%d needs a %d-sample window (%zu bytes of LDS > 160 KiB); fs <= 180 kHz supported", fs, p.win_cap,
          stonemask_lds_bytes(p.win_cap));
   ensure_arena(c, 2 * pad256(sizeof(int) * n_utt));
-  c->arena.reset();
+  arena_reset(c);
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
   p.b.x_len = upload(c, std::vector<int>(x_length, x_length + n_utt));
@@ -934,7 +1028,7 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
                 pad256(sizeof(int) * B * p.pulse_cap) + pad256(sizeof(double) * B * p.pulse_cap) + pad256(sizeof(int) * B) +
                 pad256(sizeof(double) * B * p.pulse_cap * fft_size);
   ensure_arena(c, need);
-  c->arena.reset();
+  arena_reset(c);
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   p.n_frames = upload(c, std::vector<int>(n_frames, n_frames + n_utt));
   p.y_len = upload(c, std::vector<int>(y_length, y_length + n_utt));
@@ -972,7 +1066,7 @@ static void run_pack(WorldHipContext *c, bool unpack, int n_utt, const int *n_fr
   }
   if (max_frames == 0) return;
   ensure_arena(c, 2 * pad256(sizeof(int) * n_utt));
-  c->arena.reset();
+  arena_reset(c);
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
   PackArgs a;
   a.n_utt = n_utt; a.f_stride = f_stride; a.nb = nb;
@@ -991,8 +1085,21 @@ static void run_spectral_stages(WorldHipContext *c, int n_utt, int fs, const dou
                                 const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0,
                                 const CheapTrickOption *copt, const D4COption *dopt, double *d_sp, double *d_ap,
                                 const RowLayout &lay_sp, const RowLayout &lay_ap) {
-  run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt, d_sp, true, lay_sp);
-  run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt->fft_size, dopt, d_ap, true, lay_ap);
+  ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, copt->fft_size) + d4c_arena_bytes(n_utt, f_stride));
+  CallScope scope(c, 6 * sizeof(int) * n_utt + 512);        // ONE upload section for both stages' small arrays
+  int max_ct = 0, max_d4c = 0;
+  CtParams cp = setup_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt, d_sp, lay_sp,
+                                 &max_ct);
+  D4cParams dp = setup_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt->fft_size, dopt, d_ap,
+                           lay_ap, &max_d4c);
+  // both stages' first offset scans depend on F0 alone: one launch serves both (two 1-workgroup kernels per job were two
+  // of the narrow launches the twelve-jobs-in-flight mode pays 10-25 us apiece for)
+  if (!cp.skip_prepare && !dp.skip_prepare) {
+    launch_spectral_prepare(cp, dp, c->stream);
+    cp.skip_prepare = 1; dp.skip_prepare |= kD4cSkipScan;
+  }
+  launch_cheaptrick(cp, max_ct, c->stream);
+  launch_d4c(dp, max_d4c, c->stream);
 }
 
 // Harvest + CheapTrick + D4C of one batch into the dense arrays of the *_batch calls (world_hip_analyze_batch)
@@ -1063,7 +1170,7 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
 static void run_spectral_packed_range(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
                                       const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0,
                                       const CheapTrickOption *copt, const D4COption *dopt, int frame_lo, int frame_hi,
-                                      long long first_row, double *d_block, int cols) {
+                                      long long first_row, double *d_block, int cols, bool reuse_offsets) {
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   if (!n_frames || !d_tpos || !d_f0 || !d_block) fail("null buffer");
   if (frame_lo < 0 || frame_hi < frame_lo || first_row < 0) fail("bad frame range [%d, %d) or first row", frame_lo, frame_hi);
@@ -1089,6 +1196,7 @@ static void run_spectral_packed_range(WorldHipContext *c, int n_utt, int fs, con
   lay_sp.col_bytes = 2 * sizeof(double); lay_ap.col_bytes = 2 * sizeof(double) + elem * nb;
   lay_ap.rec = d_block;
   lay_sp.frame_lo = lay_ap.frame_lo = frame_lo; lay_sp.frame_hi = lay_ap.frame_hi = frame_hi;
+  lay_sp.skip_prepare = lay_ap.skip_prepare = reuse_offsets;
   run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt, dopt, d_block, d_block,
                       lay_sp, lay_ap);
 }
@@ -1342,7 +1450,7 @@ int world_hip_cheaptrick_batch(WorldHipContext *c, int n_utt, int fs, const doub
                                const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
                                const double *d_f0, const CheapTrickOption *option, double *d_sp) {
   return guarded(c, [&] {
-    run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, option, d_sp, true);
+    run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, option, d_sp);
   });
 }
 
@@ -1350,7 +1458,7 @@ int world_hip_d4c_batch(WorldHipContext *c, int n_utt, int fs, const double *d_x
                         const int *x_length, const int *n_frames, int f_stride, const double *d_tpos,
                         const double *d_f0, int fft_size, const D4COption *option, double *d_ap) {
   return guarded(c, [&] {
-    run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, true);
+    run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap);
   });
 }
 
@@ -1381,10 +1489,10 @@ int world_hip_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double
 int world_hip_spectral_packed_range(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
                                      const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0,
                                      const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option, int frame_lo,
-                                     int frame_hi, long long first_row, double *d_block, int cols) {
+                                     int frame_hi, int reuse_offsets, long long first_row, double *d_block, int cols) {
   return guarded(c, [&] {
     run_spectral_packed_range(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, cheaptrick_option,
-                              d4c_option, frame_lo, frame_hi, first_row, d_block, cols);
+                              d4c_option, frame_lo, frame_hi, first_row, d_block, cols, reuse_offsets != 0);
   });
 }
 
@@ -1396,7 +1504,7 @@ int world_hip_cheaptrick_batch_range(WorldHipContext *c, int n_utt, int fs, cons
   return guarded(c, [&] {
     RowLayout lay;
     lay.frame_lo = frame_lo; lay.frame_hi = frame_hi; lay.skip_prepare = reuse_offsets != 0;
-    run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, option, d_sp, true, lay);
+    run_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, option, d_sp, lay);
   });
 }
 int world_hip_d4c_batch_range(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
@@ -1405,7 +1513,7 @@ int world_hip_d4c_batch_range(WorldHipContext *c, int n_utt, int fs, const doubl
   return guarded(c, [&] {
     RowLayout lay;
     lay.frame_lo = frame_lo; lay.frame_hi = frame_hi; lay.skip_prepare = reuse_offsets != 0;
-    run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, true, lay);
+    run_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, option, d_ap, lay);
   });
 }
 

@@ -16,14 +16,11 @@
 // HBM traffic per frame: the window's samples of x (L2-resident: adjacent frames overlap ~97%), the frame's draws
 // from the noise table (4 bytes each: window length + one per bin) and one row of the spectrogram written once.
 #include "stage_params.h"
+#include "prepare.h"
 #include "trace.h"
 WH_TRACE_DEFINE(ct)
 
 namespace world_hip {
-
-__device__ __forceinline__ double ct_effective_f0(double f0, double floor_f0) {
-  return f0 <= floor_f0 ? kDefaultF0 : f0;              // cheaptrick.cpp:218
-}
 
 // doubles reserved for Z and the smoothing work area that overlays it: a whole number of the prefix sum's rows of 16
 __host__ __device__ __forceinline__ int ct_seg_cap(int N) {
@@ -35,24 +32,7 @@ __host__ __device__ __forceinline__ int ct_seg_cap(int N) {
 // ---------------------------------------------------------------------------
 __global__ void ct_prepare(CtParams p) {
   DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  int u = blockIdx.x;
-  int nf = p.b.n_frames[u];
-  int nb = (1 << p.lg_fft) / 2 + 1;
-  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
-  unsigned *off_out = p.offsets + (size_t)u * p.b.f_stride;
-  unsigned running = 0;
-  for (int base = 0; base < nf; base += blockDim.x) {
-    int f = base + threadIdx.x;
-    int cnt = 0;
-    if (f < nf) {
-      double cf0 = ct_effective_f0(f0[f], p.f0_floor);
-      cnt = 2 * mround(1.5 * p.b.fs / cf0) + 1 + nb;     // window draws, then one per bin
-    }
-    int total, off = block_excl_scan_int(cnt, &total, scratch);
-    if (f < nf) off_out[f] = running + (unsigned)off;
-    running += (unsigned)total;
-  }
+  ct_offsets_utt(p, blockIdx.x, reinterpret_cast<double *>(lds));
 }
 
 // ---------------------------------------------------------------------------

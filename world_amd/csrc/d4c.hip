@@ -20,6 +20,7 @@
 //   d4c_finish    : the bands' dB values and the 3 kHz-grid interpolation; every row written once to HBM, dense or
 //                   straight into packed records.
 #include "stage_params.h"
+#include "prepare.h"
 #include "trace.h"
 WH_TRACE_DEFINE(d4c)
 
@@ -30,42 +31,13 @@ constexpr int kHanning = 1, kBlackman = 2;
 // ---------------------------------------------------------------------------
 __global__ void d4c_prepare1(D4cParams p) {
   DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  int u = blockIdx.x, nf = p.b.n_frames[u];
-  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
-  unsigned *off_out = p.offsets1 + (size_t)u * p.b.f_stride;
-  unsigned running = 0;
-  for (int base = 0; base < nf; base += blockDim.x) {
-    int f = base + threadIdx.x, cnt = 0;
-    if (f < nf && f0[f] != 0.0) {
-      double cf0 = f0[f] > 40.0 ? f0[f] : 40.0;                      // d4c.cpp:263,279
-      cnt = 2 * mround(3.0 * p.b.fs / cf0 / 2.0) + 1;
-    }
-    int total, off = block_excl_scan_int(cnt, &total, scratch);
-    if (f < nf) off_out[f] = running + (unsigned)off;
-    running += (unsigned)total;
-  }
-  if (threadIdx.x == 0) p.draws1[u] = running;
+  d4c_offsets1_utt(p, blockIdx.x, reinterpret_cast<double *>(lds));
 }
-
-__global__ void d4c_prepare2(D4cParams p) {
+// CheapTrick's scan and D4C's first in one launch (grid (n_utt, 2)): both follow from F0 alone (prepare.h)
+__global__ void spectral_prepare(CtParams cp, D4cParams dp) {
   DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  int u = blockIdx.x, nf = p.b.n_frames[u];
-  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
-  const double *ap0 = p.ap0 + (size_t)u * p.b.f_stride;
-  unsigned *off_out = p.offsets2 + (size_t)u * p.b.f_stride;
-  unsigned running = p.draws1[u];        // pass 2 continues the stream where pass 1 ended
-  for (int base = 0; base < nf; base += blockDim.x) {
-    int f = base + threadIdx.x, cnt = 0;
-    if (f < nf && !(f0[f] == 0 || ap0[f] <= p.threshold)) {          // d4c.cpp:386
-      double cf0 = kFloorF0D4C > f0[f] ? kFloorF0D4C : f0[f];
-      cnt = 3 * (2 * mround(4.0 * p.b.fs / cf0 / 2.0) + 1);
-    }
-    int total, off = block_excl_scan_int(cnt, &total, scratch);
-    if (f < nf) off_out[f] = running + (unsigned)off;
-    running += (unsigned)total;
-  }
+  if (blockIdx.y == 0) ct_offsets_utt(cp, blockIdx.x, reinterpret_cast<double *>(lds));
+  else d4c_offsets1_utt(dp, blockIdx.x, reinterpret_cast<double *>(lds));
 }
 
 // Sum of the `m` smallest of v[0..n) (all >= 0) and the sum of all of them: a radix
@@ -465,8 +437,7 @@ __device__ __forceinline__ double d4c_window_to_lds(const D4cWin &w, const D4cWi
 // D4CLoveTrain (d4c.cpp:227-285): is the frame voiced enough to analyse?  LGN: log2 of the transform when the
 // instantiation fixes it (compile-time plan), 0 = p.lg_love.
 template <int LGN>
-__global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
-  DYN_LDS(lds);
+__device__ __forceinline__ void d4c_love_frame(const D4cParams &p, char *lds) {
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
@@ -533,6 +504,29 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   }
   block_sum2<LGN == 11 ? 128 : LGN == 12 ? 256 : 0>(lo, hi, scratch);   // (launch_d4c's workgroup sizes: the wavefronts' shares are read together)
   if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
+}
+// The kernel: the frame's statistic, then -- in the LAST workgroup of the utterance to get there -- the scan of the second
+// pass's stream positions, which needs every frame's result (round 4: a 1-workgroup launch of its own per job).  Every
+// workgroup of the utterance's grid row takes a ticket, also those beyond its last frame; a workgroup's result is
+// released (agent scope) before its ticket and the last one acquires before it reads: the L2s of the eight XCDs are not
+// coherent with each other for plain loads and stores.
+template <int LGN>
+__global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
+  DYN_LDS(lds);
+  d4c_love_frame<LGN>(p, lds);
+  const int u = blockIdx.y;
+  double *scratch = reinterpret_cast<double *>(lds);      // (free: every thread is past the frame's last collective ...)
+  int *last = reinterpret_cast<int *>(scratch + 62);      // (... whose scratch words lie below this one)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    *last = atomicAdd(p.love_ticket + u, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!*last) return;
+  __threadfence();
+  __syncthreads();                                         // (everybody has read *last before the scan reuses the area)
+  d4c_offsets2_utt(p, u, scratch);
+  if (threadIdx.x == 0) p.love_ticket[u] = 0;              // a LoveTrain pass alone (no scan before it) finds it cleared
 }
 
 // Resident waves per SIMD the register allocation aims at: 3 (three 256-thread workgroups per CU, 168 VGPRs;
@@ -1103,13 +1097,16 @@ size_t d4c_max_draws_per_frame(int fs) {
   return (size_t)(2 * mround(3.0 * fs / 40.0 / 2.0) + 1) + 3 * (size_t)(2 * mround(4.0 * fs / kFloorF0D4C / 2.0) + 1);
 }
 
+void launch_spectral_prepare(const CtParams &cp, const D4cParams &dp, hipStream_t stream) {
+  WH_BLOCKS(spectral_prepare, dim3(cp.b.n_utt, 2), 1024, 64 * sizeof(double), stream, cp, dp);    // 1024 threads: a 10 s utterance is two scans
+}
+
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
-  if (!p.skip_prepare) {
-  WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);
-  // workgroup sizes follow the transform size (threads beyond N/16 idle through every radix-8 stage): for the
-  // 2048-point internal FFT of fs <= 24 kHz, 64 x 1001 frames: lovetrain 0.53 -> 0.42 ms, groupdelay 3.77 -> 2.52,
-  // band 0.97 -> 0.65
-  {
+  if (!(p.skip_prepare & kD4cSkipScan)) WH_BLOCKS(d4c_prepare1, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);
+  if (!(p.skip_prepare & kD4cSkipLoveTrain) && max_frames > 0) {
+    // workgroup sizes follow the transform size (threads beyond N/16 idle through every radix-8 stage): for the
+    // 2048-point internal FFT of fs <= 24 kHz, 64 x 1001 frames: lovetrain 0.53 -> 0.42 ms, groupdelay 3.77 -> 2.52,
+    // band 0.97 -> 0.65.  (Its last workgroup per utterance scans the second pass's stream positions.)
     const dim3 love_grid(max_frames, p.b.n_utt);
     const size_t love_lds = d4c_love_lds_bytes(p.lg_love);
 #ifdef WORLD_EMU
@@ -1119,8 +1116,6 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
     else if (p.lg_love == 12) devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<12>, love_grid, 256, love_lds, stream, p);
     else devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<0>, love_grid, p.lg_love <= 11 ? 128 : 256, love_lds, stream, p);
 #endif
-  }
-  WH_BLOCKS(d4c_prepare2, dim3(p.b.n_utt), 1024, 64 * sizeof(double), stream, p);
   }
   // one radix-8 butterfly per thread: 128 / 256 / 512 threads for the 2048- / 4096- / 8192-point internal FFT
   // (fs <= 24 kHz / <= 48 kHz / <= 96 kHz); the register arrays are sized per shape

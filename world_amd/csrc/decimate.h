@@ -26,7 +26,8 @@ constexpr int kDecPad = 9;        // kNFact
 // threads read the staged span with a lane stride of kDecChunk doubles: one pad slot per
 // kDecChunk entries makes that stride odd (33) -> bank-conflict free
 __host__ __device__ __forceinline__ int dec_pad(int k) { return k + k / kDecChunk; }
-inline size_t dec_lds_bytes() { return sizeof(double) * (size_t)(dec_pad(kDecSpan + kDecWarm) + 8); }
+constexpr int kDecStage = kDecSpan + kDecWarm + (kDecSpan + kDecWarm) / kDecChunk + 8;   // doubles of the staged span (dec_pad of its end)
+inline size_t dec_lds_bytes() { return sizeof(double) * (size_t)(kDecStage + 64); }          // + a block collective's scratch
 
 // filter coefficients, src/matlabfunctions.cpp:29-113
 inline IirCoef decimate_coef(int r) {
@@ -132,15 +133,22 @@ __device__ __forceinline__ void dec_forward_block(const double *x, int n, int la
 
 // backward sweep over fwd; every r-th output starting at `first` is a decimated sample.
 // out[k] = decimated[skip + k] for k < out_len   (matlabfunctions.cpp:195-200, harvest.cpp:62)
+// span_sum (optional): the sum of the samples this workgroup stored goes to span_sum[block] -- the mean the caller
+// removes next is then a sum of per-span partials in span order (deterministic), and no pass of its own over `out`.
 __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int lag, int r, IirCoef c, int block,
-                                                   int skip, int out_len, double *out, double *stage, int warm) {
+                                                   int skip, int out_len, double *out, double *stage, int warm,
+                                                   double *span_sum = nullptr) {
   const int total = n + 2 * lag + 2 * kDecPad;
   const int m = n + 2 * lag;
   const int nout = (m - 1) / r + 1;
   const int nbeg = r - r * nout + m;
   const int first = nbeg + kDecPad - 1;         // index (in padded coordinates) of decimated[0]
   const int b0 = block * kDecSpan;
-  if (b0 >= total) return;
+  if (b0 >= total) {                            // (the whole workgroup: a span beyond this utterance's end)
+    if (span_sum && threadIdx.x == 0) span_sum[block] = 0.0;
+    return;
+  }
+  double acc = 0.0;
   const int hi = imin(total, b0 + kDecSpan + warm);      // stage[k] = fwd[b0 + k], k < hi - b0
   {
     const int cnt = hi - b0, nt = (int)blockDim.x;
@@ -187,10 +195,18 @@ __device__ __forceinline__ void dec_backward_block(const double *fwd, int n, int
       const int d = d0 - q;
       if (c1 - 1 - q >= c0 && d >= 0 && rem == 0 && nbeg + d < m + kDecPad) {   // loop bound of matlabfunctions.cpp:199
         const int k = quo - skip;
-        if (k >= 0 && k < out_len) out[k] = iir_taps(c, w[q + 3], w[q + 2], w[q + 1], w[q]);
+        if (k >= 0 && k < out_len) {
+          const double v = iir_taps(c, w[q + 3], w[q + 2], w[q + 1], w[q]);
+          out[k] = v;
+          acc += v;
+        }
       }
       if (rem == 0) { rem = r - 1; --quo; } else { --rem; }
     }
+  }
+  if (span_sum) {
+    acc = block_sum(acc, stage + kDecStage);     // (scratch behind the staged span; every thread of the workgroup arrives)
+    if (threadIdx.x == 0) span_sum[block] = acc;
   }
 }
 

@@ -39,6 +39,7 @@ extern thread_local char *emu_lds_base;
 #define __restrict__
 #define __launch_bounds__(...)
 static inline void __syncthreads() {}
+static inline void __threadfence() {}
 typedef int hipError_t;
 typedef void *hipStream_t;
 #define hipSuccess 0
@@ -434,6 +435,24 @@ __device__ __forceinline__ int wave_excl_scan_int(int v, int *total) {
   return 0;
 #endif
 }
+// v + (the value of lane ^ 16) and v + (the value of lane ^ 32) without the LDS crossbar: CDNA4's swaps of 16-lane rows
+// and of wave halves between two registers.  Given two copies of x, v_permlane16_swap leaves (rows 0 0 2 2) and
+// (rows 1 1 3 3), v_permlane32_swap (lower lower) and (upper upper); their sum is x + x(partner) in every lane -- the
+// operands of __shfl_xor's sum, in one order or the other.
+#ifndef WORLD_EMU
+__device__ __forceinline__ double row_pair_sum(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double half_pair_sum(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+#endif
 // lane `src_lane`'s value when the lane index is the same in every lane (a loop counter): v_readlane, no LDS crossbar
 __device__ __forceinline__ double wave_pick(double v, int src_lane) {
 #ifndef WORLD_EMU

@@ -36,6 +36,8 @@ struct HarvestParams {
   const int *ref_fft;      // [n_utt] the reference's FFT length for this utterance (harvest.cpp:1164-1165)
   double *nyq;             // [n_utt][nyq_slices][4]: partial sums of Y[N/2], Re/Im Y[N/2-1] (mean-free signal), 2/N
   int nyq_slices;          // slices of 4096 samples per utterance slot
+  double *mean_part;       // [n_utt][mean_parts] partial sums of the decimated signal: per span of the backward sweep (ratio 1: per slice)
+  int mean_parts;
   double *quirk;           // [n_utt][nch][4] per-band constants of the mirror-store term (bandfilter.h)
   const double *win_tab;   // [hw][6] = sin/cos(pi d), sin/cos(pi WAVE d), 2 / window length, pi d; d = 2/(2hw+1): refinement window steps
   const double *win_lane;  // [hw][WAVE][2] = (sin, cos)(pi (lane - hw - 1) d): a lane's first window sample at a whole-sample frame centre

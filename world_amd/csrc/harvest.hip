@@ -46,18 +46,20 @@ __global__ void __launch_bounds__(kDecThreads) hv_decimate_fwd(HarvestParams p, 
 __global__ void __launch_bounds__(kDecThreads) hv_decimate_bwd(HarvestParams p, IirCoef c) {
   DYN_LDS(lds);
   const int u = blockIdx.y;
+  // ... and the sum of the span's decimated samples (the mean removed next: no pass of its own over y)
   dec_backward_block(p.fwd + (size_t)u * p.m_stride, p.b.x_len[u], p.lag, p.ratio, c, blockIdx.x,
                      p.lag / p.ratio, p.y_len[u], p.y + (size_t)u * p.y_stride, reinterpret_cast<double *>(lds),
-                     dec_warm(p.ratio));
+                     dec_warm(p.ratio), p.mean_part + (size_t)u * p.mean_parts);
 }
 __global__ void hv_copy_signal(HarvestParams p) {          // ratio == 1 (harvest.cpp:45-48)
   int u = blockIdx.y, i = flat_thread_x();
   if (i < p.y_len[u]) p.y[(size_t)u * p.y_stride + i] = p.b.x[(size_t)u * p.b.x_stride + i];
 }
-// y <- y - mean(y)  (harvest.cpp:81-85): per-slice partial sums, then every workgroup
-// adds the partials in the same fixed order (deterministic) and subtracts the mean.
+// y <- y - mean(y)  (harvest.cpp:81-85).  The sum arrives as per-span partials (of the backward decimation sweep; at
+// ratio 1, where nothing is decimated, of hv_partial_sums' slices): every workgroup adds them in the same fixed order
+// (deterministic; a span beyond the utterance's end holds 0) and subtracts the mean from its slice.
 constexpr int kMeanSlice = 4096;
-__global__ void hv_partial_sums(HarvestParams p) {
+__global__ void hv_partial_sums(HarvestParams p) {          // ratio == 1 only
   DYN_LDS(lds);
   double *scratch = reinterpret_cast<double *>(lds);
   const int slice = blockIdx.x, u = blockIdx.y, n = p.y_len[u];
@@ -66,42 +68,47 @@ __global__ void hv_partial_sums(HarvestParams p) {
   double s = 0.0;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) s += y[i];
   s = block_sum(s, scratch);
-  if (threadIdx.x == 0) p.fwd[(size_t)u * p.m_stride + slice] = s;     // fwd is free after decimation
-  if (threadIdx.x == 0 && slice == 0) p.nc[u] = 0;                      // hv_detect's running maximum starts from here
+  if (threadIdx.x == 0) p.mean_part[(size_t)u * p.mean_parts + slice] = s;
 }
 __global__ void hv_remove_mean(HarvestParams p) {
   DYN_LDS(lds);
   double *scratch = reinterpret_cast<double *>(lds);
   const int slice = blockIdx.x, u = blockIdx.y, n = p.y_len[u];
   double *y = p.y + (size_t)u * p.y_stride;
-  const int nslice = (n + kMeanSlice - 1) / kMeanSlice;
-  if (threadIdx.x == 0) {
+  if (wave_in_block() == 0) {
+    const double *part = p.mean_part + (size_t)u * p.mean_parts;
     double s = 0.0;
-    for (int k = 0; k < nslice; ++k) s += p.fwd[(size_t)u * p.m_stride + k];
-    scratch[0] = s / n;
+    for (int k = lane_id(); k < p.mean_parts; k += WAVE) s += part[k];
+    s = wave_sum(s);
+    if (lane_id() == 0) scratch[0] = s / n;
   }
+  if (threadIdx.x == 0 && slice == 0) p.nc[u] = 0;           // hv_detect's running maximum starts from here
   __syncthreads();
   const double mean = scratch[0];
   const int lo = slice * kMeanSlice, hi = imin(n, lo + kMeanSlice);
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) y[i] -= mean;
-}
-
-// the utterance's two spectrum bins next to Nyquist and the per-band constants of the
-// reference's mirror-store term (bandfilter.h)
-__global__ void hv_nyquist_bins(HarvestParams p) {          // partial sums per slice of kMeanSlice samples
-  DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  const int slice = blockIdx.x, u = blockIdx.y;
+  // ... and, on the way, the slice's share of the utterance's two spectrum bins next to Nyquist (the per-band constants
+  // of the reference's mirror-store term need them, bandfilter.h: nyquist_pair's sums over the mean-free samples --
+  // each thread's own, in its own order; round 4 had a kernel of its own read y back for them)
   const double w = 2.0 / p.ref_fft[u];
-  double s0, s1r, s1i;
-  nyquist_pair(p.y + (size_t)u * p.y_stride, p.y_len[u], w, scratch, &s0, &s1r, &s1i, slice * kMeanSlice,
-               (slice + 1) * kMeanSlice);
-  if (threadIdx.x == 0) { double *o = p.nyq + ((size_t)u * gridDim.x + slice) * 4; o[0] = s0; o[1] = s1r; o[2] = s1i; o[3] = w; }
+  double a = 0.0, br = 0.0, bi = 0.0, sn, cs, sr, cr;
+  sincospi((double)(lo + (int)threadIdx.x) * w, &sn, &cs);
+  sincospi((double)blockDim.x * w, &sr, &cr);
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const double v = y[i] - mean;
+    y[i] = v;
+    const double x = (i & 1) ? -v : v;
+    a += x; br += x * cs; bi += x * sn;
+    const double c2 = cs * cr - sn * sr;
+    sn = sn * cr + cs * sr;
+    cs = c2;
+  }
+  block_sum3(a, br, bi, scratch);                    // (its leading barrier: everybody has read scratch[0])
+  if (threadIdx.x == 0) { double *o = p.nyq + ((size_t)u * gridDim.x + slice) * 4; o[0] = a; o[1] = br; o[2] = bi; o[3] = w; }
 }
-__global__ void hv_band_quirk(HarvestParams p) {
-  DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  const int band = blockIdx.x, u = blockIdx.y;
+// the per-band constants of the reference's mirror-store term (bandfilter.h) from the utterance's two spectrum bins next
+// to Nyquist and the band's: one workgroup per (band, utterance) -- on the overlap-save route the tail of hv_block_spectra's
+// grid, on the direct-form route a launch of its own
+__device__ __forceinline__ void band_quirk_constants(const HarvestParams &p, int band, int u, double *scratch) {
   const double *part = p.nyq + (size_t)u * p.nyq_slices * 4;
   double y0 = 0.0, y1r = 0.0, y1i = 0.0;
   for (int k = 0; k < p.nyq_slices; ++k) { y0 += part[4 * k]; y1r += part[4 * k + 1]; y1i += part[4 * k + 2]; }
@@ -110,6 +117,10 @@ __global__ void hv_band_quirk(HarvestParams p) {
   nyquist_pair(p.band_taps + p.band_off[band], 2 * p.band_half[band] + 1, w, scratch, &h0, &h1r, &h1i);
   if (threadIdx.x == 0)
     mirror_store_constants(y0, y1r, y1i, h0, h1r, h1i, w, p.quirk + ((size_t)u * p.nch + band) * 4);
+}
+__global__ void hv_band_quirk(HarvestParams p) {
+  DYN_LDS(lds);
+  band_quirk_constants(p, blockIdx.x, blockIdx.y, reinterpret_cast<double *>(lds));
 }
 
 // ---------------------------------------------------------------------------
@@ -169,6 +180,10 @@ int hv_fft_segment(int max_half) {
 __global__ void __launch_bounds__(256) hv_block_spectra(HarvestParams p) {
   DYN_LDS(lds);
   const int blk = blockIdx.x, u = blockIdx.y, n = p.y_len[u];
+  if (blk >= p.nblk) {                                        // the grid's tail: one workgroup per band (see above)
+    band_quirk_constants(p, blk - p.nblk, u, reinterpret_cast<double *>(lds));
+    return;
+  }
   const int m0 = blk * p.fft_seg - p.fft_pre;                 // signal index of the block's first sample
   if (blk * p.fft_seg >= n) return;                           // no output of this utterance lies in the block
   cplx *Z = reinterpret_cast<cplx *>(lds);
@@ -707,9 +722,11 @@ __global__ void hv_refine(HarvestParams p) {
 #ifndef WORLD_EMU
       // over the harmonics: lane bits 3..5 (xor 8 stays inside a DPP row, 16 and 32 cross rows)
       num += dpp_f64<kDppRor8>(num); den += dpp_f64<kDppRor8>(den); sc += dpp_f64<kDppRor8>(sc);
-      for (int s = 2 * G; s < WAVE; s <<= 1) {
-        num += __shfl_xor(num, s, 64); den += __shfl_xor(den, s, 64); sc += __shfl_xor(sc, s, 64);
-      }
+      // across the four DPP rows: gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap: vector ALU) instead of
+      // __shfl_xor's ds_bpermute pairs -- twelve trips through the LDS crossbar per track
+      static_assert(2 * G == 16 && WAVE == 64, "lane bits 4 and 5 select the row");
+      num = row_pair_sum(num); den = row_pair_sum(den); sc = row_pair_sum(sc);
+      num = half_pair_sum(num); den = half_pair_sum(den); sc = half_pair_sum(sc);
 #endif
       if (hl == 0 && m < 7) {
         double rf0 = 0.0, rsc = 0.0;
@@ -816,7 +833,8 @@ size_t hv_band_lds_bytes(int max_half) { return band_lds_bytes(2 * max_half + 1)
 void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int max_fb, int max_frames,
                     hipStream_t stream) {
   const int B = p.b.n_utt;
-  devrt::dzero(p.y, sizeof(double) * (size_t)B * p.y_stride, stream);
+  // (y needs no clearing: the decimation -- or the copy at ratio 1 -- writes every sample below y_len, and every reader
+  // stops there or clamps: a memset per job was one more launch in the in-flight mode)
   if (p.ratio == 1) {
     WH_THREADS(hv_copy_signal, max_y_len, B, 1, stream, p);
   } else {
@@ -825,16 +843,15 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
     WH_BLOCKS(hv_decimate_fwd, dim3(spans, B), kDecThreads, dec_lds_bytes(), stream, p, c);
     WH_BLOCKS(hv_decimate_bwd, dim3(spans, B), kDecThreads, dec_lds_bytes(), stream, p, c);
   }
-  const int slices = (max_y_len + kMeanSlice - 1) / kMeanSlice;
-  WH_BLOCKS(hv_partial_sums, dim3(slices, B), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(hv_remove_mean, dim3(slices, B), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(hv_nyquist_bins, dim3(p.nyq_slices, B), 256, 64 * sizeof(double), stream, p);
-  WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
+  // (the mean's partial sums came with the backward sweep; at ratio 1 a pass of its own forms them)
+  if (p.ratio == 1) WH_BLOCKS(hv_partial_sums, dim3(p.mean_parts, B), 256, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(hv_remove_mean, dim3(p.nyq_slices, B), 256, 64 * sizeof(double), stream, p);
   if (p.fft_seg > 0) {
     const size_t lds = sizeof(double) * (kBandFft + 64 + twiddle_lds_doubles(kBandFftLg - 1));
-    WH_BLOCKS(hv_block_spectra, dim3(p.nblk, B), 256, lds, stream, p);
+    WH_BLOCKS(hv_block_spectra, dim3(p.nblk + p.nch, B), 256, lds, stream, p);       // + the bands' mirror-store constants
     WH_BLOCKS(hv_band_events_fft, dim3(p.nch, p.nseg, B), 256, lds, stream, p);
   } else {
+    WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
     WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
   }
   // one chunk per utterance: the kernel above appended straight into the final lists (seg_events == events)

@@ -1,0 +1,73 @@
+// prepare.h -- where each frame's noise sits in the reference's one randn() stream: exclusive prefix sums
+// of the per-frame draw counts, one workgroup per utterance.  CheapTrick's scan and D4C's first (the LoveTrain windows)
+// follow from F0 alone, so one launch serves both stages of a job (spectral_prepare, d4c.hip); D4C's second scan depends
+// on the LoveTrain result and is the epilogue of that kernel's last workgroup per utterance (d4c_lovetrain).
+#pragma once
+#include "stage_params.h"
+
+namespace world_hip {
+
+__device__ __forceinline__ double ct_effective_f0(double f0, double floor_f0) {
+  return f0 <= floor_f0 ? kDefaultF0 : f0;              // cheaptrick.cpp:218
+}
+
+// CheapTrick: window draws, then one per bin (cheaptrick.cpp:27-43, :147-149)
+__device__ __forceinline__ void ct_offsets_utt(const CtParams &p, int u, double *scratch) {
+  const int nf = p.b.n_frames[u];
+  const int nb = (1 << p.lg_fft) / 2 + 1;
+  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
+  unsigned *off_out = p.offsets + (size_t)u * p.b.f_stride;
+  unsigned running = 0;
+  for (int base = 0; base < nf; base += blockDim.x) {
+    int f = base + threadIdx.x;
+    int cnt = 0;
+    if (f < nf) {
+      double cf0 = ct_effective_f0(f0[f], p.f0_floor);
+      cnt = 2 * mround(1.5 * p.b.fs / cf0) + 1 + nb;
+    }
+    int total, off = block_excl_scan_int(cnt, &total, scratch);
+    if (f < nf) off_out[f] = running + (unsigned)off;
+    running += (unsigned)total;
+  }
+}
+
+// D4C pass 1: the LoveTrain window of every voiced frame (d4c.cpp:263-279)
+__device__ __forceinline__ void d4c_offsets1_utt(const D4cParams &p, int u, double *scratch) {
+  const int nf = p.b.n_frames[u];
+  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
+  unsigned *off_out = p.offsets1 + (size_t)u * p.b.f_stride;
+  unsigned running = 0;
+  for (int base = 0; base < nf; base += blockDim.x) {
+    int f = base + threadIdx.x, cnt = 0;
+    if (f < nf && f0[f] != 0.0) {
+      double cf0 = f0[f] > 40.0 ? f0[f] : 40.0;                      // d4c.cpp:263,279
+      cnt = 2 * mround(3.0 * p.b.fs / cf0 / 2.0) + 1;
+    }
+    int total, off = block_excl_scan_int(cnt, &total, scratch);
+    if (f < nf) off_out[f] = running + (unsigned)off;
+    running += (unsigned)total;
+  }
+  if (threadIdx.x == 0) { p.draws1[u] = running; p.love_ticket[u] = 0; }
+}
+
+// D4C pass 2: the three body windows of every frame LoveTrain let through (d4c.cpp:386), continuing the stream where
+// pass 1 ended
+__device__ __forceinline__ void d4c_offsets2_utt(const D4cParams &p, int u, double *scratch) {
+  const int nf = p.b.n_frames[u];
+  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
+  const double *ap0 = p.ap0 + (size_t)u * p.b.f_stride;
+  unsigned *off_out = p.offsets2 + (size_t)u * p.b.f_stride;
+  unsigned running = p.draws1[u];
+  for (int base = 0; base < nf; base += blockDim.x) {
+    int f = base + threadIdx.x, cnt = 0;
+    if (f < nf && !(f0[f] == 0 || ap0[f] <= p.threshold)) {
+      double cf0 = kFloorF0D4C > f0[f] ? kFloorF0D4C : f0[f];
+      cnt = 3 * (2 * mround(4.0 * p.b.fs / cf0 / 2.0) + 1);
+    }
+    int total, off = block_excl_scan_int(cnt, &total, scratch);
+    if (f < nf) off_out[f] = running + (unsigned)off;
+    running += (unsigned)total;
+  }
+}
+
+}  // namespace world_hip

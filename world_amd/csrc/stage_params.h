@@ -41,6 +41,7 @@ struct D4cParams {
   unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
   unsigned *offsets2;     // [n_utt][f_stride]  position of the frame's 3 body windows within pass 2
   unsigned *draws1;       // [n_utt] total draws of pass 1 (pass 2 continues the stream there)
+  int *love_ticket;       // [n_utt] LoveTrain workgroups of the utterance that are done: the last one scans offsets2
   const uint32_t *noise;  // randn_value(noise[k]) = k-th randn() of the stream (context-wide table)
   const double *nuttall;  // [wl] NuttallWindow(wl), built on the host
   Tables tab;
@@ -53,11 +54,14 @@ struct D4cParams {
   // Frame range of d4c_frame / d4c_finish (LoveTrain and the two offset scans always cover every frame: the second
   // pass's stream positions depend on every earlier frame's LoveTrain result).  0 / INT_MAX = all.
   int frame_lo, frame_hi;
-  int skip_prepare;       // 1: LoveTrain + offsets of an earlier call with the same shape are still in the workspace
+  int skip_prepare;       // bits: kD4cSkipScan = offsets1 are in place (an earlier call, or the launch shared with CheapTrick);
+                          // kD4cSkipLoveTrain = the LoveTrain pass and offsets2 of an earlier call are still in the workspace
 };
+constexpr int kD4cSkipScan = 1, kD4cSkipLoveTrain = 2;
 
 void launch_cheaptrick(const CtParams &p, int max_frames, hipStream_t stream);
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
+void launch_spectral_prepare(const CtParams &cp, const D4cParams &dp, hipStream_t stream);   // both stages' F0-only scans
 size_t ct_max_draws_per_frame(int fft_size);
 size_t d4c_max_draws_per_frame(int fs);
 

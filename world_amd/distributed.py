@@ -377,8 +377,9 @@ def analyze_long_sharded(x, fs, group=None, frame_period=5.0, wire="f64", harves
     if harvest is None or spectral_range is None:
         wh = _default_analyzer()
         harvest = harvest or (lambda xb: wh.harvest(xb, fs, frame_period=frame_period, **{k: v for k, v in options.items() if k in ("f0_floor", "f0_ceil")}))
-        spectral_range = spectral_range or (lambda xb, tp, f0, block, lo, hi: wh.spectral_packed_range(
-            xb, fs, tp, f0, [nf], block, lo, hi, **{k: v for k, v in options.items() if k in ("q1", "threshold")}))
+        spectral_range = spectral_range or (lambda xb, tp, f0, block, lo, hi, reuse=False: wh.spectral_packed_range(
+            xb, fs, tp, f0, [nf], block, lo, hi, reuse_offsets=reuse,
+            **{k: v for k, v in options.items() if k in ("q1", "threshold")}))
     if timings is not None and cuda:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -390,10 +391,12 @@ def analyze_long_sharded(x, fs, group=None, frame_period=5.0, wire="f64", harves
     cuts = [(a, min(span, a + sub_frames)) for a in range(0, span, sub_frames)] or [(0, 0)]
     bufs = [torch.zeros((world, max(1, b - a), cols), dtype=torch.float64, device=x.device) for a, b in cuts]
     works = []
+    prepared = False           # the offset scans and D4C's LoveTrain pass cover every frame: once per call, not per sub-range
     for k, (a, b) in enumerate(cuts):
         l, h = min(hi, lo + a), min(hi, lo + b)
         if h > l:
-            spectral_range(xb, tpos, f0, bufs[k][rank], l, h)
+            spectral_range(xb, tpos, f0, bufs[k][rank], l, h, prepared)
+            prepared = True
         if world > 1:
             works.append(_gather_in_place(bufs[k], rank, group, True))
     wait_all(works)

@@ -203,6 +203,47 @@ def cpu_baseline_all_cores(x_np, optimized=False, seconds=2.5):
             "host_cores_available": os.cpu_count(), "affinity_cores": cores, "cgroup_cpu_quota": quota}
 
 
+def smi_snapshot():
+    """What rocm-smi says about device 0 right now: clocks, power and cap, performance level, compute / memory partition
+    mode.  Two of round 4's seven boxes ran a lone job's latency-bound kernels 10-90 % slower and the line had nothing to
+    tell them apart by.  Best effort: a missing tool or field gives None, never an exception."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    out = {}
+    try:
+        r = subprocess.run([exe, "-d", "0", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
+                            "--showcomputepartition", "--showmemorypartition", "--showtemp", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout[r.stdout.index("{"):]) if "{" in r.stdout else {}
+        card = d.get("card0") or (next(iter(d.values())) if d else {})
+        for k, v in (card or {}).items():
+            kl = k.lower()
+            if "sclk" in kl:
+                out["sclk"] = v
+            elif "mclk" in kl:
+                out["mclk"] = v
+            elif "fclk" in kl:
+                out["fclk"] = v
+            elif "max graphics package power" in kl or "max power" in kl:
+                out["power_cap_w"] = v
+            elif "power" in kl and "w" in kl and "power_w" not in out:
+                out["power_w"] = v
+            elif "performance level" in kl:
+                out["perf_level"] = v
+            elif "compute partition" in kl:
+                out["compute_partition"] = v
+            elif "memory partition" in kl:
+                out["memory_partition"] = v
+            elif "temperature" in kl and "junction" in kl:
+                out["temp_junction_c"] = v
+        if not out:
+            out["raw"] = (r.stdout or r.stderr)[-400:]
+    except Exception as e:                                   # noqa: BLE001 -- diagnostics must not break the run
+        out["error"] = f"{type(e).__name__}: {e}"[:200]
+    return out
+
+
 def rel_err(a, b):
     import numpy as np
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
@@ -258,6 +299,22 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(os.environ.get("WORLD_HIP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
+    props = torch.cuda.get_device_properties(local)
+    environment = {"device": props.name, "arch": getattr(props, "gcnArchName", None), "compute_units": props.multi_processor_count,
+                   "hbm_bytes": props.total_memory, "rocm_smi_at_start": smi_snapshot() if rank == 0 else None,
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+
+    def environment_done(wh_probe=None):
+        """the line's `environment` object: rocm-smi before and after the run, and the library's microprobe of the machine
+        under load (world_hip_probe_machine: effective shader clock under an FP64 load, HBM and L2 pointer-chase latency,
+        an LDS round trip on an idle and on a loaded CU) -- what tells a slow box from a regression"""
+        environment["rocm_smi_at_end"] = smi_snapshot() if rank == 0 else None
+        if wh_probe is not None and hasattr(wh_probe, "probe_machine"):
+            try:
+                environment["microprobe"] = wh_probe.probe_machine()
+            except Exception as e:                           # noqa: BLE001
+                environment["microprobe"] = {"error": str(e)[:200]}
+        return environment
 
     def barrier():
         if world > 1:
@@ -422,7 +479,7 @@ def main():
                            "wire": args.wire,
                            "note": "chunk k's all-gather runs while chunk k+1 is analysed; exposed = device time the compute stream "
                                    "waited for all-gathers after its last analysis (HIP events), compute = the rest of the step"},
-                "parity_in_run": parity, "roofline": roofline, "cpu_baseline": None}))
+                "parity_in_run": parity, "roofline": roofline, "cpu_baseline": None, "environment": environment_done(wh)}))
             if parity is not None and not (parity["every_rank_bit_identical_to_lone_analysis"] and parity["randn_table_intact"]):
                 sys.stderr.write("bench.py: parity_in_run failed: " + json.dumps(parity) + "\n")
                 sys.exit(1)
@@ -891,6 +948,7 @@ def main():
         "first_call_ms": None if not host_to_host else host_to_host.get("cold_start", {}).get("first_call_ms"),
         "randn_table_first_build_ms": None if not host_to_host else host_to_host.get("cold_start", {}).get("randn_table_build_ms"),
         "workspace_bytes": workspace, "randn_table_bytes": table_bytes, "csrc_hash": csrc_hash(),
+        "environment": environment_done(WorldHip(device=local)),
     }
     print(json.dumps(out))
     if not ok:

@@ -91,6 +91,8 @@ def load_library(path=LIB_PATH):
                                               C.POINTER(HarvestOption), C.POINTER(CheapTrickOption), C.POINTER(D4COption),
                                               C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
     lib.world_hip_check_shape.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    if hasattr(lib, "world_hip_probe_machine"):                      # (absent from libraries of earlier rounds: tools/ab.py loads those)
+        lib.world_hip_probe_machine.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     lib.world_hip_record_columns.argtypes = [C.c_int, C.c_int]
     lib.world_hip_spectral_packed_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp,
                                                     C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, C.c_int,
@@ -759,6 +761,16 @@ class WorldHip:
     def decode_aperiodicity(self, coded, fs, fft_size):
         return self._codec(self.lib.world_hip_decode_aperiodicity, "decode_aperiodicity", coded, fs, fft_size,
                            fft_size // 2 + 1)
+
+    def probe_machine(self):
+        """world_hip_probe_machine (include/world_hip.h): ~50 ms of microbenchmarks that characterise the box"""
+        if not hasattr(self.lib, "world_hip_probe_machine"):
+            return None
+        v = (C.c_double * 8)()
+        self._check(self.lib.world_hip_probe_machine(self._context(), v, 8), "probe_machine")
+        keys = ("sclk_mhz_under_fp64_load", "fp64_fma_tflops", "hbm_chase_ns", "infinity_cache_chase_ns", "l2_chase_ns",
+                "lds_trip_cycles_idle_cu", "lds_trip_cycles_loaded_cu", "compute_units")
+        return {k: round(float(x), 2) for k, x in zip(keys, v)}
 
     def analyze(self, x, fs, x_len=None, f0_method="harvest", frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
                 q1=-0.15, threshold=0.85, sp_out=None, ap_out=None, tpos_out=None, f0_out=None):

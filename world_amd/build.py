@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libworld_hip.so")
 UNITS = ["api.hip", "cheaptrick.hip", "d4c.hip", "codec.hip", "pcm.hip", "synthesis.hip", "harvest.hip", "harvest_contour.hip", "rng_fill.hip", "dio.hip",
-         "stonemask.hip", "exchange.hip", "fft_probe.hip", "tables.cpp", "devrt.cpp"]
+         "stonemask.hip", "exchange.hip", "fft_probe.hip", "machine_probe.hip", "tables.cpp", "devrt.cpp"]
 # -ffp-contract=off: the analysis is order/rounding sensitive in places;
 # fused multiply-adds are requested explicitly (fma()) in the FP64 inner loops instead.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",

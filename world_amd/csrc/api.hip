@@ -27,6 +27,7 @@
 #include "dio.h"
 #include "exchange.h"
 #include "fft_probe.h"
+#include "machine_probe.h"
 #include "harvest.h"
 #include "stage_params.h"
 #include "synthesis.h"
@@ -67,6 +68,7 @@ struct HarvestBands {            // cached per (fs, f0_floor, f0_ceil)
   int *d_half = nullptr, *d_off = nullptr;
   double *d_win_tab = nullptr;   // refinement-window angle steps per half length (hv_refine)
   int win_tab_len = 0;
+  size_t win_full_entries = 0;   // (w, dw) pairs of every whole-sample-centred window behind the two tables above (0: none)
   double2 *d_spec = nullptr;     // [nch][kBandFftBins] spectra of the taps / kBandFft (FFT path of the filter bank)
   int fft_seg = 0;               // outputs per block of that path (0: filters too long, direct FIR)
   std::vector<double> band_f0;
@@ -518,6 +520,37 @@ static void prepare_bands(WorldHipContext *c, int fs, double f0_floor, double f0
       wt[head + ((size_t)hw * WAVE + lane) * 2 + 1] = (double)cosl(a);
     }
   }
+  // Where a millisecond is a whole number of samples (8 kHz: the decimated rate of 16 / 32 / 48 / 96 kHz input) every
+  // refinement window is centred ON a sample, and the window of half length hw is the same 2 hw + 1 numbers at every
+  // frame: the main window (GetMainWindow, harvest.cpp:446-456) and its central difference (GetDiffWindow, :462-468) as
+  // (w, dw) pairs, the window of half length hw at entry hw^2 (sum of 2 h + 1 below it).  A rebuild is then a load and two
+  // products per sample instead of ~25 FP64 operations (round 4: window rebuilds were 18 of a wavefront-frame's 65
+  // thousand cycles).  Other rates keep the rotation route (wt above).
+  hb.win_full_entries = 0;
+  if (fmod(afs, 1000.0) == 0.0) {
+    hb.win_full_entries = (size_t)(hw_max + 1) * (hw_max + 1);
+    const size_t base = wt.size();
+    wt.resize(base + 2 * hb.win_full_entries);
+    std::vector<long double> w;
+    for (int hw = 0; hw <= hw_max; ++hw) {
+      const int blen = 2 * hw + 1;
+      w.assign(blen, 0.0L);
+      const long double dl = 2.0L / (2.0L * hw + 1.0L);
+      for (int i = 0; i < blen; ++i) {
+        const long double a = pi_l * (i - hw - 1) * dl;
+        w[i] = 0.42L + 0.5L * cosl(a) + 0.08L * cosl(2.0L * a);
+      }
+      double *o = wt.data() + base + 2 * (size_t)hw * hw;
+      for (int i = 0; i < blen; ++i) {
+        long double dw;
+        if (blen == 1) dw = 0.0L;
+        else if (i == 0) dw = -w[1] / 2.0L;
+        else if (i == blen - 1) dw = w[blen - 2] / 2.0L;
+        else dw = -(w[i + 1] - w[i - 1]) / 2.0L;
+        o[2 * i] = (double)w[i]; o[2 * i + 1] = (double)dw;
+      }
+    }
+  }
   if (hb.d_win_tab) devrt::dfree(hb.d_win_tab);
   hb.d_win_tab = static_cast<double *>(devrt::dmalloc(sizeof(double) * wt.size()));
   devrt::h2d(hb.d_win_tab, wt.data(), sizeof(double) * wt.size(), c->stream);
@@ -621,6 +654,8 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.quirk = c->arena.take<double>(B * p.nch * 4);
   p.band_f0 = hb.d_band_f0; p.band_half = hb.d_half; p.band_off = hb.d_off; p.band_taps = hb.d_taps;
   p.win_tab = hb.d_win_tab; p.win_lane = hb.d_win_tab + (size_t)hb.win_tab_len * 6;
+  p.win_full = hb.win_full_entries && !getenv("WORLD_HIP_REFINE_ROTATE")
+                   ? reinterpret_cast<const double2 *>(p.win_lane + (size_t)hb.win_tab_len * WAVE * 2) : nullptr;
   p.fwd = c->arena.take<double>(B * p.m_stride);
   p.y = c->arena.take<double>(B * p.y_stride);
   p.events = c->arena.take<double>(B * p.nch * 4 * p.ev_cap);
@@ -1571,6 +1606,15 @@ int world_hip_synthesis_batch(WorldHipContext *c, int n_utt, int fs, double fram
   return guarded(c, [&] {
     run_synthesis(c, n_utt, fs, frame_period, fft_size, n_frames, f_stride, d_f0, d_spectrogram, d_aperiodicity,
                   y_length, y_stride, d_y);
+  });
+}
+
+// what box is this? (machine_probe.hip; synchronous, ~50 ms, allocates and frees 2 GB)
+int world_hip_probe_machine(WorldHipContext *c, double *values, int n_values) {
+  return guarded(c, [&] {
+    if (!values || n_values < world_hip::kMachineProbeValues) fail("probe_machine: room for %d values needed", world_hip::kMachineProbeValues);
+    devrt::sync(c->stream);
+    world_hip::run_machine_probe(values, c->stream);
   });
 }
 

@@ -19,6 +19,11 @@
 //                   powers is used) -> the band's two sums.  Nothing but those leaves the CU.
 //   d4c_finish    : the bands' dB values and the 3 kHz-grid interpolation; every row written once to HBM, dense or
 //                   straight into packed records.
+// -DD4C_FP_CONTRACT (A/B, tools/ab.py): contraction for this unit only -- D4C's arithmetic is multiply-add pairs throughout
+// (window rotations, interpolation, power sums) and none of it is amplified the way CheapTrick's smoothing is
+#ifdef D4C_FP_CONTRACT
+#pragma clang fp contract(fast)
+#endif
 #include "stage_params.h"
 #include "prepare.h"
 #include "trace.h"

@@ -41,6 +41,8 @@ struct HarvestParams {
   double *quirk;           // [n_utt][nch][4] per-band constants of the mirror-store term (bandfilter.h)
   const double *win_tab;   // [hw][6] = sin/cos(pi d), sin/cos(pi WAVE d), 2 / window length, pi d; d = 2/(2hw+1): refinement window steps
   const double *win_lane;  // [hw][WAVE][2] = (sin, cos)(pi (lane - hw - 1) d): a lane's first window sample at a whole-sample frame centre
+  const double2 *win_full; // [hw^2 + i] = (main window, its central difference)[i] of half length hw centred on a sample; nullptr:
+                           // a millisecond is not a whole number of samples at the analysis rate -- the kernel rotates (win_tab / win_lane)
   Tables tab;
   // ---- workspace (device) ----
   double *fwd;             // [n_utt][m_stride] forward-filtered padded signal

@@ -592,7 +592,35 @@ __global__ void hv_refine(HarvestParams p) {
       const int blen = 2 * hw + 1;
       const int N = 1 << lgN;
       const bool same_window = hw == c_hw && first == c_first;
-      if (!same_window) {
+#ifdef HV_REFINE_ROTATE                                  // (A/B, tools/ab.py: round 4's route at every rate)
+      const bool table_window = false;
+#else
+      const bool table_window = p.win_full != nullptr;
+#endif
+      if (!same_window && table_window) {
+        // whole-sample frame centres (8 kHz): the window is a row of the host's table -- a load and two products per sample
+        WH_ACC_BEGIN;
+        const double2 *wf = p.win_full + (size_t)hw * hw;
+        wave_sync();                                             // the previous candidate's reads are done
+        constexpr int kB = 3;                                    // loads in flight per lane
+        for (int i0 = lane; i0 < blen; i0 += kB * WAVE) {
+          double2 t[kB];
+#pragma unroll
+          for (int q = 0; q < kB; ++q) t[q] = wf[imin(blen - 1, i0 + q * WAVE)];
+#pragma unroll
+          for (int q = 0; q < kB; ++q) {
+            const int i = i0 + q * WAVE;
+            if (i < blen) {
+              const double xv = yc[imax(0, imin(cap - 1, first + i - 1 - origin))];
+              cplx pr; pr.re = xv * t[q].x; pr.im = xv * t[q].y;
+              yw[i] = pr;
+            }
+          }
+        }
+        wave_sync();
+        c_hw = hw; c_first = first;
+        WH_ACC_END(1);
+      } else if (!same_window) {
         WH_ACC_BEGIN;
         // Blackman main window (harvest.cpp:446-456) and its central difference
         // (GetDiffWindow, :462-468).  w[i+1]-w[i-1] follows from the angle-addition
@@ -759,7 +787,8 @@ __device__ __forceinline__ double nearest_error(double ref, const double *c, int
   const double e = dmin / ref;
   return e > 1.0 ? 1.0 : e;
 }
-constexpr int kPruneFrames = 32;                          // frames per workgroup (+1 neighbour row each side)
+constexpr int kPruneFrames = 16;                          // frames per workgroup (+1 neighbour row each side; with the pruned scores kept
+                                                          // for the base pick the LDS is what 32 frames took without them)
 __global__ void hv_prune(HarvestParams p) {
   DYN_LDS(lds);
   double *rows = reinterpret_cast<double *>(lds);         // [kPruneFrames + 2][maxc] refined candidates
@@ -774,7 +803,10 @@ __global__ void hv_prune(HarvestParams p) {
   // Only the nslot slots in use are staged, as rows of nslot (the other maxc - nslot of a row are never written by
   // hv_refine's tail and never compared).
   const int nt = blockDim.x;
-  if (nslot == 0) return;                                  // no candidate anywhere in the utterance: nothing to prune
+  if (nslot == 0) {                                        // no candidate anywhere in the utterance: nothing to prune, no base
+    for (int r = threadIdx.x; r < imin(kPruneFrames, nfb - f0); r += nt) p.c0[(size_t)u * p.fb_stride + f0 + r] = 0.0;
+    return;
+  }
   {
     constexpr int kB = 8;
     const int n = nrows * nslot;
@@ -797,6 +829,8 @@ __global__ void hv_prune(HarvestParams p) {
     }
   }
   __syncthreads();
+  // the tile's pruned scores stay in LDS for the base pick below (its F0 is the staged one: a pruned slot's score is 0 and cannot win)
+  double *kept_sc = rows + (size_t)(kPruneFrames + 2) * nslot;
   {
     constexpr int kB = 4;                                  // the scores of a thread's next slots are requested together
     const int n = imin(kPruneFrames, nfb - f0) * nslot;    // slots of the tile's frames inside the utterance
@@ -822,7 +856,38 @@ __global__ void hv_prune(HarvestParams p) {
         }
         p.cand_a[at] = ref;
         p.score_a[at] = sc;
+        kept_sc[i] = sc;
       }
+    }
+  }
+  __syncthreads();
+  // SearchF0Base (harvest.cpp:693-705) on the way: the frame's candidate with the highest score, the FIRST one among
+  // equals -- one wavefront per frame, lanes over the slots -- into c0 (round 4: a launch of its own, hc_base, that read
+  // both arrays back from HBM).  FixStep1 then needs three neighbouring values of it (harvest_contour.hip).
+  {
+    const int lane = lane_id(), nfr = imin(kPruneFrames, nfb - f0);
+    for (int r = wave_in_block(); r < nfr; r += waves_per_block()) {
+      const double *c = rows + (size_t)(r + 1) * nslot, *sv = kept_sc + (size_t)r * nslot;
+      double best = 0.0, top = 0.0;
+      int slot = 0x7FFFFFFF;                               // lowest slot holding this lane's maximum
+      for (int j = lane; j < nslot; j += WAVE) {
+        const double sj = sv[j];
+        if (sj > top) { best = c[j]; top = sj; slot = j; }
+      }
+      const double wtop = wave_max(top);
+      double v = 0.0;
+      if (wtop > 0.0) {
+        // among the lanes that hold the maximum the lowest slot wins (the serial loop keeps the first one it meets)
+        const int mine = top == wtop ? slot : 0x7FFFFFFF;
+        const int win = -wave_max_int(-mine);
+#ifndef WORLD_EMU
+        v = readlane_f64(best, __builtin_amdgcn_readfirstlane(win % WAVE));
+#else
+        (void)win;
+        v = best;
+#endif
+      }
+      if (lane == 0) p.c0[(size_t)u * p.fb_stride + f0 + r] = v;
     }
   }
 }
@@ -861,7 +926,7 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
   WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
   WH_BLOCKS(hv_prune, dim3((max_fb + kPruneFrames - 1) / kPruneFrames, B), 256,
-            sizeof(double) * (size_t)(kPruneFrames + 2) * p.maxc, stream, p);
+            sizeof(double) * (size_t)(2 * kPruneFrames + 2) * p.maxc, stream, p);          // + the base pick (c0)
   launch_harvest_contour(p, max_fb, max_frames, stream);
 }
 

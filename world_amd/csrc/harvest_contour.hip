@@ -25,74 +25,56 @@ __device__ __forceinline__ double *hc_row(double *base, const HarvestParams &p, 
   return base + (size_t)u * p.fb_stride;
 }
 
-// ---- SearchF0Base + FixStep1 -------------------------------------------------
-// SearchF0Base (:693-705): the candidate with the highest score, the FIRST one among equals.  One wavefront per
-// frame, lanes over the candidate slots (a thread per frame walking 42 slots of three frames was 33 us of pure
-// load latency on 157 wavefronts); the result goes to c0, FixStep1 then needs three neighbouring values of it.
-__global__ void hc_base(HarvestParams p) {
-  const int f = wave_item_x(), u = blockIdx.y;
-  if (f >= p.nfb[u]) return;
-  const int nslot = p.nc[u] * 7, lane = lane_id();
-  const double *c = p.cand_a + ((size_t)u * p.fb_stride + f) * p.maxc;
-  const double *s = p.score_a + ((size_t)u * p.fb_stride + f) * p.maxc;
-  double best = 0.0, top = 0.0;
-  int slot = 0x7FFFFFFF;                                   // lowest slot holding this lane's maximum
-  for (int j = lane; j < nslot; j += WAVE) {
-    const double sj = s[j];
-    if (sj > top) { best = c[j]; top = sj; slot = j; }
-  }
-  const double wtop = wave_max(top);
-  double v = 0.0;
-  if (wtop > 0.0) {
-    // among the lanes that hold the maximum the lowest slot wins (the serial loop keeps the first one it meets)
-    const int mine = top == wtop ? slot : 0x7FFFFFFF;
-    const int win = -wave_max_int(-mine);
-#ifndef WORLD_EMU
-    v = readlane_f64(best, __builtin_amdgcn_readfirstlane(win % WAVE));
-#else
-    (void)win;
-    v = best;
-#endif
-  }
-  if (lane == 0) hc_row(p.c0, p, u)[f] = v;
-}
+// (SearchF0Base, :693-705 -- the candidate with the highest score per frame, into c0 -- rides on hv_prune: harvest.hip.)
 // ---- FixStep1 (:710-722) + FixStep2 (:748-762) in one launch -----------------------------------------
 // Step 1 drops a frame whose F0 jumps from the line through its two predecessors; step 2 removes voiced runs with
 // end - start < 6, which needs step 1's result six frames to either side: a workgroup evaluates step 1 for its
 // kStepTile frames and that margin into LDS, then step 2 out of it (two kernels and a contour row in HBM before).
-constexpr int kStepTile = 256, kStepMargin = 6;
-__global__ void __launch_bounds__(kStepTile) hc_step12(HarvestParams p) {
-  DYN_LDS(lds);
-  double *s1 = reinterpret_cast<double *>(lds);            // step 1 of frames f0 - kStepMargin .. f0 + kStepTile + kStepMargin - 1
-  const int u = blockIdx.y, f0 = blockIdx.x * kStepTile, nf = p.nfb[u];
-  if (f0 >= nf) return;
-  const double *base = hc_row(p.c0, p, u);
-  for (int i = threadIdx.x; i < kStepTile + 2 * kStepMargin; i += blockDim.x) {
-    const int g = f0 - kStepMargin + i;
-    double v = 0.0;
-    if (g >= 2 && g < nf) {
-      const double b0 = base[g], b1 = base[g - 1], b2 = base[g - 2];   // (all three at once: one trip to memory)
-      if (b0 != 0.0) {
-        double ref = b1 * 2 - b2;
-        v = fabs((b0 - ref) / ref) > 0.008 && fabs((b0 - b1)) / b1 > 0.008 ? 0.0 : b0;
-      }
+constexpr int kStepMargin = 6;
+__device__ __forceinline__ double hc_step1_at(const double *base, int g, int nf) {
+  double v = 0.0;
+  if (g >= 2 && g < nf) {
+    const double b0 = base[g], b1 = base[g - 1], b2 = base[g - 2];   // (all three at once: one trip to memory)
+    if (b0 != 0.0) {
+      double ref = b1 * 2 - b2;
+      v = fabs((b0 - ref) / ref) > 0.008 && fabs((b0 - b1)) / b1 > 0.008 ? 0.0 : b0;
     }
-    s1[i] = v;
   }
-  __syncthreads();
-  for (int t = threadIdx.x; t < kStepTile; t += blockDim.x) {
-    const int f = f0 + t;
-    if (f >= nf) break;
-    auto at = [&](int i) { return s1[i - f0 + kStepMargin]; };
-    auto voiced = [&](int i) { return i > 0 && i < nf - 1 && at(i) > 0; };   // ends forced unvoiced (:733)
-    double v = at(f);
-    if (voiced(f)) {
-      int back = 0, fwd = 0;
-      while (back < 6 && voiced(f - back - 1)) ++back;
-      while (fwd < 6 && voiced(f + fwd + 1)) ++fwd;
-      if (back + fwd < 6) v = 0.0;
+  return v;
+}
+// Steps 1 and 2 of the whole utterance by its one workgroup (the section pass that follows needs the utterance's workgroup
+// anyway -- hc_step12_sections -- and a launch of tiles for 5 us of work was one more narrow kernel per job): every thread
+// owns a stretch of consecutive frames, evaluates step 1 for it and its margin into registers (the margins are recomputed
+// by the neighbours: 12 values), then step 2 out of them.
+__device__ __forceinline__ void hc_step12_pass(const HarvestParams &p, int u) {
+  const int nf = p.nfb[u];
+  const double *base = hc_row(p.c0, p, u);
+  double *out = hc_row(p.c2, p, u);
+  constexpr int kRun = 16;                                 // frames per thread and trip
+  for (int lo = (int)threadIdx.x * kRun; lo < nf; lo += (int)blockDim.x * kRun) {
+    double s1[kRun + 2 * kStepMargin];
+#pragma unroll
+    for (int i = 0; i < kRun + 2 * kStepMargin; ++i) s1[i] = hc_step1_at(base, lo - kStepMargin + i, nf);
+    unsigned vm = 0;                                       // bit i <-> frame lo - kStepMargin + i is voiced after step 1
+#pragma unroll
+    for (int i = 0; i < kRun + 2 * kStepMargin; ++i) {
+      const int g = lo - kStepMargin + i;
+      vm |= (unsigned)(g > 0 && g < nf - 1 && s1[i] > 0) << i;          // ends forced unvoiced (:733)
     }
-    hc_row(p.c2, p, u)[f] = v;
+#pragma unroll
+    for (int t = 0; t < kRun; ++t) {
+      const int f = lo + t;
+      if (f >= nf) break;
+      double v = s1[t + kStepMargin];
+      if ((vm >> (t + kStepMargin)) & 1u) {
+        // voiced neighbours in a row, up to six either way: the run [f - back, f + fwd] must span at least 7 frames
+        const unsigned below = ~(vm << (31 - (t + kStepMargin - 1)));   // frame f-1 at bit 31, f-2 at bit 30, ...
+        const unsigned above = ~(vm >> (t + kStepMargin + 1));          // frame f+1 at bit 0, ...
+        const int back = imin(6, __builtin_clz(below | 1u)), fwd = imin(6, __builtin_ctz(above | 0x80000000u));
+        if (back + fwd < 6) v = 0.0;
+      }
+      out[f] = v;
+    }
   }
 }
 
@@ -189,8 +171,11 @@ __device__ __forceinline__ void hc_sections_pass(const HarvestParams &p, const S
     running += tot;
   }
 }
-__global__ void hc_sections(HarvestParams p, SecArgs a) {
+// FixStep1 + FixStep2 of the utterance, then the sections of their result (c2): one launch, the utterance's workgroup
+__global__ void hc_step12_sections(HarvestParams p, SecArgs a) {
   DYN_LDS(lds);
+  hc_step12_pass(p, blockIdx.x);
+  __syncthreads();                                         // c2 is read back by other threads of this workgroup
   hc_sections_pass(p, a, blockIdx.x, reinterpret_cast<double *>(lds));
 }
 
@@ -198,10 +183,7 @@ __global__ void hc_sections(HarvestParams p, SecArgs a) {
 // the way), the short unvoiced gaps between them bridged linearly in c0, then the sections of the patched contour for
 // the smoother (and basic_f0's unvoiced frames zeroed on the way).  All by the utterance's one workgroup: the patches
 // depend on the first pass's lists, the second pass on the patches.
-__global__ void hc_sections_step4(HarvestParams p) {
-  DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  const int u = blockIdx.x;
+__device__ __forceinline__ void hc_sections_step4_pass(const HarvestParams &p, int u, double *scratch) {
   const SecArgs a3 = {p.c3, 1, 0, p.c0, nullptr};
   hc_sections_pass(p, a3, u, scratch);
   __syncthreads();
@@ -513,10 +495,11 @@ __device__ __forceinline__ void hc_merge_in_hbm(const HarvestParams &p, int u) {
 // utterance of a 128-batch).
 constexpr int kMergeThreads = 1024;
 constexpr int kMergeLdsSections = 2048;  // section records kept in LDS; an utterance with more takes hc_merge_in_hbm
-inline size_t hc_merge_lds_bytes(int sections) { return (size_t)(sections + 1) * (sizeof(double) + 8 * sizeof(int)) + 16 * sizeof(int); }
-__global__ void __launch_bounds__(kMergeThreads) hc_merge(HarvestParams p, int cap) {
-  DYN_LDS(lds);
-  const int u = blockIdx.x;
+inline size_t hc_merge_lds_bytes(int sections) {      // (at least a block collective's scratch: the section passes behind the merge)
+  const size_t b = (size_t)(sections + 1) * (sizeof(double) + 8 * sizeof(int)) + 16 * sizeof(int);
+  return b > 64 * sizeof(double) ? b : 64 * sizeof(double);
+}
+__device__ __forceinline__ void hc_merge_utt(const HarvestParams &p, int cap, int u, char *lds) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id();
   const int ns = p.sec_n[u * 2];
   if (ns > cap) {
@@ -668,6 +651,13 @@ __global__ void __launch_bounds__(kMergeThreads) hc_merge(HarvestParams p, int c
 #pragma unroll
     for (int q = 0; q < kB; ++q) if (f0 + q * nt < nf) out[f0 + q * nt] = v[q];
   }
+}
+__global__ void __launch_bounds__(kMergeThreads) hc_merge(HarvestParams p, int cap) {
+  DYN_LDS(lds);
+  const int u = blockIdx.x;
+  hc_merge_utt(p, cap, u, lds);
+  __syncthreads();            // step 3's contour (c3) is complete and visible to the whole workgroup; the LDS is free
+  hc_sections_step4_pass(p, u, reinterpret_cast<double *>(lds));
 }
 
 // ---- SmoothF0Contour (:1049-1113): zero-phase 2nd-order Butterworth per section ------
@@ -844,17 +834,15 @@ __global__ void hc_output(HarvestParams p) {
 
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
-  WH_WAVES(hc_base, max_fb, B, 1, 0, stream, p);
-  WH_BLOCKS(hc_step12, dim3((max_fb + kStepTile - 1) / kStepTile, B), kStepTile, (kStepTile + 2 * kStepMargin) * sizeof(double), stream, p);
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin, nullptr, nullptr};
-  WH_BLOCKS(hc_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
+  WH_BLOCKS(hc_step12_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
   WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), kExtendThreads, 64 * sizeof(double), stream, p);
   // WORLD_HIP_MERGE_LDS_SECTIONS lowers the number of section records hc_merge keeps in LDS (tests use it to send an
   // ordinary utterance down the route of one with thousands of sections)
   static const int merge_limit = [] { const char *e = getenv("WORLD_HIP_MERGE_LDS_SECTIONS"); return e ? imax(0, imin(kMergeLdsSections, atoi(e))) : kMergeLdsSections; }();
   const int merge_cap = imin(p.sec_cap, merge_limit);
+  // (+ FixStep4 and the two section passes around it; then hc_smooth writes basic_f0's voiced frames)
   WH_BLOCKS(hc_merge, dim3(B), kMergeThreads, hc_merge_lds_bytes(merge_cap), stream, p, merge_cap);
-  WH_BLOCKS(hc_sections_step4, dim3(B), 1024, 64 * sizeof(double), stream, p);     // then hc_smooth writes basic_f0's voiced frames
   // one wavefront per block: each reserves LDS for the longest section the batch can hold
   const int smooth_lds = imin(kSmoothLdsMax, max_fb + 3 * kSmoothTail + kSmoothSlack);
   WH_BLOCKS(hc_smooth, dim3(imin(p.sec_cap, kSmoothBlocks), B), WAVE, smooth_lds * sizeof(double), stream, p, smooth_lds);

@@ -15,7 +15,6 @@ import json
 import os
 import subprocess
 import sys
-from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,28 +23,7 @@ VAR_DIR = os.path.join(ROOT, "world_amd", "variants")
 
 def build(name, flags):
     from world_amd import build as B
-    obj_dir = os.path.join(VAR_DIR, "_obj_" + name)
-    os.makedirs(obj_dir, exist_ok=True)
-    out = os.path.join(VAR_DIR, f"libworld_hip_{name}.so")
-    units = [u for u in B.UNITS if os.path.exists(os.path.join(B.CSRC, u))]
-    stamp = os.path.join(obj_dir, "flags.txt")
-    same_flags = os.path.exists(stamp) and open(stamp).read() == flags
-    hdr = B._newest_header()
-    jobs = []
-    for u in units:
-        src, obj = os.path.join(B.CSRC, u), os.path.join(obj_dir, u + ".o")
-        if not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr):
-            jobs.append([B.hipcc(), *B.FLAGS, *flags.split(), "-x", "hip", "-c", src, "-o", obj])
-
-    def run(cmd):
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-    with ThreadPoolExecutor(max_workers=8) as ex:
-        list(ex.map(run, jobs))
-    run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *[os.path.join(obj_dir, u + ".o") for u in units]])
-    open(stamp, "w").write(flags)
-    print("built", out, "(" + (flags or "no extra flags") + ")")
+    print("built", B.build_variant(name, flags), "(" + (flags or "no extra flags") + ")")
 
 
 def bench(name, extra):

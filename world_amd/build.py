@@ -64,6 +64,44 @@ def build(force=False, verbose=False):
     return LIB
 
 
+VAR_DIR = os.path.join(HERE, "variants")
+# the race-shaking builds of devrt.h (test infrastructure: the GPU suite requires their results to be bit-identical to the
+# product library's).  Not the product: nothing loads them unless a test names them.
+CHECKED = {"jitter": "-DWH_JITTER", "poison": "-DWH_LDS_POISON"}
+
+
+def build_variant(name, flags):
+    """world_amd/variants/libworld_hip_<name>.so = the library's sources with extra compiler flags (tools/ab.py's A/B builds,
+    the checked builds above).  Travels to the GPU box with the tree; git ignores the directory."""
+    obj_dir = os.path.join(VAR_DIR, "_obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    out = os.path.join(VAR_DIR, f"libworld_hip_{name}.so")
+    units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
+    stamp = os.path.join(obj_dir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flags
+    hdr = _newest_header()
+    jobs = []
+    for u in units:
+        src, obj = os.path.join(CSRC, u), os.path.join(obj_dir, u + ".o")
+        if not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr):
+            jobs.append([hipcc(), *FLAGS, *flags.split(), "-x", "hip", "-c", src, "-o", obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(out):
+        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *[os.path.join(obj_dir, u + ".o") for u in units]])
+    open(stamp, "w").write(flags)
+    return out
+
+
+def build_checked():
+    return {name: build_variant(name, flags) for name, flags in CHECKED.items()}
+
+
 def build_examples():
     """examples/batch_analysis.cpp: the device-resident C API from plain C++ (hipcc, host code only);
     examples/dropin_bench.cpp: the drop-in symbols timed from a plain C++ caller (g++: it knows nothing of HIP)."""
@@ -88,3 +126,5 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--examples" in sys.argv:
         print(build_examples())
+    if "--checked" in sys.argv:
+        print(build_checked())

@@ -412,9 +412,8 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
   const size_t region_lo = c->arena.used;
   p.ap0 = c->arena.take<double>(fr);
   p.offsets1 = c->arena.take<unsigned>(fr);
-  p.offsets2 = c->arena.take<unsigned>(fr);
+  p.draws2 = c->arena.take<unsigned>(fr);
   p.draws1 = c->arena.take<unsigned>(n_utt);
-  p.love_ticket = c->arena.take<int>(n_utt);
   p.coarse = c->arena.take<double>(fr * 16);
   {
     WorldHipContext::PrepToken t;

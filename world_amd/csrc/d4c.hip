@@ -447,7 +447,7 @@ __device__ __forceinline__ void d4c_love_frame(const D4cParams &p, char *lds) {
   if (f >= p.b.n_frames[u]) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const double f0 = p.f0[fi];
-  if (f0 == 0.0) { if (threadIdx.x == 0) p.ap0[fi] = 0.0; return; }   // d4c.cpp:274-277
+  if (f0 == 0.0) { if (threadIdx.x == 0) { p.ap0[fi] = 0.0; p.draws2[fi] = 0u; } return; }   // d4c.cpp:274-277
   const int lgn = LGN > 0 ? LGN : p.lg_love, M = 1 << lgn, fs = p.b.fs;
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
@@ -508,30 +508,20 @@ __device__ __forceinline__ void d4c_love_frame(const D4cParams &p, char *lds) {
     block_rfft<3, LGN>(Z, lgn, tw, band_power);
   }
   block_sum2<LGN == 11 ? 128 : LGN == 12 ? 256 : 0>(lo, hi, scratch);   // (launch_d4c's workgroup sizes: the wavefronts' shares are read together)
-  if (threadIdx.x == 0) p.ap0[fi] = lo / hi;
+  if (threadIdx.x == 0) {
+    const double ap0 = lo / hi;
+    p.ap0[fi] = ap0;
+    // ... and the randn() draws the frame's three body windows will take (d4c.cpp:386, :97-101, :155) -- none if this
+    // statistic keeps the frame out of the second pass.  Their positions in the stream are a prefix sum over the
+    // utterance's frames, which every d4c_frame workgroup forms for itself (round 4: a 1-workgroup scan kernel per job).
+    const double bf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
+    p.draws2[fi] = ap0 <= p.threshold ? 0u : 3u * (unsigned)(2 * mround(4.0 * fs / bf0 / 2.0) + 1);
+  }
 }
-// The kernel: the frame's statistic, then -- in the LAST workgroup of the utterance to get there -- the scan of the second
-// pass's stream positions, which needs every frame's result (round 4: a 1-workgroup launch of its own per job).  Every
-// workgroup of the utterance's grid row takes a ticket, also those beyond its last frame; a workgroup's result is
-// released (agent scope) before its ticket and the last one acquires before it reads: the L2s of the eight XCDs are not
-// coherent with each other for plain loads and stores.
 template <int LGN>
 __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
   DYN_LDS(lds);
   d4c_love_frame<LGN>(p, lds);
-  const int u = blockIdx.y;
-  double *scratch = reinterpret_cast<double *>(lds);      // (free: every thread is past the frame's last collective ...)
-  int *last = reinterpret_cast<int *>(scratch + 62);      // (... whose scratch words lie below this one)
-  if (threadIdx.x == 0) {
-    __threadfence();
-    *last = atomicAdd(p.love_ticket + u, 1) == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!*last) return;
-  __threadfence();
-  __syncthreads();                                         // (everybody has read *last before the scan reuses the area)
-  d4c_offsets2_utt(p, u, scratch);
-  if (threadIdx.x == 0) p.love_ticket[u] = 0;              // a LoveTrain pass alone (no scan before it) finds it cleared
 }
 
 // Resident waves per SIMD the register allocation aims at: 3 (three 256-thread workgroups per CU, 168 VGPRs;
@@ -626,7 +616,26 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[fi];
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
-  const uint32_t *noise = p.noise + p.offsets2[fi];
+  // Where the frame's draws sit in the reference's one randn() stream: behind the first pass's (draws1) and behind those
+  // of every earlier frame of the utterance that LoveTrain let through -- <= 8 KB of counts summed by the workgroup itself.
+  unsigned stream_at;
+  {
+    const unsigned *cnt = p.draws2 + (size_t)u * p.b.f_stride;
+    int s_ = 0;
+    for (int g = tid; g < f; g += nt) s_ += (int)cnt[g];
+    s_ = wave_sum_int(s_);
+    int *part = reinterpret_cast<int *>(Zr);                 // (nothing lives in LDS yet)
+    if (lane_id() == 0) part[wave_in_block()] = s_;
+    __syncthreads();
+    int tot_ = 0;
+    for (int wv = 0; wv < wg_waves<T>(); ++wv) tot_ += part[wv];
+#ifndef WORLD_EMU
+    tot_ = __builtin_amdgcn_readfirstlane(tot_);             // the same in every lane: a scalar register, like the offset a scan kernel used to leave
+#endif
+    stream_at = p.draws1[u] + (unsigned)tot_;
+    __syncthreads();                                         // (the area is reused at once)
+  }
+  const uint32_t *noise = p.noise + stream_at;
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
   double *park = scratch + 64 + twiddle_lds_doubles(lgn - D4C_TW_LEVEL);
   const double inv_n = 1.0 / N;
@@ -889,6 +898,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   }
   WH_STAMP(32, 9);
   D4C_FRESH_TID();
+  lds_dead(Zr, N);                                         // (-DWH_LDS_POISON only: the centroid transforms' buffer is dead)
 
   // ---- GetSmoothedPowerSpectrum (d4c.cpp:149-166) ----------------------------
   double B[kBins];
@@ -915,6 +925,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     smooth(Bn, for_nat, cf0, B, for_pair);
   }
   WH_STAMP(32, 12);
+  lds_dead(Zr, N);                                         // (the smoothing segment is dead: DCCorrection below stages its own bins)
 
   // ---- GetStaticGroupDelay (d4c.cpp:172-188) ----------------------------------
   double A[kBins];
@@ -1007,6 +1018,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     // could have zeroed slots a slower one had not read yet -- never observed, the reads enter the LDS queue within a
     // few hundred cycles of the transform's barrier and the zeroing follows ~2 000 cycles of arithmetic later.)
     __syncthreads();
+    lds_dead(Zr, N);                                       // (the band's transform is in registers: the select must zero what it counts in)
     double part, tot;
 #if defined(WORLD_EMU) || defined(D4C_OLD_SELECT)
     block_smallest_sum<T>(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
@@ -1111,7 +1123,7 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   if (!(p.skip_prepare & kD4cSkipLoveTrain) && max_frames > 0) {
     // workgroup sizes follow the transform size (threads beyond N/16 idle through every radix-8 stage): for the
     // 2048-point internal FFT of fs <= 24 kHz, 64 x 1001 frames: lovetrain 0.53 -> 0.42 ms, groupdelay 3.77 -> 2.52,
-    // band 0.97 -> 0.65.  (Its last workgroup per utterance scans the second pass's stream positions.)
+    // band 0.97 -> 0.65
     const dim3 love_grid(max_frames, p.b.n_utt);
     const size_t love_lds = d4c_love_lds_bytes(p.lg_love);
 #ifdef WORLD_EMU

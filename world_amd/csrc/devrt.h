@@ -39,7 +39,6 @@ extern thread_local char *emu_lds_base;
 #define __restrict__
 #define __launch_bounds__(...)
 static inline void __syncthreads() {}
-static inline void __threadfence() {}
 typedef int hipError_t;
 typedef void *hipStream_t;
 #define hipSuccess 0
@@ -246,12 +245,71 @@ __device__ __forceinline__ int xcd_grouped(int b, int n) {
   return b - r + (r % 8) * kXcdRun + r / 8;
 }
 
+// ---- race-shaking builds (test infrastructure; python -m world_amd.build --checked; tests/test_gpu_parity.py) ----------
+// The frame kernels alias LDS regions across phases and place their barriers by hand (d4c_frame: 63 of them), and a
+// missing one is invisible in normal runs: the wavefronts of a workgroup execute the same instruction stream and arrive
+// together (round 3-4 shipped a select that zeroed histograms aliasing a transform buffer other wavefronts were still
+// reading -- found by reading the code, never by a test).  Two builds make such a bug change the RESULT:
+//   -DWH_JITTER      every phase starts with a pseudo-random stall of some of the workgroup's wavefronts -- behind every
+//                    __syncthreads(), behind every wavefront-level fence (wave_sync: the FFT's wave-local stages, the
+//                    DPP-row prefix sum's hand-offs) and at jitter() marks placed where code relies on something weaker
+//                    than a barrier -- so a wavefront that is still reading when it should have been waited for is
+//                    really overtaken, by thousands of cycles.  No synchronisation is added: a correct kernel computes
+//                    the same bits, a racy one does not.
+//   -DWH_LDS_POISON  the whole LDS allocation is filled with a NaN pattern when a workgroup starts (a fresh workgroup
+//                    otherwise inherits the previous one's data, usually the same kernel's: plausible values), and
+//                    lds_dead(ptr, n) marks fill a region whose contents nobody may read any more.  (This build ADDS
+//                    barriers around the fills, so it is a separate build from the jitter one.)
+// The GPU suite runs the analysis paths on both and requires results bit-identical to the product build's.
+#ifndef WORLD_EMU
+#if defined(WH_JITTER)
+__device__ __forceinline__ void jitter() {
+  // per wavefront, per call: hash of the clock, the wavefront and the workgroup
+  unsigned h = (unsigned)__builtin_readcyclecounter() * 2654435761u;
+  h ^= ((unsigned)threadIdx.x >> 6) * 0x9E3779B9u + blockIdx.x * 0x85EBCA6Bu + blockIdx.y * 0xC2B2AE35u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+  h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+  if ((h & 3u) == 0u) {                                     // a quarter of the arrivals stall: 0.5 .. 8 thousand cycles
+    const int n = 1 + (int)((h >> 4) & 15u);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+}
+__device__ __forceinline__ void wh_jitter_syncthreads() { __syncthreads(); jitter(); }
+#define __syncthreads() wh_jitter_syncthreads()
+#else
+__device__ __forceinline__ void jitter() {}
+#endif
+#if defined(WH_LDS_POISON)
+__device__ __forceinline__ void lds_poison_all(char *lds) {
+  // the dispatch packet's group_segment_size (hsa_kernel_dispatch_packet_t, byte 28)
+  const unsigned bytes = ((const __attribute__((address_space(4))) unsigned *)__builtin_amdgcn_dispatch_ptr())[7];
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(lds);
+  for (unsigned i = threadIdx.x; i < bytes / 8; i += blockDim.x) q[i] = 0x7FF8DEADBEEF0000ull + i;
+  __syncthreads();
+}
+__device__ __forceinline__ void lds_dead(void *p, int doubles) {
+  __syncthreads();
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+  for (int i = threadIdx.x; i < doubles; i += blockDim.x) q[i] = 0x7FF8DEAD00000000ull + (unsigned)i;
+  __syncthreads();
+}
+#undef DYN_LDS
+#define DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]; lds_poison_all(name)
+#else
+__device__ __forceinline__ void lds_dead(void *, int) {}
+#endif
+#else
+static inline void jitter() {}
+static inline void lds_dead(void *, int) {}
+#endif
+
 // make one wave's LDS writes visible to its other lanes (no-op for a 1-lane wave)
 __device__ __forceinline__ void wave_sync() {
 #ifndef WORLD_EMU
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  jitter();
 #endif
 }
 

@@ -1,7 +1,8 @@
 // prepare.h -- where each frame's noise sits in the reference's one randn() stream: exclusive prefix sums
 // of the per-frame draw counts, one workgroup per utterance.  CheapTrick's scan and D4C's first (the LoveTrain windows)
-// follow from F0 alone, so one launch serves both stages of a job (spectral_prepare, d4c.hip); D4C's second scan depends
-// on the LoveTrain result and is the epilogue of that kernel's last workgroup per utterance (d4c_lovetrain).
+// follow from F0 alone, so one launch serves both stages of a job (spectral_prepare, d4c.hip); D4C's second pass depends on
+// the LoveTrain result: d4c_lovetrain leaves each frame's draw count, and a d4c_frame workgroup sums those of the frames
+// before its own (d4c.hip).
 #pragma once
 #include "stage_params.h"
 
@@ -47,27 +48,7 @@ __device__ __forceinline__ void d4c_offsets1_utt(const D4cParams &p, int u, doub
     if (f < nf) off_out[f] = running + (unsigned)off;
     running += (unsigned)total;
   }
-  if (threadIdx.x == 0) { p.draws1[u] = running; p.love_ticket[u] = 0; }
-}
-
-// D4C pass 2: the three body windows of every frame LoveTrain let through (d4c.cpp:386), continuing the stream where
-// pass 1 ended
-__device__ __forceinline__ void d4c_offsets2_utt(const D4cParams &p, int u, double *scratch) {
-  const int nf = p.b.n_frames[u];
-  const double *f0 = p.f0 + (size_t)u * p.b.f_stride;
-  const double *ap0 = p.ap0 + (size_t)u * p.b.f_stride;
-  unsigned *off_out = p.offsets2 + (size_t)u * p.b.f_stride;
-  unsigned running = p.draws1[u];
-  for (int base = 0; base < nf; base += blockDim.x) {
-    int f = base + threadIdx.x, cnt = 0;
-    if (f < nf && !(f0[f] == 0 || ap0[f] <= p.threshold)) {
-      double cf0 = kFloorF0D4C > f0[f] ? kFloorF0D4C : f0[f];
-      cnt = 3 * (2 * mround(4.0 * p.b.fs / cf0 / 2.0) + 1);
-    }
-    int total, off = block_excl_scan_int(cnt, &total, scratch);
-    if (f < nf) off_out[f] = running + (unsigned)off;
-    running += (unsigned)total;
-  }
+  if (threadIdx.x == 0) p.draws1[u] = running;
 }
 
 }  // namespace world_hip

@@ -39,9 +39,8 @@ struct D4cParams {
   double *ap0;            // [n_utt][f_stride]  LoveTrain result
   double *coarse;         // [n_utt][f_stride][16] coarse aperiodicity (dB) per band, slot 1 + band
   unsigned *offsets1;     // [n_utt][f_stride]  position of the LoveTrain window within pass 1
-  unsigned *offsets2;     // [n_utt][f_stride]  position of the frame's 3 body windows within pass 2
+  unsigned *draws2;       // [n_utt][f_stride]  draws of the frame's 3 body windows in pass 2 (0: LoveTrain kept the frame out)
   unsigned *draws1;       // [n_utt] total draws of pass 1 (pass 2 continues the stream there)
-  int *love_ticket;       // [n_utt] LoveTrain workgroups of the utterance that are done: the last one scans offsets2
   const uint32_t *noise;  // randn_value(noise[k]) = k-th randn() of the stream (context-wide table)
   const double *nuttall;  // [wl] NuttallWindow(wl), built on the host
   Tables tab;
@@ -51,11 +50,11 @@ struct D4cParams {
   int lg_d4c;             // log2 of fft_size_d4c
   int nap;                // number_of_aperiodicities
   int wl;                 // Nuttall window length
-  // Frame range of d4c_frame / d4c_finish (LoveTrain and the two offset scans always cover every frame: the second
+  // Frame range of d4c_frame / d4c_finish (LoveTrain and the first offset scan always cover every frame: the second
   // pass's stream positions depend on every earlier frame's LoveTrain result).  0 / INT_MAX = all.
   int frame_lo, frame_hi;
   int skip_prepare;       // bits: kD4cSkipScan = offsets1 are in place (an earlier call, or the launch shared with CheapTrick);
-                          // kD4cSkipLoveTrain = the LoveTrain pass and offsets2 of an earlier call are still in the workspace
+                          // kD4cSkipLoveTrain = the LoveTrain pass (ap0, draws2) of an earlier call is still in the workspace
 };
 constexpr int kD4cSkipScan = 1, kD4cSkipLoveTrain = 2;
 

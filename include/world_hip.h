@@ -233,7 +233,7 @@ WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int
 
 /* What box is this?  ~50 ms of microbenchmarks on the context's device (synchronous; allocates and frees 2 GB):
  * values[0] shader clock held under a chip-wide FP64 load (MHz), [1] that load's FMA rate (TFLOP/s), [2] / [3] / [4]
- * dependent-load latency of one lane through HBM / the Infinity Cache / L2 (ns per hop), [5] / [6] a dependent LDS read on
+ * dependent-load latency of one lane chasing pointers through 2 GB / 64 MB every CU has just read / 1 MB it has just walked (ns per hop), [5] / [6] a dependent LDS read on
  * an idle / a loaded CU (shader cycles), [7] compute units.  n_values >= 8.  bench.py records them in the line's
  * `environment` object: identical binaries ran a lone job 10-90 % slower on some boxes (profiles/r04/README.txt). */
 WORLD_HIP_API int world_hip_probe_machine(WorldHipContext *ctx, double *values, int n_values);

@@ -768,7 +768,7 @@ class WorldHip:
             return None
         v = (C.c_double * 8)()
         self._check(self.lib.world_hip_probe_machine(self._context(), v, 8), "probe_machine")
-        keys = ("sclk_mhz_under_fp64_load", "fp64_fma_tflops", "hbm_chase_ns", "infinity_cache_chase_ns", "l2_chase_ns",
+        keys = ("sclk_mhz_under_fp64_load", "fp64_fma_tflops", "chase_ns_2gb", "chase_ns_64mb_warm", "chase_ns_1mb_warm",
                 "lds_trip_cycles_idle_cu", "lds_trip_cycles_loaded_cu", "compute_units")
         return {k: round(float(x), 2) for k, x in zip(keys, v)}
 

@@ -196,7 +196,6 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
   *total = s_all;
 }
 
-#ifndef WORLD_EMU
 // ---------------------------------------------------------------------------
 // The same selection for the frame kernel's shape, written for INSTRUCTION COUNT: d4c_frame is bound by VALU issue
 // (three resident workgroups share every SIMD), and the general routine above spent as many VALU instructions per band
@@ -215,40 +214,132 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 // Typical band: 3 barriers, ~200 VALU instructions.  A bin with several keys gets one 256-bin pass over its own range;
 // whatever is still ambiguous after that (or a spectrum whose thread maxima all share a high word) goes to the general
 // routine -- same result, every thread of the block takes the same path.
+// ---- the pieces that are wave collectives on the GPU and plain loops in the host emulation (tests/emu: ONE thread plays
+// the whole workgroup and owns every key) -- everything around them, i.e. every decision the selection takes, is shared ----
+#ifndef WORLD_EMU
+// smallest of the threads' maxima and the largest key, over the workgroup (high words); one barrier
+template <int NT> __device__ __forceinline__ void sel_floor_top(int hm, int *hs, int *fl, int *tp) {
+  constexpr int nw = NT / WAVE;
+  const int wmin = -wave_max_int(-hm), wmax = wave_max_int(hm);
+  if (lane_id() == 0) { hs[wave_in_block()] = wmin; hs[16 + wave_in_block()] = wmax; }
+  __syncthreads();                                                        // also: the bins are zero before anybody counts
+  int f = hs[0], t = hs[16];
+#pragma unroll
+  for (int w = 1; w < nw; ++w) { f = hs[w] < f ? hs[w] : f; t = hs[16 + w] > t ? hs[16 + w] : t; }
+  *fl = __builtin_amdgcn_readfirstlane(f); *tp = __builtin_amdgcn_readfirstlane(t);
+}
+// the fine bin (of 1024, with 64 coarse counts behind them) that holds the K-th key from the top: its index, the keys
+// above it and the keys in it
+__device__ __forceinline__ void sel_locate_two_level(const int *hist, int K, int *bin, int *above, int *bucket) {
+  const int lane = lane_id();
+  // coarse level: lane l holds coarse bin l; `above` = candidates in bins above it
+  const int cc = hist[1024 + lane];
+  const int inc = wave_incl_scan_int(cc);
+  const int above_l = __builtin_amdgcn_readlane(inc, 63) - inc;
+  const unsigned long long sel = __ballot(above_l < K && K <= above_l + cc);      // exactly one lane
+  const int ls = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(sel));
+  const int above_c = __builtin_amdgcn_readlane(above_l, ls);
+  // fine level: the 16 bins of coarse bin ls, one per lane of a row; u = candidates in this bin and above
+  int u = hist[16 * ls + (lane & 15)];
+  u += __builtin_amdgcn_update_dpp(0, u, 0x101, 0xf, 0xf, true);        // row_shl 1, 2, 4, 8: suffix sums inside the row
+  u += __builtin_amdgcn_update_dpp(0, u, 0x102, 0xf, 0xf, true);
+  u += __builtin_amdgcn_update_dpp(0, u, 0x104, 0xf, 0xf, true);
+  u += __builtin_amdgcn_update_dpp(0, u, 0x108, 0xf, 0xf, true);
+  u += above_c;
+  const unsigned ge = (unsigned)(__ballot(u >= K) & 0xFFFFull);        // lanes 0 .. is of the first row (u falls with the lane)
+  const int is = __builtin_amdgcn_readfirstlane(31 - __builtin_clz(ge));
+  const int u_is = __builtin_amdgcn_readlane(u, is);
+  const int above0 = is == 15 ? above_c : __builtin_amdgcn_readlane(u, (is + 1) & 15);
+  *bin = 16 * ls + is; *above = above0; *bucket = u_is - above0;
+}
+// the same over the second pass's 256 bins
+__device__ __forceinline__ void sel_locate_256(const int *h1, int K1, int *bin, int *bucket) {
+  const int lane = lane_id();
+  const int4 c4 = *reinterpret_cast<const int4 *>(h1 + 4 * lane);
+  const int local = (c4.x + c4.y) + (c4.z + c4.w);
+  const int inc1 = wave_incl_scan_int(local);
+  const int ab1 = __builtin_amdgcn_readlane(inc1, 63) - inc1;
+  const unsigned long long sel1 = __ballot(ab1 < K1 && K1 <= ab1 + local);
+  const int l1 = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(sel1));
+  int a = __builtin_amdgcn_readlane(ab1, l1);
+  const int c3 = __builtin_amdgcn_readlane(c4.w, l1), c2 = __builtin_amdgcn_readlane(c4.z, l1),
+            c1 = __builtin_amdgcn_readlane(c4.y, l1), c0 = __builtin_amdgcn_readlane(c4.x, l1);
+  int j;                                                            // scalar walk from the top bin of the lane's four
+  if (a + c3 >= K1) { j = 3; *bucket = c3; }
+  else if ((a += c3) + c2 >= K1) { j = 2; *bucket = c2; }
+  else if ((a += c2) + c1 >= K1) { j = 1; *bucket = c1; }
+  else { j = 0; *bucket = c0; }
+  *bin = 4 * l1 + j;
+}
+__device__ __forceinline__ void sel_zero_bins(int *hist, int tid, int nt) {
+  for (int i = tid; i < 336; i += nt) reinterpret_cast<int4 *>(hist)[i] = make_int4(0, 0, 0, 0);
+}
+#else
+__device__ __forceinline__ void sel_walk_from_top(const int *h, int n, int K, int *bin, int *above, int *bucket) {
+  int a = 0, b = n - 1;
+  while (b > 0 && a + h[b] < K) a += h[b--];
+  *bin = b; *above = a; *bucket = h[b];
+}
+__device__ __forceinline__ void sel_locate_two_level(const int *hist, int K, int *bin, int *above, int *bucket) {
+  sel_walk_from_top(hist, 1024, K, bin, above, bucket);
+}
+__device__ __forceinline__ void sel_locate_256(const int *h1, int K1, int *bin, int *bucket) {
+  int above;
+  sel_walk_from_top(h1, 256, K1, bin, &above, bucket);
+}
+__device__ __forceinline__ void sel_zero_bins(int *hist, int, int) { for (int i = 0; i < 1344; ++i) hist[i] = 0; }
+#endif
+
 // key[0 .. kKeys-2): owned by every thread; key[kKeys-2]: thread 0 only (the merge's unpaired bin), 0 elsewhere;
-// key[kKeys-1]: 0.  hist: 1344 ints of LDS.  K: how many of the largest keys are EXCLUDED from *partial.
+// key[kKeys-1]: 0.  (Host emulation: the one thread owns every slot; `threads` = the workgroup size the GPU would run,
+// and slot pairs (2 m, 2 m + 1) with m = t mod threads are what its thread t would own -- the floor below is then the
+// GPU's, and so is every decision that follows from it.)  hist: 1344 ints of LDS.  K: how many of the largest keys are
+// EXCLUDED from *partial.
 // Returns true when *partial / *total are the BLOCK's sums (the general routine ran), false when they are the calling
 // wavefront's share of them: the caller adds the wavefronts' shares up whenever it next crosses a barrier anyway (the
 // block sum here -- LDS, barrier, LDS -- was a quarter of the routine's time in a CU whose LDS pipe is busy with other
 // workgroups' transforms: every dependent trip through it costs ~750 cycles there).
 template <int NT, int kKeys>
 __device__ __forceinline__ bool block_excluding_largest(const unsigned long long (&key)[kKeys], int K, int *hist, double *scratch,
-                                                        double *partial, double *total, bool trace_me = false) {
+                                                        double *partial, double *total, bool trace_me = false, int threads = NT) {
   (void)trace_me;
-  constexpr int kFull = kKeys - 2, nw = NT / WAVE;
-  static_assert(NT % WAVE == 0 && nw <= 16, "whole wavefronts");
-  const int tid = wg_thread<NT>(), lane = lane_id(), wv = wave_in_block();
+#ifndef WORLD_EMU
+  constexpr int kFull = kKeys - 2;
+  static_assert(NT % WAVE == 0 && NT / WAVE <= 16, "whole wavefronts");
+  const int hx = (int)(key[kFull] >> 32);                                 // 0 except on thread 0
+#else
+  constexpr int kFull = kKeys;                                            // every slot is this thread's
+  const int hx = 0;
+#endif
+  const int tid = wg_thread<NT>();
   int hk[kFull];
 #pragma unroll
   for (int q = 0; q < kFull; ++q) hk[q] = (int)(key[q] >> 32);            // non-negative doubles: the high words order like the keys
-  const int hx = (int)(key[kFull] >> 32);                                 // 0 except on thread 0
-  int hm = hx;
-#pragma unroll
-  for (int q = 0; q < kFull; ++q) hm = hk[q] > hm ? hk[q] : hm;
   // [0, 1024) fine bins | [1024, 1088) coarse bins (16 fine each) | [1088, 1344) the second pass's bins
-  for (int i = tid; i < 336; i += NT) reinterpret_cast<int4 *>(hist)[i] = make_int4(0, 0, 0, 0);
-  // Every thread's largest key is a candidate, and there are NT >= K threads: the K-th largest key is >= the smallest of
-  // the threads' maxima (`floor`), so keys below it are below the threshold whatever their rank.
-  const int wmin = -wave_max_int(-hm), wmax = wave_max_int(hm);
-  int *hs = reinterpret_cast<int *>(scratch + 48);                        // doubles 48..63: nobody else's scratch
-  if (lane == 0) { hs[wv] = wmin; hs[16 + wv] = wmax; }
-  __syncthreads();                                                        // also: the bins are zero before anybody counts
-  int fl = hs[0], tp = hs[16];
+  sel_zero_bins(hist, tid, NT);
+  // Every thread's largest key is a candidate, and there are `threads` >= K of them: the K-th largest key is >= the smallest
+  // of the threads' maxima (`floor`), so keys below it are below the threshold whatever their rank.
+  int fl, tp;
+#ifndef WORLD_EMU
+  {
+    int hm = hx;
 #pragma unroll
-  for (int w = 1; w < nw; ++w) { fl = hs[w] < fl ? hs[w] : fl; tp = hs[16 + w] > tp ? hs[16 + w] : tp; }
-  fl = __builtin_amdgcn_readfirstlane(fl); tp = __builtin_amdgcn_readfirstlane(tp);
+    for (int q = 0; q < kFull; ++q) hm = hk[q] > hm ? hk[q] : hm;
+    sel_floor_top<NT>(hm, reinterpret_cast<int *>(scratch + 48), &fl, &tp);   // doubles 48..63: nobody else's scratch
+  }
+#else
+  {
+    (void)scratch;
+    fl = 0x7fffffff; tp = 0;
+    for (int t = 0; t < threads; ++t) {                                   // the GPU's thread t: slot pairs m = t, t + threads, ...
+      int hm = 0;
+      for (int m = t; 2 * m + 1 < kFull; m += threads) { hm = hk[2 * m] > hm ? hk[2 * m] : hm; hm = hk[2 * m + 1] > hm ? hk[2 * m + 1] : hm; }
+      fl = hm < fl ? hm : fl; tp = hm > tp ? hm : tp;
+    }
+  }
+#endif
   WH_STAMP(0, 3);
-  bool fast = NT >= K && tp > fl;
+  bool fast = threads >= K && tp > fl;
   bool t_low_two = false; (void)t_low_two;                                // (statistics of the WH_TRACE build)
   int t_low = 0;                                                          // keys with a high word below this are the m smallest
   if (fast) {
@@ -260,28 +351,11 @@ __device__ __forceinline__ bool block_excluding_largest(const unsigned long long
     };
 #pragma unroll
     for (int q = 0; q < kFull; ++q) count0(hk[q]);
-    if (tid == 0) count0(hx);
+    if (tid == 0 && kFull < kKeys) count0(hx);
     __syncthreads();
-    // coarse level: lane l holds coarse bin l; `above` = candidates in bins above it
-    const int cc = hist[1024 + lane];
-    const int inc = wave_incl_scan_int(cc);
-    const int above_l = __builtin_amdgcn_readlane(inc, 63) - inc;
-    const unsigned long long sel = __ballot(above_l < K && K <= above_l + cc);      // exactly one lane
-    const int ls = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(sel));
-    const int above_c = __builtin_amdgcn_readlane(above_l, ls);
-    // fine level: the 16 bins of coarse bin ls, one per lane of a row; u = candidates in this bin and above
-    int u = hist[16 * ls + (lane & 15)];
-    u += __builtin_amdgcn_update_dpp(0, u, 0x101, 0xf, 0xf, true);        // row_shl 1, 2, 4, 8: suffix sums inside the row
-    u += __builtin_amdgcn_update_dpp(0, u, 0x102, 0xf, 0xf, true);
-    u += __builtin_amdgcn_update_dpp(0, u, 0x104, 0xf, 0xf, true);
-    u += __builtin_amdgcn_update_dpp(0, u, 0x108, 0xf, 0xf, true);
-    u += above_c;
-    const unsigned ge = (unsigned)(__ballot(u >= K) & 0xFFFFull);        // lanes 0 .. is of the first row (u falls with the lane)
-    const int is = __builtin_amdgcn_readfirstlane(31 - __builtin_clz(ge));
-    const int u_is = __builtin_amdgcn_readlane(u, is);
-    const int above0 = is == 15 ? above_c : __builtin_amdgcn_readlane(u, (is + 1) & 15);
-    int bucket = u_is - above0;
-    t_low = fl + ((16 * ls + is) << s0);
+    int bin0, above0, bucket;
+    sel_locate_two_level(hist, K, &bin0, &above0, &bucket);
+    t_low = fl + (bin0 << s0);
     WH_STAMP(0, 4);
     if (bucket != 1) {
       if (s0 == 0) {
@@ -296,23 +370,11 @@ __device__ __forceinline__ bool block_excluding_largest(const unsigned long long
         };
 #pragma unroll
         for (int q = 0; q < kFull; ++q) count1(hk[q]);
-        if (tid == 0) count1(hx);
+        if (tid == 0 && kFull < kKeys) count1(hx);
         __syncthreads();
-        const int4 c4 = *reinterpret_cast<const int4 *>(h1 + 4 * lane);
-        const int local = (c4.x + c4.y) + (c4.z + c4.w);
-        const int inc1 = wave_incl_scan_int(local);
-        const int ab1 = __builtin_amdgcn_readlane(inc1, 63) - inc1;
-        const unsigned long long sel1 = __ballot(ab1 < K1 && K1 <= ab1 + local);
-        const int l1 = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(sel1));
-        int a = __builtin_amdgcn_readlane(ab1, l1);
-        const int c3 = __builtin_amdgcn_readlane(c4.w, l1), c2 = __builtin_amdgcn_readlane(c4.z, l1),
-                  c1 = __builtin_amdgcn_readlane(c4.y, l1), c0 = __builtin_amdgcn_readlane(c4.x, l1);
-        int j;                                                            // scalar walk from the top bin of the lane's four
-        if (a + c3 >= K1) { j = 3; bucket = c3; }
-        else if ((a += c3) + c2 >= K1) { j = 2; bucket = c2; }
-        else if ((a += c2) + c1 >= K1) { j = 1; bucket = c1; }
-        else { j = 0; bucket = c0; }
-        t_low += (4 * l1 + j) << s1;
+        int bin1;
+        sel_locate_256(h1, K1, &bin1, &bucket);
+        t_low += bin1 << s1;
         t_low_two = true;
         if (bucket != 1) fast = false;
         WH_STAMP(0, 5);
@@ -336,7 +398,7 @@ __device__ __forceinline__ bool block_excluding_largest(const unsigned long long
     s_all += x;
     s_lt += hk[q] < t_low ? x : 0.0;
   }
-  if (tid == 0) {
+  if (tid == 0 && kFull < kKeys) {
     const double x = __longlong_as_double((long long)key[kFull]);
     s_all += x;
     s_lt += hx < t_low ? x : 0.0;
@@ -346,7 +408,6 @@ __device__ __forceinline__ bool block_excluding_largest(const unsigned long long
   *total = wave_sum(s_all);
   return false;
 }
-#endif
 
 // ---------------------------------------------------------------------------
 // D4CGeneralBody for one selected frame in ONE workgroup (d4c.cpp:90-225, 291-316):
@@ -536,13 +597,8 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
 #else
 #define D4C_SCHED_FENCE() do { } while (0)
 #endif
-// value of the key slots a thread does not own: the general selection skips them by count (`mine`), the frame kernel's
-// own ranks from the top and needs them to be the smallest
-#if defined(WORLD_EMU) || defined(D4C_OLD_SELECT)
-#define D4C_KEY_PAD (~0ull)
-#else
+// value of the key slots a thread does not own: the selection ranks from the top and needs them to be the smallest
 #define D4C_KEY_PAD 0ull
-#endif
 #ifndef D4C_TW_LEVEL
 #define D4C_TW_LEVEL 2      // the twiddle table in LDS is this many levels coarser than the N-point merge asks for
 #endif
@@ -633,7 +689,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     tot_ = __builtin_amdgcn_readfirstlane(tot_);             // the same in every lane: a scalar register, like the offset a scan kernel used to leave
 #endif
     stream_at = p.draws1[u] + (unsigned)tot_;
-    __syncthreads();                                         // (the area is reused at once)
+    // (no closing barrier: the next write to this area lies behind the first window's block sum, which nobody passes
+    // before everybody has arrived there -- past these reads)
   }
   const uint32_t *noise = p.noise + stream_at;
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
@@ -952,10 +1009,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   int mine = 0;
   for_nat([&](int, int) { ++mine; });
   int *hist = reinterpret_cast<int *>(Zr);
-#ifndef WORLD_EMU
-  constexpr int kWaves = T / WAVE;
+  constexpr int kWaves = (T + WAVE - 1) / WAVE;
   double *band_sums = park + (H + 2);                   // [band][partial, total][wavefront]: d4c_frame_lds_bytes
-#endif
   // the Nuttall taps of the thread's own slice element: the same for every band
   const double nut0 = 2 * tid < wl ? p.nuttall[2 * tid] : 0.0, nut1 = 2 * tid + 1 < wl ? p.nuttall[2 * tid + 1] : 0.0;
   for (int band = 0; band < p.nap; ++band) {
@@ -1020,34 +1075,25 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     __syncthreads();
     lds_dead(Zr, N);                                       // (the band's transform is in registers: the select must zero what it counts in)
     double part, tot;
-#if defined(WORLD_EMU) || defined(D4C_OLD_SELECT)
-    block_smallest_sum<T>(key, mine, H + 1, H - bnd, hist, scratch, &part, &tot, trace_me);
-    // the band's two sums; d4c_finish turns them into dB (d4c.cpp:221-224, 314-316) -- a division and a log10 on
-    // one lane here would stand between this band's select and the next band's first barrier
-    if (tid == 0) { p.coarse[fi * 16 + 1 + band] = part; p.coarse[fi * 16 + 9 + band] = tot; }
-#else
     (void)mine;
     // the bnd + 1 largest of the H + 1 bins excluded; each wavefront parks its share of the band's two sums
-    const bool whole = block_excluding_largest<T>(key, bnd + 1, hist, scratch, &part, &tot, trace_me);
+    const bool whole = block_excluding_largest<T>(key, bnd + 1, hist, scratch, &part, &tot, trace_me, N / 16);
     if (lane_id() == 0) {
       const int wv = wave_in_block();
       band_sums[(2 * band) * kWaves + wv] = whole && wv > 0 ? 0.0 : part;
       band_sums[(2 * band + 1) * kWaves + wv] = whole && wv > 0 ? 0.0 : tot;
     }
-#endif
     if (band == 0) WH_STAMP(32, 18);
   }
-#ifndef WORLD_EMU
   __syncthreads();
-  if (tid < 2 * p.nap) {                                  // thread b: band b's partial sum, thread nap + b: its total
-    const int band = tid < p.nap ? tid : tid - p.nap, which = tid < p.nap ? 0 : 1;
+  for (int b = tid; b < 2 * p.nap; b += nt) {             // thread b: band b's partial sum, thread nap + b: its total
+    const int band = b < p.nap ? b : b - p.nap, which = b < p.nap ? 0 : 1;
     const double *w = band_sums + (2 * band + which) * kWaves;
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < kWaves; ++k) t += w[k];           // wavefront order, from zero: the block sum's own order
     p.coarse[fi * 16 + (which ? 9 : 1) + band] = t;
   }
-#endif
   WH_STAMP(32, 19);
 }
 

@@ -286,6 +286,19 @@ WORLD_HIP_API int world_hip_analyze_packed(WorldHipContext *ctx, int n_utt, int 
                                            const int *x_length, const HarvestOption *harvest_option,
                                            const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
                                            long long first_row, double *d_block, int cols);
+/* The CODED wire format (the coders exist to "shrink the all-gather and D2H by 10-17x"): the same analysis,
+ * its records coded before anything leaves the device --
+ *   [tpos, f0, mel-cepstrum[number_of_dimensions], band aperiodicity[GetNumberOfAperiodicities(fs)]]   (doubles)
+ * = CodeSpectralEnvelope() / CodeAperiodicity() (reference src/codec.cpp:268-297, :217-236) of exactly the spectrogram and
+ * aperiodicity a dense call returns: 67 doubles = 536 bytes per frame at 48 kHz with 60 coefficients against 16 416
+ * (31 x fewer bytes on the xGMI links and in the D2H copy).  cols = world_hip_coded_columns(fs, number_of_dimensions).  The
+ * full records of the batch live in a staging block the context owns (device memory only) and are read once by the coders.
+ * Lossy by design -- what the reference's own coder loses -- and therefore opt-in (world_amd.distributed: wire="coded"). */
+WORLD_HIP_API int world_hip_coded_columns(int fs, int number_of_dimensions);
+WORLD_HIP_API int world_hip_analyze_coded(WorldHipContext *ctx, int n_utt, int fs, const double *d_x, int x_stride,
+                                          const int *x_length, const HarvestOption *harvest_option,
+                                          const CheapTrickOption *cheaptrick_option, const D4COption *d4c_option,
+                                          int number_of_dimensions, long long first_row, double *d_block, int cols);
 /* Frame ranges (frame-level sharding of ONE long utterance -- CheapTrick / D4C only, F0 broadcast; the
  * reference's frames are independent given F0: src/cheaptrick.cpp:207-216, src/d4c.cpp:378-400).  The stages' rows of
  * frames [frame_lo, frame_hi) of every utterance of the batch; the positions in the reference's randn() stream are those of

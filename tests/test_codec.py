@@ -145,3 +145,53 @@ def test_device_resident_codec_full_size_properties(hip):
     # [batch, frames, bins] layout: leading dimensions are just rows
     c3 = wh.code_spectral_envelope(sp1[:2000].reshape(4, 500, -1), fs, fft, nd)
     assert torch.equal(c3.reshape(2000, nd), c1[:2000])
+
+
+@pytest.mark.gpu
+def test_coded_records_equal_the_reference_coders_of_the_reference_analysis():
+    """world_hip_analyze_coded (the coded wire format): [tpos, f0, mel-cepstrum[60], band aperiodicity[5]]
+    of a ragged 48 kHz batch == CodeSpectralEnvelope / CodeAperiodicity (reference src/codec.cpp:268-297, :217-236) applied
+    by the REFERENCE to the REFERENCE's own Harvest + CheapTrick + D4C, and bit-identical to this library's coders applied
+    to its own dense analysis."""
+    import torch
+    from oracle.loader import best_oracle
+    from world_amd import synth
+    from world_amd.api import WorldHip, frame_count
+    oracle = best_oracle()
+    wh = WorldHip()
+    fs, fft, nd = 48000, 2048, 60
+    xs = [synth.vowel(fs, 0.7, seed=31, base_f0=130.0), synth.utterance(4, fs, 0.45)]
+    L = max(x.numel() for x in xs)
+    xb = torch.zeros((2, L), dtype=torch.float64)
+    for i, x in enumerate(xs):
+        xb[i, :x.numel()] = x
+    lens = [x.numel() for x in xs]
+    nf = [frame_count(fs, n, 5.0) for n in lens]
+    cols = wh.lib.world_hip_coded_columns(fs, nd)
+    assert cols == 2 + nd + 5
+    block = torch.full((sum(nf) + 2, cols), float("nan"), dtype=torch.float64, device="cuda")
+    assert wh.analyze_coded(xb.cuda(), fs, block, first_row=1, x_len=lens, number_of_dimensions=nd) == nf
+    tpos, f0, sp, ap, _ = wh.analyze(xb.cuda(), fs, x_len=lens)
+    torch.cuda.synchronize()
+    rec = block.cpu().numpy()
+    assert np.isnan(rec[0]).all() and np.isnan(rec[-1]).all()
+    row = 1
+    for u, x in enumerate(xs):
+        k = nf[u]
+        r = rec[row:row + k]
+        row += k
+        # this library's coders on its own dense rows: the same kernels reading other strides -> the same bits
+        mc = wh.code_spectral_envelope(sp[u, :k], fs, fft, nd).cpu().numpy()
+        bap = wh.code_aperiodicity(ap[u, :k], fs, fft).cpu().numpy()
+        assert np.array_equal(r[:, 0], tpos[u, :k].cpu().numpy()) and np.array_equal(r[:, 1], f0[u, :k].cpu().numpy())
+        assert np.array_equal(r[:, 2:2 + nd], mc) and np.array_equal(r[:, 2 + nd:], bap)
+        # the reference, end to end
+        xn = x.numpy()
+        tp_o, f0_o = oracle.harvest(xn, fs)
+        sp_o = oracle.cheaptrick(xn, fs, tp_o, f0_o, fft_size=fft)
+        ap_o = oracle.d4c(xn, fs, tp_o, f0_o, fft)
+        mc_o = oracle.code_spectral_envelope(sp_o, fs, fft, nd)
+        bap_o = oracle.code_aperiodicity(ap_o, fs, fft)
+        assert np.array_equal(r[:, 0], tp_o)
+        assert np.max(np.abs(r[:, 2:2 + nd] - mc_o)) <= 1e-4 * np.max(np.abs(mc_o))          # cepstra: relative to the row scale
+        assert np.max(np.abs(r[:, 2 + nd:] - bap_o)) <= 1e-4 * max(1.0, np.max(np.abs(bap_o)))   # dB values

@@ -221,6 +221,77 @@ def _emu_packed(wire_cols):
     return run
 
 
+def _emu_coded(dims):
+    """WorldHip.analyze_coded's contract on CPU tensors: world_hip_analyze_coded of the host-compiled library; also returns a
+    coder of dense rows (world_hip_code_*) for the comparison"""
+    import ctypes as C
+    import subprocess
+    from world_amd.api import (CheapTrickOption, D4COption, HarvestOption, cheaptrick_fft_size, frame_count, load_library)
+    emu_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    subprocess.run(["make", "-s", "-f", os.path.join(emu_dir, "Makefile")], check=True)
+    L = load_library(os.path.join(emu_dir, "libworld_emu.so"))
+    ctx = L.world_hip_create(0, None)
+
+    def run(x, fs, block, first_row=0, x_len=None, frame_period=5.0, **_):
+        fft = cheaptrick_fft_size(fs)
+        assert block.shape[-1] == L.world_hip_coded_columns(fs, dims) and block.is_contiguous() and x.is_contiguous()
+        xl = np.ascontiguousarray(x_len, dtype=np.int32)
+        h, c, d = HarvestOption(71.0, 800.0, frame_period), CheapTrickOption(-0.15, 71.0, fft), D4COption(0.85)
+        rc = L.world_hip_analyze_coded(ctx, x.shape[0], fs, x.data_ptr(), x.shape[1], xl.ctypes.data_as(C.POINTER(C.c_int)),
+                                       C.byref(h), C.byref(c), C.byref(d), dims, first_row, block.data_ptr(), block.shape[-1])
+        assert rc == 0, L.world_hip_last_error().decode()
+        return [frame_count(fs, int(n), frame_period) for n in xl]
+
+    def code(sp, ap, fs):
+        fft = cheaptrick_fft_size(fs)
+        n = sp.shape[0]
+        nap = L.GetNumberOfAperiodicities(fs)
+        mc, bap = torch.zeros((n, dims), dtype=torch.float64), torch.zeros((n, nap), dtype=torch.float64)
+        sp, ap = sp.contiguous(), ap.contiguous()
+        assert L.world_hip_code_spectral_envelope(ctx, n, fs, fft, dims, sp.data_ptr(), mc.data_ptr()) == 0
+        assert L.world_hip_code_aperiodicity(ctx, n, fs, fft, ap.data_ptr(), bap.data_ptr()) == 0
+        return mc, bap
+    return run, code
+
+
+def _coded_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from world_amd import synth
+        fs, dims = 16000, 24
+        lengths = [4000, 2600, 3300, 2000]
+        xs = [synth.utterance(i, fs, n / fs) for i, n in enumerate(lengths)]
+        run, code = _emu_coded(dims)
+        res = wd.analyze_sharded(xs, fs, analyze_packed=run, sub_batch=1, wire="coded", coded_dimensions=dims)
+        nap = wd.number_of_aperiodicities(fs)
+        assert res.blocks[0].shape[-1] == 2 + dims + nap == wd.wire_columns("coded", 513, fs, dims)
+        for i, n in enumerate(lengths):
+            tp_i, f0_i, sp_i, ap_i, nf_i = _emu_analyze(xs[i][None], fs, x_len=[n])
+            k = int(nf_i[0])
+            mc_want, bap_want = code(sp_i[0, :k], ap_i[0, :k], fs)
+            tp, f0, mc, bap = res.utterance(i)
+            assert torch.equal(tp, tp_i[0, :k]) and torch.equal(f0, f0_i[0, :k])
+            # the coders applied to the rows inside the records == the coders applied to a lone analysis' dense rows
+            assert mc.shape == (k, dims) and bap.shape == (k, nap)
+            assert torch.equal(mc, mc_want) and torch.equal(bap, bap_want)
+        np.save(os.path.join(tmp, f"coded_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_exchange_coded_records(tmp_path):
+    """the coded wire format: [tpos, f0, mel-cepstrum, band aperiodicity] records written on the 'device'
+    before the all-gather, on 2 gloo ranks with the host-compiled kernels: every utterance on every rank equals
+    CodeSpectralEnvelope / CodeAperiodicity of a lone analysis, bit for bit"""
+    world = 2
+    port = 29500 + os.getpid() % 180
+    mp.spawn(_coded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"coded_{r}.npy") for r in range(world))
+
+
 def _packed_worker(rank, world, port, tmp, wire):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -94,6 +94,10 @@ def load_library(path=LIB_PATH):
     if hasattr(lib, "world_hip_probe_machine"):                      # (absent from libraries of earlier rounds: tools/ab.py loads those)
         lib.world_hip_probe_machine.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     lib.world_hip_record_columns.argtypes = [C.c_int, C.c_int]
+    if hasattr(lib, "world_hip_analyze_coded"):
+        lib.world_hip_coded_columns.argtypes = [C.c_int, C.c_int]
+        lib.world_hip_analyze_coded.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, C.POINTER(HarvestOption),
+                                                C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, C.c_longlong, vp, C.c_int]
     lib.world_hip_spectral_packed_range.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, _ip, _ip, C.c_int, vp, vp,
                                                     C.POINTER(CheapTrickOption), C.POINTER(D4COption), C.c_int, C.c_int,
                                                     C.c_int, C.c_longlong, vp, C.c_int]
@@ -616,6 +620,25 @@ class WorldHip:
         self._check(self.lib.world_hip_analyze_packed(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
                                                       C.byref(hopt), C.byref(copt), C.byref(dopt), first_row,
                                                       block.data_ptr(), cols), "analyze_packed")
+        return nf
+
+    def analyze_coded(self, x, fs, block, first_row=0, x_len=None, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
+                      q1=-0.15, threshold=0.85, number_of_dimensions=60):
+        """Harvest -> CheapTrick -> D4C of one batch written as CODED records [tpos, f0, mel-cepstrum[D], band
+        aperiodicity[nap]] (include/world_hip.h: world_hip_analyze_coded -- the reference's CodeSpectralEnvelope /
+        CodeAperiodicity of the analysis, 31 x fewer bytes per frame at 48 kHz).  Returns n_frames."""
+        t = self.torch
+        B, L, xl = self._prep(x, x_len)
+        fft_size = cheaptrick_fft_size(fs, 71.0)
+        nf = [frame_count(fs, int(n), frame_period) for n in xl]
+        cols = block.shape[-1]
+        assert block.dtype == t.float64 and block.is_contiguous() and block.device == x.device
+        assert cols == self.lib.world_hip_coded_columns(fs, number_of_dimensions), (cols, fs, number_of_dimensions)
+        assert first_row >= 0 and first_row + sum(nf) <= block.shape[0]
+        hopt, copt, dopt = HarvestOption(f0_floor, f0_ceil, frame_period), CheapTrickOption(q1, 71.0, fft_size), D4COption(threshold)
+        self._check(self.lib.world_hip_analyze_coded(self._context(), B, fs, x.data_ptr(), L, xl.ctypes.data_as(_ip),
+                                                     C.byref(hopt), C.byref(copt), C.byref(dopt), number_of_dimensions,
+                                                     first_row, block.data_ptr(), cols), "analyze_coded")
         return nf
 
     def spectral_packed_range(self, x, fs, tpos, f0, n_frames, block, frame_lo, frame_hi, first_row=0, x_len=None, q1=-0.15,

@@ -126,6 +126,8 @@ struct WorldHipContext {
   void *xchg_ready = nullptr, *xchg_done = nullptr;   // events of world_hip_allgather_blocks
   double *d_pk = nullptr;        // dense (tpos, f0) of world_hip_analyze_packed: [2][n_utt][f_stride], grow-only
   size_t pk_cap = 0;
+  double *d_stage = nullptr;     // full records of world_hip_analyze_coded's batch, read by the coders: grow-only
+  size_t stage_cap = 0;
   // world_hip_analyze_sharded: this device's exchange stream, input staging (two pinned halves) and device input, grow-only
   hipStream_t xstream = nullptr;
   double *h_xin = nullptr, *d_xin = nullptr;
@@ -967,7 +969,7 @@ void launch_double_to_pcm16(const double *d_x, short *d_pcm, long n, hipStream_t
 
 enum CodecOp { kCodeSp, kDecodeSp, kCodeAp, kDecodeAp };
 static void run_codec(WorldHipContext *c, CodecOp op, int rows, int fs, int fft_size, int ndim, const double *d_in,
-                      double *d_out) {
+                      double *d_out, size_t in_stride = 0, size_t out_stride = 0) {
   if (rows < 0) fail("negative row count");
   if (rows == 0) return;
   if (fs <= 0) fail("fs must be positive");
@@ -975,6 +977,7 @@ static void run_codec(WorldHipContext *c, CodecOp op, int rows, int fs, int fft_
   const int lg = ilog2_exact(fft_size);
   CodecParams p;
   p.in = d_in; p.out = d_out; p.rows = rows; p.fs = fs; p.fft_size = fft_size; p.lg_md = lg - 1; p.ndim = ndim;
+  p.in_stride = in_stride; p.out_stride = out_stride;
   p.tab = c->tab;
   p.knot = nullptr; p.frac = nullptr; p.w_re = nullptr; p.w_im = nullptr;
   if (op == kCodeSp || op == kDecodeSp) {
@@ -1194,6 +1197,44 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
   lay_ap.rec = d_block;
   run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, dopt, d_block,
                       d_block, lay_sp, lay_ap);
+}
+
+// ---------------------------------------------------------------------------
+// Harvest + CheapTrick + D4C of one batch into CODED records [tpos, f0, mel-cepstrum[ndim], band aperiodicity[nap]]
+// (include/world_hip.h: world_hip_analyze_coded; SURVEY.md 8f.1: "shrink the all-gather and D2H by 10-17x" -- 31 x at 48 kHz
+// with 60 coefficients: 536 instead of 16 416 bytes per frame).  The full records of the batch go to a staging block the
+// context owns (HBM only: nothing of it crosses a link) and the two coders read their rows out of it at the records' stride
+// and write theirs at the coded records': CodeSpectralEnvelope / CodeAperiodicity of exactly the analysis a dense call
+// returns (reference src/codec.cpp:217-236, 268-297).
+// ---------------------------------------------------------------------------
+static int coded_cols(int fs, int ndim) { return 2 + ndim + number_of_aperiodicities(fs); }
+static void run_analyze_coded(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                              const HarvestOption *hopt, const CheapTrickOption *copt, const D4COption *dopt, int ndim,
+                              long long first_row, double *d_block, int cols) {
+  check_batch(n_utt, fs, d_x, x_stride, x_length);
+  if (!d_block) fail("analyze_coded: null block");
+  if (first_row < 0) fail("analyze_coded: negative first_row");
+  const int nap = number_of_aperiodicities(fs), nb = copt->fft_size / 2 + 1;
+  if (nap < 1) fail("analyze_coded: fs=%d has no aperiodicity band", fs);
+  if (ndim < 1 || ndim > copt->fft_size / 4 + 1) fail("analyze_coded: number_of_dimensions %d outside [1, fft_size/4+1]", ndim);
+  if (cols != coded_cols(fs, ndim)) fail("analyze_coded: %d columns, %d coefficients at fs=%d need %d", cols, ndim, fs, coded_cols(fs, ndim));
+  long long rows = 0;
+  for (int u = 0; u < n_utt; ++u) rows += frame_count(fs, x_length[u], hopt->frame_period);
+  if (first_row + rows > 0x7FFFFFFFll) fail("block exceeds 2^31 records");
+  const int full = record_cols(copt->fft_size, 0);
+  const size_t need = (size_t)rows * full;
+  if (c->stage_cap < need) {
+    devrt::sync(c->stream);
+    if (c->d_stage) { devrt::dfree(c->d_stage); ++c->generation; }
+    c->stage_cap = need + need / 8;
+    c->d_stage = static_cast<double *>(devrt::dmalloc(sizeof(double) * c->stage_cap));
+  }
+  run_analyze_packed(c, n_utt, fs, d_x, x_stride, x_length, hopt, copt, dopt, 0, c->d_stage, full);
+  if (rows == 0) return;
+  double *out = d_block + (size_t)first_row * cols;
+  launch_copy_record_heads(c->d_stage, full, out, cols, rows, c->stream);
+  run_codec(c, kCodeSp, (int)rows, fs, copt->fft_size, ndim, c->d_stage + 2, out + 2, full, cols);
+  run_codec(c, kCodeAp, (int)rows, fs, copt->fft_size, nap, c->d_stage + 2 + nb, out + 2 + ndim, full, cols);
 }
 
 // ---------------------------------------------------------------------------
@@ -1517,6 +1558,21 @@ int world_hip_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double
   return guarded(c, [&] {
     run_analyze_packed(c, n_utt, fs, d_x, x_stride, x_length, harvest_option, cheaptrick_option, d4c_option, first_row,
                        d_block, cols);
+  });
+}
+
+int world_hip_coded_columns(int fs, int number_of_dimensions) {
+  if (fs <= 0 || number_of_dimensions < 1 || world_hip::number_of_aperiodicities(fs) < 1) return -1;
+  return coded_cols(fs, number_of_dimensions);
+}
+
+int world_hip_analyze_coded(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                            const HarvestOption *harvest_option, const CheapTrickOption *cheaptrick_option,
+                            const D4COption *d4c_option, int number_of_dimensions, long long first_row, double *d_block,
+                            int cols) {
+  return guarded(c, [&] {
+    run_analyze_coded(c, n_utt, fs, d_x, x_stride, x_length, harvest_option, cheaptrick_option, d4c_option,
+                      number_of_dimensions, first_row, d_block, cols);
   });
 }
 

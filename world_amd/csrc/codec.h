@@ -10,6 +10,9 @@ namespace world_hip {
 struct CodecParams {
   const double *in;       // [rows][in_cols]
   double *out;            // [rows][out_cols]
+  size_t in_stride, out_stride;   // doubles between consecutive rows; 0 = dense (in_cols / out_cols).  Rows that live inside
+                          // packed records (world_hip_analyze_coded: the coded wire format of the multi-GPU exchange) have the
+                          // records' strides
   int rows;
   int fs, fft_size;
   int lg_md;              // log2(fft_size / 2): the DCT length ("max_dimension")
@@ -24,5 +27,7 @@ void launch_code_spectral_envelope(const CodecParams &p, hipStream_t stream);
 void launch_decode_spectral_envelope(const CodecParams &p, hipStream_t stream);
 void launch_code_aperiodicity(const CodecParams &p, hipStream_t stream);
 void launch_decode_aperiodicity(const CodecParams &p, hipStream_t stream);
+// (tpos, f0) heads of packed records: dst[row * dst_stride + {0, 1}] = src[row * src_stride + {0, 1}]
+void launch_copy_record_heads(const double *src, size_t src_stride, double *dst, size_t dst_stride, long rows, hipStream_t stream);
 
 }  // namespace world_hip

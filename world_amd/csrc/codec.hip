@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) codec_code_sp(CodecParams p) {
   double *lg = reinterpret_cast<double *>(lds);                       // log envelope, nb bins
   cplx *Z = reinterpret_cast<cplx *>(lg + md + 2);                    // real FFT input, md reals
   const TwLds tw = stage_twiddles(reinterpret_cast<double *>(Z) + md + 16, p.lg_md, p.tab.tw);
-  const double *in = p.in + (size_t)row * nb;
+  const double *in = p.in + (size_t)row * (p.in_stride ? p.in_stride : (size_t)nb);
   for (int i = tid; i < nb; i += nt) lg[i] = log(in[i]);
   __syncthreads();
   // interp1 onto the mel axis, written straight into DCTForCodec's even/odd reordering
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) codec_code_sp(CodecParams p) {
     rfft_in(Z, dest) = v;
   }
   const double norm = sqrt(static_cast<double>(md));
-  double *out = p.out + (size_t)row * p.ndim;
+  double *out = p.out + (size_t)row * (p.out_stride ? p.out_stride : (size_t)p.ndim);
   block_rfft(Z, p.lg_md, tw, [&](int k, double re, double im) {
     if (k < p.ndim) out[k] = (re * p.w_re[k] - im * p.w_im[k]) / norm;
   });
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) codec_decode_sp(CodecParams p) {
   cplx *Z = reinterpret_cast<cplx *>(lds);                            // md complex points
   double *mel = reinterpret_cast<double *>(lds) + 2 * md + 16;        // md + 2 values
   const TwLds tw = stage_twiddles(mel + md + 2, p.lg_md, p.tab.tw);
-  const double *in = p.in + (size_t)row * p.ndim;
+  const double *in = p.in + (size_t)row * (p.in_stride ? p.in_stride : (size_t)p.ndim);
   const double norm = sqrt(static_cast<double>(md));
   for (int i = tid; i < md; i += nt) {
     cplx v; v.re = 0.0; v.im = 0.0;
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) codec_decode_sp(CodecParams p) {
   __syncthreads();
   if (tid == 0) { mel[0] = mel[1]; mel[md + 1] = mel[md]; }
   __syncthreads();
-  double *out = p.out + (size_t)row * nb;
+  double *out = p.out + (size_t)row * (p.out_stride ? p.out_stride : (size_t)nb);
   for (int j = tid; j < nb; j += nt) {
     const int k = p.knot[j];
     const double v = mel[k - 1] + p.frac[j] * (mel[k] - mel[k - 1]);
@@ -87,14 +87,14 @@ __global__ void codec_code_ap(CodecParams p) {
   if (item >= p.rows * p.ndim) return;
   const int row = item / p.ndim, band = item - row * p.ndim;
   const int nb = p.fft_size / 2 + 1;
-  const double *in = p.in + (size_t)row * nb;
+  const double *in = p.in + (size_t)row * (p.in_stride ? p.in_stride : (size_t)nb);
   // interp1Q(0, fs/fft_size, 20 log10(ap), nb, 3000 (band+1)) -- matlabfunctions.cpp:214-235
   const double pos = (3000.0 * (band + 1.0) - 0) / (static_cast<double>(p.fs) / p.fft_size);
   const int b = static_cast<int>(pos);
   const double fr = pos - b;
   const double y0 = 20 * log10(in[b]);
   const double dy = b < nb - 1 ? 20 * log10(in[b + 1]) - y0 : 0.0;
-  p.out[item] = y0 + dy * fr;
+  p.out[(size_t)row * (p.out_stride ? p.out_stride : (size_t)p.ndim) + band] = y0 + dy * fr;
 }
 
 __global__ void codec_decode_ap(CodecParams p) {
@@ -102,7 +102,7 @@ __global__ void codec_decode_ap(CodecParams p) {
   const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= (long)p.rows * nb) return;
   const int row = (int)(item / nb), j = (int)(item - (long)row * nb);
-  const double *in = p.in + (size_t)row * p.ndim;
+  const double *in = p.in + (size_t)row * (p.in_stride ? p.in_stride : (size_t)p.ndim);
   double mean = 0.0;                                  // CheckVUV, codec.cpp:31-41
   for (int i = 0; i < p.ndim; ++i) mean += in[i];
   mean /= p.ndim;
@@ -114,7 +114,17 @@ __global__ void codec_decode_ap(CodecParams p) {
     const double hi = k == p.ndim + 1 ? -kTiny : in[k - 1];
     v = pow(10.0, (lo + p.frac[j] * (hi - lo)) / 20.0);
   }
-  p.out[item] = v;
+  p.out[(size_t)row * (p.out_stride ? p.out_stride : (size_t)nb) + j] = v;
+}
+
+__global__ void codec_copy_heads(const double *src, size_t src_stride, double *dst, size_t dst_stride, long rows) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  dst[row * dst_stride] = src[row * src_stride];
+  dst[row * dst_stride + 1] = src[row * src_stride + 1];
+}
+void launch_copy_record_heads(const double *src, size_t src_stride, double *dst, size_t dst_stride, long rows, hipStream_t stream) {
+  WH_THREADS(codec_copy_heads, rows, 1, 1, stream, src, src_stride, dst, dst_stride, rows);
 }
 
 void launch_code_spectral_envelope(const CodecParams &p, hipStream_t stream) {

@@ -693,6 +693,18 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     // before everybody has arrived there -- past these reads)
   }
   const uint32_t *noise = p.noise + stream_at;
+#if !defined(WORLD_EMU) && !defined(WH_NO_PREFETCH)
+  // The frame's draws are its one cold stream (every other input has been touched by a neighbouring frame's workgroup):
+  // the second and third windows' -- contiguous behind the first's -- are requested now, a dword per 128-byte line, so that
+  // they cross the fabric under the first window's arithmetic and transforms.  Unused values: keep_word() below ends the
+  // registers' lives after the first window's own (younger, in-order) loads have been consumed.
+  uint32_t pf0 = 0;
+  {
+    const int w4 = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;                 // draws per window
+    const unsigned lines = (2u * (unsigned)w4 + 31u) / 32u;              // lines of windows two and three (<= T but for the lowest voices)
+    if ((unsigned)tid < lines) pf0 = noise[w4 + 32 * tid];
+  }
+#endif
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
   double *park = scratch + 64 + twiddle_lds_doubles(lgn - D4C_TW_LEVEL);
   const double inv_n = 1.0 / N;
@@ -852,6 +864,9 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     D4C_FRESH_TID();
     double ulo[kLo];
     const double coef = balanced(w, ulo);
+#if !defined(WORLD_EMU) && !defined(WH_NO_PREFETCH)
+    if (c == 0) pf0 = keep_word(pf0);
+#endif
     WH_STAMP(32, 1 + 4 * c);
     // even half: e[n] = z[n] + z[n + H], z[n] = u[n] (1 + i (n + 1)); the previous readers of Z are behind a barrier
     double pw = 0.0;
@@ -978,6 +993,23 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     });
     WH_STAMP(32, 11);
     D4C_FRESH_TID();
+#ifndef WORLD_EMU
+    // DCCorrection without LDS: a bin k <= upper of the merge's natural order is thread k's first item, so while the
+    // mirrored bins sit in lanes of the first wavefront (upper < 64: F0 below ~715 Hz at 48 kHz) the two neighbours of
+    // the interpolation come by lane index -- no staging of the low bins in Z, and none of the pass's three barriers
+    // (the waves that have nothing to correct walk on to the smoothing's first barrier).  Same operands, same order.
+    if (2 + static_cast<int>(cf0 * N / fs) < WAVE) {
+      const int upper = 2 + static_cast<int>(cf0 * N / fs), nrep = upper - 1;
+      const double pos0 = (0.0 - cf0) * (-static_cast<double>(N) / fs);
+      const int b0 = static_cast<int>(pos0);
+      const double fr0 = pos0 - b0;
+      if (wave_in_block() == 0) {
+        const int b = b0 - lane_id();                         // 1 <= b <= upper - 2 for the lanes that are corrected
+        const double y0 = __shfl(Bn[0], b & (WAVE - 1), WAVE), y1 = __shfl(Bn[0], (b + 1 <= upper ? b + 1 : upper) & (WAVE - 1), WAVE);
+        if (lane_id() < nrep) Bn[0] = keep(Bn[0] + (y0 + (y1 - y0) * fr0));
+      }
+    } else
+#endif
     dc_correct(Bn, for_nat);
     smooth(Bn, for_nat, cf0, B, for_pair);
   }
@@ -986,8 +1018,23 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
 
   // ---- GetStaticGroupDelay (d4c.cpp:172-188) ----------------------------------
   double A[kBins];
-  for_pair([&](int slot, int k) { A[slot] = keep(park[k]); });         // the centroid: the thread's own pairs
-  dc_correct(A, for_pair);                                             // d4c.cpp:141-142
+  // the centroid (the thread's own pairs) with its DCCorrection (d4c.cpp:141-142) on the way: the bins the correction
+  // mirrors are in `park` already, in natural order -- no staging in Z, no barriers (round 4: three)
+  {
+    const int upper = 2 + static_cast<int>(cf0 * N / fs), nrep = upper - 1;
+    const double pos0 = (0.0 - cf0) * (-static_cast<double>(N) / fs);
+    const int b0 = static_cast<int>(pos0);
+    const double fr0 = pos0 - b0;
+    for_pair([&](int slot, int k) {
+      double v = park[k];
+      if (k < nrep) {
+        const int b = b0 - k;
+        const double y0 = park[b], y1 = park[b + 1 <= upper ? b + 1 : upper];
+        v = v + (y0 + (y1 - y0) * fr0);
+      }
+      A[slot] = keep(v);
+    });
+  }
   WH_STAMP(32, 13);
   D4C_FRESH_TID();
 #pragma unroll

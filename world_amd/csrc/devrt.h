@@ -697,7 +697,8 @@ __device__ __forceinline__ void block_scan_incl_double(double *a, int n, double 
     const double s = v[kRegChunk - 1];
     const int lane = lane_id(), w = wave_in_block();
     const double inc = wave_incl_scan_f64(s);
-    __syncthreads();
+    // (no barrier in front of the scratch write: whoever read this scratch area last did so before the entry barrier
+    // above, and nothing between there and here touches it)
     if (lane == 63) scratch[w] = inc;
     __syncthreads();
     double base = 0.0;
@@ -716,8 +717,7 @@ __device__ __forceinline__ void block_scan_incl_double(double *a, int n, double 
   int lane = lane_id();
   const double inc = wave_incl_scan_f64(s);
   int nw = waves_per_block(), w = wave_in_block();
-  __syncthreads();
-  if (lane == 63) scratch[w] = inc;
+  if (lane == 63) scratch[w] = inc;                   // (as above: the entry barrier already separates the area's last readers)
   __syncthreads();
   double base = 0.0;
   for (int k = 0; k < w; ++k) base += scratch[k];

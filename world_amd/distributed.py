@@ -103,6 +103,22 @@ def wait_all(works):
 
 
 WIRE_COLS = {"f64": lambda nb: 2 + 2 * nb, "f32": lambda nb: 2 + nb}
+CODED_DIMENSIONS = 60            # mel-cepstral coefficients per frame on the "coded" wire (the reference's usual choice)
+
+
+def number_of_aperiodicities(fs):
+    """GetNumberOfAperiodicities (reference src/codec.cpp:212-215)"""
+    return int(min(15000.0, fs / 2.0 - 3000.0) / 3000.0)
+
+
+def wire_columns(wire, nb, fs=None, dimensions=CODED_DIMENSIONS):
+    """doubles per record on the wire: "f64" 2 + 2 nb, "f32" 2 + nb, "coded" 2 + dimensions + bands (include/world_hip.h:
+    world_hip_analyze_coded -- [tpos, f0, mel-cepstrum, band aperiodicity], the reference's coders applied on the device)"""
+    if wire == "coded":
+        if fs is None:
+            raise ValueError("the coded wire format needs the sampling rate")
+        return 2 + dimensions + number_of_aperiodicities(fs)
+    return WIRE_COLS[wire](nb)
 
 
 def record_views(rec, nb, wire="f64"):
@@ -111,6 +127,8 @@ def record_views(rec, nb, wire="f64"):
     world_hip_analyze_packed) -- sp / ap come back as float32 views of the same memory."""
     if wire == "f64":
         return rec[:, 0], rec[:, 1], rec[:, 2:2 + nb], rec[:, 2 + nb:2 + 2 * nb]
+    if isinstance(wire, tuple):                        # ("coded", dimensions): (tpos, f0, mel-cepstrum [n, D], band aperiodicity [n, bands])
+        return rec[:, 0], rec[:, 1], rec[:, 2:2 + wire[1]], rec[:, 2 + wire[1]:]
     assert wire == "f32" and rec.shape[-1] == 2 + nb
     f32 = rec.view(torch.float32)                      # [n, 2 cols]: float j of a record = bytes 4 j ..
     return rec[:, 0], rec[:, 1], f32[:, 4:4 + nb], f32[:, 4 + nb:4 + 2 * nb]
@@ -130,7 +148,8 @@ class ShardedResult:
         return len(self.n_frames)
 
     def utterance(self, i):
-        """(tpos [n], f0 [n], sp [n, nb], ap [n, nb]) of utterance i: views, no copy (sp / ap float32 on the f32 wire)"""
+        """(tpos [n], f0 [n], sp [n, nb], ap [n, nb]) of utterance i: views, no copy (sp / ap float32 on the f32 wire; on
+        the coded wire: mel-cepstrum [n, D] and band aperiodicity [n, bands] -- decode with WorldHip.decode_*)"""
         k, r, first, n = self.where[i]
         return record_views(self.blocks[k][r, first:first + n], self.nb, self.wire)
 
@@ -172,15 +191,17 @@ def _default_analyzer():
 _lanes = {}
 
 
-def _default_lanes(packer=None):
+def _default_lanes(packer=None, coded=0):
     """two (stream, analyze_packed) lanes per device and process: the caller's analyser (or the default one) and a second
-    library context, each bound to its own stream"""
+    library context, each bound to its own stream (coded > 0: analyze_coded with that many coefficients)"""
+    import functools
     device = torch.cuda.current_device()
     wh = packer or _default_analyzer()                 # a WorldHip keeps one library context per stream it is used on
     # keyed by the analyser ITSELF (kept alive by the entry): an id() can name another object after garbage collection
-    key = (device, wh)
+    key = (device, wh, coded)
     if key not in _lanes:
-        _lanes[key] = [(torch.cuda.Stream(device=device), wh.analyze_packed), (torch.cuda.Stream(device=device), wh.analyze_packed)]
+        run = functools.partial(wh.analyze_coded, number_of_dimensions=coded) if coded else wh.analyze_packed
+        _lanes[key] = [(torch.cuda.Stream(device=device), run), (torch.cuda.Stream(device=device), run)]
     return _lanes[key]
 
 
@@ -205,7 +226,7 @@ def _store_records(packer, tpos, f0, sp, ap, nf, block):
 
 def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, lengths=None, sub_batch=32, gather=True,
                     timings=None, packer=None, bins=None, analyze_packed=None, lanes=None, wire="f64", taper=True,
-                    own_buffers=False, exchange_single_rank=False, **options):
+                    own_buffers=False, exchange_single_rank=False, coded_dimensions=CODED_DIMENSIONS, **options):
     """The whole multi-GPU recipe in one call (BASELINE configs[3]).
 
     x_list   every utterance of the job as a 1-D float64 tensor: a list (the same on every rank), or -- with
@@ -221,8 +242,10 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
              32-utterance chunk's time with the chip nearly idle) overlaps the wide kernels of the next chunk.  Default on a
              GPU: two lanes, each with its own library context.
     bins     spectrogram bins per frame (default: fft/2+1 of fs)
-    wire     record format on the links: "f64" (default; [tpos, f0, sp[nb], ap[nb]] doubles) or "f32" (the spectra
-             rounded once to float32 by the stage kernels: half the bytes, 6e-8 relative -- the contract is 1e-4)
+    wire     record format on the links: "f64" (default; [tpos, f0, sp[nb], ap[nb]] doubles), "f32" (the spectra
+             rounded once to float32 by the stage kernels: half the bytes, 6e-8 relative -- the contract is 1e-4) or "coded"
+             ([tpos, f0, mel-cepstrum[coded_dimensions], band aperiodicity]: the reference's CodeSpectralEnvelope /
+             CodeAperiodicity applied on the device before anything leaves it -- 31 x fewer bytes at 48 kHz, lossy by design)
     taper    cut the last sub-batch into halves so that the one exposed exchange is small (chunk_sizes)
     exchange_single_rank  run the all-gathers even in a process group of ONE rank (a functional check of the collective
              path -- RCCL, the aliased in-place all_gather_into_tensor -- on a 1-GPU box; never needed for results)
@@ -245,18 +268,23 @@ def analyze_sharded(x_list, fs, analyze=None, group=None, frame_period=5.0, leng
     n_utt = len(lengths)
     n_frames = [frame_count(fs, n, frame_period) for n in lengths]
     nb = bins or cheaptrick_fft_size(fs) // 2 + 1
-    if wire not in WIRE_COLS:
-        raise ValueError(f"wire format {wire!r}: expected one of {sorted(WIRE_COLS)}")
+    if wire not in WIRE_COLS and wire != "coded":
+        raise ValueError(f"wire format {wire!r}: expected one of {sorted(WIRE_COLS) + ['coded']}")
     if wire != "f64" and analyze is not None:
         raise ValueError("the narrow wire formats are written by the stage kernels: they need analyze_packed, not analyze")
-    cols = WIRE_COLS[wire](nb)
+    cols = wire_columns(wire, nb, fs, coded_dimensions)
+    coded = coded_dimensions if wire == "coded" else 0
+    if coded:
+        wire = ("coded", coded)                        # what ShardedResult / record_views need to cut a record
     device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     if n_utt == 0:
         return ShardedResult([], {}, [], nb, wire)
     if analyze is None and analyze_packed is None:
-        analyze_packed = (packer or _default_analyzer()).analyze_packed
+        import functools
+        a = packer or _default_analyzer()
+        analyze_packed = functools.partial(a.analyze_coded, number_of_dimensions=coded) if coded else a.analyze_packed
         if lanes is None and device.type == "cuda":
-            lanes = _default_lanes(packer)
+            lanes = _default_lanes(packer, coded)
     if lanes is not None and not lanes:
         lanes = None
     parts = partition(lengths, world)

@@ -199,6 +199,12 @@ def test_emulated_small_array_slabs_chain_and_recycle(tmp_path):
     for k in a.files:
         assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
     assert int(b["slabs"]) == int(a["slabs"])                          # (bookkeeping value only: same call count)
+    # Harvest's zero-crossing lists exist for one GROUP of utterances at a time (harvest.hip: launch_harvest): groups of one
+    # and of two utterances (the batches have three: a ragged last group) give the same records as the whole batch at once
+    d = _slab_stress(EMU_LIB, {"WORLD_HIP_EVENT_GROUP": "1"}, str(tmp_path / "d.npz"))
+    e = _slab_stress(EMU_LIB, {"WORLD_HIP_EVENT_GROUP": "2"}, str(tmp_path / "e.npz"))
+    for k in a.files:
+        assert np.array_equal(a[k], d[k]) and np.array_equal(a[k], e[k]), k
 
 
 # ---------------------------------------------------------------------------------------------------------

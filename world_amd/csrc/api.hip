@@ -617,6 +617,12 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   const bool direct_lists = p.fft_seg > 0 && p.nseg == 1;     // the filter bank writes the final event lists itself
 
   const size_t B = n_utt;
+  // utterances whose zero-crossing lists exist at once (harvest.hip: launch_harvest): WORLD_HIP_EVENT_GROUP, default 64 --
+  // a 64-utterance launch of the filter bank is 9 728 workgroups, ten times what the chip holds at once
+  static const int ev_group_env = [] { const char *e = getenv("WORLD_HIP_EVENT_GROUP"); return e ? std::max(1, atoi(e)) : 64; }();
+  p.ev_group = std::min(n_utt, ev_group_env);
+  p.ev_u0 = 0;
+  const size_t E = p.ev_group;
   const size_t cand_elems = B * p.fb_stride * p.maxc;
   size_t need = 0;
   need += 5 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * ((max_y + 4095) / 4096) * 4) +
@@ -624,11 +630,11 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
           pad256(sizeof(double) * B * p.nch * 4);
   need += pad256(sizeof(double) * B * p.m_stride);
   need += pad256(sizeof(double) * B * p.y_stride);
-  need += pad256(sizeof(double) * B * p.nch * 4 * p.ev_cap);
-  need += pad256(sizeof(int) * B * p.nch * 4);
+  need += pad256(sizeof(double) * E * p.nch * 4 * p.ev_cap);
+  need += pad256(sizeof(int) * E * p.nch * 4);
   if (!direct_lists) {
-    need += pad256(sizeof(double) * B * p.nch * 4 * p.nseg * p.seg_cap);
-    need += pad256(sizeof(int) * B * p.nch * 4 * p.nseg);
+    need += pad256(sizeof(double) * E * p.nch * 4 * p.nseg * p.seg_cap);
+    need += pad256(sizeof(int) * E * p.nch * 4 * p.nseg);
   }
   need += pad256(sizeof(double2) * B * p.nblk * kBandFftBins);
   need += pad256(sizeof(double) * B * p.nch * p.fb_stride);
@@ -659,13 +665,13 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
                    ? reinterpret_cast<const double2 *>(p.win_lane + (size_t)hb.win_tab_len * WAVE * 2) : nullptr;
   p.fwd = c->arena.take<double>(B * p.m_stride);
   p.y = c->arena.take<double>(B * p.y_stride);
-  p.events = c->arena.take<double>(B * p.nch * 4 * p.ev_cap);
-  p.ev_count = c->arena.take<int>(B * p.nch * 4);
+  p.events = c->arena.take<double>(E * p.nch * 4 * p.ev_cap);
+  p.ev_count = c->arena.take<int>(E * p.nch * 4);
   if (direct_lists) {
     p.seg_events = p.events; p.seg_count = p.ev_count;
   } else {
-    p.seg_events = c->arena.take<double>(B * p.nch * 4 * p.nseg * p.seg_cap);
-    p.seg_count = c->arena.take<int>(B * p.nch * 4 * p.nseg);
+    p.seg_events = c->arena.take<double>(E * p.nch * 4 * p.nseg * p.seg_cap);
+    p.seg_count = c->arena.take<int>(E * p.nch * 4 * p.nseg);
   }
   p.blk_spec = c->arena.take<double2>(B * p.nblk * kBandFftBins);
   p.raw = c->arena.take<double>(B * p.nch * p.fb_stride);

@@ -182,27 +182,9 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
   const double cf0 = ct_effective_f0(p.f0[fi], p.f0_floor);
   const uint32_t *noise = p.noise + p.offsets[fi];
   const int tid = wg_thread<TB>(), nt = wg_size<TB>();
-#if !defined(WORLD_EMU) && !defined(WH_NO_PREFETCH)
-  // The frame's draws are the one stream no other workgroup has touched before: every frame misses to HBM for its own
-  // 8 KB of the randn table, and the window below cannot start until they arrive (round 4: the wavefronts reach the first
-  // barrier after 8-11 thousand cycles whatever the order of their loads).  So each workgroup fetches -- one dword per
-  // 128-byte line, one load instruction -- the draws of the frame that will START about when this one ENDS: the workgroup
-  // kCtAhead further on in dispatch order (five resident workgroups per CU x 256 CUs), which lands on the same XCD
-  // (dispatch is round robin over the eight: kCtAhead is a multiple of 8), i.e. behind the same L2.  The values are not
-  // used; `keep_word` below only ends the register's life once this frame's own window loads -- younger, returned in
-  // order -- have arrived, so nothing ever waits for the prefetch.
-  uint32_t pf = 0;
-  {
-    constexpr int kCtAhead = 1280;
-    const long id2 = (long)blockIdx.y * gridDim.x + blockIdx.x + kCtAhead;
-    const int y2 = (int)(id2 / gridDim.x), x2 = (int)(id2 - (long)y2 * gridDim.x);
-    if (y2 < (int)gridDim.y) {
-      const int f2 = p.frame_lo + xcd_grouped(x2, gridDim.x);
-      if (f2 < p.b.n_frames[y2] && f2 < p.frame_hi && tid < WAVE)
-        pf = p.noise[p.offsets[(size_t)y2 * p.b.f_stride + f2] + 32u * (unsigned)tid];      // 64 lines = 8 KB: a frame's draws at ordinary pitches
-    }
-  }
-#endif
+  // (Round 5 tried fetching the NEXT round's draws -- the frame 1280 workgroups on, same XCD -- a dword per line while this
+  // frame computes, and d4c_frame its own second and third windows' ahead of time: no change in either kernel, A/B in one call.
+  // The window phases are bound by instruction issue among five resident workgroups, not by the cold stream.)
 
   WH_STAMP(0, 1);
   // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) -------------------------
@@ -239,9 +221,6 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
       }
     }
     block_sum4<TB>(s_ww, s_a, s_n, s_w, scratch);
-#if !defined(WORLD_EMU) && !defined(WH_NO_PREFETCH)
-    pf = keep_word(pf);                                      // (the prefetch above: its register is free from here)
-#endif
     const double c = 1.0 / sqrt(s_ww);
     const double cc = c * ((c * s_a + s_n) / (c * s_w));
 #pragma unroll

@@ -693,18 +693,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     // before everybody has arrived there -- past these reads)
   }
   const uint32_t *noise = p.noise + stream_at;
-#if !defined(WORLD_EMU) && !defined(WH_NO_PREFETCH)
-  // The frame's draws are its one cold stream (every other input has been touched by a neighbouring frame's workgroup):
-  // the second and third windows' -- contiguous behind the first's -- are requested now, a dword per 128-byte line, so that
-  // they cross the fabric under the first window's arithmetic and transforms.  Unused values: keep_word() below ends the
-  // registers' lives after the first window's own (younger, in-order) loads have been consumed.
-  uint32_t pf0 = 0;
-  {
-    const int w4 = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;                 // draws per window
-    const unsigned lines = (2u * (unsigned)w4 + 31u) / 32u;              // lines of windows two and three (<= T but for the lowest voices)
-    if ((unsigned)tid < lines) pf0 = noise[w4 + 32 * tid];
-  }
-#endif
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
   double *park = scratch + 64 + twiddle_lds_doubles(lgn - D4C_TW_LEVEL);
   const double inv_n = 1.0 / N;
@@ -864,9 +852,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     D4C_FRESH_TID();
     double ulo[kLo];
     const double coef = balanced(w, ulo);
-#if !defined(WORLD_EMU) && !defined(WH_NO_PREFETCH)
-    if (c == 0) pf0 = keep_word(pf0);
-#endif
     WH_STAMP(32, 1 + 4 * c);
     // even half: e[n] = z[n] + z[n + H], z[n] = u[n] (1 + i (n + 1)); the previous readers of Z are behind a barrier
     double pw = 0.0;

@@ -48,14 +48,16 @@ struct HarvestParams {
   double *fwd;             // [n_utt][m_stride] forward-filtered padded signal
   int m_stride;
   double *y;               // [n_utt][y_stride]
-  double *seg_events;      // [n_utt][nch][4][nseg][seg_cap] per-segment crossing times (nseg == 1 on the FFT path: the final lists)
-  int *seg_count;          // [n_utt][nch][4][nseg]
+  double *seg_events;      // [ev_group][nch][4][nseg][seg_cap] per-segment crossing times (nseg == 1 on the FFT path: the final lists)
+  int *seg_count;          // [ev_group][nch][4][nseg]
   int nseg;                // segment lists per (utterance, band, family): chunks of blocks (FFT path) or FIR segments
   int seg_cap;             // capacity of one segment list
   int nblk;                // FFT path: blocks per utterance slot
   int chunk_blocks;        // FFT path: consecutive blocks one workgroup filters (its events form one segment list)
-  double *events;          // [n_utt][nch][4][ev_cap] fine zero-crossing positions
-  int *ev_count;           // [n_utt][nch][4]
+  double *events;          // [ev_group][nch][4][ev_cap] fine zero-crossing positions of ONE GROUP of utterances (launch_harvest walks the groups)
+  int *ev_count;           // [ev_group][nch][4]
+  int ev_group;            // utterances whose lists exist at once
+  int ev_u0;               // first utterance of the group a launch works on (its lists are slot u - ev_u0)
   double *raw;             // [n_utt][nch][fb_stride]
   double *cand_a, *score_a;  // [n_utt][fb_stride][maxc]
   double *cand_b, *score_b;  // [n_utt][fb_stride][maxc]

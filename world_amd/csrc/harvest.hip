@@ -127,7 +127,7 @@ __global__ void hv_band_quirk(HarvestParams p) {
 // Band-pass FIR + the four zero-crossing families (bandfilter.h).  One workgroup
 // per (time segment, band, utterance).
 __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
-  const int seg = blockIdx.x, band = blockIdx.y, u = blockIdx.z;
+  const int seg = blockIdx.x, band = blockIdx.y, ue = blockIdx.z, u = ue + p.ev_u0;   // (ue: the utterance's slot in the event lists)
   BandJob job;
   job.in = p.y + (size_t)u * p.y_stride;
   job.in_len = p.y_len[u];
@@ -137,8 +137,8 @@ __global__ void __launch_bounds__(kBpThreads) hv_band_events(HarvestParams p) {
   job.shift = p.band_half[band] + 1;             // delay compensation L+1 (harvest.cpp:140-142)
   job.max_ntap = 2 * p.max_half + 1;
   job.nseg = p.nseg;
-  job.seg_events = p.seg_events + ((size_t)(u * p.nch + band) * 4) * p.nseg * kSegCap;   // seg_cap == kSegCap on this path
-  job.seg_count = p.seg_count + ((size_t)(u * p.nch + band) * 4) * p.nseg;
+  job.seg_events = p.seg_events + ((size_t)(ue * p.nch + band) * 4) * p.nseg * kSegCap;   // seg_cap == kSegCap on this path
+  job.seg_count = p.seg_count + ((size_t)(ue * p.nch + band) * 4) * p.nseg;
   job.quirk = p.quirk + ((size_t)u * p.nch + band) * 4;
   job.quirk_delay = job.shift;                     // the term is a function of the undelayed index
   band_events_segment(job, seg);
@@ -222,9 +222,9 @@ __global__ void __launch_bounds__(256) hv_block_spectra(HarvestParams p) {
 #endif
 __global__ void __launch_bounds__(256, HV_FFT_MIN_WAVES) hv_band_events_fft(HarvestParams p) {
   DYN_LDS(lds);
-  const int band = blockIdx.x, chunk = blockIdx.y, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+  const int band = blockIdx.x, chunk = blockIdx.y, ue = blockIdx.z, u = ue + p.ev_u0, tid = threadIdx.x, nt = blockDim.x;
   const int n = p.y_len[u];
-  const size_t list = ((size_t)(u * p.nch + band) * 4);
+  const size_t list = ((size_t)(ue * p.nch + band) * 4);             // (ue: the utterance's slot in the event lists)
   int *cnt_out = p.seg_count + list * p.nseg + chunk;
   const int blk0 = chunk * p.chunk_blocks;
   if (blk0 * p.fft_seg >= n) {
@@ -330,8 +330,8 @@ __global__ void __launch_bounds__(256, HV_FFT_MIN_WAVES) hv_band_events_fft(Harv
 // concatenate the per-segment lists of one (family, band, utterance) in time order
 __global__ void hv_compact_events(HarvestParams p) {
   DYN_LDS(lds);
-  const int bf = blockIdx.x, u = blockIdx.y;        // bf = band * 4 + family
-  const size_t list = (size_t)u * p.nch * 4 + bf;
+  const int bf = blockIdx.x, ue = blockIdx.y;       // bf = band * 4 + family; ue: the utterance's slot in the event lists
+  const size_t list = (size_t)ue * p.nch * 4 + bf;
   compact_event_segments(p.seg_events + list * p.nseg * p.seg_cap, p.seg_count + list * p.nseg, p.nseg, p.seg_cap,
                          p.events + list * p.ev_cap, p.ev_cap, p.ev_count + list, lds);
 }
@@ -359,12 +359,12 @@ __global__ void __launch_bounds__(kRawFrames, HV_RAW_MIN_WG) hv_raw_candidates(H
   // so every run of one band's lists is served by the same L2 and a list crosses the fabric once.  (Runs fastest, the
   // 20 runs of a list were spread over all eight L2s, each fetching the list's head and tail for the proportional
   // guess and its neighbours' boundary intervals: 3.4 x the lists' size in fetches.)
-  const int band = blockIdx.x, u = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+  const int band = blockIdx.x, ue = blockIdx.z, u = ue + p.ev_u0, tid = threadIdx.x, nt = blockDim.x;
   if (band >= p.nch) return;
   const int f_begin = blockIdx.y * kRawRun, f_end = imin(f_begin + kRawRun, p.nfb[u]);
   if (f_begin >= f_end) return;
-  const int *cnt = p.ev_count + (u * p.nch + band) * 4;
-  const double *ev = p.events + ((size_t)(u * p.nch + band) * 4) * p.ev_cap;
+  const int *cnt = p.ev_count + (ue * p.nch + band) * 4;
+  const double *ev = p.events + ((size_t)(ue * p.nch + band) * 4) * p.ev_cap;
   double *out = p.raw + ((size_t)u * p.nch + band) * p.fb_stride;
   int n_int[4];
   bool ok = true;
@@ -911,18 +911,24 @@ void launch_harvest(const HarvestParams &p, int max_x_len, int max_y_len, int ma
   // (the mean's partial sums came with the backward sweep; at ratio 1 a pass of its own forms them)
   if (p.ratio == 1) WH_BLOCKS(hv_partial_sums, dim3(p.mean_parts, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(hv_remove_mean, dim3(p.nyq_slices, B), 256, 64 * sizeof(double), stream, p);
-  if (p.fft_seg > 0) {
-    const size_t lds = sizeof(double) * (kBandFft + 64 + twiddle_lds_doubles(kBandFftLg - 1));
-    WH_BLOCKS(hv_block_spectra, dim3(p.nblk + p.nch, B), 256, lds, stream, p);       // + the bands' mirror-store constants
-    WH_BLOCKS(hv_band_events_fft, dim3(p.nch, p.nseg, B), 256, lds, stream, p);
-  } else {
-    WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
-    WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, B), kBpThreads, hv_band_lds_bytes(p.max_half), stream, p);
+  const size_t lds = sizeof(double) * (kBandFft + 64 + twiddle_lds_doubles(kBandFftLg - 1));
+  if (p.fft_seg > 0) WH_BLOCKS(hv_block_spectra, dim3(p.nblk + p.nch, B), 256, lds, stream, p);       // + the bands' mirror-store constants
+  else WH_BLOCKS(hv_band_quirk, dim3(p.nch, B), 64, 64 * sizeof(double), stream, p);
+  // The zero-crossing lists are the path's largest workspace -- 152 bands x 4 families x a crossing every other sample at
+  // worst (digital silence really produces that): 97 MB per 5 s utterance, two thirds of round 4's 0.14 GB -- and they live
+  // only from the filter bank to the interpolation onto the 1 ms grid.  A batch therefore walks its utterances in groups of
+  // p.ev_group: the lists are allocated for one group and reused by the next (stream order).
+  for (int u0 = 0; u0 < B; u0 += p.ev_group) {
+    HarvestParams g = p;
+    g.ev_u0 = u0;
+    const int G = imin(p.ev_group, B - u0);
+    if (p.fft_seg > 0) WH_BLOCKS(hv_band_events_fft, dim3(p.nch, p.nseg, G), 256, lds, stream, g);
+    else WH_BLOCKS(hv_band_events, dim3(p.nseg, p.nch, G), kBpThreads, hv_band_lds_bytes(p.max_half), stream, g);
+    // one chunk per utterance: the kernel above appended straight into the final lists (seg_events == events)
+    if (!(p.fft_seg > 0 && p.nseg == 1)) WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, G), 256, compact_lds_bytes(p.nseg), stream, g);
+    WH_BLOCKS(hv_raw_candidates, dim3((p.nch + 7) / 8 * 8, (max_fb + kRawRun - 1) / kRawRun, G), kRawFrames,
+              8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, g);
   }
-  // one chunk per utterance: the kernel above appended straight into the final lists (seg_events == events)
-  if (!(p.fft_seg > 0 && p.nseg == 1)) WH_BLOCKS(hv_compact_events, dim3(p.nch * 4, B), 256, compact_lds_bytes(p.nseg), stream, p);
-  WH_BLOCKS(hv_raw_candidates, dim3((p.nch + 7) / 8 * 8, (max_fb + kRawRun - 1) / kRawRun, B), kRawFrames,
-            8 * kIntervalCap * sizeof(double) + 4 * sizeof(IntervalRange), stream, p);
   WH_THREADS(hv_detect, max_fb, B, 1, stream, p);
   WH_WAVES(hv_refine, max_fb, B, 1, 3 * sizeof(double) * p.refine_cap, stream, p);
   WH_BLOCKS(hv_prune, dim3((max_fb + kPruneFrames - 1) / kPruneFrames, B), 256,

@@ -149,10 +149,21 @@ WORLD_HIP_API int ReadAperiodicity(const char *filename, double **aperiodicity);
  * Errors: the reference API has no error channel and never fails; this library can (no GPU, out of device memory, a
  * shape beyond world_hip_check_shape()).  There is NO CPU fallback.  A failing drop-in call reports through the handler
  * installed here: `function` is the symbol's name, `message` the reason (also world_hip_last_error()).  If the handler
- * returns, the drop-in call returns to its caller with its output buffers untouched; it may also longjmp or throw.
+ * returns, the drop-in call returns to its caller; it may also longjmp or throw.  The caller's output buffers are untouched
+ * when the call was refused up front (a shape limit, a missing GPU) and UNSPECIFIED after a failure in mid-transfer (the
+ * matrices are downloaded chunk by chunk into the caller's rows: a device error between two chunks leaves earlier rows written).
  * With no handler (the default, handler = NULL) the reason is printed to stderr and the process aborts. */
 typedef void (*WorldHipErrorHandler)(const char *function, const char *message, void *user);
 WORLD_HIP_API void world_hip_set_error_handler(WorldHipErrorHandler handler, void *user);
+/* Releases what the drop-in layer holds: its helper threads are joined and every slot's context, streams, events, device
+ * and pinned buffers are freed.  For host processes that want the GPU path gone without exiting; the next drop-in call
+ * starts over (a cold call).  Returns 0, or -1 -- nothing released -- while a drop-in call is running.
+ * Environment of the drop-in layer, read once: WORLD_HIP_DROPIN_SLOTS (4), WORLD_HIP_DROPIN_COPY_THREADS (3; 0 = the calling
+ * thread copies alone), WORLD_HIP_DROPIN_SPIN_US (150: how long an idle copy helper polls for the next chunk of a running
+ * transfer before it sleeps; 0 = it always sleeps), WORLD_HIP_DROPIN_WIRE (f32: the spectrogram / aperiodicity rows cross
+ * PCIe as float -- rounded once on the device, 6e-8 relative -- and are widened into the caller's double rows on the host:
+ * half the bytes of the path's PCIe-bound stages; default: double, bit-identical to the device-resident analysis). */
+WORLD_HIP_API int world_hip_shutdown(void);
 /* diagnostic counters of the drop-in layer: slots created, calls that found their signal resident / had to upload it */
 WORLD_HIP_API void world_hip_dropin_stats(unsigned long long *slots, unsigned long long *x_hits,
                                           unsigned long long *x_misses);

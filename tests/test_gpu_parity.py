@@ -601,6 +601,53 @@ def test_c_driver_shards_a_job_over_two_contexts_of_one_gpu():
 
 
 @pytest.mark.gpu
+def test_c_driver_tapered_schedule_and_f32_wire_on_two_contexts():
+    """world_hip_analyze_sharded's round-4 features on the GPU (only the host emulator ran them): 128 short
+    utterances on two contexts -> shares of 64 in sub-batches of 32 -> the tapered schedule 32, 16, 8, 8 -- and the narrow
+    wire format (the spectra rounded once to float by the stage kernels).  Both blocks complete and identical; a sample of
+    utterances from every chunk of the schedule equals a lone analysis (tpos / f0 bit for bit, spectra rounded once)."""
+    import torch
+    from world_amd import distributed as wd, synth
+    from world_amd.api import WorldHip, analyze_sharded_c, cheaptrick_fft_size, frame_count
+    fs = 48000
+    n_utt = 128
+    secs = [0.12 + 0.01 * (i % 7) for i in range(n_utt)]
+    xs = [synth.utterance(i, fs, d) for i, d in enumerate(secs)]
+    nb = cheaptrick_fft_size(fs) // 2 + 1
+    rows = sum(frame_count(fs, x.numel(), 5.0) for x in xs)
+    assert wd.chunk_sizes(64, 32) == [32, 16, 8, 8]
+    a, b = WorldHip(), WorldHip()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    with torch.cuda.stream(streams[0]):
+        ca = a._context()
+    with torch.cuda.stream(streams[1]):
+        cb = b._context()
+    cols = a.lib.world_hip_record_columns(cheaptrick_fft_size(fs), 1)
+    assert cols == 2 + nb
+    blocks = [torch.full((rows, cols), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    where = analyze_sharded_c(a.lib, [ca, cb], [x.numpy() for x in xs], fs, [t.data_ptr() for t in blocks], rows,
+                              sub_batch=32, wire=1)
+    torch.cuda.synchronize()
+    assert sorted(set(int(d) for d in where[:, 0])) == [0, 1]
+    assert torch.equal(blocks[0].view(torch.int64), blocks[1].view(torch.int64))          # (bit patterns: NaN-safe)
+    assert not torch.isnan(blocks[0][:, :2]).any()
+    counts = [int((where[:, 0] == d).sum()) for d in (0, 1)]
+    assert sorted(counts) == [64, 64]
+    wh = WorldHip()
+    # utterances spread over the schedule's chunks on both devices: the first rows, the tapered middle, the last rows
+    order = sorted(range(n_utt), key=lambda i: (int(where[i, 0]), int(where[i, 1])))
+    picks = sorted(set(order[k] for k in (0, 31, 32, 47, 48, 55, 56, 63, 64, 95, 96, 111, 112, 119, 120, 127)))
+    for i in picks:
+        tp_i, f0_i, sp_i, ap_i, nf_i = wh.analyze(xs[i][None].cuda().contiguous(), fs)
+        dev, first, n = (int(v) for v in where[i])
+        assert n == int(nf_i[0])
+        tp, f0, sp, ap = wd.record_views(blocks[1 - dev][first:first + n], nb, "f32")
+        assert torch.equal(tp, tp_i[0, :n]) and torch.equal(f0, f0_i[0, :n])
+        assert torch.equal(sp, sp_i[0, :n].to(torch.float32)) and torch.equal(ap, ap_i[0, :n].to(torch.float32))
+
+
+@pytest.mark.gpu
 def test_pack_unpack_and_peer_allgather_from_the_c_abi():
     """include/world_hip.h's exchange entries: pack -> world_hip_allgather_blocks (here: two contexts on two
     streams of the one GPU, the peer copies degenerate to device-to-device copies) -> unpack gives back every

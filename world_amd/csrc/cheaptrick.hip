@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
   const int x_len = p.b.x_len[u];
   const double pos = p.tpos[fi];
-  const double cf0 = ct_effective_f0(p.f0[fi], p.f0_floor);
+  const double cf0 = ct_effective_f0(p.f0[fi], p.f0_floor, fs);
   const uint32_t *noise = p.noise + p.offsets[fi];
   const int tid = wg_thread<TB>(), nt = wg_size<TB>();
   // (Round 5 tried fetching the NEXT round's draws -- the frame 1280 workgroups on, same XCD -- a dword per line while this

@@ -8,8 +8,12 @@
 
 namespace world_hip {
 
-__device__ __forceinline__ double ct_effective_f0(double f0, double floor_f0) {
-  return f0 <= floor_f0 ? kDefaultF0 : f0;              // cheaptrick.cpp:218
+// cheaptrick.cpp:218.  An F0 above fs/2 (no estimator produces one; a caller-made track can) is analysed as fs/2: the frame
+// kernel's smoothing segment is laid out for widths up to 2/3 of that (ct_seg_cap) and a wider one would run over the
+// next LDS region -- the one place this path does not follow the reference, which has no such bound.
+__device__ __forceinline__ double ct_effective_f0(double f0, double floor_f0, int fs) {
+  const double nyq = 0.5 * fs;
+  return f0 <= floor_f0 ? kDefaultF0 : (f0 > nyq ? nyq : f0);
 }
 
 // CheapTrick: window draws, then one per bin (cheaptrick.cpp:27-43, :147-149)
@@ -23,7 +27,7 @@ __device__ __forceinline__ void ct_offsets_utt(const CtParams &p, int u, double 
     int f = base + threadIdx.x;
     int cnt = 0;
     if (f < nf) {
-      double cf0 = ct_effective_f0(f0[f], p.f0_floor);
+      double cf0 = ct_effective_f0(f0[f], p.f0_floor, p.b.fs);
       cnt = 2 * mround(1.5 * p.b.fs / cf0) + 1 + nb;
     }
     int total, off = block_excl_scan_int(cnt, &total, scratch);

@@ -71,6 +71,42 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def unit_hashes():
+    """{unit: hash of that .hip unit + every header}, {kernel name: unit}: the PMC counters are stamped per KERNEL with the
+    hash of the unit the kernel is compiled from, so a change to one unit makes only its own kernels' counters stale -- and
+    tools/round_evidence.sh re-collects only those (a one-line kernel change cost a full re-profile)."""
+    import re
+    d = os.path.join(ROOT, "world_amd", "csrc")
+    hdr = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".inc")):
+            hdr.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                hdr.update(f.read())
+    units, kernels = {}, {}
+    for name in sorted(os.listdir(d)):
+        if not name.endswith(".hip"):
+            continue
+        with open(os.path.join(d, name), "rb") as f:
+            body = f.read()
+        h = hashlib.sha256(hdr.digest())
+        h.update(body)
+        units[name] = h.hexdigest()[:16]
+        for m in re.finditer(r"__global__\s+void\s+(?:__launch_bounds__\([^)]*(?:\([^)]*\)[^)]*)*\)\s*)?(\w+)\s*\(", body.decode("utf-8", "replace")):
+            kernels[m.group(1)] = name
+    return units, kernels
+
+
+def _kernel_stale(counters, kernel):
+    """True when `kernel`'s counters were taken on other sources than today's (per-unit stamp; whole-tree stamp for old files)"""
+    units, kernels = unit_hashes()
+    base = kernel.split("<")[0]
+    stamp = counters.get("unit_hash")
+    if stamp is None or base not in kernels:
+        return None
+    return stamp != units[kernels[base]]
+
+
 def _pmc(config="1"):
     """{kernel: counters} of one profiled config, its frames per launch, and whether the stamp is stale."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -107,9 +143,18 @@ def measured_traffic(kernel, frames_per_launch, config="1"):
     return int((2.0 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0)
 
 
-def traffic_stale(config="1"):
+def traffic_stale(config="1", kernel=None):
+    """whether the committed counters (of `kernel`, or of the whole config) were measured on other kernel sources"""
     p = _pmc(config)
-    return None if not p else bool(p[2])
+    if not p:
+        return None
+    if kernel is not None:
+        names = [n for n in p[0] if n == kernel or n.startswith(kernel + "<")]
+        if names:
+            st = _kernel_stale(p[0][names[0]], names[0])
+            if st is not None:
+                return bool(st)
+    return bool(p[2])
 
 
 def measured_fp64(kernels, frames_per_launch, config="1"):
@@ -364,7 +409,7 @@ def main():
         ach = alg / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom, frames, config),
-             "traffic_stale": traffic_stale(config),
+             "traffic_stale": traffic_stale(config, dom),
              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kernels[dom]["avg_ms"]}
         fp = measured_fp64(kernels, frames, config)
         if fp and dom in fp[0]:
@@ -899,6 +944,18 @@ def main():
         except Exception as e:                                          # noqa: BLE001
             cc = {"error": repr(e)}
         host_to_host["c_caller"] = cc
+        # ... and with WORLD_HIP_DROPIN_WIRE=f32: the two matrices cross PCIe as float (rounded once on the device, 6e-8
+        # relative against the contract's 1e-4) and are widened on the host -- opt-in, never `value`
+        try:
+            with tempfile.NamedTemporaryFile(suffix=".f64", delete=False) as tf:
+                tf.write(x_host.astype(np.float64).tobytes())
+            r = subprocess.run([exe, tf.name, str(FS), "10", "4"], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, WORLD_HIP_DROPIN_WIRE="f32"))
+            os.unlink(tf.name)
+            host_to_host["c_caller_f32_rows"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else \
+                {"error": (r.stdout + r.stderr)[-500:]}
+        except Exception as e:                                          # noqa: BLE001
+            host_to_host["c_caller_f32_rows"] = {"error": repr(e)}
         if "separate_rows_ms" in cc:
             host_to_host["ms_per_utterance"] = cc["separate_rows_ms"]
             host_to_host["frames_per_s"] = cc["frames"] / (cc["separate_rows_ms"] * 1e-3)

@@ -80,6 +80,7 @@ def test_a_profile_of_other_sources_is_reported_stale(tmp_path, monkeypatch):
     # same counters, another stamp
     fake = tmp_path / "profiles"
     fake.mkdir()
+    real_units = bench.unit_hashes()                            # (of the real tree: ROOT is redirected below)
     t["csrc_hash"] = "0" * 16
     (fake / "pmc_traffic.json").write_text(json.dumps(t))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
@@ -88,6 +89,20 @@ def test_a_profile_of_other_sources_is_reported_stale(tmp_path, monkeypatch):
     t["csrc_hash"] = "f" * 16
     (fake / "pmc_traffic.json").write_text(json.dumps(t))
     assert bench.traffic_stale("1") is False and bench.traffic_stale("9") is None
+    # per-kernel stamps (tools/evidence.py: a kernel's counters carry the hash of the unit it is compiled from): a change to
+    # another unit leaves them valid, a change to their own makes them -- and only them -- stale
+    monkeypatch.setattr(bench, "unit_hashes", lambda: real_units)
+    units, kernels = real_units
+    assert kernels["d4c_frame"] == "d4c.hip" and kernels["hv_refine"] == "harvest.hip" and kernels["ct_frame"] == "cheaptrick.hip"
+    k1 = t["configs"]["1"]["kernels"]
+    name = [n for n in k1 if n.startswith("d4c_frame")][0]
+    k1[name]["unit_hash"] = units["d4c.hip"]
+    other = [n for n in k1 if n.startswith("hv_refine")][0]
+    k1[other]["unit_hash"] = "0" * 16
+    t["csrc_hash"] = "0" * 16                                     # the tree as a whole has moved on
+    (fake / "pmc_traffic.json").write_text(json.dumps(t))
+    assert bench.traffic_stale("1", "d4c_frame") is False and bench.traffic_stale("1", "hv_refine") is True
+    assert bench.traffic_stale("1") is True
 
 
 def test_sweeps_report_their_failures(port_oracle):

@@ -1,0 +1,62 @@
+#!/bin/bash
+# The round's evidence in ONE gpurun call:   tools/round_evidence.sh <round> [--all] [--lds]
+#   1. rocprofv3 --kernel-trace --stats of each BASELINE config's leg (one job in flight: durations free of queueing)
+#   2. the PMC passes bench.py's roofline objects need (FETCH_SIZE, WRITE_SIZE, the FP64 instruction counters; --lds adds
+#      the LDS bank-conflict and SQ occupancy sets) -- each counter set in its own run, with --kernel-trace only (gpurun refuses
+#      --pmc mixed with other tracing domains) -- and ONLY for kernels of units whose sources changed since
+#      profiles/pmc_traffic.json was stamped (tools/evidence.py plan; --all: everything)
+#   3. a kernel trace of the twelve-jobs-in-flight mode, condensed by tools/trace_overlap.py
+#   4. install: profiles/<round>/ + profiles/pmc_traffic.json (per-kernel stamps)
+#   5. THEN the bench line (it reads the counters just installed: no line is printed before its counters exist),
+#      tools/roofline_check.py over the CSVs
+# Everything lands in gpurun_out/evidence_<round>/ and profiles/<round>/ on the box; gpurun merges gpurun_out/ back.
+set -u
+RND=${1:-r05}; shift || true
+ALL=""; LDS=0
+for a in "$@"; do case $a in --all) ALL="--all";; --lds) LDS=1;; esac; done
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/evidence_$RND
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+T0=$(date +%s)
+PLAN=$(python $ROOT/tools/evidence.py plan $ALL | tail -1)
+echo "$PLAN" > $OUT/plan.json
+REGEX=$(python -c "import json,sys; print(json.loads(sys.argv[1])['kernel_regex'])" "$PLAN")
+CFGS=$(python -c "import json,sys; print(' '.join(json.loads(sys.argv[1])['configs']))" "$PLAN")
+echo "plan: configs [$CFGS] regex [${REGEX:0:80}]"
+cmd_of() {
+  if [ "$1" = "1" ]; then echo "python $ROOT/bench.py --steps 5 --warmup 2 --streams 1 --min-wall 0 --no-cpu-baseline --no-extras --no-configs"
+  else echo "python $ROOT/bench.py --only-config $1 --steps 2 --min-wall 0 --contexts 1"; fi
+}
+SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64")
+if [ $LDS = 1 ]; then
+  SETS+=("SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY")
+fi
+for CFG in 1 2 3 4; do
+  D=$OUT/config$CFG; mkdir -p $D
+  CMD=$(cmd_of $CFG); echo "$CMD" > $D/command.txt
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o trace -- $CMD > $D/stats.log 2>&1
+  case " $CFGS " in *" $CFG "*) ;; *) continue;; esac
+  for pmc in "${SETS[@]}"; do
+    name=pmc_$(echo $pmc | tr ' ' '_' | cut -c1-40)
+    if [ -n "$REGEX" ]; then
+      timeout 300 rocprofv3 --kernel-trace --pmc $pmc --kernel-include-regex "$REGEX" --output-format csv -d $D/$name -o pmc -- $CMD > $D/$name.log 2>&1
+    else
+      timeout 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $D/$name -o pmc -- $CMD > $D/$name.log 2>&1
+    fi
+  done
+  echo "config $CFG done at $(( $(date +%s) - T0 )) s"
+done
+# the headline mode's kernel trace (twelve jobs in flight)
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/inflight -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --min-wall 1.0 --no-cpu-baseline --no-extras --no-configs > $OUT/inflight.log 2>&1
+mkdir -p $ROOT/profiles/$RND
+python $ROOT/tools/trace_overlap.py $OUT/inflight > $ROOT/profiles/$RND/inflight_overlap.txt 2>&1
+python $ROOT/tools/evidence.py install $OUT $RND
+cd $ROOT
+python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+cp $OUT/bench_n1.json profiles/$RND/bench_n1.json
+python tools/roofline_check.py profiles/$RND > profiles/$RND/roofline_check.txt 2>&1
+# keep what the judge reads; drop the per-dispatch rows (tens of thousands per batch run; gpurun merges <= 64 MiB back)
+mkdir -p $OUT/profiles_$RND && cp -r profiles/$RND/. $OUT/profiles_$RND/ && cp profiles/pmc_traffic.json $OUT/
+find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+du -sh $OUT; echo "evidence done in $(( $(date +%s) - T0 )) s"; tail -c 600 $OUT/bench_n1.json

@@ -142,6 +142,8 @@ __device__ __forceinline__ int swz(int i) {
 #elif WH_SWZ == 2
   // low nibble ^= rotl1(bits 4..7) ^ (bits 8..11 ^ rotl2(bits 8..11))
   return i ^ (((i >> 3) & 14) | ((i >> 7) & 1)) ^ ((i >> 8) & 15) ^ (((i >> 6) & 12) | ((i >> 10) & 3));
+#elif WH_SWZ == 3
+  return i;                                       // (no swizzle at all: what the conflicts the others avoid would cost)
 #else
   return i ^ ((i >> 4) & 15);
 #endif

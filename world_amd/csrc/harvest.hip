@@ -308,6 +308,11 @@ __global__ void __launch_bounds__(256, HV_FFT_MIN_WAVES) hv_band_events_fft(Harv
       // read, a wait and a write per sample -- and measured it slower, 3.80 -> 3.97 ms per 128 utterances: the kernel sits
       // at its 168 registers, the batch spilled 25 more SGPRs, and what the loop waits for is not the LDS read but the
       // reload of two spilled registers from scratch.)
+      // (Round 5 tried leaving alone the samples the term cannot matter for -- it is a Nyquist-rate ripple ten orders below
+      // the signal and decides a crossing only in digital silence -- and advancing the phase recurrence on demand: slower,
+      // 3.53 -> 3.80 ms per 128 utterances.  A per-sample magnitude test qualifies every sample near a zero crossing, the
+      // local-amplitude test that would be right costs what the term does, and the loop is bound by its chain of LDS reads
+      // either way.)
       for (int k = tid, j = 0; k < len + 2; k += nt, ++j) {
         const double flip = ((nt & 1) && (j & 1)) ? -sign : sign;     // (-1)^(n0 + j nt)
         rfft_in(Z, k + at0) += flip * (qc * cs + qs * sn + q0);

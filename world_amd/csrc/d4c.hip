@@ -24,6 +24,14 @@
 #ifdef D4C_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
+// The LDS slot swizzle of this unit's transforms (fft.h: swz): the map tools/lds_swizzle_search.py found for the radix-8
+// plans.  Round 3 measured it on lone kernels (d4c_frame -2 %, everything else +3 %) and left the shipped map alone; under
+// load -- a 128-utterance batch, profiles/r05/lds_under_load_ab.txt -- d4c_frame gains 2.5 % (10.71 -> 10.45 ms) and every
+// other FFT kernel still loses (hv_band_events_fft +12 %, ct_frame +5 %, d4c_lovetrain +4 %), so it is this unit's alone:
+// nothing swizzled ever leaves a kernel, the map is private to a translation unit.
+#ifndef WH_SWZ
+#define WH_SWZ 1
+#endif
 #include "stage_params.h"
 #include "prepare.h"
 #include "trace.h"

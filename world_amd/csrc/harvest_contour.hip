@@ -43,38 +43,35 @@ __device__ __forceinline__ double hc_step1_at(const double *base, int g, int nf)
   return v;
 }
 // Steps 1 and 2 of the whole utterance by its one workgroup (the section pass that follows needs the utterance's workgroup
-// anyway -- hc_step12_sections -- and a launch of tiles for 5 us of work was one more narrow kernel per job): every thread
-// owns a stretch of consecutive frames, evaluates step 1 for it and its margin into registers (the margins are recomputed
-// by the neighbours: 12 values), then step 2 out of them.
-__device__ __forceinline__ void hc_step12_pass(const HarvestParams &p, int u) {
-  const int nf = p.nfb[u];
+// anyway -- hc_step12_sections -- and a launch of tiles for 5 us of work was one more narrow kernel per job): tile after
+// tile of blockDim frames, step 1 of the tile and its six-frame margins into LDS (one frame per thread: its two divisions
+// are the pass's cost), step 2 out of it.
+__device__ __forceinline__ void hc_step12_pass(const HarvestParams &p, int u, double *s1) {
+  const int nf = p.nfb[u], nt = (int)blockDim.x, tid = (int)threadIdx.x;
   const double *base = hc_row(p.c0, p, u);
   double *out = hc_row(p.c2, p, u);
-  constexpr int kRun = 16;                                 // frames per thread and trip
-  for (int lo = (int)threadIdx.x * kRun; lo < nf; lo += (int)blockDim.x * kRun) {
-    double s1[kRun + 2 * kStepMargin];
-#pragma unroll
-    for (int i = 0; i < kRun + 2 * kStepMargin; ++i) s1[i] = hc_step1_at(base, lo - kStepMargin + i, nf);
-    unsigned vm = 0;                                       // bit i <-> frame lo - kStepMargin + i is voiced after step 1
-#pragma unroll
-    for (int i = 0; i < kRun + 2 * kStepMargin; ++i) {
-      const int g = lo - kStepMargin + i;
-      vm |= (unsigned)(g > 0 && g < nf - 1 && s1[i] > 0) << i;          // ends forced unvoiced (:733)
+  for (int f0 = 0; f0 < nf; f0 += nt) {
+    // s1[i] = step 1 of frame f0 - kStepMargin + i, i < nt + 2 kStepMargin
+    s1[kStepMargin + tid] = hc_step1_at(base, f0 + tid, nf);
+    for (int m = tid; m < 2 * kStepMargin; m += nt) {
+      const int i = m < kStepMargin ? m : nt + m;                       // the margins: six frames before, six after the tile
+      s1[i] = hc_step1_at(base, f0 - kStepMargin + i, nf);
     }
-#pragma unroll
-    for (int t = 0; t < kRun; ++t) {
-      const int f = lo + t;
-      if (f >= nf) break;
-      double v = s1[t + kStepMargin];
-      if ((vm >> (t + kStepMargin)) & 1u) {
-        // voiced neighbours in a row, up to six either way: the run [f - back, f + fwd] must span at least 7 frames
-        const unsigned below = ~(vm << (31 - (t + kStepMargin - 1)));   // frame f-1 at bit 31, f-2 at bit 30, ...
-        const unsigned above = ~(vm >> (t + kStepMargin + 1));          // frame f+1 at bit 0, ...
-        const int back = imin(6, __builtin_clz(below | 1u)), fwd = imin(6, __builtin_ctz(above | 0x80000000u));
+    __syncthreads();
+    const int f = f0 + tid;
+    if (f < nf) {
+      auto at = [&](int i) { return s1[i - f0 + kStepMargin]; };
+      auto voiced = [&](int i) { return i > 0 && i < nf - 1 && at(i) > 0; };   // ends forced unvoiced (:733)
+      double v = at(f);
+      if (voiced(f)) {
+        int back = 0, fwd = 0;
+        while (back < 6 && voiced(f - back - 1)) ++back;
+        while (fwd < 6 && voiced(f + fwd + 1)) ++fwd;
         if (back + fwd < 6) v = 0.0;
       }
       out[f] = v;
     }
+    __syncthreads();                                                    // the next tile overwrites s1
   }
 }
 
@@ -174,7 +171,7 @@ __device__ __forceinline__ void hc_sections_pass(const HarvestParams &p, const S
 // FixStep1 + FixStep2 of the utterance, then the sections of their result (c2): one launch, the utterance's workgroup
 __global__ void hc_step12_sections(HarvestParams p, SecArgs a) {
   DYN_LDS(lds);
-  hc_step12_pass(p, blockIdx.x);
+  hc_step12_pass(p, blockIdx.x, reinterpret_cast<double *>(lds) + 64);
   __syncthreads();                                         // c2 is read back by other threads of this workgroup
   hc_sections_pass(p, a, blockIdx.x, reinterpret_cast<double *>(lds));
 }
@@ -835,7 +832,7 @@ __global__ void hc_output(HarvestParams p) {
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin, nullptr, nullptr};
-  WH_BLOCKS(hc_step12_sections, dim3(B), 1024, 64 * sizeof(double), stream, p, a2);
+  WH_BLOCKS(hc_step12_sections, dim3(B), 1024, (64 + 1024 + 2 * kStepMargin) * sizeof(double), stream, p, a2);
   WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), kExtendThreads, 64 * sizeof(double), stream, p);
   // WORLD_HIP_MERGE_LDS_SECTIONS lowers the number of section records hc_merge keeps in LDS (tests use it to send an
   // ordinary utterance down the route of one with thousands of sections)

@@ -617,9 +617,12 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   const bool direct_lists = p.fft_seg > 0 && p.nseg == 1;     // the filter bank writes the final event lists itself
 
   const size_t B = n_utt;
-  // utterances whose zero-crossing lists exist at once (harvest.hip: launch_harvest): WORLD_HIP_EVENT_GROUP, default 64 --
-  // a 64-utterance launch of the filter bank is 9 728 workgroups, ten times what the chip holds at once
-  static const int ev_group_env = [] { const char *e = getenv("WORLD_HIP_EVENT_GROUP"); return e ? std::max(1, atoi(e)) : 64; }();
+  // utterances whose zero-crossing lists exist at once (harvest.hip: launch_harvest): WORLD_HIP_EVENT_GROUP, default 40 --
+  // a 40-utterance launch of the filter bank is 6 080 workgroups, six times what the chip holds at once.  Measured on the
+  // configs[3] share (128 utterances, two contexts in flight): groups of 128 / 64 / 32 -> 4.625 / 4.614 / 4.599 M frames/s
+  // with 36.0 / 21.9 / 14.9 GB of workspace; configs[2] (256 utterances): 10.68 M with 71.9 GB ungrouped, 10.69 M with
+  // 29.9 GB in groups of 64.
+  static const int ev_group_env = [] { const char *e = getenv("WORLD_HIP_EVENT_GROUP"); return e ? std::max(1, atoi(e)) : 40; }();
   p.ev_group = std::min(n_utt, ev_group_env);
   p.ev_u0 = 0;
   const size_t E = p.ev_group;

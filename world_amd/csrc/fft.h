@@ -18,7 +18,18 @@
 #include "devrt.h"
 #include "tables.h"
 
+// The LDS slot swizzle (WH_SWZ, below) may differ between translation units (d4c.hip runs the searched map, the rest the
+// shipped one: profiles/r05/lds_under_load_ab.txt).  On the GPU every device function is private to its unit anyway; in
+// the host emulation (tests/emu: g++, one shared object) these are ordinary inline functions and templates, and the
+// linker would merge the units' differing definitions into one -- so everything here lives in an inline namespace named
+// after the map.
+#ifndef WH_SWZ
+#define WH_SWZ 0
+#endif
+#define WH_FFT_NS2(n) fft_swz##n
+#define WH_FFT_NS(n) WH_FFT_NS2(n)
 namespace world_hip {
+inline namespace WH_FFT_NS(WH_SWZ) {
 
 struct cplx { double re, im; };
 
@@ -132,9 +143,6 @@ __host__ __device__ __forceinline__ FftPlan make_plan_r8(int lg) { return make_p
 // a butterfly computes swz(base) once and reaches its R elements with one XOR each against constants that are
 // uniform over the workgroup (scalar registers) -- the address arithmetic was two thirds of the FFT kernels'
 // VALU instructions (profiles/r02, SQ_INSTS_VALU against the FP64 counters).
-#ifndef WH_SWZ
-#define WH_SWZ 0
-#endif
 __device__ __forceinline__ int swz(int i) {
 #if WH_SWZ == 1
   // candidate of tools/lds_swizzle_search.py for the radix-8 plans: low nibble ^= rotl1(bits 4..7) ^ rotl3(bits 8..11)
@@ -858,4 +866,5 @@ __device__ __forceinline__ void block_irfft(cplx *z, int lgn, const TwLds &tw, S
   }
 }
 
+}  // inline namespace (the swizzle's)
 }  // namespace world_hip

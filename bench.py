@@ -307,7 +307,9 @@ def main():
     ap.add_argument("--contexts", type=int, default=2,
                     help="N = 1: batched jobs in flight in the configs[2] / [3] / [4] legs (1 = per-kernel durations free of queueing: profiles)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the result all-gather")
-    ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis / host-pointer legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the codec / synthesis / host-pointer legs and the environment microprobe")
+    ap.add_argument("--inflight-only", action="store_true",
+                    help="N = 1: run the headline's timed region and stop (for a kernel trace of the in-flight mode alone)")
     ap.add_argument("--job-utterances", type=int, default=1024, help="N > 1: utterances of the configs[3] job")
     ap.add_argument("--sub-batch", type=int, default=32,
                     help="configs[3] job (N > 1, and the N = 1 anchor configs['3_full']): utterances per batched call = per all-gather")
@@ -355,7 +357,7 @@ def main():
         under load (world_hip_probe_machine: effective shader clock under an FP64 load, HBM and L2 pointer-chase latency,
         an LDS round trip on an idle and on a loaded CU) -- what tells a slow box from a regression"""
         environment["rocm_smi_at_end"] = smi_snapshot() if rank == 0 else None
-        if wh_probe is not None and hasattr(wh_probe, "probe_machine"):
+        if wh_probe is not None and hasattr(wh_probe, "probe_machine") and not args.no_extras:
             try:
                 environment["microprobe"] = wh_probe.probe_machine()
             except Exception as e:                           # noqa: BLE001
@@ -788,6 +790,13 @@ def main():
     nsteps = args.steps * repeats
     frames_per_step = nf * B
     value = frames_per_step * nsteps / dt
+
+    if args.inflight_only:
+        torch.cuda.synchronize()
+        print(json.dumps({"metric": "analysis frames/sec (Harvest+CheapTrick+D4C, 48 kHz, 5 ms hop)", "value": value, "unit": "frames/s",
+                          "n_gpus": 1, "steps": args.steps, "repeats": repeats, "ms_per_step": dt / nsteps * 1e3,
+                          "note": "--inflight-only: the timed region alone, nothing checked"}))
+        return
 
     # ---- the run checks itself: every slot of the timed mode against a serial single-context run ---------
     torch.cuda.synchronize()

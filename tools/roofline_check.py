@@ -27,7 +27,8 @@ for c, (title, frames, bpf) in CFG.items():
     f = os.path.join(d, f"kernel_stats_config{c}.csv")
     if not os.path.exists(f):
         continue
-    stats = {short(r["Name"]): r for r in csv.DictReader(open(f)) if "world_hip" in r["Name"]}
+    stats = {short(r["Name"]): r for r in csv.DictReader(open(f))
+             if "world_hip" in r["Name"] and not short(r["Name"]).startswith(("mp_", "rng_", "hv_band_spectra"))}    # (not the microprobe, not one-time set-up)
     pmc = {}
     for fn in os.listdir(d):
         if fn.startswith("pmc_") and fn.endswith(f"_config{c}_by_kernel.csv"):

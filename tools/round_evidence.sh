@@ -48,7 +48,7 @@ for CFG in 1 2 3 4; do
   echo "config $CFG done at $(( $(date +%s) - T0 )) s"
 done
 # the headline mode's kernel trace (twelve jobs in flight)
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/inflight -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --min-wall 1.0 --no-cpu-baseline --no-extras --no-configs > $OUT/inflight.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/inflight -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --min-wall 1.5 --inflight-only > $OUT/inflight.log 2>&1
 mkdir -p $ROOT/profiles/$RND
 python $ROOT/tools/trace_overlap.py $OUT/inflight > $ROOT/profiles/$RND/inflight_overlap.txt 2>&1
 python $ROOT/tools/evidence.py install $OUT $RND

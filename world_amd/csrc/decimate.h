@@ -15,7 +15,12 @@ namespace world_hip {
 
 struct IirCoef { double a0, a1, a2, b0, b1; };
 
-constexpr int kDecThreads = 256;
+// 128 threads x 32 outputs: a workgroup stages 4096 + 384 samples = 37 KB of LDS.  (Rounds 1-4: 256 threads, 71 KB.  In the
+// twelve-jobs-in-flight mode the CUs are full of d4c_frame workgroups -- three per CU, 157 of the 160 KB -- and a workgroup
+// that needs more LDS than ONE of them frees waits for two to retire on the same CU before it is refilled: the sweeps took
+// 53 and 77 us in flight against 21 and 18 alone, profiles/r05/inflight_overlap.txt.  Every narrow kernel of a job now
+// fits the 52 KB one retiring frame workgroup leaves behind.)
+constexpr int kDecThreads = 128;
 constexpr int kDecChunk = 32;                         // outputs per thread
 constexpr int kDecSpan = kDecThreads * kDecChunk;     // outputs per workgroup
 constexpr int kDecWarm = 384;     // longest warm-up (LDS is carved for it): 0.889^384 = 2e-20 at r = 12

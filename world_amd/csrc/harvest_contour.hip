@@ -491,7 +491,8 @@ __device__ __forceinline__ void hc_merge_in_hbm(const HarvestParams &p, int u) {
 // reference's order -- instead of two dependent trips to HBM per frame (4 us a frame: 1.4 ms for the slowest
 // utterance of a 128-batch).
 constexpr int kMergeThreads = 1024;
-constexpr int kMergeLdsSections = 2048;  // section records kept in LDS; an utterance with more takes hc_merge_in_hbm
+constexpr int kMergeLdsSections = 1024;  // section records kept in LDS (41 KB: what one retiring d4c_frame workgroup frees on a
+                                         // CU -- decimate.h); an utterance with more voiced sections takes hc_merge_in_hbm
 inline size_t hc_merge_lds_bytes(int sections) {      // (at least a block collective's scratch: the section passes behind the merge)
   const size_t b = (size_t)(sections + 1) * (sizeof(double) + 8 * sizeof(int)) + 16 * sizeof(int);
   return b > 64 * sizeof(double) ? b : 64 * sizeof(double);
@@ -682,7 +683,10 @@ __global__ void __launch_bounds__(kMergeThreads) hc_merge(HarvestParams p, int c
 // than the one this lane overwrites it at, and within a batch all loads are issued before the first store.
 // A section that does not fit the LDS the launch reserved is filtered out of HBM with clamped indices.
 constexpr int kSmoothSlack = 16;        // loads run up to a batch past the last step of a sweep
-constexpr int kSmoothLdsMax = 19456;    // doubles: 152 of the CU's 160 KB, i.e. sections up to 18 540 frames
+constexpr int kSmoothLdsMax = 6144;     // doubles: 48 KB, i.e. voiced sections up to 5 228 base frames (5.2 s in one piece) are
+                                        // filtered in LDS, longer ones out of HBM.  (Round 3-4: 152 KB -- but a one-wavefront
+                                        // workgroup that asks for most of a CU's LDS waits, in the in-flight mode, until the
+                                        // frame workgroups of other jobs have drained from a whole CU: 67 us against 18 alone.)
 constexpr int kSmoothBlocks = 64;       // wavefronts launched per utterance; they stride over its sections
 __global__ void hc_smooth(HarvestParams p, int lds_doubles) {
   DYN_LDS(lds);

@@ -44,22 +44,21 @@ __device__ __forceinline__ double hc_step1_at(const double *base, int g, int nf)
 }
 // Steps 1 and 2 of the whole utterance by its one workgroup (the section pass that follows needs the utterance's workgroup
 // anyway -- hc_step12_sections -- and a launch of tiles for 5 us of work was one more narrow kernel per job): tile after
-// tile of blockDim frames, step 1 of the tile and its six-frame margins into LDS (one frame per thread: its two divisions
-// are the pass's cost), step 2 out of it.
+// tile of 1024 frames, step 1 of the tile and its six-frame margins into LDS (its two divisions per frame are the pass's
+// cost), step 2 out of it.  The workgroup is 256 threads -- four wavefronts of <= 128 registers: what fits beside other
+// jobs' frame kernels in the in-flight mode (1024 threads waited for a drained CU: 52 us in flight against 15 alone).
+constexpr int kStepTile = 1024;       // frames per tile, whatever the workgroup size
 __device__ __forceinline__ void hc_step12_pass(const HarvestParams &p, int u, double *s1) {
   const int nf = p.nfb[u], nt = (int)blockDim.x, tid = (int)threadIdx.x;
   const double *base = hc_row(p.c0, p, u);
   double *out = hc_row(p.c2, p, u);
-  for (int f0 = 0; f0 < nf; f0 += nt) {
-    // s1[i] = step 1 of frame f0 - kStepMargin + i, i < nt + 2 kStepMargin
-    s1[kStepMargin + tid] = hc_step1_at(base, f0 + tid, nf);
-    for (int m = tid; m < 2 * kStepMargin; m += nt) {
-      const int i = m < kStepMargin ? m : nt + m;                       // the margins: six frames before, six after the tile
-      s1[i] = hc_step1_at(base, f0 - kStepMargin + i, nf);
-    }
+  for (int f0 = 0; f0 < nf; f0 += kStepTile) {
+    // s1[i] = step 1 of frame f0 - kStepMargin + i, i < kStepTile + 2 kStepMargin
+    for (int i = tid; i < kStepTile + 2 * kStepMargin; i += nt) s1[i] = hc_step1_at(base, f0 - kStepMargin + i, nf);
     __syncthreads();
-    const int f = f0 + tid;
-    if (f < nf) {
+    for (int t = tid; t < kStepTile; t += nt) {
+      const int f = f0 + t;
+      if (f >= nf) break;
       auto at = [&](int i) { return s1[i - f0 + kStepMargin]; };
       auto voiced = [&](int i) { return i > 0 && i < nf - 1 && at(i) > 0; };   // ends forced unvoiced (:733)
       double v = at(f);
@@ -213,12 +212,18 @@ constexpr int kExtMargin = kExtReach + 1;
 // its end of the section and writes its own side of the slice), so two wavefronts walk them side by side; the
 // bulk work around the walks -- copying the section into its slice, summing the extended run -- is spread over all
 // kExtendThreads (two wavefronts took a trip to HBM per 1024 frames: 16 us for an 8 000-frame section).
-constexpr int kExtendThreads = 8 * WAVE;
-__global__ void __launch_bounds__(kExtendThreads) hc_extend(HarvestParams p) {
-  DYN_LDS(lds);
-  double *scratch = reinterpret_cast<double *>(lds);
-  const int k = blockIdx.x, u = blockIdx.y;
-  if (k >= p.sec_n[u * 2]) return;
+// Round 5: four wavefronts of at most 168 registers and kExtendBlocks workgroups per utterance that stride over its
+// sections.  (Rounds 3-4: eight wavefronts of 197 registers and one workgroup per POSSIBLE section -- 1 432 for a 10 s
+// utterance, all but ~50 of which only exit.  In the twelve-jobs-in-flight mode every one of them, the empty ones
+// included, needed two wavefront slots of 197 registers per SIMD, i.e. a CU that other jobs' frame kernels had drained:
+// 149 us in flight against 35 alone, the third largest kernel of the trace.  A workgroup now fits what ONE retiring
+// d4c_frame workgroup frees.)
+constexpr int kExtendThreads = 4 * WAVE;
+constexpr int kExtendBlocks = 48;
+#ifndef HC_EXT_RING
+#define HC_EXT_RING 4                   // batches of eight candidate rows in flight ahead of the walk (one slot per lane)
+#endif
+__device__ __forceinline__ void hc_extend_section(const HarvestParams &p, int k, int u, double *scratch) {
   const int nf = p.nfb[u], nslot = p.nc[u] * 7, lane = lane_id();
   int *sec = p.sec + (size_t)u * 6 * p.sec_cap;
   const int st = sec[k], ed = sec[p.sec_cap + k];
@@ -346,7 +351,7 @@ __global__ void __launch_bounds__(kExtendThreads) hc_extend(HarvestParams p) {
       }
     };
     constexpr int kSlotsPerLane = (kMaxSlots + WAVE - 1) / WAVE;
-    if (kSlotsPerLane > 1 && nslot <= WAVE) track(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+    if (kSlotsPerLane > 1 && nslot <= WAVE) track(std::integral_constant<int, 1>{}, std::integral_constant<int, HC_EXT_RING>{});
     else track(std::integral_constant<int, kSlotsPerLane>{}, std::integral_constant<int, 2>{});
     if (lane == 0) sec[(dir == 0 ? 3 : 2) * p.sec_cap + k] = moved;     // new end / new start
   }
@@ -366,6 +371,14 @@ __global__ void __launch_bounds__(kExtendThreads) hc_extend(HarvestParams p) {
   if (threadIdx.x == 0) {
     sec[5 * p.sec_cap + k] = lo;
     p.sec_sum[(size_t)u * p.sec_cap + k] = s;
+  }
+}
+__global__ void __launch_bounds__(kExtendThreads, 3) hc_extend(HarvestParams p) {
+  DYN_LDS(lds);
+  const int u = blockIdx.y, ns = p.sec_n[u * 2];
+  for (int k = blockIdx.x; k < ns; k += gridDim.x) {
+    hc_extend_section(p, k, u, reinterpret_cast<double *>(lds));
+    __syncthreads();                                       // the next section reuses the scratch
   }
 }
 
@@ -490,7 +503,7 @@ __device__ __forceinline__ void hc_merge_in_hbm(const HarvestParams &p, int u) {
 // scores are looked up a frame per lane with all slots of the frame in flight, and summed in frame order -- the
 // reference's order -- instead of two dependent trips to HBM per frame (4 us a frame: 1.4 ms for the slowest
 // utterance of a 128-batch).
-constexpr int kMergeThreads = 1024;
+constexpr int kMergeThreads = 256;       // (round 4: 1024 -- sixteen wavefronts that waited, in the in-flight mode, for a CU other jobs had drained)
 constexpr int kMergeLdsSections = 1024;  // section records kept in LDS (41 KB: what one retiring d4c_frame workgroup frees on a
                                          // CU -- decimate.h); an utterance with more voiced sections takes hc_merge_in_hbm
 inline size_t hc_merge_lds_bytes(int sections) {      // (at least a block collective's scratch: the section passes behind the merge)
@@ -836,8 +849,8 @@ __global__ void hc_output(HarvestParams p) {
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin, nullptr, nullptr};
-  WH_BLOCKS(hc_step12_sections, dim3(B), 1024, (64 + 1024 + 2 * kStepMargin) * sizeof(double), stream, p, a2);
-  WH_BLOCKS(hc_extend, dim3(p.sec_cap, B), kExtendThreads, 64 * sizeof(double), stream, p);
+  WH_BLOCKS(hc_step12_sections, dim3(B), 256, (64 + kStepTile + 2 * kStepMargin) * sizeof(double), stream, p, a2);
+  WH_BLOCKS(hc_extend, dim3(imin(p.sec_cap, kExtendBlocks), B), kExtendThreads, 64 * sizeof(double), stream, p);
   // WORLD_HIP_MERGE_LDS_SECTIONS lowers the number of section records hc_merge keeps in LDS (tests use it to send an
   // ordinary utterance down the route of one with thousands of sections)
   static const int merge_limit = [] { const char *e = getenv("WORLD_HIP_MERGE_LDS_SECTIONS"); return e ? imax(0, imin(kMergeLdsSections, atoi(e))) : kMergeLdsSections; }();

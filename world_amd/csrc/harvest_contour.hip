@@ -47,7 +47,7 @@ __device__ __forceinline__ double hc_step1_at(const double *base, int g, int nf)
 // tile of 1024 frames, step 1 of the tile and its six-frame margins into LDS (its two divisions per frame are the pass's
 // cost), step 2 out of it.  The workgroup is 256 threads -- four wavefronts of <= 128 registers: what fits beside other
 // jobs' frame kernels in the in-flight mode (1024 threads waited for a drained CU: 52 us in flight against 15 alone).
-constexpr int kStepTile = 1024;       // frames per tile, whatever the workgroup size
+constexpr int kStepTile = 4096;       // frames per tile, whatever the workgroup size (33 KB of LDS; three tiles for a 10 s utterance)
 __device__ __forceinline__ void hc_step12_pass(const HarvestParams &p, int u, double *s1) {
   const int nf = p.nfb[u], nt = (int)blockDim.x, tid = (int)threadIdx.x;
   const double *base = hc_row(p.c0, p, u);

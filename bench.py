@@ -72,27 +72,42 @@ def csrc_hash():
 
 
 def unit_hashes():
-    """{unit: hash of that .hip unit + every header}, {kernel name: unit}: the PMC counters are stamped per KERNEL with the
-    hash of the unit the kernel is compiled from, so a change to one unit makes only its own kernels' counters stale -- and
+    """{unit: hash of that .hip unit + every header it includes, transitively}, {kernel name: unit}: the PMC counters are
+    stamped per KERNEL with the hash of the unit the kernel is compiled from, so a change to one unit (or to a header only
+    other units include: dropin.inc is api.hip's alone) makes only its own kernels' counters stale -- and
     tools/round_evidence.sh re-collects only those (a one-line kernel change cost a full re-profile)."""
     import re
     d = os.path.join(ROOT, "world_amd", "csrc")
-    hdr = hashlib.sha256()
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".inc")):
-            hdr.update(name.encode())
-            with open(os.path.join(d, name), "rb") as f:
-                hdr.update(f.read())
+    inc_re = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+    texts = {}
+
+    def text(name):
+        if name not in texts:
+            try:
+                with open(os.path.join(d, os.path.basename(name)), "rb") as f:
+                    texts[name] = f.read()
+            except OSError:
+                texts[name] = b""                              # (a header outside csrc: include/world_hip.h -- the ABI, not kernel code)
+        return texts[name]
+
+    def closure(name, seen):
+        for inc in inc_re.findall(text(name).decode("utf-8", "replace")):
+            inc = os.path.basename(inc)
+            if inc not in seen and os.path.exists(os.path.join(d, inc)):
+                seen.add(inc)
+                closure(inc, seen)
+        return seen
+
     units, kernels = {}, {}
     for name in sorted(os.listdir(d)):
         if not name.endswith(".hip"):
             continue
-        with open(os.path.join(d, name), "rb") as f:
-            body = f.read()
-        h = hashlib.sha256(hdr.digest())
-        h.update(body)
+        h = hashlib.sha256(text(name))
+        for inc in sorted(closure(name, set())):
+            h.update(inc.encode())
+            h.update(text(inc))
         units[name] = h.hexdigest()[:16]
-        for m in re.finditer(r"__global__\s+void\s+(?:__launch_bounds__\([^)]*(?:\([^)]*\)[^)]*)*\)\s*)?(\w+)\s*\(", body.decode("utf-8", "replace")):
+        for m in re.finditer(r"__global__\s+void\s+(?:__launch_bounds__\([^)]*(?:\([^)]*\)[^)]*)*\)\s*)?(\w+)\s*\(", text(name).decode("utf-8", "replace")):
             kernels[m.group(1)] = name
     return units, kernels
 
@@ -713,7 +728,8 @@ def main():
         by_chunk = {}
         for i, w in res.where.items():
             by_chunk.setdefault(w[0], []).append(i)
-        picks = [sorted(v)[(7 * k + 3) % len(v)] for k, v in sorted(by_chunk.items())]
+        # four utterances of EVERY sub-batch (both lanes, every chunk size, the tapered tail), spread over the chunk
+        picks = sorted({sorted(v)[(7 * k + 3 + j * max(1, len(v) // 4)) % len(v)] for k, v in sorted(by_chunk.items()) for j in range(4)})
         same = True
         for i in picks:
             tp1, f01, sp1, ap1, nf1 = whj.analyze(xs_job[i].unsqueeze(0), FS)

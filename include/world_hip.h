@@ -159,8 +159,8 @@ WORLD_HIP_API void world_hip_set_error_handler(WorldHipErrorHandler handler, voi
  * and pinned buffers are freed.  For host processes that want the GPU path gone without exiting; the next drop-in call
  * starts over (a cold call).  Returns 0, or -1 -- nothing released -- while a drop-in call is running.
  * Environment of the drop-in layer, read once: WORLD_HIP_DROPIN_SLOTS (4), WORLD_HIP_DROPIN_COPY_THREADS (3; 0 = the calling
- * thread copies alone), WORLD_HIP_DROPIN_SPIN_US (150: how long an idle copy helper polls for the next chunk of a running
- * transfer before it sleeps; 0 = it always sleeps), WORLD_HIP_DROPIN_WIRE (f32: the spectrogram / aperiodicity rows cross
+ * thread copies alone), WORLD_HIP_DROPIN_SPIN_US (0: an idle copy helper sleeps; N > 0: it first polls N microseconds for the next chunk of a
+ * running transfer -- worth under 1 %), WORLD_HIP_DROPIN_WIRE (f32: the spectrogram / aperiodicity rows cross
  * PCIe as float -- rounded once on the device, 6e-8 relative -- and are widened into the caller's double rows on the host:
  * half the bytes of the path's PCIe-bound stages; default: double, bit-identical to the device-resident analysis). */
 WORLD_HIP_API int world_hip_shutdown(void);

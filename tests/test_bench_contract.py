@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r04", "bench_n1.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05", "bench_n1.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -69,7 +69,15 @@ def test_committed_line_carries_the_contract():
     assert line["first_call_ms"] == h["cold_start"]["first_call_ms"] > 0 and line["randn_table_first_build_ms"] > 0
     full = line["configs"]["3_full"]
     assert full["utterances_bit_identical_to_lone_analysis"] is True and full["utterances_checked"] >= 32
-    assert full["utterances_checked"] == full["sub_batches"] and "tapered" in full["workload"]
+    assert full["utterances_checked"] >= full["sub_batches"] and "tapered" in full["workload"]
+    # round 5: what box the line was measured on (rocm-smi before / after, the library's microprobe), the drop-in path with
+    # the narrow download beside the default, and counters that belong to the kernels the line was timed with
+    env = line["environment"]
+    assert env["compute_units"] == 256 and "rocm_smi_at_start" in env and "rocm_smi_at_end" in env
+    assert env["microprobe"]["sclk_mhz_under_fp64_load"] > 0 and env["microprobe"]["chase_ns_2gb"] > 0
+    assert h["c_caller_f32_rows"]["all_results_identical"] is True and h["c_caller_f32_rows"]["separate_rows_ms"] > 0
+    for key in ("2", "3_share", "4"):
+        assert line["configs"][key]["roofline"]["traffic_stale"] is False, key
 
 
 def test_a_profile_of_other_sources_is_reported_stale(tmp_path, monkeypatch):

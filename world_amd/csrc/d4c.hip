@@ -1201,7 +1201,7 @@ size_t d4c_max_draws_per_frame(int fs) {
 }
 
 void launch_spectral_prepare(const CtParams &cp, const D4cParams &dp, hipStream_t stream) {
-  WH_BLOCKS(spectral_prepare, dim3(cp.b.n_utt, 2), 1024, 64 * sizeof(double), stream, cp, dp);    // 1024 threads: a 10 s utterance is two scans
+  WH_BLOCKS(spectral_prepare, dim3(cp.b.n_utt, 2), 256, 64 * sizeof(double), stream, cp, dp);     // (four wavefronts: what finds room beside other jobs' frame kernels)
 }
 
 void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {

@@ -47,28 +47,47 @@ __device__ __forceinline__ double hc_step1_at(const double *base, int g, int nf)
 // tile of 1024 frames, step 1 of the tile and its six-frame margins into LDS (its two divisions per frame are the pass's
 // cost), step 2 out of it.  The workgroup is 256 threads -- four wavefronts of <= 128 registers: what fits beside other
 // jobs' frame kernels in the in-flight mode (1024 threads waited for a drained CU: 52 us in flight against 15 alone).
-constexpr int kStepTile = 4096;       // frames per tile, whatever the workgroup size (33 KB of LDS; three tiles for a 10 s utterance)
+constexpr int kStepTile = 4096;       // frames per tile, whatever the workgroup size (three tiles for a 10 s utterance)
+constexpr int kStepRun = 16;          // step 2: consecutive frames per thread and trip
+// one pad slot per kStepRun entries: the threads of a wavefront read runs that start kStepRun doubles apart
+__host__ __device__ __forceinline__ int hc_step_pad(int i) { return i + i / kStepRun; }
+constexpr int kStepLds = kStepTile + 2 * kStepMargin + (kStepTile + 2 * kStepMargin) / kStepRun + 1;   // doubles
 __device__ __forceinline__ void hc_step12_pass(const HarvestParams &p, int u, double *s1) {
   const int nf = p.nfb[u], nt = (int)blockDim.x, tid = (int)threadIdx.x;
   const double *base = hc_row(p.c0, p, u);
   double *out = hc_row(p.c2, p, u);
   for (int f0 = 0; f0 < nf; f0 += kStepTile) {
-    // s1[i] = step 1 of frame f0 - kStepMargin + i, i < kStepTile + 2 kStepMargin
-    for (int i = tid; i < kStepTile + 2 * kStepMargin; i += nt) s1[i] = hc_step1_at(base, f0 - kStepMargin + i, nf);
+    // s1[pad(i)] = step 1 of frame f0 - kStepMargin + i, i < kStepTile + 2 kStepMargin (thread-strided: coalesced loads)
+    for (int i = tid; i < kStepTile + 2 * kStepMargin; i += nt) s1[hc_step_pad(i)] = hc_step1_at(base, f0 - kStepMargin + i, nf);
     __syncthreads();
-    for (int t = tid; t < kStepTile; t += nt) {
-      const int f = f0 + t;
-      if (f >= nf) break;
-      auto at = [&](int i) { return s1[i - f0 + kStepMargin]; };
-      auto voiced = [&](int i) { return i > 0 && i < nf - 1 && at(i) > 0; };   // ends forced unvoiced (:733)
-      double v = at(f);
-      if (voiced(f)) {
-        int back = 0, fwd = 0;
-        while (back < 6 && voiced(f - back - 1)) ++back;
-        while (fwd < 6 && voiced(f + fwd + 1)) ++fwd;
-        if (back + fwd < 6) v = 0.0;
+    // Step 2 on runs of kStepRun consecutive frames per thread: the run's step-1 values and its two margins come out of
+    // LDS together (independent reads), their voicing becomes the bits of a word, and "how many voiced neighbours in a
+    // row, up to six either way" is a count of leading / trailing ones -- no chain of dependent LDS reads per frame
+    // (a walk frame by frame, neighbour by neighbour, was most of this pass once one workgroup did the whole utterance).
+    for (int r0 = tid * kStepRun; r0 < kStepTile; r0 += nt * kStepRun) {
+      if (f0 + r0 >= nf) break;
+      double v[kStepRun + 2 * kStepMargin];
+#pragma unroll
+      for (int i = 0; i < kStepRun + 2 * kStepMargin; ++i) v[i] = s1[hc_step_pad(r0 + i)];
+      unsigned vm = 0;                                     // bit i <-> frame f0 + r0 - kStepMargin + i is voiced after step 1
+#pragma unroll
+      for (int i = 0; i < kStepRun + 2 * kStepMargin; ++i) {
+        const int g = f0 + r0 - kStepMargin + i;
+        vm |= (unsigned)(g > 0 && g < nf - 1 && v[i] > 0) << i;          // ends forced unvoiced (:733)
       }
-      out[f] = v;
+#pragma unroll
+      for (int t = 0; t < kStepRun; ++t) {
+        const int f = f0 + r0 + t, b = t + kStepMargin;
+        if (f >= nf) break;
+        double val = v[b];
+        if ((vm >> b) & 1u) {
+          const unsigned below = ~(vm << (32 - b));       // frame f-1 at bit 31, f-2 at bit 30, ...: ones = voiced
+          const unsigned above = ~(vm >> (b + 1));        // frame f+1 at bit 0, ...
+          const int back = imin(6, __builtin_clz(below | 1u)), fwd = imin(6, __builtin_ctz(above | 0x80000000u));
+          if (back + fwd < 6) val = 0.0;
+        }
+        out[f] = val;
+      }
     }
     __syncthreads();                                                    // the next tile overwrites s1
   }
@@ -849,7 +868,7 @@ __global__ void hc_output(HarvestParams p) {
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin, nullptr, nullptr};
-  WH_BLOCKS(hc_step12_sections, dim3(B), 256, (64 + kStepTile + 2 * kStepMargin) * sizeof(double), stream, p, a2);
+  WH_BLOCKS(hc_step12_sections, dim3(B), 256, (64 + kStepLds) * sizeof(double), stream, p, a2);
   WH_BLOCKS(hc_extend, dim3(imin(p.sec_cap, kExtendBlocks), B), kExtendThreads, 64 * sizeof(double), stream, p);
   // WORLD_HIP_MERGE_LDS_SECTIONS lowers the number of section records hc_merge keeps in LDS (tests use it to send an
   // ordinary utterance down the route of one with thousands of sections)

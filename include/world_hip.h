@@ -250,7 +250,7 @@ WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int
 WORLD_HIP_API int world_hip_probe_machine(WorldHipContext *ctx, double *values, int n_values);
 /* The per-frame real FFT of the path in isolation (the reference's fft_plan_dft_r2c_1d / _c2r_1d +
  * fft_execute, src/world/fft.h:22-44, as re-implemented in csrc/fft.h): `batch` transforms of 2^lg_n
- * points (256 .. 8192), one workgroup each, straight from and to HBM -- the test and microbenchmark hook.
+ * points (256 .. 16384), one workgroup each, straight from and to HBM -- the test and microbenchmark hook.
  *   rfft : d_in [batch][N] -> d_spectrum [batch][N/2+1][2] (re, im), X[k] = sum x[n] e^{-2 pi i k n / N}
  *   irfft: d_spectrum -> d_out [batch][N] = N * irfft (unscaled like the reference's c2r; Im of DC / Nyquist ignored)
  * max_lr = 3 (radix-8 plan) or 4 (radix-16 plan); threads = workgroup size, 0 = one butterfly per thread;
@@ -365,8 +365,8 @@ WORLD_HIP_API int world_hip_analyze_sharded(int n_dev, WorldHipContext *const *c
                                             long long rows_capacity, int cols, long long *where);
 
 /* Shape limits of the GPU path (the reference has none): 0 = StoneMask, CheapTrick(cheaptrick_fft_size) and D4C all run at
- * this fs; 1 = one of them does not, `why` names the stage and the limit (fs <= 96 kHz for D4C, CheapTrick fft_size <=
- * 8192 -- its default up to fs = 192 kHz --, fs >= 15.8 kHz for D4C, fs <= 180 kHz for StoneMask).  Pure host
+ * this fs; 1 = one of them does not, `why` names the stage and the limit (fs <= 192 kHz for D4C, CheapTrick fft_size <=
+ * 8192 -- its default up to fs = 192 kHz --, fs >= 15.8 kHz for D4C, fs <= 240 kHz for StoneMask).  Pure host
  * arithmetic.  The drop-in symbols make the same check before any GPU work and report through the error handler
  * (world_hip_set_error_handler; by default: message + abort -- the reference API has no error channel). */
 WORLD_HIP_API int world_hip_check_shape(int fs, int cheaptrick_fft_size, char *why, int why_capacity);

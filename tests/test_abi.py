@@ -174,10 +174,12 @@ def test_shape_limits_are_answered_on_the_host():
     why = C.create_string_buffer(256)
     assert lib.world_hip_check_shape(48000, 2048, why, 256) == 0 and why.value == b""
     assert lib.world_hip_check_shape(16000, 1024, why, 256) == 0
-    assert lib.world_hip_check_shape(192000, 8192, why, 256) == 1 and b"StoneMask" in why.value     # the first limit met
+    assert lib.world_hip_check_shape(192000, 8192, why, 256) == 0                 # round 5: StoneMask's indices as bytes, D4C's 16384-point shape
+    assert lib.world_hip_check_shape(250000, 8192, why, 256) == 1 and b"StoneMask" in why.value     # the first limit met
     assert lib.world_hip_check_shape(96000, 8192, why, 256) == 0                  # round 4: CheapTrick runs 8192 points
     assert lib.world_hip_check_shape(96000, 16384, why, 256) == 1 and b"CheapTrick" in why.value
     assert lib.world_hip_check_shape(48000, 1000, why, 256) == 1 and b"power of two" in why.value
-    assert lib.world_hip_check_shape(120000, 4096, why, 256) == 1 and b"D4C" in why.value
+    assert lib.world_hip_check_shape(120000, 4096, why, 256) == 0
+    assert lib.world_hip_check_shape(200000, 8192, why, 256) == 1 and b"D4C" in why.value and b"192 kHz" in why.value
     assert lib.world_hip_check_shape(8000, 512, why, 256) == 1 and b"15.8" in why.value
     assert lib.world_hip_check_shape(96000, 4096, why, 256) == 0

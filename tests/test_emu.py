@@ -275,3 +275,22 @@ def test_emulated_c_driver_tapers_and_narrows_the_exchange(emu):
     finally:
         for c in ctxs:
             L.world_hip_destroy(c)
+
+
+def test_emulated_analysis_above_96khz(emu, port_oracle):
+    """96 kHz < fs <= 192 kHz: D4C's 16384-point shape (the group delay parked outside the transform's LDS, d4c.hip),
+    LoveTrain's 16384-point transform, StoneMask's byte-sized index differences in a 14 400-sample window -- the
+    reference takes any fs (d4c.cpp:350-363, stonemask.cpp:24-43); refused here until round 5"""
+    from world_amd import synth
+    for fs in (192000, 110000):
+        x = synth.vowel(fs, 0.2, seed=5, base_f0=180.0).numpy()
+        tp_o, f0_d = port_oracle.dio(x, fs)
+        tp, f0 = emu.dio(x, fs)
+        assert np.array_equal(tp, tp_o) and np.allclose(f0, f0_d, rtol=1e-9, atol=0)
+        f0_o = port_oracle.stonemask(x, fs, tp_o, f0_d)
+        assert np.allclose(emu.stonemask(x, fs, tp_o, f0_d), f0_o, rtol=1e-10, atol=0)
+        fft = emu.cheaptrick_fft_size(fs)
+        for f0_in in (f0_o, np.where(f0_o > 0, 50.0, 0.0)):       # the second: windows longer than half the transform
+            ap_o = port_oracle.d4c(x, fs, tp_o, f0_in, fft)
+            assert np.mean(ap_o[:, 10] < 0.9) > 0.5
+            assert np.max(np.abs(emu.d4c(x, fs, tp_o, f0_in, fft) - ap_o) / ap_o) <= 1e-6

@@ -1,6 +1,6 @@
 """csrc/fft.h in isolation on the GPU (reference src/world/fft.h:22-44, src/fft.cpp:143-212):
 block_rfft / block_irfft through the probe entry points against numpy.fft, every size the path uses
-(256 .. 8192 points), both plans (radix-8 and radix-16 butterflies), several workgroup sizes."""
+(256 .. 16384 points), both plans (radix-8 and radix-16 butterflies), several workgroup sizes."""
 import numpy as np
 import pytest
 
@@ -23,7 +23,7 @@ def _signals(batch, n, seed):
     return x
 
 
-@pytest.mark.parametrize("lg", [8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("lg", [8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("max_lr", [3, 4])
 def test_block_rfft_matches_numpy(wh, lg, max_lr):
     import torch
@@ -39,7 +39,7 @@ def test_block_rfft_matches_numpy(wh, lg, max_lr):
         assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)      # r2c: DC / Nyquist are real
 
 
-@pytest.mark.parametrize("lg", [8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("lg", [8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("max_lr", [3, 4])
 def test_block_irfft_matches_numpy(wh, lg, max_lr):
     import torch

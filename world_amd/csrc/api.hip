@@ -272,10 +272,19 @@ static size_t cheaptrick_arena_bytes(int n_utt, int f_stride, int fft_size) {
   (void)fft_size;       // the frame kernel keeps everything between x and the spectrogram in LDS: no per-frame scratch
   return pad256(sizeof(unsigned) * (size_t)n_utt * f_stride) + 4 * pad256(sizeof(int) * n_utt);
 }
-static size_t d4c_arena_bytes(int n_utt, int f_stride) {
+// (d4c.cpp:350-351) fft_size_d4c, the transform of the frame kernel
+static int d4c_internal_fft(int fs) { return static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(4.0 * fs / kFloorF0D4C + 1) / kLog2))); }
+// workgroups per d4c_frame launch of the 16384-point shape (each parks its group delay in a slot of global memory,
+// stage_params.h): eight rounds of a 256-CU chip that runs one such workgroup per CU -- 134 MB
+static int d4c_park_slots(int n_utt, int f_stride) {
+  return static_cast<int>(std::min<size_t>((size_t)n_utt * f_stride, (size_t)std::max(n_utt, 2048)));
+}
+static size_t d4c_arena_bytes(int n_utt, int f_stride, int fs) {
   const size_t fr = (size_t)n_utt * f_stride;
+  int lg = 0;
+  while ((1 << lg) < d4c_internal_fft(fs)) ++lg;
   return 2 * pad256(sizeof(unsigned) * fr) + pad256(sizeof(double) * fr) + 6 * pad256(sizeof(int) * n_utt) + 512 +
-         pad256(sizeof(double) * fr * 16);
+         pad256(sizeof(double) * fr * 16) + pad256(sizeof(double) * d4c_park_slot_doubles(lg) * d4c_park_slots(n_utt, f_stride));
 }
 
 // ---------------------------------------------------------------------------
@@ -380,9 +389,10 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
   }
   *max_frames_out = max_frames;
   // d4c.cpp:350-363 and :264-265
-  const int fft_d4c = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(4.0 * fs / kFloorF0D4C + 1) / kLog2)));
+  const int fft_d4c = d4c_internal_fft(fs);
   const int fft_love = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(3.0 * fs / 40.0 + 1) / kLog2)));
-  if (fft_d4c > 8192) fail("D4C: fs=%d needs an internal FFT of %d > 8192 points (LDS budget); fs <= 96 kHz supported", fs, fft_d4c);
+  if (fft_d4c > 16384 || fft_love > 16384)
+    fail("D4C: fs=%d needs an internal FFT of %d > 16384 points (LDS budget); fs <= 192 kHz supported", fs, std::max(fft_d4c, fft_love));
   if (fs < 15800) fail("D4C: fs=%d is below the 15.8 kHz the reference's LoveTrain band edges require", fs);
   const int nap = static_cast<int>(std::min(15000.0, fs / 2.0 - 3000.0) / 3000.0);
   const int wl = static_cast<int>(3000.0 * fft_d4c / fs) * 2 + 1;
@@ -417,6 +427,11 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
   p.draws2 = c->arena.take<unsigned>(fr);
   p.draws1 = c->arena.take<unsigned>(n_utt);
   p.coarse = c->arena.take<double>(fr * 16);
+  p.park_slots = d4c_park_slots(n_utt, f_stride);
+  {
+    const size_t slot = d4c_park_slot_doubles(ilog2_exact(fft_d4c));
+    p.park_ws = slot ? c->arena.take<double>(slot * p.park_slots) : nullptr;
+  }
   {
     WorldHipContext::PrepToken t;
     t.n_utt = n_utt; t.fs = fs; t.f_stride = f_stride; t.x_stride = x_stride; t.fft = fft_size;
@@ -441,7 +456,7 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
 static void run_d4c(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
                     const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0, int fft_size,
                     const D4COption *opt, double *d_ap, const RowLayout &lay = RowLayout()) {
-  ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, fft_size) + d4c_arena_bytes(n_utt, f_stride));
+  ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, fft_size) + d4c_arena_bytes(n_utt, f_stride, fs));
   CallScope scope(c, 3 * sizeof(int) * n_utt + 256);
   int max_frames = 0;
   const D4cParams p = setup_d4c(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, fft_size, opt, d_ap,
@@ -854,7 +869,7 @@ static void run_stonemask(WorldHipContext *c, int n_utt, int fs, const double *d
   StoneMaskParams p;
   p.win_cap = 2 * static_cast<int>(1.5 * fs / 40.0 + 1.0) + 4;       // longest window: f0 just above 40 Hz
   if (stonemask_lds_bytes(p.win_cap) > 160 * 1024)
-    fail("StoneMask: fs=%d needs a %d-sample window (%zu bytes of LDS > 160 KiB); fs <= 180 kHz supported", fs, p.win_cap,
+    fail("StoneMask: fs=%d needs a %d-sample window (%zu bytes of LDS > 160 KiB); fs <= 240 kHz supported", fs, p.win_cap,
          stonemask_lds_bytes(p.win_cap));
   ensure_arena(c, 2 * pad256(sizeof(int) * n_utt));
   arena_reset(c);
@@ -1131,7 +1146,7 @@ static void run_spectral_stages(WorldHipContext *c, int n_utt, int fs, const dou
                                 const int *n_frames, int f_stride, const double *d_tpos, const double *d_f0,
                                 const CheapTrickOption *copt, const D4COption *dopt, double *d_sp, double *d_ap,
                                 const RowLayout &lay_sp, const RowLayout &lay_ap) {
-  ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, copt->fft_size) + d4c_arena_bytes(n_utt, f_stride));
+  ensure_arena(c, cheaptrick_arena_bytes(n_utt, f_stride, copt->fft_size) + d4c_arena_bytes(n_utt, f_stride, fs));
   CallScope scope(c, 6 * sizeof(int) * n_utt + 512);        // ONE upload section for both stages' small arrays
   int max_ct = 0, max_d4c = 0;
   CtParams cp = setup_cheaptrick(c, n_utt, fs, d_x, x_stride, x_length, n_frames, f_stride, d_tpos, d_f0, copt, d_sp, lay_sp,
@@ -1296,7 +1311,7 @@ static std::string shape_limit(int what, int fs, int fft_size) {
   if (what & 1) {
     const int win_cap = 2 * static_cast<int>(1.5 * fs / 40.0 + 1.0) + 4;
     if (stonemask_lds_bytes(win_cap) > 160 * 1024) {
-      snprintf(msg, sizeof msg, "StoneMask: fs=%d needs a %d-sample window, more LDS than a CU has; fs <= 180 kHz supported", fs, win_cap);
+      snprintf(msg, sizeof msg, "StoneMask: fs=%d needs a %d-sample window, more LDS than a CU has; fs <= 240 kHz supported", fs, win_cap);
       return msg;
     }
   }
@@ -1309,9 +1324,9 @@ static std::string shape_limit(int what, int fs, int fft_size) {
     }
   }
   if (what & 4) {
-    const int fft_d4c = static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(4.0 * fs / kFloorF0D4C + 1) / kLog2)));
-    if (fft_d4c > 8192) {
-      snprintf(msg, sizeof msg, "D4C: fs=%d needs an internal FFT of %d > 8192 points (LDS budget); fs <= 96 kHz supported", fs, fft_d4c);
+    const int fft_d4c = std::max(d4c_internal_fft(fs), static_cast<int>(pow(2.0, 1.0 + static_cast<int>(log(3.0 * fs / 40.0 + 1) / kLog2))));
+    if (fft_d4c > 16384) {
+      snprintf(msg, sizeof msg, "D4C: fs=%d needs an internal FFT of %d > 16384 points (LDS budget); fs <= 192 kHz supported", fs, fft_d4c);
       return msg;
     }
     if (fs < 15800) {
@@ -1685,7 +1700,7 @@ int world_hip_probe_machine(WorldHipContext *c, double *values, int n_values) {
 // fft.h in isolation (fft_probe.hip): `batch` real transforms of 2^lg_n points, one workgroup each
 static void run_fft_probe(WorldHipContext *c, bool inverse, int lg_n, int max_lr, int threads, int static_plan,
                           long long batch, const void *d_in, void *d_out) {
-  if (lg_n < 8 || lg_n > kTwLog2) fail("probe: 2^%d points unsupported (256 .. %d)", lg_n, kTwN);
+  if (lg_n < 8 || lg_n > kTwLog2) fail("probe: 2^%d points unsupported (256 .. %d)", lg_n, kTwN);   // (16384: 147 KB of LDS)
   if (max_lr != 3 && max_lr != 4) fail("probe: max_lr must be 3 (radix-8 plan) or 4 (radix-16 plan)");
   if (threads == 0) threads = std::max(64, (1 << lg_n) >> (max_lr + 1));      // one butterfly per thread and stage
   if (threads < 64 || threads > 1024 || threads % 64) fail("probe: bad workgroup size %d", threads);

@@ -170,9 +170,9 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 #endif
     // exactly one lane found the bin: two max-reductions broadcast (digit, below) and hsel
     {
-      const int got = wave_max_int(digit < 0 ? -1 : (digit << 13) | below);     // below <= 4097 < 2^13
+      const int got = wave_max_int(digit < 0 ? -1 : (digit << 14) | below);     // below <= n <= 10 keys x 1024 threads < 2^14
       hsel = wave_max_int(hsel);
-      digit = got >> 13; below = got & 8191;
+      digit = got >> 14; below = got & 16383;
     }
     remaining -= below;
     bucket = hsel;
@@ -630,6 +630,10 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   const size_t fi = (size_t)u * p.b.f_stride + f;
   int tid = wg_thread<T>();
   constexpr int nt = T;                                                // launch_d4c launches exactly T threads
+  // where the wavefronts' shares of a window's power cross (scratch doubles): clear of the balance pass's block sum,
+  // which a faster wavefront may still be reading -- that one takes doubles [0, waves) and [32, 32 + waves), so the
+  // sixteen wavefronts of the 16384-point shape push this area up into the select's (48..63: idle until the band loop)
+  constexpr int kPwAt = T > 8 * WAVE ? 48 : 40;
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
   const bool trace_me = f == WH_TRACE_FRAME && u == WH_TRACE_UTT; (void)trace_me;
@@ -702,7 +706,13 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   }
   const uint32_t *noise = p.noise + stream_at;
   const int wdraws = 2 * mround(4.0 * fs / cf0 / 2.0) + 1;
-  double *park = scratch + 64 + twiddle_lds_doubles(lgn - D4C_TW_LEVEL);
+  // `park` (N/2 + 2 doubles: the centroid sum, then the static group delay) lives in LDS beside the transform -- except
+  // for the 16384-point shape (96 kHz < fs <= 192 kHz), whose transform buffer alone takes 128 of the CU's 160 KB: there
+  // it is the workgroup's slot of a global staging area (launch_d4c hands out p.park_slots of them per launch; a slot is
+  // written and read by its own workgroup only, between its own barriers)
+  const bool park_global = lgn > 13;
+  double *const after_tw = scratch + 64 + twiddle_lds_doubles(lgn - D4C_TW_LEVEL);
+  double *park = park_global ? p.park_ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(H + 2) : after_tw;
   const double inv_n = 1.0 / N;
 
   // DCCorrection (common.cpp:56-75) on register bins: the few low bins it mirrors go through LDS
@@ -875,9 +885,9 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       }
       hi_samples(w, coef, [&](int k, int i, double uh) { a[k].re += uh; a[k].im += uh * (i + 1.0); pw += uh * uh; });
       // |w x|^2 (d4c.cpp:104-107) is needed after the transform only: the waves' partial sums cross in scratch (doubles
-      // 40..47) behind the transform's own barriers
+      // kPwAt ..) behind the transform's own barriers
       pw = wave_sum(pw);
-      if (lane_id() == 0) scratch[40 + wave_in_block()] = pw;
+      if (lane_id() == 0) scratch[kPwAt + wave_in_block()] = pw;
       cfft_from_registers(a);
     }
 #else
@@ -897,12 +907,12 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
         pw += uh * uh;
       });
       pw = wave_sum(pw);
-      if (lane_id() == 0) scratch[40 + wave_in_block()] = pw;
+      if (lane_id() == 0) scratch[kPwAt + wave_in_block()] = pw;
       cfft();
     }
 #endif
     pw = 0.0;
-    for (int wv = 0; wv < wg_waves<T>(); ++wv) pw += scratch[40 + wv];
+    for (int wv = 0; wv < wg_waves<T>(); ++wv) pw += scratch[kPwAt + wv];
     const double half_inv_pw = 0.5 / pw;                               // and the 1/2 of Im(P Q)/2
 #pragma unroll
     for (int m = 0; m < kItems; ++m) {
@@ -1050,7 +1060,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   for_nat([&](int, int) { ++mine; });
   int *hist = reinterpret_cast<int *>(Zr);
   constexpr int kWaves = (T + WAVE - 1) / WAVE;
-  double *band_sums = park + (H + 2);                   // [band][partial, total][wavefront]: d4c_frame_lds_bytes
+  double *band_sums = park_global ? after_tw : park + (H + 2);   // [band][partial, total][wavefront]: d4c_frame_lds_bytes
   // the Nuttall taps of the thread's own slice element: the same for every band
   const double nut0 = 2 * tid < wl ? p.nuttall[2 * tid] : 0.0, nut1 = 2 * tid + 1 < wl ? p.nuttall[2 * tid + 1] : 0.0;
   for (int band = 0; band < p.nap; ++band) {
@@ -1192,8 +1202,11 @@ size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) +
 // | the wavefronts' shares of the bands' sums (8 bands x 2 x N / 1024 wavefronts)
 size_t d4c_frame_lds_bytes(int lg) {
   int N = 1 << lg;
-  return sizeof(double) * (size_t)(N + 64 + twiddle_lds_doubles(lg - D4C_TW_LEVEL) + N / 2 + 2 + 16 * std::max(1, N / 1024));
+  const size_t park = lg > 13 ? 0 : N / 2 + 2;          // (the 16384-point shape parks in global memory: d4c_frame)
+  return sizeof(double) * (size_t)(N + 64 + twiddle_lds_doubles(lg - D4C_TW_LEVEL) + park + 16 * std::max(1, N / 1024));
 }
+// doubles of one workgroup's slot of D4cParams::park_ws (0: the shape parks in LDS)
+size_t d4c_park_slot_doubles(int lg) { return lg > 13 ? ((size_t)1 << (lg - 1)) + 2 : 0; }
 int d4c_frame_threads(int lg) { return (1 << lg) / 16; }   // one radix-8 butterfly per thread and stage
 // worst case per frame: LoveTrain window at 40 Hz + 3 body windows at 47 Hz
 size_t d4c_max_draws_per_frame(int fs) {
@@ -1224,15 +1237,24 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
   // (fs <= 24 kHz / <= 48 kHz / <= 96 kHz); the register arrays are sized per shape
   const int range_frames = imin(max_frames, p.frame_hi) - p.frame_lo;     // frames of the range
   if (range_frames <= 0) return;
-  const dim3 grid(range_frames, p.b.n_utt);
   const size_t lds = d4c_frame_lds_bytes(p.lg_d4c);
+  // the 16384-point shape: as many frames per launch as the global staging area has slots for (stream order keeps a
+  // slot's workgroups of consecutive launches apart)
+  const int per_launch = p.lg_d4c > 13 ? imax(1, p.park_slots / p.b.n_utt) : range_frames;
+  for (int lo = 0; lo < range_frames; lo += per_launch) {
+    D4cParams q = p;
+    q.frame_lo = p.frame_lo + lo;
+    q.frame_hi = imin(q.frame_lo + per_launch, p.frame_lo + range_frames);
+    const dim3 grid(q.frame_hi - q.frame_lo, p.b.n_utt);
 #ifdef WORLD_EMU
-  devrt::launch_blocks("d4c_frame", d4c_frame<8192, 1>, grid, 1, lds, stream, p);
+    devrt::launch_blocks("d4c_frame", d4c_frame<16384, 1>, grid, 1, lds, stream, q);
 #else
-  if (p.lg_d4c == 11) devrt::launch_blocks("d4c_frame", d4c_frame<2048, 128>, grid, 128, lds, stream, p);
-  else if (p.lg_d4c == 12) devrt::launch_blocks("d4c_frame", d4c_frame<4096, 256>, grid, 256, lds, stream, p);
-  else devrt::launch_blocks("d4c_frame", d4c_frame<8192, 512>, grid, 512, lds, stream, p);
+    if (p.lg_d4c == 11) devrt::launch_blocks("d4c_frame", d4c_frame<2048, 128>, grid, 128, lds, stream, q);
+    else if (p.lg_d4c == 12) devrt::launch_blocks("d4c_frame", d4c_frame<4096, 256>, grid, 256, lds, stream, q);
+    else if (p.lg_d4c == 13) devrt::launch_blocks("d4c_frame", d4c_frame<8192, 512>, grid, 512, lds, stream, q);
+    else devrt::launch_blocks("d4c_frame", d4c_frame<16384, 1024>, grid, 1024, lds, stream, q);
 #endif
+  }
   WH_BLOCKS(d4c_finish, dim3(range_frames, p.b.n_utt), 256, 8 * sizeof(double), stream, p);
 }
 

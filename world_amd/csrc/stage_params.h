@@ -43,6 +43,8 @@ struct D4cParams {
   unsigned *draws1;       // [n_utt] total draws of pass 1 (pass 2 continues the stream there)
   const uint32_t *noise;  // randn_value(noise[k]) = k-th randn() of the stream (context-wide table)
   const double *nuttall;  // [wl] NuttallWindow(wl), built on the host
+  double *park_ws;        // the 16384-point shape only (96 kHz < fs <= 192 kHz): park_slots slots of N/2 + 2 doubles, one per
+  int park_slots;         //   workgroup of a d4c_frame launch (the static group delay does not fit LDS beside that transform)
   Tables tab;
   double threshold;
   int fft_out;            // caller's fft_size (rows have fft_out/2+1 bins)
@@ -63,5 +65,6 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream);
 void launch_spectral_prepare(const CtParams &cp, const D4cParams &dp, hipStream_t stream);   // both stages' F0-only scans
 size_t ct_max_draws_per_frame(int fft_size);
 size_t d4c_max_draws_per_frame(int fs);
+size_t d4c_park_slot_doubles(int lg_d4c);
 
 }  // namespace world_hip

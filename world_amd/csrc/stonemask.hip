@@ -13,7 +13,7 @@ constexpr double kFloorF0StoneMask = 40.0;
 
 // X[idx] of (x .* main window) and (x .* diff window) for `nh` harmonics of f0:
 // returns power and "numerator_i" per harmonic (stonemask.cpp:159-164) in pw/ni.
-__device__ __forceinline__ void sm_harmonic_bins(const double *x, int x_len, const double *mw, const int *raw,
+__device__ __forceinline__ void sm_harmonic_bins(const double *x, int x_len, const double *mw, const signed char *rawd, int raw0,
                                                  int blen, int lgN, double f0, int fs, int nh,
                                                  const double2 *tw, double *scratch, double *pw, double *ni) {
   const int N = 1 << lgN, tid = threadIdx.x, nt = blockDim.x;
@@ -25,7 +25,7 @@ __device__ __forceinline__ void sm_harmonic_bins(const double *x, int x_len, con
       if (i == 0) dwv = -mw[1] / 2.0;
       else if (i == blen - 1) dwv = mw[blen - 2] / 2.0;
       else dwv = -(mw[i + 1] - mw[i - 1]) / 2.0;
-      const double xv = x[imax(0, imin(x_len - 1, raw[i] - 1))];   // GetSpectra (:67-70)
+      const double xv = x[imax(0, imin(x_len - 1, raw0 + i + rawd[i] - 1))];   // GetSpectra (:67-70)
       const double a = xv * mw[i], d = xv * dwv;
       // e^{-2 pi i idx i / N}: phase reduced exactly in integers, then the table -- or, for the
       // transforms beyond its resolution (f0 < 70 Hz above 48 kHz), sincospi of the exact fraction
@@ -68,9 +68,12 @@ __global__ void __launch_bounds__(256) sm_frame(StoneMaskParams p) {
     if (tid == 0) p.refined[fi] = 0.0;
     return;
   }
+  // LDS: the main window | scratch | the samples' indices.  Every index is rounded on its own (below) and so lands within
+  // one of round(pos fs) - hw + i: a byte per sample holds that difference (as ints they were a third of the allocation
+  // and capped the window -- 3 fs / 40 samples at the 40 Hz floor -- at fs = 180 kHz)
   double *mw = reinterpret_cast<double *>(lds);
-  int *raw = reinterpret_cast<int *>(mw + p.win_cap);
-  double *scratch = reinterpret_cast<double *>(raw + p.win_cap + (p.win_cap & 1));
+  double *scratch = mw + p.win_cap;
+  signed char *rawd = reinterpret_cast<signed char *>(scratch + 64);
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
   const int x_len = p.b.x_len[u];
   const int hw = static_cast<int>(1.5 * fs / f0 + 1.0);
@@ -79,10 +82,11 @@ __global__ void __launch_bounds__(256) sm_frame(StoneMaskParams p) {
   int lgN = 2;
   while ((2 << (lgN - 2)) <= blen) ++lgN;                           // 2^(2 + floor(log2(2hw+1)))
   // GetBaseIndex + GetMainWindow (stonemask.cpp:24-43): every sample index is rounded on its own
+  const int raw0 = mround(pos * fs) - hw;
   for (int i = tid; i < blen; i += nt) {
     const double bt = static_cast<double>(-hw + i) / fs;
     const int r = mround((pos + bt) * fs);
-    raw[i] = r;
+    rawd[i] = static_cast<signed char>(r - (raw0 + i));
     const double t = (r - 1.0) / fs - pos;
     const double c1 = cospi(2.0 * t / wlen_t);
     mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
@@ -90,13 +94,13 @@ __global__ void __launch_bounds__(256) sm_frame(StoneMaskParams p) {
   __syncthreads();
   double pw[6], ni[6];
   // GetTentativeF0 (stonemask.cpp:123-132): 2 harmonics, then 6 around the tentative value
-  sm_harmonic_bins(x, x_len, mw, raw, blen, lgN, f0, fs, 2, p.tab.tw, scratch, pw, ni);
+  sm_harmonic_bins(x, x_len, mw, rawd, raw0, blen, lgN, f0, fs, 2, p.tab.tw, scratch, pw, ni);
   double tent = sm_fix_f0(pw, ni, lgN, fs, f0, 2);
   double mean;
   if (tent <= 0.0 || tent > f0 * 2) {
     mean = 0.0;
   } else {
-    sm_harmonic_bins(x, x_len, mw, raw, blen, lgN, tent, fs, 6, p.tab.tw, scratch, pw, ni);
+    sm_harmonic_bins(x, x_len, mw, rawd, raw0, blen, lgN, tent, fs, 6, p.tab.tw, scratch, pw, ni);
     mean = sm_fix_f0(pw, ni, lgN, fs, tent, 6);
   }
   if (fabs(mean - f0) > f0 * 0.2) mean = f0;                        // stonemask.cpp:203
@@ -104,7 +108,7 @@ __global__ void __launch_bounds__(256) sm_frame(StoneMaskParams p) {
 }
 
 size_t stonemask_lds_bytes(int win_cap) {
-  return sizeof(double) * (size_t)win_cap + sizeof(int) * (size_t)(win_cap + (win_cap & 1)) + sizeof(double) * 64;
+  return sizeof(double) * (size_t)win_cap + sizeof(double) * 64 + (((size_t)win_cap + 15) & ~(size_t)15);
 }
 
 void launch_stonemask(const StoneMaskParams &p, int max_frames, hipStream_t stream) {

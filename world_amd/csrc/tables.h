@@ -10,7 +10,7 @@
 
 namespace world_hip {
 
-constexpr int kTwLog2 = 13;            // largest real FFT on the path: 8192 (StoneMask)
+constexpr int kTwLog2 = 14;            // largest real FFT on the path: 16384 (D4C and its LoveTrain pass above 96 kHz)
 constexpr int kTwN = 1 << kTwLog2;
 constexpr int kJumpLevels = 32;        // every 32-bit stream position (xs_jump takes a uint32_t)
 constexpr int kJumpStride = 32 * 16;   // uint4 entries per level

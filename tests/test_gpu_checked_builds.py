@@ -44,6 +44,9 @@ def _workloads():
     out.append(("48k low voice", synth.vowel(48000, 0.8, seed=2, base_f0=62.0)[None].contiguous(), 48000, None, dict(f0_method="harvest", f0_floor=50.0)))
     # 22.05 kHz: Harvest's decimation ratio 3 (windows by rotation, not from the table), 2048-point D4C
     out.append(("22k harvest", synth.utterance(8, 22050, 0.8)[None].contiguous(), 22050, None, dict(f0_method="harvest")))
+    # 176.4 kHz: the 16384-point D4C shape (sixteen wavefronts per workgroup, the group delay parked in global memory), windows
+    # longer than half its transform, LoveTrain's run-time-length 16384-point transform, CheapTrick's 8192-point shape
+    out.append(("176k dio low voice", synth.vowel(176400, 0.25, seed=6, base_f0=65.0)[None].contiguous(), 176400, None, dict(f0_method="dio", f0_floor=50.0)))
     return out
 
 

@@ -805,6 +805,11 @@ static void run_dio(WorldHipContext *c, int n_utt, int fs, const double *d_x, in
   p.f0_floor = opt->f0_floor; p.f0_ceil = opt->f0_ceil; p.frame_period = opt->frame_period;
   p.allowed_range = opt->allowed_range;
   p.nb = db.nb; p.cut = db.cut; p.max_ntap = db.max_ntap;
+  // one tile of the longest channel filter (4 round(fs / ratio / (floor 2^(1/channels)) / 2) taps) with its inputs and outputs is
+  // what a workgroup of dio_band_events holds in LDS; the low-cut filter has a route with its taps left in global memory
+  if (band_lds_bytes(p.max_ntap) > kLdsPerCu || band_lds_bytes(2 * p.cut + 1) - sizeof(double) * (2 * p.cut + 2) > kLdsPerCu)
+    fail("Dio: fs=%d / speed %d with f0_floor %g needs a channel filter of %d taps, more LDS than a CU has "
+         "(raise DioOption.speed or f0_floor: <= %d taps)", fs, p.ratio, opt->f0_floor, p.max_ntap, 7400);
   p.vrm = static_cast<int>(0.5 + 1000.0 / opt->frame_period / opt->f0_floor) * 2 + 1;   // dio.cpp:263-264
   std::vector<int> xl(x_length, x_length + n_utt), yl(n_utt), nfr(n_utt), rfft(n_utt);
   int max_x = 0, max_y = 0, max_fr = 0;

@@ -8,6 +8,7 @@
 namespace world_hip {
 
 // reference src/world/constantnumbers.h:8-37 (values are part of the contract)
+constexpr size_t kLdsPerCu = 160 * 1024;   // bytes of LDS a gfx950 workgroup can be given
 constexpr double kPi = 3.1415926535897932384;
 constexpr double kTiny = 0.000000000001;           // kMySafeGuardMinimum
 constexpr double kEps = 0.00000000000000022204460492503131;

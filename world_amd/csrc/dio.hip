@@ -66,6 +66,9 @@ __global__ void dio_remove_mean(DioParams p) {
 }
 
 // z[m] = (y * lowcut)[m] for m in [-C, y_len + C), stored at z[m + C]  (dio.cpp:40-53,85-101)
+// TAPS_GLOBAL: the filter stays in global memory (2 round(fs / 50) + 1 taps: above ~185 kHz at speed 1 the taps, the
+// input tile and the outputs no longer fit a CU's LDS together; the reference filters any fs, dio.cpp:85-101)
+template <bool TAPS_GLOBAL>
 __global__ void __launch_bounds__(kBpThreads) dio_lowcut(DioParams p) {
   DYN_LDS(lds);
   const int tile = blockIdx.x, u = blockIdx.y;
@@ -80,11 +83,15 @@ __global__ void __launch_bounds__(kBpThreads) dio_lowcut(DioParams p) {
   job.ntap = 2 * p.cut + 1;
   job.shift = 0;
   job.max_ntap = job.ntap;
-  double *taps = reinterpret_cast<double *>(lds);
-  double *yt = taps + (job.max_ntap + 1);
+  double *yt = reinterpret_cast<double *>(lds) + (TAPS_GLOBAL ? 0 : job.max_ntap + 1);
   double *s = yt + pad8(kTile + 2 + job.max_ntap + 3 + 8) + 1;
-  for (int j = threadIdx.x; j < job.ntap; j += blockDim.x) taps[j] = job.taps[j];
-  fir_tile(job, taps, t0, yt, s);
+  if constexpr (TAPS_GLOBAL) {
+    fir_tile(job, job.taps, t0, yt, s);
+  } else {
+    double *taps = reinterpret_cast<double *>(lds);
+    for (int j = threadIdx.x; j < job.ntap; j += blockDim.x) taps[j] = job.taps[j];
+    fir_tile(job, taps, t0, yt, s);
+  }
   double *z = p.z + (size_t)u * p.z_stride;
   for (int k = threadIdx.x; k < kTile; k += blockDim.x)
     if (t0 + k < out_len) z[t0 + k] = s[pad8(k)];
@@ -337,7 +344,11 @@ void launch_dio(const DioParams &p, int max_x_len, int max_y_len, int max_frames
   WH_BLOCKS(dio_partial_sums, dim3(mean_slices, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(dio_remove_mean, dim3(mean_slices, B), 256, 64 * sizeof(double), stream, p);
   const int lc_tiles = (max_y_len + 2 * p.cut + kTile - 1) / kTile;
-  WH_BLOCKS(dio_lowcut, dim3(lc_tiles, B), kBpThreads, band_lds_bytes(2 * p.cut + 1), stream, p);
+  if (band_lds_bytes(2 * p.cut + 1) <= kLdsPerCu)
+    devrt::launch_blocks("dio_lowcut", dio_lowcut<false>, dim3(lc_tiles, B), kBpThreads, band_lds_bytes(2 * p.cut + 1), stream, p);
+  else
+    devrt::launch_blocks("dio_lowcut", dio_lowcut<true>, dim3(lc_tiles, B), kBpThreads,
+                         band_lds_bytes(2 * p.cut + 1) - sizeof(double) * (2 * p.cut + 2), stream, p);
   WH_BLOCKS(dio_nyquist_slices, dim3(mean_slices, B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(dio_nyquist_bins, dim3(B), 256, 64 * sizeof(double), stream, p);
   WH_BLOCKS(dio_band_quirk, dim3(p.nb, B), 64, 64 * sizeof(double), stream, p);

@@ -21,7 +21,11 @@ def run(seed=0, n_cases=40, hip=None, orc=None, verbose=True):
         # 11.025 kHz: Harvest's decimation ratio is 1 there (round(11025 / 8000); 12 kHz already rounds to 2): the longest
         # filters of the bank at the full rate.  D4C needs fs >= 15.8 kHz (the reference reads out of bounds below), so
         # D4C and what consumes its output are skipped at that rate
-        fs = int(rng.choice([11025, 16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000]))
+        # (round 5: 128 / 176.4 / 192 kHz -- D4C's 16384-point shape, StoneMask's longest windows, Harvest at a decimated
+        # rate of 16 kHz; WORLD_FUZZ_RATES=a,b,.. narrows the sweep to given rates)
+        rates = [11025, 16000, 22050, 24000, 32000, 44100, 48000, 64000, 96000, 128000, 176400, 192000]
+        if os.environ.get("WORLD_FUZZ_RATES"): rates = [int(r) for r in os.environ["WORLD_FUZZ_RATES"].split(",")]
+        fs = int(rng.choice(rates))
         dur = float(rng.uniform(0.03, 0.25)) if rng.random() < 0.2 else float(rng.uniform(0.25, 1.2))
         kind = rng.choice(['vowel', 'utt', 'noise', 'mix', 'gappy', 'quiet', 'dc', 'clip', 'impulses'])
         seed_c = int(rng.integers(1, 10**6))
@@ -75,14 +79,15 @@ def run(seed=0, n_cases=40, hip=None, orc=None, verbose=True):
             ap_o, ap = orc.d4c(x, fs, tp_o, f0_o, fft, threshold=thr), hip.d4c(x, fs, tp_o, f0_o, fft, threshold=thr)
             e = max_rel(ap, ap_o)
             if e > 1e-5: msg.append(f'd4c rel={e:.1e}')
-            y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
-            e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
-            if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
-            # parameter modification as in test.cpp:221-240: shifted F0, other output length
             f0m = f0_o * float(rng.choice([0.5, 0.8, 1.5, 2.0])); ylen = int(len(x) * float(rng.uniform(0.5, 1.0))) + 1   # beyond the parameters the reference extrapolates f0 and overruns its buffers
-            y_o, y = orc.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen), hip.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen)
-            e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
-            if e > 1e-7: msg.append(f'synthesis(modified) peak-rel={e:.1e}')
+            if fft <= 4096:                            # Synthesis() keeps one pulse's N-point complex transform in LDS: fft_size <= 4096 (fs <= 96 kHz by default)
+                y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
+                e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
+                if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')
+                # parameter modification as in test.cpp:221-240: shifted F0, other output length
+                y_o, y = orc.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen), hip.synthesis(f0m, sp_o, ap_o, fft, hopt['frame_period'], fs, ylen)
+                e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
+                if e > 1e-7: msg.append(f'synthesis(modified) peak-rel={e:.1e}')
             nd = int(rng.choice([1, 24, 60])); 
             e = float(np.max(np.abs(hip.code_spectral_envelope(sp_o, fs, fft, nd) - orc.code_spectral_envelope(sp_o, fs, fft, nd))))
             if e > 1e-9: msg.append(f'mcep abs={e:.1e}')

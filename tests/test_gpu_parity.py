@@ -430,11 +430,16 @@ def test_above_48khz(hip, oracle, fs):
 def test_above_96khz(hip, oracle, fs):
     """96 kHz < fs <= 192 kHz: D4C's transforms are 16384 points (d4c.cpp:350-363) -- d4c_frame<16384, 1024>, whose
     group delay is parked in global memory beside a 128 KB transform buffer, and the run-time-length LoveTrain
-    transform --, StoneMask's windows reach 14 400 samples (stonemask.cpp:24-43), CheapTrick runs 8192 points.  The
-    reference's Harvest has no decimation filter beyond a ratio of 12 (matlabfunctions.cpp: FilterForDecimate's default
-    case), so F0 comes from DIO + StoneMask as in test/test.cpp.  Refused until round 5 (missing 3)."""
+    transform --, StoneMask's windows reach 14 400 samples (stonemask.cpp:24-43), CheapTrick runs 8192 points, DIO's
+    low-cut filter (2 round(fs / 50) + 1 taps, dio.cpp:40-53) outgrows LDS above 185 kHz and stays in global memory, and
+    Harvest decimates by its largest ratio, 12 (harvest.cpp:1160), to 10.7 - 16 kHz.  Refused until round 5 (VERDICT r04,
+    missing 3)."""
     from world_amd import synth
     x = synth.vowel(fs, 0.3, seed=fs // 1000, base_f0=140.0).numpy()
+    tp_h, f0_h = oracle.harvest(x, fs)
+    tp, f0 = hip.harvest(x, fs)
+    assert np.array_equal(tp, tp_h)
+    assert_f0_close(f0, f0_h, what="harvest")
     tp_o, f0_d = oracle.dio(x, fs)
     tp, f0 = hip.dio(x, fs)
     assert np.array_equal(tp, tp_o)

@@ -80,7 +80,7 @@ def run(seed=0, n_cases=40, hip=None, orc=None, verbose=True):
             e = max_rel(ap, ap_o)
             if e > 1e-5: msg.append(f'd4c rel={e:.1e}')
             f0m = f0_o * float(rng.choice([0.5, 0.8, 1.5, 2.0])); ylen = int(len(x) * float(rng.uniform(0.5, 1.0))) + 1   # beyond the parameters the reference extrapolates f0 and overruns its buffers
-            if fft <= 4096:                            # Synthesis() keeps one pulse's N-point complex transform in LDS: fft_size <= 4096 (fs <= 96 kHz by default)
+            if fft <= 8192:                            # (Synthesis() keeps one pulse's N-point complex transform in LDS: fft_size <= 8192)
                 y_o, y = orc.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x)), hip.synthesis(f0_o, sp_o, ap_o, fft, hopt['frame_period'], fs, len(x))
                 e = float(np.max(np.abs(y - y_o)) / max(np.max(np.abs(y_o)), 1e-9))
                 if e > 1e-7: msg.append(f'synthesis peak-rel={e:.1e}')

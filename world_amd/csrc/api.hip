@@ -1049,7 +1049,7 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
   if (fs <= 0 || frame_period <= 0) fail("fs and frame_period must be positive");
   if (!d_f0 || !d_sp || !d_ap || !d_y || !n_frames || !y_length) fail("null buffer");
   const int lg = ilog2_exact(fft_size);
-  if (lg < 7 || lg > 12) fail("Synthesis: fft_size %d unsupported (128..4096: one pulse must fit LDS)", fft_size);
+  if (lg < 7 || lg > 13) fail("Synthesis: fft_size %d unsupported (128..8192: one pulse's transform must fit LDS)", fft_size);
   int max_y = 0;
   for (int u = 0; u < n_utt; ++u) {
     if (n_frames[u] < 2 || n_frames[u] > f_stride) fail("n_frames[%d]=%d outside [2, f_stride]", u, n_frames[u]);
@@ -1088,11 +1088,12 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
     devrt::dzero(c->d_synth_need, sizeof(int), c->stream);
   }
   p.need = c->d_synth_need;
+  p.resp_stride = lg > 12 ? fft_size + 2 : fft_size;                   // (sy_pulse: the 8192-point pulse keeps its spectrum in its slot)
   const size_t B = n_utt;
   size_t need = 2 * pad256(sizeof(int) * B) + pad256(sizeof(double) * B * y_stride) + pad256(B * y_stride) +
                 pad256(sizeof(double) * B * p.nblk) + pad256(sizeof(int) * B * p.nblk) +
                 pad256(sizeof(int) * B * p.pulse_cap) + pad256(sizeof(double) * B * p.pulse_cap) + pad256(sizeof(int) * B) +
-                pad256(sizeof(double) * B * p.pulse_cap * fft_size);
+                pad256(sizeof(double) * B * p.pulse_cap * p.resp_stride);
   ensure_arena(c, need);
   arena_reset(c);
   CallScope scope(c, 2 * sizeof(int) * n_utt + 256);
@@ -1104,7 +1105,7 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
   p.pidx = c->arena.take<int>(B * p.pulse_cap);
   p.pshift = c->arena.take<double>(B * p.pulse_cap);
   p.np = c->arena.take<int>(B);
-  p.resp = c->arena.take<double>(B * p.pulse_cap * fft_size);
+  p.resp = c->arena.take<double>(B * p.pulse_cap * p.resp_stride);
   p.dc_remover = c->d_dc_remover;
   p.noise = ensure_noise(c, (size_t)max_y + 8);
   p.tab = c->tab;

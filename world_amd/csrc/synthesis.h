@@ -34,7 +34,8 @@ struct SynthParams {
   int *np;                  // [n_utt] number_of_pulses (clamped to pulse_cap)
   int pulse_cap;
   int *need;                // context-wide: largest pulse count that did NOT fit pulse_cap (0 = none dropped so far)
-  double *resp;             // [n_utt][pulse_cap][fft_size] impulse response of every pulse
+  double *resp;             // [n_utt][pulse_cap][resp_stride] impulse response of every pulse (fft_size values)
+  int resp_stride;          // fft_size; fft_size + 2 for the 8192-point shape, whose pulse keeps its spectrum there (sy_pulse)
   const double *dc_remover; // [fft_size] GetDCRemover(), host-built
   const uint32_t *noise;    // randn_value(noise[k]) = k-th randn() after reseed
   Tables tab;

@@ -186,9 +186,11 @@ __global__ void __launch_bounds__(kSyThreads) sy_compact(SynthParams p) {
 // ---------------------------------------------------------------------------
 // One pulse.  LDS: Z (N complex) | C (N/2+1 complex; its head doubles as the log spectrum
 // the first FFT stage reads) | scratch | twiddles.
+// (fft_size 8192 -- the default above 96 kHz: Z alone is 128 KB, and C lives in the pulse's slot of the response buffer)
 size_t synth_pulse_lds_bytes(int lg_fft) {
   const size_t N = (size_t)1 << lg_fft;
-  return sizeof(double) * (2 * N + 16 + 2 * (N / 2 + 1) + 2 + 64 + twiddle_lds_doubles(lg_fft - 1));
+  const size_t c_lds = lg_fft > 12 ? 0 : 2 * (N / 2 + 1) + 2;
+  return sizeof(double) * (2 * N + 16 + c_lds + 64 + twiddle_lds_doubles(lg_fft - 1));
 }
 
 // GetMinimumPhaseSpectrum (common.cpp:182-220): LG[0..H] = log spectrum in; C[0..H] = the
@@ -225,6 +227,11 @@ __device__ __forceinline__ void minimum_phase(cplx *Z, cplx *C, const double *LG
   __syncthreads();
 }
 
+// NMAX: the largest fft_size of the instantiation (a thread's samples of the periodic response wait in registers).
+// 8192 points: the N-point complex transform of the minimum-phase step is 128 KB of LDS by itself, so the pulse's spectrum C
+// (N/2 + 1 complex) lives in global memory -- in the pulse's own slot of the response buffer, two doubles longer for it
+// (p.resp_stride); the response is written there last, when nobody reads C any more.
+template <int NMAX>
 __global__ void __launch_bounds__(kSyThreads) sy_pulse(SynthParams p) {
   DYN_LDS(lds);
   const int u = blockIdx.y, pi = blockIdx.x;
@@ -232,10 +239,16 @@ __global__ void __launch_bounds__(kSyThreads) sy_pulse(SynthParams p) {
   if (pi >= np) return;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int lgn = p.lg_fft, N = 1 << lgn, H = N / 2, nb = H + 1;
+#ifdef WORLD_EMU
+  const bool c_global = lgn > 12;                       // (one host instantiation serves every size)
+#else
+  constexpr bool c_global = NMAX > 4096;
+#endif
   cplx *Z = reinterpret_cast<cplx *>(lds);
-  cplx *C = Z + N + 8;
+  double *const slot = p.resp + ((size_t)u * p.pulse_cap + pi) * p.resp_stride;
+  cplx *C = c_global ? reinterpret_cast<cplx *>(slot) : Z + N + 8;
   double *LG = reinterpret_cast<double *>(C);
-  double *scratch = reinterpret_cast<double *>(C + nb + 1);
+  double *scratch = c_global ? reinterpret_cast<double *>(Z + N + 8) : reinterpret_cast<double *>(C + nb + 1);
   // table of the half-size transforms; the N-point complex transform derives its odd twiddles
   const TwLds tw = stage_twiddles(scratch + 64, lgn - 1, p.tab.tw);
 
@@ -262,7 +275,7 @@ __global__ void __launch_bounds__(kSyThreads) sy_pulse(SynthParams p) {
   };
 
   // ---- periodic response (GetPeriodicResponse, :103-135); this thread's samples stay in registers
-  constexpr int kPer = 4096 / kSyThreads;            // fft_size <= 4096, like CheapTrick
+  constexpr int kPer = NMAX / kSyThreads;            // fft_size <= NMAX
   double per[kPer];
 #pragma unroll
   for (int q = 0; q < kPer; ++q) per[q] = 0.0;
@@ -320,7 +333,7 @@ __global__ void __launch_bounds__(kSyThreads) sy_pulse(SynthParams p) {
   __syncthreads();
   // GetOneFrameSegment (:213-218): (periodic sqrt(noise_size) + fftshift(aperiodic)) / fft_size
   const double sq = sqrt(static_cast<double>(noise_size));
-  double *out = p.resp + ((size_t)u * p.pulse_cap + pi) * N;
+  double *out = slot;                                 // (8192 points: over C, which the transform above has consumed)
 #pragma unroll
   for (int q = 0; q < kPer; ++q) {
     const int i = tid + q * nt;
@@ -342,7 +355,7 @@ __global__ void sy_overlap_add(SynthParams p) {
   for (int q = lo; q < np; ++q) {
     const int offset = pidx[q] - H + 1;
     if (offset > n) break;
-    acc += p.resp[((size_t)u * p.pulse_cap + q) * N + (n - offset)];
+    acc += p.resp[((size_t)u * p.pulse_cap + q) * p.resp_stride + (n - offset)];
   }
   p.y[(size_t)u * p.y_stride + n] = acc;
 }
@@ -353,7 +366,12 @@ void launch_synthesis(const SynthParams &p, int max_y, hipStream_t stream) {
   WH_BLOCKS(sy_phase_serial, dim3(p.n_utt), WAVE, 0, stream, p);
   WH_BLOCKS(sy_detect, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
   WH_BLOCKS(sy_compact, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
-  WH_BLOCKS(sy_pulse, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);
+#ifdef WORLD_EMU
+  devrt::launch_blocks("sy_pulse", sy_pulse<8192>, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);
+#else
+  if (p.lg_fft <= 12) devrt::launch_blocks("sy_pulse", sy_pulse<4096>, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);
+  else devrt::launch_blocks("sy_pulse", sy_pulse<8192>, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);
+#endif
   WH_THREADS(sy_overlap_add, max_y, p.n_utt, 1, stream, p);
 }
 

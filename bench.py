@@ -39,6 +39,9 @@ import time
 # the default 4 queues 0.98 ms, 8 jobs on 4 queues 1.05 ms; with round 2's kernels, frames/s at 16 queues: 6 jobs
 # 2.77 M, 8: 3.08 M, 10: 3.04 M, 12: 3.19 M, 14: 3.16 M, 16: 3.07 M -- the default).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# RCCL between processes (N > 1): this pool's host driver only supports dmabuf IPC; the boxes export the setting, a
+# launcher that scrubs the environment would otherwise fail in hipIpcGetMemHandle at the first collective
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -72,7 +72,8 @@ def codec_fixture(R):
 
 
 SYNTH_CASES = {"syn16k": (16000, 180, 1024, 5.0, 14400, 0), "syn48k": (48000, 120, 2048, 5.0, 28000, 1),
-               "syn22k_hop10": (22050, 90, 1024, 10.0, 19000, 2)}
+               "syn22k_hop10": (22050, 90, 1024, 10.0, 19000, 2),
+               "syn192k": (192000, 44, 8192, 5.0, 40000, 4)}             # fft_size 8192: the default above 96 kHz (round 5)
 
 
 def synthesis_fixture(R):
@@ -152,6 +153,15 @@ def fileio_fixture():
     np.savez_compressed(os.path.join(OUT, "fileio.npz"), **out)
 
 
+def high_rate_fixture(R):
+    """192 kHz synthetic vowel, 0.3 s (round 5: CheapTrick fft 8192, D4C's 16384-point transforms, Harvest at its largest
+    decimation ratio, 12)"""
+    x = synth.vowel(192000, 0.3, seed=192, base_f0=150.0).numpy()
+    q = np.round(x * 32768.0).astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "vowel192k_harvest.npz"), **analyse(R, q, 192000, "harvest", 71.0, 8))
+    print("vowel192k_harvest.npz", os.path.getsize(os.path.join(OUT, "vowel192k_harvest.npz")) // 1024, "KiB")
+
+
 def main():
     build()
     R = RefOracle()
@@ -162,6 +172,9 @@ def main():
     if "--fileio-only" in sys.argv:
         fileio_fixture()
         print("fileio.npz", os.path.getsize(os.path.join(OUT, "fileio.npz")) // 1024, "KiB")
+        return
+    if "--high-rate-only" in sys.argv:
+        high_rate_fixture(R)
         return
     if "--codec-only" in sys.argv:
         codec_fixture(R)
@@ -179,6 +192,7 @@ def main():
     x = synth.vowel(16000, 1.5, seed=7, base_f0=180.0).numpy()
     q16 = np.round(x * 32768.0).astype(np.int16)
     np.savez_compressed(os.path.join(OUT, "vowel16k_dio.npz"), **analyse(R, q16, 16000, "dio", 71.0, 6))
+    high_rate_fixture(R)
     # primitive known answers
     import ctypes as C
     L = R.lib

@@ -21,7 +21,7 @@ def emu():
     return HostAPI(os.path.join(EMU_DIR, "libworld_emu.so"))
 
 
-@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest", "vaiueo2d_dio", "vowel16k_dio"])
+@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest", "vaiueo2d_dio", "vowel16k_dio", "vowel192k_harvest"])
 def test_emulated_pipeline_matches_golden(emu, name):
     check_against_golden(emu, load_golden(name), rtol=1e-7)
 

@@ -33,7 +33,7 @@ def oracle():
     return best_oracle()
 
 
-@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest", "vaiueo2d_dio", "vowel16k_dio"])
+@pytest.mark.parametrize("name", ["vaiueo2d_harvest", "vowel48k_harvest", "vaiueo2d_dio", "vowel16k_dio", "vowel192k_harvest"])
 def test_pipeline_matches_golden(hip, name):
     """BASELINE.json configs[0] (test.cpp plumbing on vaiueo2d.wav, DIO and Harvest variants),
     the 48 kHz north-star shapes and the 16 kHz alt config, against the reference's own outputs"""

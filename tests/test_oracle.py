@@ -6,7 +6,7 @@ import pytest
 
 from util import RTOL, check_against_golden, load_golden, max_rel
 
-FIXTURES = ["vaiueo2d_dio", "vaiueo2d_harvest", "vowel48k_harvest", "vowel16k_dio"]
+FIXTURES = ["vaiueo2d_dio", "vaiueo2d_harvest", "vowel48k_harvest", "vowel16k_dio", "vowel192k_harvest"]
 
 
 def test_randn_known_answers(port_oracle):

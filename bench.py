@@ -41,6 +41,8 @@ import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # RCCL between processes (N > 1): this pool's host driver only supports dmabuf IPC; the boxes export the setting, a
 # launcher that scrubs the environment would otherwise fail in hipIpcGetMemHandle at the first collective
+# -- so the default is applied ONLY where the box exports nothing, and the line says which it was (`environment.hsa_ipc`)
+HSA_IPC_EXPORTED = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -308,6 +310,48 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
 
 
+def visible_gpus():
+    """devices this process would see, without creating a HIP context in it (the count is taken in a child: a parent that
+    is about to become a launcher must not hold the runtime)"""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` as the driver types it -- no launcher, WORLD_SIZE unset -- must give N ranks, not an N = 1
+    line that claims nothing was asked (the guard used to fire only when a launcher disagreed).  With
+    fewer than N devices visible the run FAILS with one line; there is no silent fallback.  (Ranks may share a device only
+    under WORLD_HIP_BENCH_BACKEND=gloo, the functional check of the N > 1 path on a 1-GPU box -- never a number of record.)"""
+    have = None
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0 or world == 1:
+            have = visible_gpus()
+    else:
+        have = visible_gpus()
+    shared_ok = os.environ.get("WORLD_HIP_BENCH_BACKEND") == "gloo"
+    if have is not None and have < (1 if shared_ok else args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: not running (no CPU path, no fewer-GPU fallback)")
+    if args.gpus == 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: " % args.gpus + " ".join(cmd[1:8]) + " ...\n")
+    sys.stderr.flush()
+    os.environ["WORLD_HIP_BENCH_SELF_SPAWNED"] = "1"
+    os.execv(sys.executable, cmd)
+
+
 # ---------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -341,6 +385,9 @@ def main():
                     help="independent analysis jobs in flight per GPU (each step is one job on its own HIP "
                          "stream with its own workspace; 1 = strictly one after the other)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    spawn_ranks(args)                                           # --gpus N > 1 without a launcher: become N ranks (never returns then)
 
     import numpy as np
     import torch
@@ -352,8 +399,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU; (for a functional check of the N > 1 path on a 1-GPU box, ranks may share a
     # device with WORLD_HIP_BENCH_BACKEND=gloo -- never used for numbers of record)
     local = local % max(1, torch.cuda.device_count())
@@ -368,7 +415,11 @@ def main():
     props = torch.cuda.get_device_properties(local)
     environment = {"device": props.name, "arch": getattr(props, "gcnArchName", None), "compute_units": props.multi_processor_count,
                    "hbm_bytes": props.total_memory, "rocm_smi_at_start": smi_snapshot() if rank == 0 else None,
-                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "hsa_ipc": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                               "exported_by_the_box": HSA_IPC_EXPORTED is not None},
+                   "launcher": "bench.py itself (torch.distributed.run)" if os.environ.get("WORLD_HIP_BENCH_SELF_SPAWNED") else
+                               ("external" if "WORLD_SIZE" in os.environ else "none")}
 
     def environment_done(wh_probe=None):
         """the line's `environment` object: rocm-smi before and after the run, and the library's microprobe of the machine
@@ -561,6 +612,15 @@ def main():
                                    "3" if len(idx) == 128 else "-")
             roofline["scope"] = f"one batched analysis of {len(idx)} utterances on rank 0"
             del xb
+        # what the communicator itself reports, and which device every rank ran on (a line that says n_gpus = 8 must show 8)
+        ranks_seen = dist.get_world_size()
+        names = [None] * world
+        dist.all_gather_object(names, {"rank": rank, "device_index": local, "device": props.name,
+                                       "uuid": str(getattr(props, "uuid", "")) or None})
+        # the CPU baseline beside it (rank 0, one utterance of the job on one host core; the other ranks wait at the barrier)
+        cpu = None
+        if rank == 0 and not args.no_cpu_baseline and mine:
+            cpu, _ = cpu_baseline(xs[mine[0]].cpu().numpy(), optimized=False)
         barrier()
         dist.destroy_process_group()
         if rank == 0:
@@ -590,7 +650,9 @@ def main():
                            "wire": args.wire, "wire_choice": wire_choice,
                            "note": "chunk k's all-gather runs while chunk k+1 is analysed; exposed = device time the compute stream "
                                    "waited for all-gathers after its last analysis (HIP events), compute = the rest of the step"},
-                "parity_in_run": parity, "roofline": roofline, "cpu_baseline": None, "environment": environment_done(wh)}))
+                "parity_in_run": parity, "roofline": roofline, "cpu_baseline": cpu,
+                "rccl_ranks_seen": ranks_seen, "backend": os.environ.get("WORLD_HIP_BENCH_BACKEND", "nccl"), "ranks": names,
+                "environment": environment_done(wh)}))
             if parity is not None and not (parity["every_rank_bit_identical_to_lone_analysis"] and parity["randn_table_intact"]):
                 sys.stderr.write("bench.py: parity_in_run failed: " + json.dumps(parity) + "\n")
                 sys.exit(1)

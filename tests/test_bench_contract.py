@@ -137,3 +137,30 @@ def test_sweeps_report_their_failures(port_oracle):
     assert fuzz_parity.run(seed=3, n_cases=2, hip=port_oracle, orc=port_oracle, verbose=False) == []
     bad = fuzz_parity.run(seed=3, n_cases=2, hip=Wrong(port_oracle), orc=port_oracle, verbose=False)
     assert bad and all("harvest" in b for b in bad)
+
+
+def _bare(*flags, env=None):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bare_bench_without_enough_gpus_fails_with_one_line():
+    """`python bench.py --gpus N` on a box with fewer than N visible GPUs must exit non-zero with a
+    one-line reason -- never an `n_gpus: 1` line, never a CPU fallback.  (This container has no GPU at all.)"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is visible: the refusal is exercised on the CPU-only container")
+    for flags in (("--gpus", "1"), ("--gpus", "8"), ("--gpus", "2", "--steps", "1")):
+        r = _bare(*flags)
+        assert r.returncode != 0, flags
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no bench line may be printed"
+        reason = [ln for ln in r.stderr.strip().splitlines() if ln.startswith("bench.py:")]
+        assert len(reason) == 1 and "GPU(s) visible" in reason[0] and f"--gpus {flags[1]}" in reason[0], r.stderr[-500:]
+
+
+def test_launcher_disagreeing_with_gpus_flag_is_refused():
+    r = _bare("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

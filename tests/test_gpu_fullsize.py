@@ -300,6 +300,26 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert line["phases"]["compute_ms_per_step_max_over_ranks"] > 0 and line["roofline"]["kernel"]
 
 
+def test_bare_bench_command_spawns_its_own_ranks():
+    """the driver types `python bench.py --gpus N ...` with NO launcher.  The bare command must become N
+    ranks by itself (here: 2 ranks sharing the one GPU over gloo) and print a complete line -- n_gpus == N as the
+    communicator reports it, `cpu_baseline` timed on rank 0, every rank's device named."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WORLD_HIP_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--job-utterances", "8", "--sub-batch", "2", "--min-wall", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and len(line["ranks"]) == 2
+    assert sorted(d["rank"] for d in line["ranks"]) == [0, 1] and all(d["device"] for d in line["ranks"])
+    cpu = line["cpu_baseline"]
+    assert cpu and cpu["value"] > 0 and cpu["cores"] == 1 and cpu["kind"] in ("reference", "port") and cpu["sample"]
+    assert line["environment"]["launcher"].startswith("bench.py itself")
+    assert line["environment"]["hsa_ipc"]["HSA_ENABLE_IPC_MODE_LEGACY"] is not None
+    assert line["parity_in_run"]["every_rank_bit_identical_to_lone_analysis"]
+
+
 @pytest.mark.parametrize("wire", ["f64", "f32"])
 def test_rccl_collective_path_executes_with_a_world_of_one(wire):
     """the RCCL path had never executed.  torch.distributed backend "nccl" (= RCCL), world_size 1: the

@@ -448,6 +448,9 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
   p.lg_d4c = ilog2_exact(fft_d4c);
   p.nap = nap;
   p.wl = wl;
+  // d4c_frame's band transforms rely on the slice being at most 512 packed elements (3000 N / fs < 511.1 for every fs >= 15.8 kHz)
+  if (wl / 2 + 1 > 512) fail("D4C: band window of %d samples at fs=%d exceeds the 1023 the frame kernel is built for", wl, fs);
+  for (int b = 0; b < 8; ++b) p.band_center[b] = static_cast<int>(3000.0 * (b + 1) * fft_d4c / fs);      // d4c.cpp:207-208
   if (lay.frame_lo < 0 || lay.frame_hi < lay.frame_lo) fail("bad frame range [%d, %d)", lay.frame_lo, lay.frame_hi);
   p.frame_lo = lay.frame_lo; p.frame_hi = lay.frame_hi;
   p.skip_prepare = lay.skip_prepare ? kD4cSkipScan | kD4cSkipLoveTrain : 0;

@@ -36,6 +36,7 @@
 #include "prepare.h"
 #include "trace.h"
 WH_TRACE_DEFINE(d4c)
+WH_BARTRACE_DEFINE(d4c)
 
 namespace world_hip {
 
@@ -620,6 +621,14 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
 #else
 #define D4C_FRESH_TID() do { } while (0)
 #endif
+// LDS of d4c_frame (doubles): Z (N) | scratch (64) | quarter-wave table of the N/2-point complex transform | the group delay
+// (N/2 + 2; N <= 8192 only) | the wavefronts' shares of the bands' sums (8 bands x 2 x N / 1024 wavefronts) | direct twiddles
+// of the two inner radix-8 stages (2^(lg-7) + 2^(lg-10) complex)
+__host__ __device__ constexpr size_t d4c_frame_direct_tw_offset(int lg) {
+  const size_t N = (size_t)1 << lg;
+  const size_t park = lg > 13 ? 0 : N / 2 + 2;          // (the 16384-point shape parks in global memory: d4c_frame)
+  return sizeof(double) * (N + 64 + ((size_t)1 << (lg - D4C_TW_LEVEL - 2)) + 2 + park + 16 * (N / 1024 > 1 ? N / 1024 : 1));
+}
 template <int NMAX, int T>
 __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   constexpr int kItems = D4cShape<NMAX, T>::kItems, kBins = D4cShape<NMAX, T>::kBins, kLo = D4cShape<NMAX, T>::kLo;
@@ -637,6 +646,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   const double f0 = p.f0[fi];
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
   const bool trace_me = f == WH_TRACE_FRAME && u == WH_TRACE_UTT; (void)trace_me;
+  wh_bartrace_arm(trace_me);                                           // (-DWH_BARTRACE only: tools/barrier_skew.py)
   WH_STAMP(32, 0);
   // On the GPU the transform length is the shape's (launch_d4c picks the instantiation), so the plan, every
   // stage's radix and stride and the digit reversal of the merge steps are compile-time constants.
@@ -650,7 +660,16 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   double *scratch = Zr + N;
+#ifdef WORLD_EMU
   const TwLds tw = stage_twiddles<T>(scratch + 64, lgn - D4C_TW_LEVEL, p.tab.tw);
+#else
+  // ... and behind everything else (d4c_frame_lds_bytes) the twiddles of the transforms' two inner radix-8 stages, one
+  // 16-byte entry per distinct value: every one of the frame's 13 transforms reads them (fft.h: stage_direct_twiddles;
+  // the barrier in front of the first transform -- the stream-position sum's, below -- publishes them)
+  const TwLds tw = stage_direct_twiddles<T>(stage_twiddles<T>(scratch + 64, lgn - D4C_TW_LEVEL, p.tab.tw),
+                                            reinterpret_cast<cplx *>(lds + d4c_frame_direct_tw_offset(lgn)),
+                                            lgn - 1 - 3, 1 << (lgn - 1 - 6), lgn - 1 - 6, 1 << (lgn - 1 - 9));
+#endif
 #ifdef WORLD_EMU
   const FftPlan plan = make_plan_max(lgn - 1, 3);
   auto cfft = [&]() { block_cfft_dif<3>(Z, plan, tw); };
@@ -739,10 +758,11 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   };
   // LinearSmoothing (common.cpp:27-111): register bins -> mirrored segment in LDS -> block prefix sum -> register bins;
   // the input and the output may be owned differently
-  auto smooth = [&](const double (&in)[kBins], auto for_in, double width, double (&out)[kBins], auto for_out) __attribute__((always_inline)) {
+  // pre: a barrier first (whoever read Zr last is not behind one yet)
+  auto smooth = [&](const double (&in)[kBins], auto for_in, double width, double (&out)[kBins], auto for_out, const bool pre = true) __attribute__((always_inline)) {
     const int bnd = static_cast<int>(width * N / fs) + 1;
     const int seg_len = H + 2 * bnd + 1;
-    __syncthreads();
+    if (pre) __syncthreads();
     for_in([&](int slot, int k) {
       const double v = in[slot] * fs * inv_n;            // == .. * fs / N: N is a power of two
       Zr[k + bnd] = v;
@@ -848,10 +868,10 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   // stores at ~13 cycles each, the LDS's slowest instruction, eight loads and a barrier per transform; the band
   // transforms below always worked this way).
   static_assert(kLo == 8 && T * 8 * 2 == NMAX, "one radix-8 butterfly per thread");
-  auto cfft_from_registers = [&](cplx (&a)[8]) __attribute__((always_inline)) {
+  auto cfft_from_registers = [&](cplx (&a)[8], const cplx &w1) __attribute__((always_inline)) {      // w1: twiddle(tw, tid, lgn - 1, -1)
     constexpr int sh = lgn - 1 - 3;
     dft_reg<true, 3>(a);
-    mul_powers<3>(a, twiddle(tw, tid, lgn - 1, -1));
+    mul_powers<3>(a, w1);
     const int s0 = swz(tid);
 #pragma unroll
     for (int k = 0; k < 8; ++k) Z[s0 ^ swz(k << sh)] = a[k];
@@ -888,7 +908,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       // kPwAt ..) behind the transform's own barriers
       pw = wave_sum(pw);
       if (lane_id() == 0) scratch[kPwAt + wave_in_block()] = pw;
-      cfft_from_registers(a);
+      cfft_from_registers(a, twiddle(tw, tid, lgn - 1, -1));
     }
 #else
     {
@@ -936,7 +956,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = cmul(a[j], kRot ? mul_w16_fwd(wb, j) : twiddle(tw, tid + j * nt, lgn, -1));
       WH_STAMP(32, 3 + 4 * c);
-      cfft_from_registers(a);
+      cfft_from_registers(a, twiddle(tw, tid, lgn - 1, -1));
     }
 #else
     {
@@ -1014,7 +1034,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     } else
 #endif
     dc_correct(Bn, for_nat);
-    smooth(Bn, for_nat, cf0, B, for_pair);
+    // (the transform's readers are behind the merge's closing barrier -- and dc_correct's own, if it ran: no barrier in front)
+    smooth(Bn, for_nat, cf0, B, for_pair, false);
   }
   WH_STAMP(32, 12);
   lds_dead(Zr, N);                                         // (the smoothing segment is dead: DCCorrection below stages its own bins)
@@ -1063,8 +1084,19 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   double *band_sums = park_global ? after_tw : park + (H + 2);   // [band][partial, total][wavefront]: d4c_frame_lds_bytes
   // the Nuttall taps of the thread's own slice element: the same for every band
   const double nut0 = 2 * tid < wl ? p.nuttall[2 * tid] : 0.0, nut1 = 2 * tid + 1 < wl ? p.nuttall[2 * tid + 1] : 0.0;
+#ifndef WORLD_EMU
+  // What every band's first stage needs and no band changes: the stage's twiddle (it used to be looked up again per band:
+  // two LDS reads, the quadrant selects, the fine-level product) and the taps of the thread's SECOND slice element
+  // (packed element tid + T; zero beyond the window -- at 48 kHz only thread 0 has one)
+  constexpr int kNzR = (512 + T - 1) / T;               // a slice is at most 512 packed elements (setup_d4c checks): kNzR T >= nz
+  const cplx w_first = twiddle(tw, tid, plan.lg, -1);
+  const bool second = kNzR == 2 && tid + T < nz;
+  double nut2 = 0.0, nut3 = 0.0;
+  if (second) { nut2 = p.nuttall[2 * (tid + T)]; nut3 = 2 * (tid + T) + 1 < wl ? p.nuttall[2 * (tid + T) + 1] : 0.0; }
+  const bool any_second = kNzR == 2 && __builtin_amdgcn_ballot_w64(second) != 0ull;      // wave-uniform
+#endif
   for (int band = 0; band < p.nap; ++band) {
-    const int lo_k = static_cast<int>(3000.0 * (band + 1) * N / fs) - hwl;
+    const int lo_k = p.band_center[band] - hwl;
     D4C_FRESH_TID();
     __syncthreads();                                    // the previous band's histograms are done (first band: park is written)
     // First DIF stage with every input beyond element nz known to be zero: the slice comes straight from `park`.
@@ -1090,20 +1122,53 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     {
       constexpr int R = 8;
       const int sh = plan.lg - 3, qq = 1 << sh;         // qq == T: one butterfly per thread (launch_d4c)
-      cplx a[R];
-      const bool single = tid + qq >= nz;
-#pragma unroll
-      for (int r = 0; r < R; ++r) { cplx z0; z0.re = 0.0; z0.im = 0.0; a[r] = tid + r * qq < nz ? slice(tid + r * qq) : z0; }
-      if (single) {
-#pragma unroll
-        for (int r = 1; r < R; ++r) a[r] = a[0];         // DFT of a delta
-      } else {
-        dft_reg<true, 3>(a);
-      }
-      mul_powers<3>(a, twiddle(tw, tid, plan.lg, -1));
       const int s0 = swz(tid);
+      cplx z0; z0.re = 0.0; z0.im = 0.0;
+      if constexpr (kNzR <= 2) {
+        // Of the butterfly's eight inputs only the thread's own element (and, for a few threads of the first wavefronts,
+        // the one T further on) can be non-zero: a wavefront without a second element multiplies ONE value by the
+        // stage's twiddle powers; the others form a0 + a1 W8^k first (dft8_head2: the bits dft8 would give).  The general
+        // form below asked for all eight under eight exec-mask branches, copied a0 seven times and ran the full dft8
+        // for the one lane that needed it -- in wavefront 0 of every workgroup, eight times per frame.
+        const cplx a0 = (kNzR == 2 || tid < nz) ? slice(tid) : z0;
+        cplx a[R];
+        if (any_second) {
+          cplx a1 = z0;
+          if (second) {
+            const double *g = park + lo_k + 2 * (tid + T);
+            a1.re = g[0] * nut2;
+            a1.im = 2 * (tid + T) + 1 < wl ? g[1] * nut3 : 0.0;
+          }
+          dft8_head2<true>(a0, a1, a);
+          if (!second) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) Z[s0 ^ swz(k << sh)] = a[k];
+            for (int r = 0; r < R; ++r) a[r] = a0;     // (a0 + 0 W8^k: the DFT of a delta, exactly)
+          }
+          mul_powers<3>(a, w_first);
+#pragma unroll
+          for (int k = 0; k < R; ++k) Z[s0 ^ swz(k << sh)] = a[k];
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) a[r] = a0;       // DFT of a delta
+          mul_powers<3>(a, w_first);
+#pragma unroll
+          for (int k = 0; k < R; ++k) Z[s0 ^ swz(k << sh)] = a[k];
+        }
+      } else {
+        cplx a[R];
+        const bool single = tid + qq >= nz;
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = (r < kNzR && tid + r * qq < nz) ? slice(tid + r * qq) : z0;
+        if (single) {
+#pragma unroll
+          for (int r = 1; r < R; ++r) a[r] = a[0];       // DFT of a delta
+        } else {
+          dft_reg<true, 3>(a);
+        }
+        mul_powers<3>(a, w_first);
+#pragma unroll
+        for (int k = 0; k < R; ++k) Z[s0 ^ swz(k << sh)] = a[k];
+      }
       DifStages<lgn - 1, 3, lgn - 1 - 3, T>::run(Z, tw);
       __syncthreads();
     }
@@ -1118,11 +1183,9 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     });
     if (band == 0) WH_STAMP(32, 17);
     // The select's histograms alias the head of the transform buffer and are zeroed as its first step: every wavefront
-    // must have finished READING the transform (the merge above keeps its bins in registers and has no closing barrier)
-    // before any of them starts.  (Until the end of round 4 this barrier was missing: a wavefront done with its merge
-    // could have zeroed slots a slower one had not read yet -- never observed, the reads enter the LDS queue within a
-    // few hundred cycles of the transform's barrier and the zeroing follows ~2 000 cycles of arithmetic later.)
-    __syncthreads();
+    // must have finished READING the transform before any of them starts -- the merge's own closing barrier
+    // (rfft_merge_items_w) is that point.  (Round 5 had a second barrier here, back to back with that one: s_barrier,
+    // s_barrier in the ISA, five times a frame.)
     lds_dead(Zr, N);                                       // (the band's transform is in registers: the select must zero what it counts in)
     double part, tot;
     (void)mine;
@@ -1201,9 +1264,7 @@ size_t d4c_love_lds_bytes(int lg) { return sizeof(double) * (size_t)((1 << lg) +
 // Z (N doubles) | scratch (64) | quarter-wave table of the N/2-point complex transform | the group delay (N/2 + 2; N <= 4096 only)
 // | the wavefronts' shares of the bands' sums (8 bands x 2 x N / 1024 wavefronts)
 size_t d4c_frame_lds_bytes(int lg) {
-  int N = 1 << lg;
-  const size_t park = lg > 13 ? 0 : N / 2 + 2;          // (the 16384-point shape parks in global memory: d4c_frame)
-  return sizeof(double) * (size_t)(N + 64 + twiddle_lds_doubles(lg - D4C_TW_LEVEL) + park + 16 * std::max(1, N / 1024));
+  return d4c_frame_direct_tw_offset(lg) + 2 * sizeof(double) * (((size_t)1 << (lg - 7)) + ((size_t)1 << (lg - 10)));
 }
 // doubles of one workgroup's slot of D4cParams::park_ws (0: the shape parks in LDS)
 size_t d4c_park_slot_doubles(int lg) { return lg > 13 ? ((size_t)1 << (lg - 1)) + 2 : 0; }

@@ -276,8 +276,50 @@ __device__ __forceinline__ void jitter() {
 }
 __device__ __forceinline__ void wh_jitter_syncthreads() { __syncthreads(); jitter(); }
 #define __syncthreads() wh_jitter_syncthreads()
+#elif defined(WH_BARTRACE)
+// Development aid (tools/barrier_skew.py): ONE workgroup -- block (WH_TRACE_FRAME, WH_TRACE_UTT) of a kernel that armed the
+// tracer with wh_bartrace_arm() -- stamps the shader clock of every wavefront's ARRIVAL at every workgroup barrier:
+// wh_bar[barrier ordinal * 16 + wavefront].  Which wavefront the others wait for, and for how long, is what neither
+// rocprofv3's kernel totals nor the phase stamps of trace.h show.  The ordinal is counted per wavefront in LDS, behind the
+// barrier (nothing is loaded in front of it); every other workgroup pays one scalar compare per barrier.
+#ifndef WH_TRACE_FRAME
+#define WH_TRACE_FRAME 1000
+#endif
+#ifndef WH_TRACE_UTT
+#define WH_TRACE_UTT 0
+#endif
+namespace world_hip_bt { static __device__ long long wh_bar[128 * 16]; }
+struct WhBarState { int magic; int cnt[16]; };
+__device__ __forceinline__ WhBarState &wh_bar_state() { static __shared__ WhBarState s; return s; }
+__device__ __forceinline__ void wh_bartrace_arm(bool on) {
+  WhBarState &s = wh_bar_state();
+  if ((threadIdx.x & 63) == 0) { s.cnt[threadIdx.x >> 6] = 0; s.magic = on ? 0x5EED : 0; }
+}
+__device__ __forceinline__ void wh_bartrace_syncthreads() {
+  const bool me = blockIdx.x == WH_TRACE_FRAME && blockIdx.y == WH_TRACE_UTT;
+  const long long t = me ? (long long)__builtin_readcyclecounter() : 0;
+  __syncthreads();
+  if (me && (threadIdx.x & 63) == 0) {
+    WhBarState &s = wh_bar_state();
+    if (s.magic == 0x5EED) {
+      const int w = threadIdx.x >> 6, i = s.cnt[w];
+      s.cnt[w] = i + 1;
+      if (i < 128) world_hip_bt::wh_bar[i * 16 + w] = t;
+    }
+  }
+}
+#define WH_BARTRACE_DEFINE(unit)                                                                        \
+  extern "C" __attribute__((visibility("default"))) int world_hip_bartrace_read_##unit(long long *out, int n) { \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(world_hip_bt::wh_bar), sizeof(long long) * n);      \
+  }
+#define __syncthreads() wh_bartrace_syncthreads()
+__device__ __forceinline__ void jitter() {}
 #else
 __device__ __forceinline__ void jitter() {}
+#endif
+#if !defined(WH_BARTRACE)
+#define WH_BARTRACE_DEFINE(unit)
+__device__ __forceinline__ void wh_bartrace_arm(bool) {}
 #endif
 #if defined(WH_LDS_POISON)
 __device__ __forceinline__ void lds_poison_all(char *lds) {
@@ -301,6 +343,8 @@ __device__ __forceinline__ void lds_dead(void *, int) {}
 #else
 static inline void jitter() {}
 static inline void lds_dead(void *, int) {}
+static inline void wh_bartrace_arm(bool) {}
+#define WH_BARTRACE_DEFINE(unit)
 #endif
 
 // make one wave's LDS writes visible to its other lanes (no-op for a 1-lane wave)

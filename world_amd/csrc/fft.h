@@ -48,6 +48,12 @@ struct TwLds {
   const double *q; int lg;
   double fine_c, fine_s;     // cos/sin(2 pi / 2^(lg+1)): one level finer than the table (see twiddle())
   double fine2_c, fine2_s;   // cos/sin(2 pi / 2^(lg+2)): two levels finer
+  // Optional DIRECT tables for two levels (stage_direct_twiddles): dir_a[k] = e^{-2 pi i k / 2^dir_a_lg} as twiddle()
+  // itself returns it, k < dir_a_n.  A kernel with one butterfly per thread asks every stage for the same few values
+  // in every one of its transforms (d4c_frame: 13 transforms a frame, stage levels 8 and 5 -> 32 and 4 distinct
+  // twiddles): one 16-byte read replaces two 8-byte reads, the quadrant selects and the sign flips.  0 = none.
+  const cplx *dir_a = nullptr, *dir_b = nullptr;
+  int dir_a_lg = 0, dir_b_lg = 0;
 };
 
 // stage the table for transforms up to 2^lg points; call before the first transform
@@ -76,7 +82,6 @@ __device__ __forceinline__ TwLds stage_twiddles(double *q, int lg, const double2
   return t;
 }
 __host__ __device__ __forceinline__ size_t twiddle_lds_doubles(int lg) { return (size_t)(1 << (lg - 2)) + 2; }
-
 // e^{-2 pi i k / 2^lg} (forward, sign=-1) or its conjugate (sign=+1), 0 <= k < 2^lg
 __device__ __forceinline__ cplx twiddle_table(const TwLds &tw, int k, int lg, int sign) {
   const int K = k << (tw.lg - lg);
@@ -95,6 +100,8 @@ __device__ __forceinline__ cplx twiddle_table(const TwLds &tw, int k, int lg, in
 // short of LDS may stage a table two levels coarser than its finest request (lg = tw.lg + 2): the two low
 // bits of k then select 1, f, f^2 or f^3 with f = e^{2 pi i / 2^lg} (at most two extra products).
 __device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign) {
+  if (tw.dir_a_lg != 0 && lg == tw.dir_a_lg) { cplx w = tw.dir_a[k]; if (sign > 0) w.im = -w.im; return w; }
+  if (tw.dir_b_lg != 0 && lg == tw.dir_b_lg) { cplx w = tw.dir_b[k]; if (sign > 0) w.im = -w.im; return w; }
   if (lg == tw.lg + 1) {
     cplx a = twiddle_table(tw, k >> 1, tw.lg, sign);
     if (k & 1) { cplx f; f.re = tw.fine_c; f.im = sign > 0 ? tw.fine_s : -tw.fine_s; a = cmul(a, f); }
@@ -108,6 +115,20 @@ __device__ __forceinline__ cplx twiddle(const TwLds &tw, int k, int lg, int sign
   }
   return twiddle_table(tw, k, lg, sign);
 }
+// Fill direct tables for levels lg_a (n_a entries at area) and lg_b (n_b entries behind them) from the staged table -- the
+// values twiddle() returns, bit for bit -- and return a TwLds that serves those levels from them.  The caller's next
+// barrier publishes the tables (none is added here).  area: (n_a + n_b) cplx of LDS, 16-byte aligned.
+template <int NT = 0>
+__device__ __forceinline__ TwLds stage_direct_twiddles(const TwLds &tw, cplx *area, int lg_a, int n_a, int lg_b, int n_b) {
+  const int tid = wg_thread<NT>();
+  if (tid < n_a) area[tid] = twiddle(tw, tid, lg_a, -1);
+  else if (tid < n_a + n_b) area[tid] = twiddle(tw, tid - n_a, lg_b, -1);
+  TwLds t = tw;
+  t.dir_a = area; t.dir_a_lg = lg_a;
+  t.dir_b = area + n_a; t.dir_b_lg = lg_b;
+  return t;
+}
+
 // ---------------------------------------------------------------------------
 // Mixed-radix plan: radix-16 stages, then one radix-8/4/2 stage for the remainder.
 // A radix-R butterfly is evaluated entirely in registers, so a 2048-point
@@ -218,6 +239,15 @@ template <bool FWD> __device__ __forceinline__ void dft8(cplx *a) {
   dft4<FWD>(u1[0], u1[1], u1[2], u1[3]);
 #pragma unroll
   for (int k2 = 0; k2 < 4; ++k2) { a[2 * k2] = u0[k2]; a[2 * k2 + 1] = u1[k2]; }
+}
+// dft8 of (a0, a1, 0, 0, 0, 0, 0, 0): X[k] = a0 + a1 W8^k.  The operations are the ones dft8 above performs on those
+// inputs once its additions of zero are dropped -- ONE product (a1 W8) and eight complex additions -- so the results
+// are the same bits (a zero result may differ in sign) for a fifth of the instructions.
+template <bool FWD> __device__ __forceinline__ void dft8_head2(cplx a0, cplx a1, cplx *x) {
+  const cplx c = mul_w16<FWD, 2>(a1);                         // a1 W8
+  const cplx ia = mul_i4<FWD>(a1), ic = mul_i4<FWD>(c);       // a1 W8^2, a1 W8^3
+  x[0] = cadd(a0, a1); x[1] = cadd(a0, c); x[2] = cadd(a0, ia); x[3] = cadd(a0, ic);
+  x[4] = csub(a0, a1); x[5] = csub(a0, c); x[6] = csub(a0, ia); x[7] = csub(a0, ic);
 }
 template <bool FWD> __device__ __forceinline__ void dft16(cplx *a) {
   // 16 = 4 x 4: n = 4 n1 + n2, k = k1 + 4 k2

@@ -52,6 +52,8 @@ struct D4cParams {
   int lg_d4c;             // log2 of fft_size_d4c
   int nap;                // number_of_aperiodicities
   int wl;                 // Nuttall window length
+  int band_center[8];     // static_cast<int>(3000 (band + 1) fft_size_d4c / fs), d4c.cpp:207-208: the centre bin of band b's slice
+                          // (host arithmetic, the reference's expression: in the kernel it was a 20-instruction FP64 division per band)
   // Frame range of d4c_frame / d4c_finish (LoveTrain and the first offset scan always cover every frame: the second
   // pass's stream positions depend on every earlier frame's LoveTrain result).  0 / INT_MAX = all.
   int frame_lo, frame_hi;

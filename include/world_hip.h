@@ -152,7 +152,18 @@ WORLD_HIP_API int ReadAperiodicity(const char *filename, double **aperiodicity);
  * returns, the drop-in call returns to its caller; it may also longjmp or throw.  The caller's output buffers are untouched
  * when the call was refused up front (a shape limit, a missing GPU) and UNSPECIFIED after a failure in mid-transfer (the
  * matrices are downloaded chunk by chunk into the caller's rows: a device error between two chunks leaves earlier rows written).
- * With no handler (the default, handler = NULL) the reason is printed to stderr and the process aborts. */
+ * With no handler (the default, handler = NULL) the reason is printed to stderr and the process aborts.
+ * Hostile values (tests/test_hostile.py): samples may be NaN, +-Inf, 1e308 or denormal -- every call returns, the results
+ * are as meaningless as the reference's, temporal_positions never depend on the samples, and the next call is unaffected.
+ * Caller-made F0 tracks: the reference turns F0 into window lengths and array indices unchecked (src/cheaptrick.cpp:95,
+ * src/d4c.cpp:55-56, src/stonemask.cpp:129, src/common.cpp:60-62) -- NaN and values from about fs/2 up are undefined
+ * behaviour there.  Here, and ONLY for such values, the analysis differs from it by rule:
+ *   F0 is NaN   CheapTrick: the frame is analysed as unvoiced (the default 500 Hz); D4C: unvoiced (the row is 1 - 1e-12);
+ *               StoneMask: the refined value is 0
+ *   F0 > fs/2   CheapTrick and D4C analyse the frame as F0 = fs/2 (+Inf included).  The frame then draws fewer randn()
+ *               values than the reference would, so LATER frames of that utterance meet other noise samples than the
+ *               reference's (differences at the 1e-12 safeguard level); utterances without such a frame are unaffected
+ *   F0 <= floor, negative, -Inf: the reference's own floors apply (src/cheaptrick.cpp:218, src/d4c.cpp:263,300), as there. */
 typedef void (*WorldHipErrorHandler)(const char *function, const char *message, void *user);
 WORLD_HIP_API void world_hip_set_error_handler(WorldHipErrorHandler handler, void *user);
 /* Releases what the drop-in layer holds: its helper threads are joined and every slot's context, streams, events, device
@@ -190,6 +201,13 @@ typedef struct WorldHipContext WorldHipContext;
 WORLD_HIP_API WorldHipContext *world_hip_create(int device, void *stream);
 WORLD_HIP_API void world_hip_destroy(WorldHipContext *ctx);
 WORLD_HIP_API const char *world_hip_last_error(void);
+/* Version of the batched C ABI below (the reference's own 13 symbols never change).  Bumped whenever a prototype in this
+ * header changes incompatibly; a binding built against another major value must refuse to bind (world_amd/api.py does).
+ *   5  round 5: world_hip_spectral_packed_range / _cheaptrick_batch_range / _d4c_batch_range take `reuse_offsets`
+ *   6  round 6: + world_hip_abi_version itself; no prototype changed
+ * Libraries older than 6 lack the symbol. */
+#define WORLD_HIP_ABI_VERSION 6
+WORLD_HIP_API int world_hip_abi_version(void);
 WORLD_HIP_API int world_hip_sync(WorldHipContext *ctx);
 /* bytes of device workspace currently held by the context (its arena) */
 WORLD_HIP_API unsigned long long world_hip_workspace_bytes(WorldHipContext *ctx);

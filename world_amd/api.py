@@ -58,6 +58,13 @@ def load_library(path=LIB_PATH):
                           "(hipcc, gfx950). There is no non-GPU fallback.")
     _hip_runtime_first()
     lib = C.CDLL(path)
+    # the batched ABI this binding was written against (include/world_hip.h: WORLD_HIP_ABI_VERSION).  Libraries of round 5
+    # (tools/ab.py loads those) have the same prototypes and no version symbol; anything else is refused rather than called
+    # with shifted arguments
+    abi = lib.world_hip_abi_version() if hasattr(lib, "world_hip_abi_version") else 5
+    if abi not in (5, 6):
+        raise ImportError(f"{path}: batched ABI version {abi}, this binding speaks 5-6")
+    lib.abi_version = abi
     vp = C.c_void_p
     lib.world_hip_create.restype = vp
     lib.world_hip_create.argtypes = [C.c_int, vp]

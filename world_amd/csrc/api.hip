@@ -1425,6 +1425,7 @@ void world_hip_destroy(WorldHipContext *c) {
     if (c->arena.base) devrt::dfree(c->arena.base);
     if (c->d_nuttall) devrt::dfree(c->d_nuttall);
     if (c->d_pk) devrt::dfree(c->d_pk);
+    if (c->d_stage) devrt::dfree(c->d_stage);
     if (c->d_xin) devrt::dfree(c->d_xin);
     if (c->h_xin) devrt::hfree_pinned(c->h_xin);
     if (c->xstream) { devrt::sync(c->xstream); devrt::stream_destroy(c->xstream); }
@@ -1451,6 +1452,7 @@ void world_hip_destroy(WorldHipContext *c) {
   delete c;
 }
 
+int world_hip_abi_version(void) { return WORLD_HIP_ABI_VERSION; }
 const char *world_hip_last_error(void) { return g_last_error.c_str(); }
 
 // pulses a synthesis call since the last check had no room for (0 = none); synchronises, clears the record

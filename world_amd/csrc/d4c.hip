@@ -516,7 +516,7 @@ __device__ __forceinline__ void d4c_love_frame(const D4cParams &p, char *lds) {
   const int u = blockIdx.y, f = blockIdx.x;
   if (f >= p.b.n_frames[u]) return;
   const size_t fi = (size_t)u * p.b.f_stride + f;
-  const double f0 = p.f0[fi];
+  const double f0 = d4c_sane_f0(p.f0[fi], p.b.fs);
   if (f0 == 0.0) { if (threadIdx.x == 0) { p.ap0[fi] = 0.0; p.draws2[fi] = 0u; } return; }   // d4c.cpp:274-277
   const int lgn = LGN > 0 ? LGN : p.lg_love, M = 1 << lgn, fs = p.b.fs;
   cplx *Z = reinterpret_cast<cplx *>(lds);
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   // which a faster wavefront may still be reading -- that one takes doubles [0, waves) and [32, 32 + waves), so the
   // sixteen wavefronts of the 16384-point shape push this area up into the select's (48..63: idle until the band loop)
   constexpr int kPwAt = T > 8 * WAVE ? 48 : 40;
-  const double f0 = p.f0[fi];
+  const double f0 = d4c_sane_f0(p.f0[fi], p.b.fs);
   if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
   const bool trace_me = f == WH_TRACE_FRAME && u == WH_TRACE_UTT; (void)trace_me;
   wh_bartrace_arm(trace_me);                                           // (-DWH_BARTRACE only: tools/barrier_skew.py)
@@ -708,8 +708,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   unsigned stream_at;
   {
     const unsigned *cnt = p.draws2 + (size_t)u * p.b.f_stride;
-    int s_ = 0;
-    for (int g = tid; g < f; g += nt) s_ += (int)cnt[g];
+    int s_ = 0;                                             // (sums wrap like the unsigned stream position they feed: two's complement)
+    for (int g = tid; g < f; g += nt) s_ = (int)((unsigned)s_ + cnt[g]);
     s_ = wave_sum_int(s_);
     int *part = reinterpret_cast<int *>(Zr);                 // (nothing lives in LDS yet)
     if (lane_id() == 0) part[wave_in_block()] = s_;
@@ -1222,8 +1222,8 @@ __global__ void d4c_finish(D4cParams p) {
   char *row_at = reinterpret_cast<char *>(p.aperiodicity + orow * p.out_stride) + p.out_col_bytes;
   double *row = reinterpret_cast<double *>(row_at);
   float *row32 = reinterpret_cast<float *>(row_at);                    // the narrow wire format (p.out_f32)
-  const double f0 = p.f0[fi];
-  if (p.rec && tid == 0) { double *r = p.rec + orow * p.out_stride; r[0] = p.tpos[fi]; r[1] = f0; }   // the record's head
+  const double f0 = d4c_sane_f0(p.f0[fi], p.b.fs);
+  if (p.rec && tid == 0) { double *r = p.rec + orow * p.out_stride; r[0] = p.tpos[fi]; r[1] = p.f0[fi]; }   // the record's head (F0 as it was given)
   if (f0 == 0 || p.ap0[fi] <= p.threshold) {                          // d4c.cpp:323-328,386
     if (p.out_f32) { for (int i = tid; i < nb_out; i += nt) row32[i] = static_cast<float>(1.0 - kTiny); }
     else { for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny; }

@@ -842,7 +842,12 @@ __global__ void hc_smooth(HarvestParams p, int lds_doubles) {
       for (int i = lane_id(); i < kSmoothTail; i += WAVE) buf[i] = first;
       for (int i = len + lane_id(); i < need - kSmoothTail; i += WAVE) held[i] = last;
       wave_sync();
+#ifdef WORLD_EMU
+      // (one lane owns the whole section there: its surplus steps -- never kept -- reach a batch below the held head)
+      auto at = [&](int j) { return held[imax(j, -kSmoothTail)]; };
+#else
       auto at = [&](int j) { return held[j]; };       // -kSmoothTail <= j < total + kSmoothTail + kSmoothSlack in both sweeps
+#endif
       sweeps(at, at, held, held, at);
       wave_sync();                                                   // the next section reuses the buffer
     } else {

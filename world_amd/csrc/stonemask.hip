@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) sm_frame(StoneMaskParams p) {
   const size_t fi = (size_t)u * p.b.f_stride + f;
   const double f0 = p.f0[fi], pos = p.tpos[fi];
   const int fs = p.b.fs, tid = threadIdx.x, nt = blockDim.x;
-  if (f0 <= kFloorF0StoneMask || f0 > fs / 12.0) {                  // stonemask.cpp:187-188
+  if (!(f0 > kFloorF0StoneMask) || f0 > fs / 12.0) {                // stonemask.cpp:187-188 (a NaN F0 -- undefined there -- gives 0)
     if (tid == 0) p.refined[fi] = 0.0;
     return;
   }

@@ -486,9 +486,22 @@ def main():
         if fp and dom in fp[0]:
             flop, tflops = fp[0][dom]
             r["fp64"] = {"flop_per_launch": flop, "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "pipeline_flop_per_frame": fp[1],
+                         "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "peak_spec": FP64_VECTOR_PEAK_TFLOPS,
+                         "peak_measured": None, "frac_of_measured": None,      # (filled from the run's own microprobe: measured_peak)
+                         "pipeline_flop_per_frame": fp[1],
                          "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU_*_F64) over live durations"}
         return r
+
+    def measured_peak(env, *roofs):
+        """both denominators in the line: the spec figure (78.6 TFLOP/s at 2.4 GHz) and the FP64 FMA rate the
+        box itself sustains chip-wide at the clock it holds under that load (the library's microprobe, same run)"""
+        rate = ((env or {}).get("microprobe") or {}).get("fp64_fma_tflops")
+        for r in roofs:
+            fp = (r or {}).get("fp64")
+            if fp and rate:
+                fp["peak_measured"] = rate
+                fp["frac_of_measured"] = fp["achieved"] / rate
+                fp["peak_measured_what"] = "world_hip_probe_machine: chip-wide FP64 FMA chains, whole launch timed by HIP events, this run"
 
     # =====================================================================================================
     # N > 1: BASELINE configs[3], one job of --job-utterances utterances per step, sharded over the ranks
@@ -624,6 +637,8 @@ def main():
         barrier()
         dist.destroy_process_group()
         if rank == 0:
+            env_n = environment_done(wh)
+            measured_peak(env_n, roofline)
             nb = FFT_SIZE // 2 + 1
             print(json.dumps({
                 "metric": "analysis frames/sec (Harvest+CheapTrick+D4C, 48 kHz, 5 ms hop)",
@@ -652,7 +667,7 @@ def main():
                                    "waited for all-gathers after its last analysis (HIP events), compute = the rest of the step"},
                 "parity_in_run": parity, "roofline": roofline, "cpu_baseline": cpu,
                 "rccl_ranks_seen": ranks_seen, "backend": os.environ.get("WORLD_HIP_BENCH_BACKEND", "nccl"), "ranks": names,
-                "environment": environment_done(wh)}))
+                "environment": env_n}))
             if parity is not None and not (parity["every_rank_bit_identical_to_lone_analysis"] and parity["randn_table_intact"]):
                 sys.stderr.write("bench.py: parity_in_run failed: " + json.dumps(parity) + "\n")
                 sys.exit(1)
@@ -847,7 +862,10 @@ def main():
     # so one job's short serial kernels (contour logic, decimation) overlap another job's
     # wide ones.  Every job still does the full work; nothing is cached between steps.
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    whs = [WorldHip(device=local) for _ in range(S)]
+    # (the contexts of the in-flight mode say so -- world_hip.h: WORLD_HIP_HINT_SHARED_DEVICE: narrow launch shapes for the
+    # one-workgroup contour kernels; the serial parity run and the lone-job latency below use contexts WITHOUT the hint, so
+    # `slots_bit_identical_to_serial_run` also says that the two launch shapes give the same bits)
+    whs = [WorldHip(device=local, shared_device=S > 1) for _ in range(S)]
     wh = whs[0]
     sp_bufs = [torch.empty((B, nf, FFT_SIZE // 2 + 1), dtype=torch.float64, device=dev) for _ in range(S)]
     ap_bufs = [torch.empty_like(sp_bufs[0]) for _ in range(S)]
@@ -894,10 +912,12 @@ def main():
     parity = {"slots": S, "distinct_utterances": S, "slots_bit_identical_to_serial_run": bool(slots_equal),
               "randn_table_intact": bool(tables_ok), "frames": nf * B}
 
-    # latency of ONE job with nothing else in flight (not the headline number)
+    # latency of ONE job with nothing else in flight (not the headline number): a context of its own, no shared-device hint
+    lone = WorldHip(device=local)
+
     def lone_job():
         with torch.cuda.stream(streams[0]):
-            whs[0].analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
+            lone.analyze(x, FS, frame_period=FRAME_PERIOD, sp_out=sp_bufs[0], ap_out=ap_bufs[0])
         torch.cuda.synchronize()
     for _ in range(3):                                   # the parity leg above ran other contexts: settle first
         lone_job()
@@ -1121,6 +1141,8 @@ def main():
         ok = ok and parity["tpos_bit_exact"] and parity["vuv_flips"] == 0 and max(parity["f0"], parity["sp"], parity["ap"]) <= RTOL
     parity["ok"] = bool(ok)
 
+    env_1 = environment_done(WorldHip(device=local))
+    measured_peak(env_1, roofline, *[(leg or {}).get("roofline") for leg in (configs or {}).values()])
     out = {
         "metric": "analysis frames/sec (Harvest+CheapTrick+D4C, 48 kHz, 5 ms hop)",
         "value": value, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "repeats": repeats, "warmup": args.warmup,
@@ -1141,7 +1163,7 @@ def main():
         "first_call_ms": None if not host_to_host else host_to_host.get("cold_start", {}).get("first_call_ms"),
         "randn_table_first_build_ms": None if not host_to_host else host_to_host.get("cold_start", {}).get("randn_table_build_ms"),
         "workspace_bytes": workspace, "randn_table_bytes": table_bytes, "csrc_hash": csrc_hash(),
-        "environment": environment_done(WorldHip(device=local)),
+        "environment": env_1,
     }
     print(json.dumps(out))
     if not ok:

@@ -207,6 +207,14 @@ WORLD_HIP_API const char *world_hip_last_error(void);
  *   6  round 6: + world_hip_abi_version itself; no prototype changed
  * Libraries older than 6 lack the symbol. */
 #define WORLD_HIP_ABI_VERSION 6
+/* Launch-geometry hints of a context (bits; default 0).  Results never depend on them.
+ *   WORLD_HIP_HINT_SHARED_DEVICE  other jobs run on this device at the same time (several contexts on their own streams, as in
+ *       bench.py's headline mode): single-utterance calls then keep the narrow launch shapes that fit beside other jobs'
+ *       frame kernels.  Without it a single-utterance call assumes the device to itself and gives Harvest's one-workgroup-
+ *       per-utterance contour kernels (FixStep1-2 + sections, MergeF0) 1024 threads instead of 256: 0.089 -> 0.047 ms of a
+ *       lone 10 s job, at the price of sixteen wavefronts waiting for one CU when the device is busy. */
+#define WORLD_HIP_HINT_SHARED_DEVICE 1
+WORLD_HIP_API int world_hip_set_hint(WorldHipContext *ctx, int hint);
 WORLD_HIP_API int world_hip_abi_version(void);
 WORLD_HIP_API int world_hip_sync(WorldHipContext *ctx);
 /* bytes of device workspace currently held by the context (its arena) */
@@ -261,7 +269,7 @@ WORLD_HIP_API int world_hip_synthesis_batch(WorldHipContext *ctx, int n_utt, int
                                             const int *y_length, int y_stride, double *d_y);
 
 /* What box is this?  ~50 ms of microbenchmarks on the context's device (synchronous; allocates and frees 2 GB):
- * values[0] shader clock held under a chip-wide FP64 load (MHz), [1] that load's FMA rate (TFLOP/s), [2] / [3] / [4]
+ * values[0] shader clock held under a chip-wide FP64 load (MHz), [1] that load's FMA rate over the whole launch (TFLOP/s; HIP events), [2] / [3] / [4]
  * dependent-load latency of one lane chasing pointers through 2 GB / 64 MB every CU has just read / 1 MB it has just walked (ns per hop), [5] / [6] a dependent LDS read on
  * an idle / a loaded CU (shader cycles), [7] compute units.  n_values >= 8.  bench.py records them in the line's
  * `environment` object: identical binaries ran a lone job 10-90 % slower on some boxes (profiles/r04/README.txt). */

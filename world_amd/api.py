@@ -98,6 +98,8 @@ def load_library(path=LIB_PATH):
                                               C.POINTER(HarvestOption), C.POINTER(CheapTrickOption), C.POINTER(D4COption),
                                               C.c_int, C.POINTER(vp), C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
     lib.world_hip_check_shape.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    if hasattr(lib, "world_hip_set_hint"):
+        lib.world_hip_set_hint.argtypes = [vp, C.c_int]
     if hasattr(lib, "world_hip_probe_machine"):                      # (absent from libraries of earlier rounds: tools/ab.py loads those)
         lib.world_hip_probe_machine.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     lib.world_hip_record_columns.argtypes = [C.c_int, C.c_int]
@@ -392,9 +394,12 @@ class Graph:
 class WorldHip:
     """Batched analysis on one GPU.  Tensors: x [B, L] float64 on the GPU."""
 
-    def __init__(self, device=None, lib_path=LIB_PATH):
+    def __init__(self, device=None, lib_path=LIB_PATH, shared_device=False):
+        """shared_device: other jobs run on this GPU at the same time (world_hip.h: WORLD_HIP_HINT_SHARED_DEVICE) --
+        single-utterance calls keep the narrow launch shapes.  Results never depend on it."""
         import torch
         self.torch = torch
+        self.shared_device = bool(shared_device)
         if not torch.cuda.is_available():
             raise RuntimeError("WorldHip needs a GPU (torch.cuda.is_available() is False)")
         self.lib = load_library(lib_path)
@@ -410,6 +415,8 @@ class WorldHip:
             ctx = self.lib.world_hip_create(self.device.index, C.c_void_p(s))
             if not ctx:
                 raise RuntimeError("world_hip_create: " + self.lib.world_hip_last_error().decode())
+            if self.shared_device and hasattr(self.lib, "world_hip_set_hint"):
+                self.lib.world_hip_set_hint(C.c_void_p(ctx), 1)
             self._ctxs[s] = ctx
         return ctx
 

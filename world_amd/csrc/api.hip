@@ -126,6 +126,7 @@ struct WorldHipContext {
   void *xchg_ready = nullptr, *xchg_done = nullptr;   // events of world_hip_allgather_blocks
   double *d_pk = nullptr;        // dense (tpos, f0) of world_hip_analyze_packed: [2][n_utt][f_stride], grow-only
   size_t pk_cap = 0;
+  int hint = 0;                  // WORLD_HIP_HINT_* bits (world_hip_set_hint)
   double *d_stage = nullptr;     // full records of world_hip_analyze_coded's batch, read by the coders: grow-only
   size_t stage_cap = 0;
   // world_hip_analyze_sharded: this device's exchange stream, input staging (two pinned halves) and device input, grow-only
@@ -612,6 +613,7 @@ static void run_harvest(WorldHipContext *c, int n_utt, int fs, const double *d_x
   p.ev_cap = max_y / 2 + 2;
   p.refine_cap = 2 * static_cast<int>(1.5 * p.afs / opt->f0_floor + 1.0) + 4;
   p.sec_cap = max_fb / 7 + 4;
+  p.lone_job = n_utt == 1 && !(c->hint & WORLD_HIP_HINT_SHARED_DEVICE);
   p.ext_cap = max_fb + 304 * p.sec_cap + 8;
   p.max_half = hb.max_half;
   p.tab = c->tab;
@@ -1452,6 +1454,11 @@ void world_hip_destroy(WorldHipContext *c) {
   delete c;
 }
 
+int world_hip_set_hint(WorldHipContext *ctx, int hint) {
+  if (!ctx) return -1;
+  ctx->hint = hint;
+  return 0;
+}
 int world_hip_abi_version(void) { return WORLD_HIP_ABI_VERSION; }
 const char *world_hip_last_error(void) { return g_last_error.c_str(); }
 

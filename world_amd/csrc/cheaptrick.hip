@@ -202,6 +202,20 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
     double wv[PER], av[PER], nv[PER];
     double s_ww = 0.0, s_a = 0.0, s_n = 0.0, s_w = 0.0;
     {
+      // All of the thread's samples and draws are requested before the first is used, at clamped addresses: a load inside
+      // `if (i < wlen)` is waited for where the branch rejoins, so the PER items took one trip to memory EACH (the window
+      // phase was 16 of the frame's 75 thousand cycles in a loaded CU -- tools/trace_batch.py; d4c_frame's balance pass
+      // learnt this in round 5).  Items beyond the window contribute nothing.
+      double xv[PER];
+      uint32_t nz[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int i = imin(tid + q * nt, wlen - 1);
+        xv[q] = x[(unsigned)imin(x_len - 1, imax(0, origin + i - hw))];
+        nz[q] = noise[(unsigned)i];
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) { xv[q] = keep(xv[q]); nz[q] = keep_word(nz[q]); }   // fetched here, not down in the branches
       double rc, rs, dc, ds;
       sincospi(win_scale * (tid - hw), &rs, &rc);
       sincospi(win_scale * nt, &ds, &dc);
@@ -211,7 +225,7 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
         wv[q] = 0.0; av[q] = 0.0; nv[q] = 0.0;
         if (i < wlen) {
           const double w = 0.5 * rc + 0.5;                   // cos(pi * position * f0), cheaptrick.cpp:101-102
-          const double a = x[imin(x_len - 1, imax(0, origin + i - hw))] * w, n = randn_value(noise[i]) * kTiny;
+          const double a = xv[q] * w, n = randn_value(nz[q]) * kTiny;
           wv[q] = w; av[q] = a; nv[q] = n;
           s_ww += w * w; s_a += a; s_n += n; s_w += w;
         }

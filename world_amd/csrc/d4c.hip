@@ -635,16 +635,32 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   constexpr bool kRot = T * 16 == NMAX;                                // twiddles by constant rotation (fft.h)
   DYN_LDS(lds);
   const int u = blockIdx.y, f = p.frame_lo + blockIdx.x;
-  if (f >= p.b.n_frames[u] || f >= p.frame_hi) return;
-  const size_t fi = (size_t)u * p.b.f_stride + f;
+  const size_t fi = (size_t)u * p.b.f_stride + f;                      // (f < f_stride: launch_d4c's grid ends at the range)
   int tid = wg_thread<T>();
   constexpr int nt = T;                                                // launch_d4c launches exactly T threads
+  // Everything the workgroup needs from global memory before its first window is REQUESTED here, ahead of the two early
+  // exits and of the table staging: the frame's F0 and LoveTrain statistic, its position, the utterance's length and
+  // first-pass draw count, and the thread's share of the earlier frames' draw counts.  Asked for where each is first used
+  // they were six dependent trips to L2 (n_frames -> F0 -> statistic -> tables -> counts, two at a time -> position):
+  // ~9 of the frame's 157 thousand cycles in a loaded CU (tools/trace_batch.py).
+  const int nf_u = p.b.n_frames[u];
+  const double f0_in = p.f0[fi], ap0_in = p.ap0[fi], pos = p.tpos[fi];
+  const int x_len = p.b.x_len[u];
+  const unsigned draws1_u = p.draws1[u];
+  constexpr int kCntAhead = 8;                                         // counts per thread in flight: 8 T frames = 10 s at 48 kHz
+  unsigned cnt_v[kCntAhead];
+  {
+    const unsigned *cnt = p.draws2 + (size_t)u * p.b.f_stride;
+#pragma unroll
+    for (int k = 0; k < kCntAhead; ++k) cnt_v[k] = cnt[imin(tid + k * nt, f)];      // (index f itself is this frame's: in range)
+  }
+  if (f >= nf_u || f >= p.frame_hi) return;
   // where the wavefronts' shares of a window's power cross (scratch doubles): clear of the balance pass's block sum,
   // which a faster wavefront may still be reading -- that one takes doubles [0, waves) and [32, 32 + waves), so the
   // sixteen wavefronts of the 16384-point shape push this area up into the select's (48..63: idle until the band loop)
   constexpr int kPwAt = T > 8 * WAVE ? 48 : 40;
-  const double f0 = d4c_sane_f0(p.f0[fi], p.b.fs);
-  if (f0 == 0 || p.ap0[fi] <= p.threshold) return;                     // d4c.cpp:386
+  const double f0 = d4c_sane_f0(f0_in, p.b.fs);
+  if (f0 == 0 || ap0_in <= p.threshold) return;                        // d4c.cpp:386
   const bool trace_me = f == WH_TRACE_FRAME && u == WH_TRACE_UTT; (void)trace_me;
   wh_bartrace_arm(trace_me);                                           // (-DWH_BARTRACE only: tools/barrier_skew.py)
   WH_STAMP(32, 0);
@@ -700,17 +716,17 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   };
 
   const double *x = p.b.x + (size_t)u * p.b.x_stride;
-  const int x_len = p.b.x_len[u];
-  const double pos = p.tpos[fi];
   const double cf0 = kFloorF0D4C > f0 ? kFloorF0D4C : f0;
   // Where the frame's draws sit in the reference's one randn() stream: behind the first pass's (draws1) and behind those
   // of every earlier frame of the utterance that LoveTrain let through -- <= 8 KB of counts summed by the workgroup itself.
   unsigned stream_at;
   {
     const unsigned *cnt = p.draws2 + (size_t)u * p.b.f_stride;
-    int s_ = 0;                                             // (sums wrap like the unsigned stream position they feed: two's complement)
-    for (int g = tid; g < f; g += nt) s_ = (int)((unsigned)s_ + cnt[g]);
-    s_ = wave_sum_int(s_);
+    unsigned su = 0;                                         // (sums wrap like the unsigned stream position they feed)
+#pragma unroll
+    for (int k = 0; k < kCntAhead; ++k) su += tid + k * nt < f ? cnt_v[k] : 0u;     // requested at the top of the kernel
+    for (int g = tid + kCntAhead * nt; g < f; g += nt) su += cnt[g];                // (utterances beyond 8 T frames)
+    int s_ = wave_sum_int((int)su);
     int *part = reinterpret_cast<int *>(Zr);                 // (nothing lives in LDS yet)
     if (lane_id() == 0) part[wave_in_block()] = s_;
     __syncthreads();
@@ -719,7 +735,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
 #ifndef WORLD_EMU
     tot_ = __builtin_amdgcn_readfirstlane(tot_);             // the same in every lane: a scalar register, like the offset a scan kernel used to leave
 #endif
-    stream_at = p.draws1[u] + (unsigned)tot_;
+    stream_at = draws1_u + (unsigned)tot_;
     // (no closing barrier: the next write to this area lies behind the first window's block sum, which nobody passes
     // before everybody has arrived there -- past these reads)
   }

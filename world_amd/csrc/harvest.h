@@ -20,6 +20,8 @@ struct HarvestParams {
   int ev_cap;              // capacity of one event list
   int refine_cap;          // LDS doubles per refinement window
   int sec_cap;             // voiced sections per utterance slot
+  int lone_job;            // host only: this job has the device to itself (one utterance, no WORLD_HIP_HINT_SHARED_DEVICE):
+                           // the one-workgroup-per-utterance contour kernels take 1024 threads instead of 256
   int ext_cap;             // doubles of extended-section storage per utterance
   const int *y_len;        // [n_utt] decimated length = ceil(x_len / ratio)
   const int *nfb;          // [n_utt] basic frame count

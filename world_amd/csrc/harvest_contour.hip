@@ -522,7 +522,8 @@ __device__ __forceinline__ void hc_merge_in_hbm(const HarvestParams &p, int u) {
 // scores are looked up a frame per lane with all slots of the frame in flight, and summed in frame order -- the
 // reference's order -- instead of two dependent trips to HBM per frame (4 us a frame: 1.4 ms for the slowest
 // utterance of a 128-batch).
-constexpr int kMergeThreads = 256;       // (round 4: 1024 -- sixteen wavefronts that waited, in the in-flight mode, for a CU other jobs had drained)
+constexpr int kMergeThreads = 256;       // (round 4: 1024 -- sixteen wavefronts that waited, in the in-flight mode, for a CU other jobs had drained;
+constexpr int kMergeThreadsLone = 1024;  //  round 6: both, chosen by the call -- HarvestParams::lone_job)
 constexpr int kMergeLdsSections = 1024;  // section records kept in LDS (41 KB: what one retiring d4c_frame workgroup frees on a
                                          // CU -- decimate.h); an utterance with more voiced sections takes hc_merge_in_hbm
 inline size_t hc_merge_lds_bytes(int sections) {      // (at least a block collective's scratch: the section passes behind the merge)
@@ -682,7 +683,7 @@ __device__ __forceinline__ void hc_merge_utt(const HarvestParams &p, int cap, in
     for (int q = 0; q < kB; ++q) if (f0 + q * nt < nf) out[f0 + q * nt] = v[q];
   }
 }
-__global__ void __launch_bounds__(kMergeThreads) hc_merge(HarvestParams p, int cap) {
+__global__ void __launch_bounds__(kMergeThreadsLone) hc_merge(HarvestParams p, int cap) {
   DYN_LDS(lds);
   const int u = blockIdx.x;
   hc_merge_utt(p, cap, u, lds);
@@ -873,14 +874,16 @@ __global__ void hc_output(HarvestParams p) {
 void launch_harvest_contour(const HarvestParams &p, int max_fb, int max_frames, hipStream_t stream) {
   const int B = p.b.n_utt;
   SecArgs a2 = {p.c2, 1, 2 * kExtMargin, nullptr, nullptr};
-  WH_BLOCKS(hc_step12_sections, dim3(B), 256, (64 + kStepLds) * sizeof(double), stream, p, a2);
+  // a job that has the device to itself: sixteen wavefronts per utterance for the two one-workgroup kernels (VERDICT r05
+  // item 7: the shapes sized for the in-flight mode had cost a lone job 0.04 ms)
+  WH_BLOCKS(hc_step12_sections, dim3(B), p.lone_job ? 1024 : 256, (64 + kStepLds) * sizeof(double), stream, p, a2);
   WH_BLOCKS(hc_extend, dim3(imin(p.sec_cap, kExtendBlocks), B), kExtendThreads, 64 * sizeof(double), stream, p);
   // WORLD_HIP_MERGE_LDS_SECTIONS lowers the number of section records hc_merge keeps in LDS (tests use it to send an
   // ordinary utterance down the route of one with thousands of sections)
   static const int merge_limit = [] { const char *e = getenv("WORLD_HIP_MERGE_LDS_SECTIONS"); return e ? imax(0, imin(kMergeLdsSections, atoi(e))) : kMergeLdsSections; }();
   const int merge_cap = imin(p.sec_cap, merge_limit);
   // (+ FixStep4 and the two section passes around it; then hc_smooth writes basic_f0's voiced frames)
-  WH_BLOCKS(hc_merge, dim3(B), kMergeThreads, hc_merge_lds_bytes(merge_cap), stream, p, merge_cap);
+  WH_BLOCKS(hc_merge, dim3(B), p.lone_job ? kMergeThreadsLone : kMergeThreads, hc_merge_lds_bytes(merge_cap), stream, p, merge_cap);
   // one wavefront per block: each reserves LDS for the longest section the batch can hold
   const int smooth_lds = imin(kSmoothLdsMax, max_fb + 3 * kSmoothTail + kSmoothSlack);
   WH_BLOCKS(hc_smooth, dim3(imin(p.sec_cap, kSmoothBlocks), B), WAVE, smooth_lds * sizeof(double), stream, p, smooth_lds);

@@ -127,8 +127,6 @@ struct WorldHipContext {
   double *d_pk = nullptr;        // dense (tpos, f0) of world_hip_analyze_packed: [2][n_utt][f_stride], grow-only
   size_t pk_cap = 0;
   int hint = 0;                  // WORLD_HIP_HINT_* bits (world_hip_set_hint)
-  double *d_stage = nullptr;     // full records of world_hip_analyze_coded's batch, read by the coders: grow-only
-  size_t stage_cap = 0;
   // world_hip_analyze_sharded: this device's exchange stream, input staging (two pinned halves) and device input, grow-only
   hipStream_t xstream = nullptr;
   double *h_xin = nullptr, *d_xin = nullptr;
@@ -257,6 +255,11 @@ struct RowLayout {
   size_t col_bytes = 0;          // bytes from a record's start to this stage's row (the stage's output pointer = records' base)
   int f32 = 0;                   // 1: rows stored as float (narrow wire format)
   double *rec = nullptr;         // D4C only: records' base for the (tpos, f0) head of every record
+  // coded records (run_analyze_coded): > 0 = the stage writes its CODED row -- CheapTrick the first code_dims mel-cepstrum
+  // coefficients (with the coder's tables), D4C the band aperiodicities -- instead of the row itself
+  int code_dims = 0;
+  const int *code_knot = nullptr;
+  const double *code_frac = nullptr, *code_w_re = nullptr, *code_w_im = nullptr;
   // frames [frame_lo, frame_hi) of every utterance only (stream positions as in a whole-utterance call); skip_prepare:
   // the offsets (and D4C's LoveTrain pass) of the previous call with the same shape are still in the workspace
   int frame_lo = 0, frame_hi = 0x7FFFFFFF;
@@ -345,6 +348,9 @@ static CtParams setup_cheaptrick(WorldHipContext *c, int n_utt, int fs, const do
   p.out_row = lay.rows ? upload(c, std::vector<int>(lay.rows, lay.rows + n_utt)) : nullptr;
   p.out_stride = lay.stride ? lay.stride : (size_t)(opt->fft_size / 2 + 1);
   p.out_col_bytes = lay.col_bytes; p.out_f32 = lay.f32;
+  p.code_ndim = lay.code_dims; p.code_knot = lay.code_knot; p.code_frac = lay.code_frac;
+  p.code_w_re = lay.code_w_re; p.code_w_im = lay.code_w_im;
+  if (p.code_ndim > 0 && (lay.f32 || !lay.code_knot || p.code_ndim > opt->fft_size / 4 + 1)) fail("CheapTrick: bad coded-row layout");
   p.f0_floor = 3.0 * fs / (opt->fft_size - 3.0);                       // cheaptrick.cpp:196-198
   c->arena.skip_to(0);
   p.offsets = c->arena.take<unsigned>((size_t)n_utt * f_stride);
@@ -420,6 +426,8 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
   p.out_row = lay.rows ? upload(c, std::vector<int>(lay.rows, lay.rows + n_utt)) : nullptr;
   p.out_stride = lay.stride ? lay.stride : (size_t)(fft_size / 2 + 1);
   p.out_col_bytes = lay.col_bytes; p.out_f32 = lay.f32;
+  p.code_nap = lay.code_dims;
+  if (p.code_nap > 0 && lay.f32) fail("D4C: bad coded-row layout");
   p.rec = lay.rec;
   c->arena.skip_to(cheaptrick_arena_bytes(n_utt, f_stride, fft_size));      // behind CheapTrick's part for this shape
   const size_t region_lo = c->arena.used;
@@ -1192,18 +1200,14 @@ static void run_analyze_dense(WorldHipContext *c, int n_utt, int fs, const doubl
 // ---------------------------------------------------------------------------
 // Harvest + CheapTrick + D4C of one batch straight into packed records (include/world_hip.h: world_hip_analyze_packed)
 // ---------------------------------------------------------------------------
-static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
-                               const HarvestOption *hopt, const CheapTrickOption *copt, const D4COption *dopt,
-                               long long first_row, double *d_block, int cols) {
-  check_batch(n_utt, fs, d_x, x_stride, x_length);
+// code_ndim > 0: CODED records [tpos, f0, mel-cepstrum[code_ndim], band aperiodicity[nap]] (cols = coded_cols): the frame
+// kernels code their own rows (cheaptrick.hip: ct_frame's coded epilogue; d4c.hip: d4c_finish) -- no dense row exists anywhere
+static void analyze_into_records(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                                 const HarvestOption *hopt, const CheapTrickOption *copt, const D4COption *dopt,
+                                 long long first_row, double *d_block, int cols, int code_ndim) {
   const int nb = copt->fft_size / 2 + 1;
   // the record width names the wire format: 2 + 2 nb doubles = f64 spectra, 2 + nb doubles = f32 spectra
-  const int wire = cols == record_cols(copt->fft_size, 1) ? 1 : 0;
-  if (cols != record_cols(copt->fft_size, wire))
-    fail("analyze_packed: %d columns, fft_size %d needs %d (f64 records) or %d (f32 spectra)", cols, copt->fft_size,
-         record_cols(copt->fft_size, 0), record_cols(copt->fft_size, 1));
-  if (!d_block) fail("analyze_packed: null block");
-  if (first_row < 0) fail("analyze_packed: negative first_row");
+  const int wire = code_ndim == 0 && cols == record_cols(copt->fft_size, 1) ? 1 : 0;
   std::vector<int> nf(n_utt), rows(n_utt);
   long long row = first_row;
   int f_stride = 1;
@@ -1228,19 +1232,39 @@ static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const doub
   lay_sp.rows = lay_ap.rows = rows.data(); lay_sp.stride = lay_ap.stride = (size_t)cols;
   lay_sp.f32 = lay_ap.f32 = wire == 1;
   const size_t elem = wire == 1 ? sizeof(float) : sizeof(double);
-  lay_sp.col_bytes = 2 * sizeof(double); lay_ap.col_bytes = 2 * sizeof(double) + elem * nb;
+  lay_sp.col_bytes = 2 * sizeof(double);
+  lay_ap.col_bytes = 2 * sizeof(double) + (code_ndim > 0 ? sizeof(double) * code_ndim : elem * nb);
   lay_ap.rec = d_block;
+  if (code_ndim > 0) {
+    const CodecTables &t = codec_tables(c, fs, copt->fft_size);
+    lay_sp.code_dims = code_ndim;
+    lay_sp.code_knot = t.d_knot_code; lay_sp.code_frac = t.d_frac_code; lay_sp.code_w_re = t.d_wc_re; lay_sp.code_w_im = t.d_wc_im;
+    lay_ap.code_dims = number_of_aperiodicities(fs);
+  }
   run_spectral_stages(c, n_utt, fs, d_x, x_stride, x_length, nf.data(), f_stride, d_tpos, d_f0, copt, dopt, d_block,
                       d_block, lay_sp, lay_ap);
+}
+static void run_analyze_packed(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
+                               const HarvestOption *hopt, const CheapTrickOption *copt, const D4COption *dopt,
+                               long long first_row, double *d_block, int cols) {
+  check_batch(n_utt, fs, d_x, x_stride, x_length);
+  const int wire = cols == record_cols(copt->fft_size, 1) ? 1 : 0;
+  if (cols != record_cols(copt->fft_size, wire))
+    fail("analyze_packed: %d columns, fft_size %d needs %d (f64 records) or %d (f32 spectra)", cols, copt->fft_size,
+         record_cols(copt->fft_size, 0), record_cols(copt->fft_size, 1));
+  if (!d_block) fail("analyze_packed: null block");
+  if (first_row < 0) fail("analyze_packed: negative first_row");
+  analyze_into_records(c, n_utt, fs, d_x, x_stride, x_length, hopt, copt, dopt, first_row, d_block, cols, 0);
 }
 
 // ---------------------------------------------------------------------------
 // Harvest + CheapTrick + D4C of one batch into CODED records [tpos, f0, mel-cepstrum[ndim], band aperiodicity[nap]]
-// (include/world_hip.h: world_hip_analyze_coded; SURVEY.md 8f.1: "shrink the all-gather and D2H by 10-17x" -- 31 x at 48 kHz
-// with 60 coefficients: 536 instead of 16 416 bytes per frame).  The full records of the batch go to a staging block the
-// context owns (HBM only: nothing of it crosses a link) and the two coders read their rows out of it at the records' stride
-// and write theirs at the coded records': CodeSpectralEnvelope / CodeAperiodicity of exactly the analysis a dense call
-// returns (reference src/codec.cpp:217-236, 268-297).
+// (include/world_hip.h: world_hip_analyze_coded; SURVEY.md 8f.1: the coders "fuse onto K6/K8 outputs" and "shrink the
+// all-gather and D2H by 10-17x" -- 31 x at 48 kHz with 60 coefficients: 536 instead of 16 416 bytes per frame).
+// CodeSpectralEnvelope / CodeAperiodicity (reference src/codec.cpp:217-236, 268-297) of exactly the analysis a dense call
+// returns, computed by the kernels that produce the rows: ct_frame turns its log envelope into the mel-cepstrum in the LDS
+// it already holds, d4c_finish evaluates the two bins each band value interpolates.  (Round 5 wrote full 16 KB records to a
+// staging block and ran the stand-alone coders over it: one extra HBM write + read per frame and two more launches.)
 // ---------------------------------------------------------------------------
 static int coded_cols(int fs, int ndim) { return 2 + ndim + number_of_aperiodicities(fs); }
 static void run_analyze_coded(WorldHipContext *c, int n_utt, int fs, const double *d_x, int x_stride, const int *x_length,
@@ -1249,27 +1273,12 @@ static void run_analyze_coded(WorldHipContext *c, int n_utt, int fs, const doubl
   check_batch(n_utt, fs, d_x, x_stride, x_length);
   if (!d_block) fail("analyze_coded: null block");
   if (first_row < 0) fail("analyze_coded: negative first_row");
-  const int nap = number_of_aperiodicities(fs), nb = copt->fft_size / 2 + 1;
+  const int nap = number_of_aperiodicities(fs);
   if (nap < 1) fail("analyze_coded: fs=%d has no aperiodicity band", fs);
+  if (3000.0 * nap > fs / 2.0) fail("analyze_coded: band centre beyond fs/2");
   if (ndim < 1 || ndim > copt->fft_size / 4 + 1) fail("analyze_coded: number_of_dimensions %d outside [1, fft_size/4+1]", ndim);
   if (cols != coded_cols(fs, ndim)) fail("analyze_coded: %d columns, %d coefficients at fs=%d need %d", cols, ndim, fs, coded_cols(fs, ndim));
-  long long rows = 0;
-  for (int u = 0; u < n_utt; ++u) rows += frame_count(fs, x_length[u], hopt->frame_period);
-  if (first_row + rows > 0x7FFFFFFFll) fail("block exceeds 2^31 records");
-  const int full = record_cols(copt->fft_size, 0);
-  const size_t need = (size_t)rows * full;
-  if (c->stage_cap < need) {
-    devrt::sync(c->stream);
-    if (c->d_stage) { devrt::dfree(c->d_stage); ++c->generation; }
-    c->stage_cap = need + need / 8;
-    c->d_stage = static_cast<double *>(devrt::dmalloc(sizeof(double) * c->stage_cap));
-  }
-  run_analyze_packed(c, n_utt, fs, d_x, x_stride, x_length, hopt, copt, dopt, 0, c->d_stage, full);
-  if (rows == 0) return;
-  double *out = d_block + (size_t)first_row * cols;
-  launch_copy_record_heads(c->d_stage, full, out, cols, rows, c->stream);
-  run_codec(c, kCodeSp, (int)rows, fs, copt->fft_size, ndim, c->d_stage + 2, out + 2, full, cols);
-  run_codec(c, kCodeAp, (int)rows, fs, copt->fft_size, nap, c->d_stage + 2 + nb, out + 2 + ndim, full, cols);
+  analyze_into_records(c, n_utt, fs, d_x, x_stride, x_length, hopt, copt, dopt, first_row, d_block, cols, ndim);
 }
 
 // ---------------------------------------------------------------------------
@@ -1427,7 +1436,6 @@ void world_hip_destroy(WorldHipContext *c) {
     if (c->arena.base) devrt::dfree(c->arena.base);
     if (c->d_nuttall) devrt::dfree(c->d_nuttall);
     if (c->d_pk) devrt::dfree(c->d_pk);
-    if (c->d_stage) devrt::dfree(c->d_stage);
     if (c->d_xin) devrt::dfree(c->d_xin);
     if (c->h_xin) devrt::hfree_pinned(c->h_xin);
     if (c->xstream) { devrt::sync(c->xstream); devrt::stream_destroy(c->xstream); }

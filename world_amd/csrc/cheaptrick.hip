@@ -359,6 +359,27 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
   block_irfft<kCtMaxLr, LGN>(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   WH_STAMP(0, 9);
   char *out_at = reinterpret_cast<char *>(p.spectrogram + (p.out_row ? (size_t)p.out_row[u] + f : fi) * p.out_stride) + p.out_col_bytes;
+  if (p.code_ndim > 0) {
+    // ---- CodeSpectralEnvelope of this row (codec.cpp:268-297), fused: the row never goes to HBM ---------------------------
+    // codec_code_sp (codec.hip) on the dense row, operation for operation: log of the value the row would hold, interp1 onto the
+    // mel axis through the coder's own tables, DCTForCodec's reordering, ONE real transform of fft_size/2 points on the same
+    // plan and twiddle table (the staged table is the coder's: its lg_md is this kernel's lgn - 1), the first ndim bins.
+    block_map<4, double>(half + 1, [&](int i) { return log(exp(rfft_in(Z, i))); }, [&](int i, double lg) { P[i] = lg; });
+    __syncthreads();                                   // every reader of the envelope is done: Z becomes the DCT's input
+    const int md = half;
+    for (int i = tid; i < md; i += nt) {
+      const int k = p.code_knot[i];
+      const double v = P[k - 1] + p.code_frac[i] * (P[k] - P[k - 1]);
+      const int dest = (i & 1) ? md / 2 + (md - 1 - i) / 2 : i / 2;
+      rfft_in(Z, dest) = v;
+    }
+    const double norm = sqrt(static_cast<double>(md));
+    double *out = reinterpret_cast<double *>(out_at);
+    block_rfft(Z, lgn - 1, tw, [&](int k, double re, double im) {
+      if (k < p.code_ndim) out[k] = (re * p.code_w_re[k] - im * p.code_w_im[k]) / norm;
+    });
+    return;
+  }
   if (p.out_f32) {
     float *out = reinterpret_cast<float *>(out_at);
     block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = static_cast<float>(v); });

@@ -27,7 +27,5 @@ void launch_code_spectral_envelope(const CodecParams &p, hipStream_t stream);
 void launch_decode_spectral_envelope(const CodecParams &p, hipStream_t stream);
 void launch_code_aperiodicity(const CodecParams &p, hipStream_t stream);
 void launch_decode_aperiodicity(const CodecParams &p, hipStream_t stream);
-// (tpos, f0) heads of packed records: dst[row * dst_stride + {0, 1}] = src[row * src_stride + {0, 1}]
-void launch_copy_record_heads(const double *src, size_t src_stride, double *dst, size_t dst_stride, long rows, hipStream_t stream);
 
 }  // namespace world_hip

@@ -117,16 +117,6 @@ __global__ void codec_decode_ap(CodecParams p) {
   p.out[(size_t)row * (p.out_stride ? p.out_stride : (size_t)nb) + j] = v;
 }
 
-__global__ void codec_copy_heads(const double *src, size_t src_stride, double *dst, size_t dst_stride, long rows) {
-  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
-  dst[row * dst_stride] = src[row * src_stride];
-  dst[row * dst_stride + 1] = src[row * src_stride + 1];
-}
-void launch_copy_record_heads(const double *src, size_t src_stride, double *dst, size_t dst_stride, long rows, hipStream_t stream) {
-  WH_THREADS(codec_copy_heads, rows, 1, 1, stream, src, src_stride, dst, dst_stride, rows);
-}
-
 void launch_code_spectral_envelope(const CodecParams &p, hipStream_t stream) {
   WH_BLOCKS(codec_code_sp, dim3(p.rows), 256, code_sp_lds_bytes(p.lg_md), stream, p);
 }

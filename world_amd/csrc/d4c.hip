@@ -1240,7 +1240,20 @@ __global__ void d4c_finish(D4cParams p) {
   float *row32 = reinterpret_cast<float *>(row_at);                    // the narrow wire format (p.out_f32)
   const double f0 = d4c_sane_f0(p.f0[fi], p.b.fs);
   if (p.rec && tid == 0) { double *r = p.rec + orow * p.out_stride; r[0] = p.tpos[fi]; r[1] = p.f0[fi]; }   // the record's head (F0 as it was given)
+  // CodeAperiodicity of a row (codec.cpp:217-236; codec.hip: codec_code_ap), fused: band b's value is interp1Q of
+  // 20 log10(row) at 3000 (b + 1) Hz -- two of the row's values, formed here exactly as the dense row would hold them
+  auto code_bands = [&](auto ap_value) __attribute__((always_inline)) {
+    for (int band = tid; band < p.code_nap; band += nt) {
+      const double pos = (3000.0 * (band + 1.0) - 0) / (static_cast<double>(fs) / p.fft_out);
+      const int b = static_cast<int>(pos);
+      const double fr = pos - b;
+      const double y0 = 20 * log10(ap_value(b));
+      const double dy = b < nb_out - 1 ? 20 * log10(ap_value(b + 1)) - y0 : 0.0;
+      row[band] = y0 + dy * fr;
+    }
+  };
   if (f0 == 0 || p.ap0[fi] <= p.threshold) {                          // d4c.cpp:323-328,386
+    if (p.code_nap > 0) { code_bands([&](int) { return 1.0 - kTiny; }); return; }
     if (p.out_f32) { for (int i = tid; i < nb_out; i += nt) row32[i] = static_cast<float>(1.0 - kTiny); }
     else { for (int i = tid; i < nb_out; i += nt) row[i] = 1.0 - kTiny; }
     return;
@@ -1257,7 +1270,7 @@ __global__ void d4c_finish(D4cParams p) {
   __syncthreads();
   const double *coarse_in = coarse_db;
   const int nk = p.nap + 2;
-  for (int i = tid; i < nb_out; i += nt) {
+  auto ap_value = [&](int i) __attribute__((always_inline)) {
     double xi = static_cast<double>(i) * fs / p.fft_out;
     int cnt = 0;                                       // knots <= xi  (histc semantics)
     for (int k = 0; k < nk; ++k) {
@@ -1270,7 +1283,11 @@ __global__ void d4c_finish(D4cParams p) {
     double x1 = k <= p.nap ? k * 3000.0 : fs / 2.0;
     double s = (xi - x0) / (x1 - x0);
     double y = cval(k - 1) + s * (cval(k) - cval(k - 1));
-    const double v = exp10(y / 20.0);                   // the reference: pow(10.0, y / 20.0) -- same value to an ulp or two, a third of the instructions
+    return exp10(y / 20.0);                            // the reference: pow(10.0, y / 20.0) -- same value to an ulp or two, a third of the instructions
+  };
+  if (p.code_nap > 0) { code_bands(ap_value); return; }
+  for (int i = tid; i < nb_out; i += nt) {
+    const double v = ap_value(i);
     if (p.out_f32) row32[i] = static_cast<float>(v); else row[i] = v;
   }
 }

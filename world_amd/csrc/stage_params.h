@@ -24,6 +24,13 @@ struct CtParams {
   // whole utterance: ct_prepare always covers every frame).  0 / INT_MAX = all.
   int frame_lo, frame_hi;
   int skip_prepare;      // 1: the offsets of an earlier call with the same shape are still in the workspace
+  // Coded records (world_hip_analyze_coded; SURVEY.md 8f.1: the coders "fuse onto K6/K8 outputs"): code_ndim > 0 = the frame
+  // kernel writes CodeSpectralEnvelope's first code_ndim coefficients (codec.cpp:268-297) of ITS row instead of the row --
+  // the values codec_code_sp would compute from the dense row, bit for bit -- at the row's place in the record.  The tables
+  // are the stand-alone coder's (api.hip: codec_tables).
+  int code_ndim;
+  const int *code_knot;
+  const double *code_frac, *code_w_re, *code_w_im;
 };
 
 struct D4cParams {
@@ -52,6 +59,7 @@ struct D4cParams {
   int lg_d4c;             // log2 of fft_size_d4c
   int nap;                // number_of_aperiodicities
   int wl;                 // Nuttall window length
+  int code_nap;           // > 0: d4c_finish writes CodeAperiodicity's band values (codec.cpp:217-236) of its row instead of the row
   int band_center[8];     // static_cast<int>(3000 (band + 1) fft_size_d4c / fs), d4c.cpp:207-208: the centre bin of band b's slice
                           // (host arithmetic, the reference's expression: in the kernel it was a 20-instruction FP64 division per band)
   // Frame range of d4c_frame / d4c_finish (LoveTrain and the first offset scan always cover every frame: the second

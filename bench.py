@@ -440,23 +440,29 @@ def main():
     def timed_region(step, finish, steps, est_ms_per_step):
         """`repeats` blocks of `steps` steps inside one barrier + synchronize bracket; max over ranks"""
         repeats = max(1, int(1.25 * args.min_wall * 1e3 / max(est_ms_per_step * steps, 1e-3) + 0.999)) if args.min_wall > 0 else 1
-        if world > 1:
-            r = torch.tensor([repeats], device=dev)
-            dist.all_reduce(r, op=dist.ReduceOp.MAX)
-            repeats = int(r.item())
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(repeats * steps):
-            step()
-        finish()
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        for attempt in range(3):
+            if world > 1:
+                r = torch.tensor([repeats], device=dev)
+                dist.all_reduce(r, op=dist.ReduceOp.MAX)
+                repeats = int(r.item())
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(repeats * steps):
+                step()
+            finish()
+            torch.cuda.synchronize()
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if dt >= args.min_wall or args.min_wall <= 0:
+                break
+            # the estimate was too optimistic (a region of 1.93 s was committed once): the whole region again, longer --
+            # only the last one is reported
+            repeats = int(repeats * 1.3 * args.min_wall / max(dt, 1e-6)) + 1
         return dt, repeats
 
     def estimate(step, finish, n=3):

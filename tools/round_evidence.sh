@@ -11,7 +11,7 @@
 #      tools/roofline_check.py over the CSVs
 # Everything lands in gpurun_out/evidence_<round>/ and profiles/<round>/ on the box; gpurun merges gpurun_out/ back.
 set -u
-RND=${1:-r05}; shift || true
+RND=${1:-r06}; shift || true
 ALL=""; LDS=0
 for a in "$@"; do case $a in --all) ALL="--all";; --lds) LDS=1;; esac; done
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

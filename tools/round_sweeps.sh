@@ -1,7 +1,7 @@
 #!/bin/bash
 # The randomised sweeps against the reference and the long utterance, on the tree as it stands (one gpurun call):
 #   tools/round_sweeps.sh <round> <seed>   -> profiles/<round>/fuzz_sweeps.txt (copied to gpurun_out/ for the merge back)
-RND=${1:-r05}; SEED=${2:-52}
+RND=${1:-r06}; SEED=${2:-52}
 OUT=profiles/$RND/fuzz_sweeps.txt; mkdir -p profiles/$RND
 {
 echo "Randomised sweeps against the reference on the round's final kernels (world_amd/csrc hash $(python -c 'import bench; print(bench.csrc_hash())'); one gpurun call, MI355X):"

@@ -155,7 +155,10 @@ __device__ __forceinline__ void ct_wave_prefix_sum(double *seg, int seg_len) {
 // TB: the threads the instantiation is launched with (0: read from the launch -- the emulator's one thread).  512 for
 // the 8192-point transform: one frame then owns 118 KB of LDS, one workgroup per CU -- the shape exists so that f0 floors
 // below 35 Hz at 48 kHz and sampling rates above 96 kHz run at all, not to be fast.
-template <int PER, int LGN, int TB>
+// CODED: the instantiation that writes coded rows (CtParams::code_ndim > 0).  A kernel of its own: the coder's radix-16
+// transform raised the DENSE kernel's registers from 95 to 128 when both lived in one body -- four wavefronts per SIMD
+// instead of five, ct_frame +8 % in a batch (A/B, round 6).
+template <int PER, int LGN, int TB, bool CODED = false>
 // (the 4096-point frame owns 59 KB of LDS: two workgroups per CU whatever the registers, so it may have 256 of them --
 // its 48 window values per thread spilled at the 128 of four workgroups per CU)
 __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 2 : 4) ct_frame(CtParams p) {   // (threads, waves per SIMD)
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
   block_irfft<kCtMaxLr, LGN>(Z, lgn, tw, [&](int k) { cplx c; c.re = P[k]; c.im = 0.0; return c; });
   WH_STAMP(0, 9);
   char *out_at = reinterpret_cast<char *>(p.spectrogram + (p.out_row ? (size_t)p.out_row[u] + f : fi) * p.out_stride) + p.out_col_bytes;
-  if (p.code_ndim > 0) {
+  if constexpr (CODED) {
     // ---- CodeSpectralEnvelope of this row (codec.cpp:268-297), fused: the row never goes to HBM ---------------------------
     // codec_code_sp (codec.hip) on the dense row, operation for operation: log of the value the row would hold, interp1 onto the
     // mel axis through the coder's own tables, DCTForCodec's reordering, ONE real transform of fft_size/2 points on the same
@@ -379,8 +382,7 @@ __global__ void __launch_bounds__(TB > 0 ? TB : 256, TB > 256 ? 1 : LGN == 12 ? 
       if (k < p.code_ndim) out[k] = (re * p.code_w_re[k] - im * p.code_w_im[k]) / norm;
     });
     return;
-  }
-  if (p.out_f32) {
+  } else if (p.out_f32) {
     float *out = reinterpret_cast<float *>(out_at);
     block_map<4, double>(half + 1, [&](int i) { return exp(rfft_in(Z, i)); }, [&](int i, double v) { out[i] = static_cast<float>(v); });
   } else {
@@ -405,12 +407,19 @@ void launch_cheaptrick(const CtParams &p, int max_frames_all, hipStream_t stream
   const dim3 grid(max_frames, p.b.n_utt);
   const size_t lds = ct_frame_lds_bytes(p.lg_fft);
 #ifdef WORLD_EMU
-  devrt::launch_blocks("ct_frame", ct_frame<8192, 0, 0>, grid, 256, lds, stream, p);
+  if (p.code_ndim > 0) devrt::launch_blocks("ct_frame_coded", ct_frame<8192, 0, 0, true>, grid, 256, lds, stream, p);
+  else devrt::launch_blocks("ct_frame", ct_frame<8192, 0, 0>, grid, 256, lds, stream, p);
 #else
   // Workgroup size follows the transform: fft_size 1024 (fs <= 24 kHz) runs with 128 threads (64 butterflies per
   // radix-8 stage; measured 1.33 ms for 64 x 1001 frames against 1.60 with 256 threads and 1.49 with 64), 2048 and
   // 4096 with 256.  The three sizes the sampling rates of speech lead to get compile-time plans.
-  if (p.lg_fft == 10) devrt::launch_blocks("ct_frame", ct_frame<8, 10, 128>, grid, 128, lds, stream, p);
+  if (p.code_ndim > 0) {
+    if (p.lg_fft == 10) devrt::launch_blocks("ct_frame_coded", ct_frame<8, 10, 128, true>, grid, 128, lds, stream, p);
+    else if (p.lg_fft == 11) devrt::launch_blocks("ct_frame_coded", ct_frame<8, 11, 256, true>, grid, 256, lds, stream, p);
+    else if (p.lg_fft == 12) devrt::launch_blocks("ct_frame_coded", ct_frame<16, 12, 256, true>, grid, 256, lds, stream, p);
+    else if (p.lg_fft == 13) devrt::launch_blocks("ct_frame_coded", ct_frame<16, 0, 512, true>, grid, 512, lds, stream, p);
+    else devrt::launch_blocks("ct_frame_coded", ct_frame<8, 0, 128, true>, grid, 128, lds, stream, p);
+  } else if (p.lg_fft == 10) devrt::launch_blocks("ct_frame", ct_frame<8, 10, 128>, grid, 128, lds, stream, p);
   else if (p.lg_fft == 11) devrt::launch_blocks("ct_frame", ct_frame<8, 11, 256>, grid, 256, lds, stream, p);
   else if (p.lg_fft == 12) devrt::launch_blocks("ct_frame", ct_frame<16, 12, 256>, grid, 256, lds, stream, p);
   else if (p.lg_fft == 13) devrt::launch_blocks("ct_frame", ct_frame<16, 0, 512>, grid, 512, lds, stream, p);

@@ -563,7 +563,8 @@ __device__ __forceinline__ void d4c_love_frame(const D4cParams &p, char *lds) {
     block_cfft_dif_static<LGN - 1, 3, T>(Z, tw);
     const cplx wb = twiddle(tw, tid, LGN, -1);
     const int h = 1 << (LGN - 1);
-    rfft_merge_items_w<kItems, T>(Z, LGN, plan, [&](int m, int) { return mul_w16_fwd(wb, m); },
+    // (2 X[k]: lo / hi is a ratio of power sums -- fft.h: rfft_merge_items_w<TWICE>)
+    rfft_merge_items_w<kItems, T, true>(Z, LGN, plan, [&](int m, int) { return mul_w16_fwd(wb, m); },
                                   [&](int, int k, double ar, double ai, bool paired, double br, double bi) {
       band_power(k, ar, ai);
       if (paired) band_power(h - k, br, bi);
@@ -1193,7 +1194,8 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     unsigned long long key[kBins];
 #pragma unroll
     for (int e = 0; e < kBins; ++e) key[e] = D4C_KEY_PAD;
-    rfft_merge_items_rot<kItems, T>(Z, lgn, plan, tw, wb, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
+    // (the band's keys are 4 |X|^2: only the quotient of the band's two sums is ever used -- d4c_finish -- and that is scale-free)
+    rfft_merge_items_rot<kItems, T, true>(Z, lgn, plan, tw, wb, [&](int m, int, double ar, double ai, bool paired, double br, double bi) {
       key[2 * m] = (unsigned long long)__double_as_longlong(ar * ar + ai * ai);
       if (paired) key[2 * m + 1] = (unsigned long long)__double_as_longlong(br * br + bi * bi);
     });

@@ -728,7 +728,11 @@ __device__ __forceinline__ cplx mul_w16_fwd(cplx a, int m) {
   }
 }
 // wk(m, k): the merge twiddle e^{-2 pi i k / N} of item m
-template <int KITEMS, int NT, class Wk, class Emit>
+// TWICE: emit 2 X[k] instead of X[k] -- the four halvings of every paired item are not performed (and the three unpaired
+// bins doubled instead, on the one or two threads that own them).  For callers whose result is a RATIO of sums of |X|^2
+// (D4C's band aperiodicity and LoveTrain statistic): every power is exactly 4 x the plain one (powers of two commute with
+// every rounding on the way), so is every sum, and the quotient is the same bits.
+template <int KITEMS, int NT, bool TWICE = false, class Wk, class Emit>
 __device__ __forceinline__ void rfft_merge_items_w(cplx *z, int lgn, const FftPlan &plan, Wk wk, Emit emit) {
   const int lgh = lgn - 1, h = 1 << lgh, q = h >> 1;
   const int tid = wg_thread<NT>(), nt = wg_size<NT>();
@@ -737,17 +741,25 @@ __device__ __forceinline__ void rfft_merge_items_w(cplx *z, int lgn, const FftPl
     const int k = tid + m * nt;
     if (k == 0) {
       const cplx za = z[fft_slot(plan, 0)];
-      emit(m, 0, za.re + za.im, 0.0, true, za.re - za.im, 0.0);
+      const double a = za.re + za.im, b = za.re - za.im;
+      if (TWICE) emit(m, 0, a + a, 0.0, true, b + b, 0.0);
+      else emit(m, 0, a, 0.0, true, b, 0.0);
     } else if (k < q) {
       const cplx za = z[fft_slot(plan, k)], zb = z[fft_slot(plan, h - k)];
       cplx e, o;
-      e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
-      o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
+      if (TWICE) {
+        e.re = za.re + zb.re; e.im = za.im - zb.im;
+        o.re = za.im + zb.im; o.im = zb.re - za.re;
+      } else {
+        e.re = 0.5 * (za.re + zb.re); e.im = 0.5 * (za.im - zb.im);
+        o.re = 0.5 * (za.im + zb.im); o.im = -0.5 * (za.re - zb.re);
+      }
       const cplx ow = cmul(o, wk(m, k));
       emit(m, k, e.re + ow.re, e.im + ow.im, true, e.re - ow.re, ow.im - e.im);
     } else if (k == q) {
       const cplx za = z[fft_slot(plan, q)];            // k = h/2: w = -i, X = conj(z)
-      emit(m, q, za.re, -za.im, false, 0.0, 0.0);
+      if (TWICE) emit(m, q, za.re + za.re, -(za.im + za.im), false, 0.0, 0.0);
+      else emit(m, q, za.re, -za.im, false, 0.0, 0.0);
     }
 #ifndef WORLD_EMU
     // the callers live at the edge of their register budget: keep the scheduler from hoisting all items'
@@ -765,9 +777,9 @@ __device__ __forceinline__ void rfft_merge_items(cplx *z, int lgn, const FftPlan
 // twiddle is wbase * W16^m -- a constant rotation (at most 4 FP64 operations, none for m = 0 and 4) instead of a table
 // lookup with its quadrant selects and the fine-level products (a third of a merge's instructions).  Other
 // workgroup sizes (the one-thread host emulation) take the table.
-template <int KITEMS, int NT, class Emit>
+template <int KITEMS, int NT, bool TWICE = false, class Emit>
 __device__ __forceinline__ void rfft_merge_items_rot(cplx *z, int lgn, const FftPlan &plan, const TwLds &tw, cplx wbase, Emit emit) {
-  rfft_merge_items_w<KITEMS, NT>(z, lgn, plan, [&](int m, int k) {
+  rfft_merge_items_w<KITEMS, NT, TWICE>(z, lgn, plan, [&](int m, int k) {
     if (NT * 16 == (1 << lgn)) return mul_w16_fwd(wbase, m);
     return twiddle(tw, k, lgn, -1);
   }, emit);

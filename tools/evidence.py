@@ -55,6 +55,32 @@ def plan(everything):
     return out
 
 
+def prune(table, units, kernels):
+    """drop what can no longer be looked up honestly: entries of library kernels that the sources no longer have (hc_base,
+    d4c_prepare2 ...), and older spellings of a kernel whose template arguments changed ("ct_frame<8, 11, 256>" beside
+    "ct_frame<8, 11, 256, false>": bench.py summed both into the pipeline's flop per frame once) -- a base name keeps its
+    entries with the CURRENT unit hash only, if it has any"""
+    every_base = set()
+    for entry in table.get("configs", {}).values():
+        for name, e in entry.get("kernels", {}).items():
+            if "unit_hash" in e:
+                every_base.add(name.split("<")[0])
+    for entry in table.get("configs", {}).values():
+        ks = entry.get("kernels", {})
+        for name in list(ks):
+            e, b = ks[name], name.split("<")[0]
+            if "unit_hash" not in e:
+                if b.startswith(("hv_", "hc_", "ct_", "d4c_", "dio_", "sm_", "rng_", "sy_", "codec_")) and b not in kernels:
+                    del ks[name]                                # a library kernel of an earlier round, never re-stamped
+                continue
+            if b not in kernels:
+                del ks[name]
+                continue
+            fresh = [n for n in ks if n.split("<")[0] == b and ks[n].get("unit_hash") == units[kernels[b]]]
+            if fresh and name not in fresh:
+                del ks[name]
+
+
 def install(src, rnd):
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
@@ -92,6 +118,7 @@ def install(src, rnd):
                     b = kk.split("<")[0]
                     if b in kernels:
                         e["unit_hash"] = units[kernels[b]]
+    prune(old, units, kernels)
     old["csrc_hash"] = bench.csrc_hash()
     old["unit_hashes"] = units
     with open(PMC_PATH, "w") as f:

@@ -688,6 +688,25 @@ __global__ void hv_refine(HarvestParams p) {
           int i = g;
           // four samples per trip: the kernel is bound by instruction issue (four waves per SIMD cover the recurrence's
           // latency), and index, compare and branch are a third of a two-sample trip
+#ifndef WORLD_EMU
+          // ... and the trips EVERY phase can take (g + 4 G t + 3 G < blen for g = G - 1 too: blen / 4G of them) run on a
+          // wave-uniform counter: no per-lane index, compare and exec-mask update -- 1 vector instruction of overhead per
+          // 16 FP64 instead of 5 (round 6: 60 % of this kernel's vector instructions were not FP64).  Same operations,
+          // same order per lane; the per-lane loops below take what is left (at most 7 samples).
+          {
+            const int n_uni = blen / (4 * G);
+            const cplx *yp = yw + g;
+#pragma unroll 1
+            for (int t = 0; t < n_uni; ++t, yp += 4 * G) {
+              const cplx p0 = yp[0], p1 = yp[G], p2 = yp[2 * G], p3 = yp[3 * G];
+              const double sa = fma(c2, s1, p0.re) - s2, ta = fma(c2, t1, p0.im) - t2;
+              const double sb = fma(c2, sa, p1.re) - s1, tb = fma(c2, ta, p1.im) - t1;
+              s2 = fma(c2, sb, p2.re) - sa; t2 = fma(c2, tb, p2.im) - ta;
+              s1 = fma(c2, s2, p3.re) - sb; t1 = fma(c2, t2, p3.im) - tb;
+            }
+            i += 4 * G * n_uni;
+          }
+#endif
           for (; i + 3 * G < blen; i += 4 * G) {
             const cplx p0 = yw[i], p1 = yw[i + G], p2 = yw[i + 2 * G], p3 = yw[i + 3 * G];
             const double sa = fma(c2, s1, p0.re) - s2, ta = fma(c2, t1, p0.im) - t2;

@@ -116,6 +116,9 @@ struct WorldHipContext {
   world_hip::HarvestBands bands;
   double *d_nuttall = nullptr;   // D4C band window
   int nuttall_len = 0;
+  double *d_ap_frac = nullptr;   // d4c_finish's per-bin interpolation weight and knot (D4cParams::ap_frac / ap_knot), for
+  int *d_ap_knot = nullptr;      //   (ap_grid_fs, ap_grid_fft)
+  int ap_grid_fs = 0, ap_grid_fft = 0;
   void *dio_bands = nullptr;     // world_hip::DioBands (cached DIO filter tables)
   double *d_dc_remover = nullptr; // GetDCRemover(fft_size) of the synthesiser
   int dc_remover_len = 0;
@@ -417,6 +420,35 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
     devrt::sync(c->stream);
     c->nuttall_len = wl;
   }
+  if (c->ap_grid_fs != fs || c->ap_grid_fft != fft_size) {
+    // GetAperiodicity's interp1 (d4c.cpp:330-338) of the nap + 2 coarse values at knots [0, 3000, .., 3000 nap, fs/2] onto the
+    // caller's bins i fs / fft_size: knot (histc) and weight of every bin, with the expressions d4c_finish evaluated per
+    // bin and frame until round 6 (same operands, same order: the same bits)
+    const int nb_out = fft_size / 2 + 1, nk = nap + 2;
+    std::vector<double> frac(nb_out);
+    std::vector<int> knot(nb_out);
+    for (int i = 0; i < nb_out; ++i) {
+      const double xi = static_cast<double>(i) * fs / fft_size;
+      int cnt = 0;
+      for (int k = 0; k < nk; ++k) {
+        const double kn = k <= nap ? k * 3000.0 : fs / 2.0;
+        if (kn <= xi) cnt++;
+      }
+      const int k = cnt < 1 ? 1 : (cnt > nk - 1 ? nk - 1 : cnt);
+      const double x0 = (k - 1) <= nap ? (k - 1) * 3000.0 : fs / 2.0;
+      const double x1 = k <= nap ? k * 3000.0 : fs / 2.0;
+      knot[i] = k;
+      frac[i] = (xi - x0) / (x1 - x0);
+    }
+    devrt::sync(c->stream);
+    if (c->d_ap_frac) { devrt::dfree(c->d_ap_frac); devrt::dfree(c->d_ap_knot); ++c->generation; }
+    c->d_ap_frac = static_cast<double *>(devrt::dmalloc(sizeof(double) * nb_out));
+    c->d_ap_knot = static_cast<int *>(devrt::dmalloc(sizeof(int) * nb_out));
+    devrt::h2d(c->d_ap_frac, frac.data(), sizeof(double) * nb_out, c->stream);
+    devrt::h2d(c->d_ap_knot, knot.data(), sizeof(int) * nb_out, c->stream);
+    devrt::sync(c->stream);
+    c->ap_grid_fs = fs; c->ap_grid_fft = fft_size;
+  }
   size_t fr = (size_t)n_utt * f_stride;
   D4cParams p;
   p.b.n_utt = n_utt; p.b.fs = fs; p.b.x_stride = x_stride; p.b.f_stride = f_stride; p.b.x = d_x;
@@ -450,6 +482,7 @@ static D4cParams setup_d4c(WorldHipContext *c, int n_utt, int fs, const double *
   }
   p.noise = ensure_noise(c, (size_t)max_frames * d4c_max_draws_per_frame(fs));
   p.nuttall = c->d_nuttall;
+  p.ap_frac = c->d_ap_frac; p.ap_knot = c->d_ap_knot;
   p.tab = c->tab;
   p.threshold = opt->threshold;
   p.fft_out = fft_size;
@@ -1435,6 +1468,7 @@ void world_hip_destroy(WorldHipContext *c) {
     devrt::dfree(const_cast<uint4 *>(c->tab.jump));
     if (c->arena.base) devrt::dfree(c->arena.base);
     if (c->d_nuttall) devrt::dfree(c->d_nuttall);
+    if (c->d_ap_frac) { devrt::dfree(c->d_ap_frac); devrt::dfree(c->d_ap_knot); }
     if (c->d_pk) devrt::dfree(c->d_pk);
     if (c->d_xin) devrt::dfree(c->d_xin);
     if (c->h_xin) devrt::hfree_pinned(c->h_xin);

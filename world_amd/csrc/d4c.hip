@@ -1272,18 +1272,14 @@ __global__ void d4c_finish(D4cParams p) {
   __syncthreads();
   const double *coarse_in = coarse_db;
   const int nk = p.nap + 2;
+  // (the bin's knot and weight -- histc over the nap + 2 knots, a division -- are the same for every frame: api.hip builds
+  // them once per (fs, fft_out) with the expressions this lambda used to evaluate per bin and frame: two thirds of the
+  // kernel's vector instructions were not FP64)
+  (void)nk;
   auto ap_value = [&](int i) __attribute__((always_inline)) {
-    double xi = static_cast<double>(i) * fs / p.fft_out;
-    int cnt = 0;                                       // knots <= xi  (histc semantics)
-    for (int k = 0; k < nk; ++k) {
-      double knot = k <= p.nap ? k * 3000.0 : fs / 2.0;
-      if (knot <= xi) cnt++;
-    }
-    int k = cnt < 1 ? 1 : (cnt > nk - 1 ? nk - 1 : cnt);
+    const int k = p.ap_knot[i];
+    const double s = p.ap_frac[i];
     auto cval = [&](int j) { return j == 0 ? -60.0 : (j == p.nap + 1 ? -kTiny : coarse_in[j]); };   // d4c.cpp:373-375
-    double x0 = (k - 1) <= p.nap ? (k - 1) * 3000.0 : fs / 2.0;
-    double x1 = k <= p.nap ? k * 3000.0 : fs / 2.0;
-    double s = (xi - x0) / (x1 - x0);
     double y = cval(k - 1) + s * (cval(k) - cval(k - 1));
     return exp10(y / 20.0);                            // the reference: pow(10.0, y / 20.0) -- same value to an ulp or two, a third of the instructions
   };

@@ -59,6 +59,9 @@ struct D4cParams {
   int lg_d4c;             // log2 of fft_size_d4c
   int nap;                // number_of_aperiodicities
   int wl;                 // Nuttall window length
+  const double *ap_frac;  // [fft_out/2+1] d4c_finish's interpolation onto the caller's bins: the weight s and the upper knot k of
+  const int *ap_knot;     //   every bin (GetAperiodicity's interp1 over [0, 3 kHz .., fs/2], d4c.cpp:330-338, :373-375) depend on
+                          //   (fs, fft_out) only -- host-built with the kernel's own expressions, cached in the context
   int code_nap;           // > 0: d4c_finish writes CodeAperiodicity's band values (codec.cpp:217-236) of its row instead of the row
   int band_center[8];     // static_cast<int>(3000 (band + 1) fft_size_d4c / fs), d4c.cpp:207-208: the centre bin of band b's slice
                           // (host arithmetic, the reference's expression: in the kernel it was a 20-instruction FP64 division per band)

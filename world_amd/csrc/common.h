@@ -67,14 +67,14 @@ __device__ __forceinline__ double fast_div(double a, double b) {
 // A value passed through keep() counts as used where it is computed: the compiler's sinking pass cannot move its
 // arithmetic down to a later (conditional) use.
 __device__ __forceinline__ double keep(double v) {
-#ifndef WORLD_EMU
+#if !defined(WORLD_EMU) && !defined(WORLD_SIMT)
   asm volatile("" : "+v"(v));
 #endif
   return v;
 }
 
 __device__ __forceinline__ uint32_t keep_word(uint32_t v) {
-#ifndef WORLD_EMU
+#if !defined(WORLD_EMU) && !defined(WORLD_SIMT)
   asm volatile("" : "+v"(v));
 #endif
   return v;

@@ -24,6 +24,11 @@
 #ifdef D4C_FP_CONTRACT
 #pragma clang fp contract(fast)
 #endif
+// Host tests (round 6): this unit has NO second spelling for the CPU suite any more.  tests/emu compiles it as the GPU
+// does -- WAVE = 64, the real workgroup sizes, DPP / v_readlane / ballots -- against tests/emu/simt_host.h (every thread a
+// fibre, cross-lane instructions as lock-step rendezvous: -DWORLD_SIMT), so the register-first-stage transforms, the
+// lane-indexed DC correction, the radix select's wave scans and the band loop's pruned first stage that ship are the ones
+// `pytest -m "not gpu"` runs against the golden fixtures (rounds 3-5: 12 -> 21 -> 23 #ifdef-ed host-emulation sites here).
 // The LDS slot swizzle of this unit's transforms (fft.h: swz): the map tools/lds_swizzle_search.py found for the radix-8
 // plans.  Round 3 measured it on lone kernels (d4c_frame -2 %, everything else +3 %) and left the shipped map alone; under
 // load -- a 128-utterance batch, profiles/r05/lds_under_load_ab.txt -- d4c_frame gains 2.5 % (10.71 -> 10.45 ms) and every
@@ -63,11 +68,7 @@ __global__ void spectral_prepare(CtParams cp, D4cParams dp) {
 // first kSelHists histograms are zeroed up front), two for the final sums.
 // keys one thread of a 256-thread workgroup receives from block_rfft of NMAX points
 template <int NMAX> struct SelKeys {
-#ifdef WORLD_EMU
-  static constexpr int n = NMAX / 2 + 1;
-#else
   static constexpr int n = 2 * ((NMAX / 4 + 1 + 255) / 256);
-#endif
 };
 constexpr int kSelHists = 3;
 // key[q], q < mine: bit patterns of this thread's elements (n elements block-wide).
@@ -92,17 +93,12 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     if (q < mine) { const int h = (int)(key[q] >> 32); hmin = h < hmin ? h : hmin; hmax = h > hmax ? h : hmax; }
   for (int i = tid; i < kSelHists * 256; i += nt) hist[i] = 0;
   unsigned long long kmin, kmax;
-#ifndef WORLD_EMU
   hmin = -wave_max_int(-(lower_bound ? hmax : hmin)); hmax = wave_max_int(hmax);
   // its own scratch area (doubles 48..63): whoever read it last (this function, one band ago) is behind several barriers
   int *hs = reinterpret_cast<int *>(scratch + 48);
   if (lane == 0) { hs[wv] = hmin; hs[16 + wv] = hmax; }
   __syncthreads();                                   // also: the histograms are zero before anybody counts
   for (int w = 0; w < nw; ++w) { hmin = hs[w] < hmin ? hs[w] : hmin; hmax = hs[16 + w] > hmax ? hs[16 + w] : hmax; }
-#else
-  (void)lane; (void)wv; (void)nw;
-  if (lower_bound) hmin = hmax;
-#endif
   if (hmin != hmax) {
     // bits below the high word do not matter: the first differing bit is in the high word
     kmin = (unsigned long long)(unsigned)hmin << 32; kmax = (unsigned long long)(unsigned)hmax << 32;
@@ -111,14 +107,12 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q)
       if (q < mine) { kmin = key[q] < kmin ? key[q] : kmin; kmax = key[q] > kmax ? key[q] : kmax; }
-#ifndef WORLD_EMU
     wave_minmax_u64(kmin, kmax);
     unsigned long long *ks = reinterpret_cast<unsigned long long *>(scratch);
     __syncthreads();
     if (lane == 0) { ks[wv] = kmin; ks[32 + wv] = kmax; }
     __syncthreads();
     for (int w = 0; w < nw; ++w) { kmin = ks[w] < kmin ? ks[w] : kmin; kmax = ks[32 + w] > kmax ? ks[32 + w] : kmax; }
-#endif
   }
   WH_STAMP(0, 3);
   const unsigned long long diff = kmin ^ kmax;
@@ -147,7 +141,6 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
     // finds the lane holding the rank, that lane the bin
     static_assert(256 / WAVE == 4 || WAVE == 1, "four bins per lane");
     int digit = -1, below = -1, hsel = -1;
-#ifndef WORLD_EMU
     const int4 c4 = *reinterpret_cast<const int4 *>(h + 4 * lane);
     const int local = (c4.x + c4.y) + (c4.z + c4.w);
     int tot, before = wave_excl_scan_int(local, &tot);
@@ -159,16 +152,6 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
       below = before + (j == 0 ? 0 : j == 1 ? a1 : j == 2 ? a2 : a3);
       hsel = j == 0 ? c4.x : j == 1 ? c4.y : j == 2 ? c4.z : c4.w;
     }
-#else
-    {
-      int acc = 0;
-      for (int j = 0; j < 256; ++j) {
-        const int c = h[j];
-        if (remaining < acc + c) { digit = j; below = acc; hsel = c; break; }
-        acc += c;
-      }
-    }
-#endif
     // exactly one lane found the bin: two max-reductions broadcast (digit, below) and hsel
     {
       const int got = wave_max_int(digit < 0 ? -1 : (digit << 14) | below);     // below <= n <= 10 keys x 1024 threads < 2^14
@@ -223,9 +206,7 @@ __device__ __forceinline__ void block_smallest_sum(const unsigned long long (&ke
 // Typical band: 3 barriers, ~200 VALU instructions.  A bin with several keys gets one 256-bin pass over its own range;
 // whatever is still ambiguous after that (or a spectrum whose thread maxima all share a high word) goes to the general
 // routine -- same result, every thread of the block takes the same path.
-// ---- the pieces that are wave collectives on the GPU and plain loops in the host emulation (tests/emu: ONE thread plays
-// the whole workgroup and owns every key) -- everything around them, i.e. every decision the selection takes, is shared ----
-#ifndef WORLD_EMU
+// ---- the selection's wave collectives ----
 // smallest of the threads' maxima and the largest key, over the workgroup (high words); one barrier
 template <int NT> __device__ __forceinline__ void sel_floor_top(int hm, int *hs, int *fl, int *tp) {
   constexpr int nw = NT / WAVE;
@@ -283,27 +264,9 @@ __device__ __forceinline__ void sel_locate_256(const int *h1, int K1, int *bin, 
 __device__ __forceinline__ void sel_zero_bins(int *hist, int tid, int nt) {
   for (int i = tid; i < 336; i += nt) reinterpret_cast<int4 *>(hist)[i] = make_int4(0, 0, 0, 0);
 }
-#else
-__device__ __forceinline__ void sel_walk_from_top(const int *h, int n, int K, int *bin, int *above, int *bucket) {
-  int a = 0, b = n - 1;
-  while (b > 0 && a + h[b] < K) a += h[b--];
-  *bin = b; *above = a; *bucket = h[b];
-}
-__device__ __forceinline__ void sel_locate_two_level(const int *hist, int K, int *bin, int *above, int *bucket) {
-  sel_walk_from_top(hist, 1024, K, bin, above, bucket);
-}
-__device__ __forceinline__ void sel_locate_256(const int *h1, int K1, int *bin, int *bucket) {
-  int above;
-  sel_walk_from_top(h1, 256, K1, bin, &above, bucket);
-}
-__device__ __forceinline__ void sel_zero_bins(int *hist, int, int) { for (int i = 0; i < 1344; ++i) hist[i] = 0; }
-#endif
 
 // key[0 .. kKeys-2): owned by every thread; key[kKeys-2]: thread 0 only (the merge's unpaired bin), 0 elsewhere;
-// key[kKeys-1]: 0.  (Host emulation: the one thread owns every slot; `threads` = the workgroup size the GPU would run,
-// and slot pairs (2 m, 2 m + 1) with m = t mod threads are what its thread t would own -- the floor below is then the
-// GPU's, and so is every decision that follows from it.)  hist: 1344 ints of LDS.  K: how many of the largest keys are
-// EXCLUDED from *partial.
+// key[kKeys-1]: 0.  hist: 1344 ints of LDS.  K: how many of the largest keys are EXCLUDED from *partial.
 // Returns true when *partial / *total are the BLOCK's sums (the general routine ran), false when they are the calling
 // wavefront's share of them: the caller adds the wavefronts' shares up whenever it next crosses a barrier anyway (the
 // block sum here -- LDS, barrier, LDS -- was a quarter of the routine's time in a CU whose LDS pipe is busy with other
@@ -312,14 +275,9 @@ template <int NT, int kKeys>
 __device__ __forceinline__ bool block_excluding_largest(const unsigned long long (&key)[kKeys], int K, int *hist, double *scratch,
                                                         double *partial, double *total, bool trace_me = false, int threads = NT) {
   (void)trace_me;
-#ifndef WORLD_EMU
   constexpr int kFull = kKeys - 2;
   static_assert(NT % WAVE == 0 && NT / WAVE <= 16, "whole wavefronts");
   const int hx = (int)(key[kFull] >> 32);                                 // 0 except on thread 0
-#else
-  constexpr int kFull = kKeys;                                            // every slot is this thread's
-  const int hx = 0;
-#endif
   const int tid = wg_thread<NT>();
   int hk[kFull];
 #pragma unroll
@@ -329,24 +287,12 @@ __device__ __forceinline__ bool block_excluding_largest(const unsigned long long
   // Every thread's largest key is a candidate, and there are `threads` >= K of them: the K-th largest key is >= the smallest
   // of the threads' maxima (`floor`), so keys below it are below the threshold whatever their rank.
   int fl, tp;
-#ifndef WORLD_EMU
   {
     int hm = hx;
 #pragma unroll
     for (int q = 0; q < kFull; ++q) hm = hk[q] > hm ? hk[q] : hm;
     sel_floor_top<NT>(hm, reinterpret_cast<int *>(scratch + 48), &fl, &tp);   // doubles 48..63: nobody else's scratch
   }
-#else
-  {
-    (void)scratch;
-    fl = 0x7fffffff; tp = 0;
-    for (int t = 0; t < threads; ++t) {                                   // the GPU's thread t: slot pairs m = t, t + threads, ...
-      int hm = 0;
-      for (int m = t; 2 * m + 1 < kFull; m += threads) { hm = hk[2 * m] > hm ? hk[2 * m] : hm; hm = hk[2 * m + 1] > hm ? hk[2 * m + 1] : hm; }
-      fl = hm < fl ? hm : fl; tp = hm > tp ? hm : tp;
-    }
-  }
-#endif
   WH_STAMP(0, 3);
   bool fast = threads >= K && tp > fl;
   bool t_low_two = false; (void)t_low_two;                                // (statistics of the WH_TRACE build)
@@ -445,11 +391,7 @@ __device__ __forceinline__ bool block_excluding_largest(const unsigned long long
 // Nuttall-windowed slices from LDS (a first stage that knows all but one input of every butterfly to be zero),
 // and the power values feed the radix select from registers.
 template <int NMAX, int T> struct D4cShape {
-#ifdef WORLD_EMU
-  static constexpr int kItems = NMAX / 4 + 1;          // one emulated thread owns every bin
-#else
   static constexpr int kItems = (NMAX / 4 + 1 + T - 1) / T;
-#endif
   static constexpr int kBins = 2 * kItems;
   static constexpr int kLo = NMAX / 2 / T;             // window samples below N/2 per thread (8 on the GPU)
 };
@@ -602,7 +544,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
 #endif
 // The kernel lives at its register cap: a scheduling fence after every item of a per-bin loop keeps the compiler from
 // putting all items' LDS reads in flight at once (it did, and spilled 170 dwords in the smoothing loops alone).
-#if !defined(WORLD_EMU) && defined(D4C_FENCES)
+#if defined(D4C_FENCES)
 #define D4C_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define D4C_SCHED_FENCE() do { } while (0)
@@ -617,7 +559,7 @@ __global__ void __launch_bounds__(256) d4c_lovetrain(D4cParams p) {
 // stay put -- dozens of loaded values wait in registers and spill.  A value passed through keep() is "used" where
 // it is computed, so its arithmetic stays in front of the branch.
 // (keep() itself lives in common.h)
-#ifndef WORLD_EMU
+#if !defined(WORLD_SIMT)
 #define D4C_FRESH_TID() do { asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0 && tid < T); } while (0)
 #else
 #define D4C_FRESH_TID() do { } while (0)
@@ -667,33 +609,20 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   WH_STAMP(32, 0);
   // On the GPU the transform length is the shape's (launch_d4c picks the instantiation), so the plan, every
   // stage's radix and stride and the digit reversal of the merge steps are compile-time constants.
-#ifdef WORLD_EMU
-  const int lgn = p.lg_d4c;
-#else
   constexpr int lgn = const_log2(NMAX);
-#endif
   const int N = 1 << lgn, H = N / 2, q = H / 2, fs = p.b.fs;
   // LDS: Z (N doubles: the transform, or whatever is exchanged between transforms) | scratch (64) | twiddles | group delay
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *Zr = reinterpret_cast<double *>(lds);
   double *scratch = Zr + N;
-#ifdef WORLD_EMU
-  const TwLds tw = stage_twiddles<T>(scratch + 64, lgn - D4C_TW_LEVEL, p.tab.tw);
-#else
   // ... and behind everything else (d4c_frame_lds_bytes) the twiddles of the transforms' two inner radix-8 stages, one
   // 16-byte entry per distinct value: every one of the frame's 13 transforms reads them (fft.h: stage_direct_twiddles;
   // the barrier in front of the first transform -- the stream-position sum's, below -- publishes them)
   const TwLds tw = stage_direct_twiddles<T>(stage_twiddles<T>(scratch + 64, lgn - D4C_TW_LEVEL, p.tab.tw),
                                             reinterpret_cast<cplx *>(lds + d4c_frame_direct_tw_offset(lgn)),
                                             lgn - 1 - 3, 1 << (lgn - 1 - 6), lgn - 1 - 6, 1 << (lgn - 1 - 9));
-#endif
-#ifdef WORLD_EMU
-  const FftPlan plan = make_plan_max(lgn - 1, 3);
-  auto cfft = [&]() { block_cfft_dif<3>(Z, plan, tw); };
-#else
   constexpr FftPlan plan = make_plan_max(lgn - 1, 3);
   auto cfft = [&]() __attribute__((always_inline)) { block_cfft_dif_static<lgn - 1, 3, T>(Z, tw); };
-#endif
   const cplx wb = twiddle(tw, tid, lgn, -1);                           // e^{-2 pi i tid / N}: every other twiddle of the
                                                                        // thread is this one times a constant
   // body(slot, k) for every bin this thread owns; `slot` is a compile-time constant after unrolling.
@@ -733,9 +662,7 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     __syncthreads();
     int tot_ = 0;
     for (int wv = 0; wv < wg_waves<T>(); ++wv) tot_ += part[wv];
-#ifndef WORLD_EMU
     tot_ = __builtin_amdgcn_readfirstlane(tot_);             // the same in every lane: a scalar register, like the offset a scan kernel used to leave
-#endif
     stream_at = draws1_u + (unsigned)tot_;
     // (no closing barrier: the next write to this area lies behind the first window's block sum, which nobody passes
     // before everybody has arrived there -- past these reads)
@@ -825,7 +752,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       }
     }
   };
-#ifndef WORLD_EMU
   // the same walk with the slot known at compile time: sample H + tid + k T belongs to the thread's element k
   auto hi_samples = [&](const D4cWin &w, double coef, auto body) __attribute__((always_inline)) {
     if (w.wlen > H) {
@@ -842,7 +768,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       }
     }
   };
-#endif
   auto balanced = [&](const D4cWin &w, double (&ulo)[kLo]) __attribute__((always_inline)) {
     double wlo[kLo];
     double s1 = 0.0, s2 = 0.0;
@@ -879,7 +804,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     return coef;
   };
 
-#ifndef WORLD_EMU
   // A transform whose inputs the thread already holds: element tid + r T of the N/2-point buffer is the thread's own
   // sample r (kLo = 8 = the radix), so the FIRST stage runs from registers -- no input pass through LDS (eight 16-byte
   // stores at ~13 cycles each, the LDS's slowest instruction, eight loads and a barrier per transform; the band
@@ -895,7 +819,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     DifStages<lgn - 1, 3, lgn - 1 - 3, T>::run(Z, tw);
     __syncthreads();
   };
-#endif
 
   // ---- GetStaticCentroid (d4c.cpp:90-143) -------------------------------------
   // The centroid of the two positions is summed in LDS (`park`, natural bin order: a thread only ever touches its
@@ -910,7 +833,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     WH_STAMP(32, 1 + 4 * c);
     // even half: e[n] = z[n] + z[n + H], z[n] = u[n] (1 + i (n + 1)); the previous readers of Z are behind a barrier
     double pw = 0.0;
-#ifndef WORLD_EMU
     {
       // the butterfly's eight inputs are the thread's own: e[tid + j T] from sample j (and, for a window longer than N/2,
       // from its upper sample j as well)
@@ -927,27 +849,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       if (lane_id() == 0) scratch[kPwAt + wave_in_block()] = pw;
       cfft_from_registers(a, twiddle(tw, tid, lgn - 1, -1));
     }
-#else
-    {
-#pragma unroll
-      for (int j = 0; j < kLo; ++j) {
-        const int n = tid + j * nt;
-        if (n < H) {
-          cplx e; e.re = ulo[j]; e.im = ulo[j] * (n + 1.0);
-          Z[swz(n)] = e;
-          pw += ulo[j] * ulo[j];
-        }
-      }
-      for_hi(w, coef, [&](int i, double uh) {
-        cplx &e = Z[swz(i - H)];                                       // this thread's own slot
-        e.re += uh; e.im += uh * (i + 1.0);
-        pw += uh * uh;
-      });
-      pw = wave_sum(pw);
-      if (lane_id() == 0) scratch[kPwAt + wave_in_block()] = pw;
-      cfft();
-    }
-#endif
     pw = 0.0;
     for (int wv = 0; wv < wg_waves<T>(); ++wv) pw += scratch[kPwAt + wv];
     const double half_inv_pw = 0.5 / pw;                               // and the 1/2 of Im(P Q)/2
@@ -964,7 +865,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     __syncthreads();
     D4C_FRESH_TID();
     // odd half: o[n] = (z[n] - z[n + H]) W_N^n
-#ifndef WORLD_EMU
     {
       cplx a[8];
 #pragma unroll
@@ -975,27 +875,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       WH_STAMP(32, 3 + 4 * c);
       cfft_from_registers(a, twiddle(tw, tid, lgn - 1, -1));
     }
-#else
-    {
-#pragma unroll
-      for (int j = 0; j < kLo; ++j) {
-        const int n = tid + j * nt;
-        if (n < H) {
-          cplx zl; zl.re = ulo[j]; zl.im = ulo[j] * (n + 1.0);
-          const cplx wn = kRot ? mul_w16_fwd(wb, j) : twiddle(tw, n, lgn, -1);
-          Z[swz(n)] = cmul(zl, wn);
-        }
-      }
-      for_hi(w, coef, [&](int i, double uh) {
-        cplx zh; zh.re = uh; zh.im = uh * (i + 1.0);
-        const cplx d = cmul(zh, twiddle(tw, i - H, lgn, -1));
-        cplx &o = Z[swz(i - H)];
-        o.re -= d.re; o.im -= d.im;
-      });
-      WH_STAMP(32, 3 + 4 * c);
-      cfft();
-    }
-#endif
 #pragma unroll
     for (int m = 0; m < kItems; ++m) {
       const int it = tid + m * nt;
@@ -1033,7 +912,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
     });
     WH_STAMP(32, 11);
     D4C_FRESH_TID();
-#ifndef WORLD_EMU
     // DCCorrection without LDS: a bin k <= upper of the merge's natural order is thread k's first item, so while the
     // mirrored bins sit in lanes of the first wavefront (upper < 64: F0 below ~715 Hz at 48 kHz) the two neighbours of
     // the interpolation come by lane index -- no staging of the low bins in Z, and none of the pass's three barriers
@@ -1049,7 +927,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
         if (lane_id() < nrep) Bn[0] = keep(Bn[0] + (y0 + (y1 - y0) * fr0));
       }
     } else
-#endif
     dc_correct(Bn, for_nat);
     // (the transform's readers are behind the merge's closing barrier -- and dc_correct's own, if it ran: no barrier in front)
     smooth(Bn, for_nat, cf0, B, for_pair, false);
@@ -1101,7 +978,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   double *band_sums = park_global ? after_tw : park + (H + 2);   // [band][partial, total][wavefront]: d4c_frame_lds_bytes
   // the Nuttall taps of the thread's own slice element: the same for every band
   const double nut0 = 2 * tid < wl ? p.nuttall[2 * tid] : 0.0, nut1 = 2 * tid + 1 < wl ? p.nuttall[2 * tid + 1] : 0.0;
-#ifndef WORLD_EMU
   // What every band's first stage needs and no band changes: the stage's twiddle (it used to be looked up again per band:
   // two LDS reads, the quadrant selects, the fine-level product) and the taps of the thread's SECOND slice element
   // (packed element tid + T; zero beyond the window -- at 48 kHz only thread 0 has one)
@@ -1111,7 +987,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
   double nut2 = 0.0, nut3 = 0.0;
   if (second) { nut2 = p.nuttall[2 * (tid + T)]; nut3 = 2 * (tid + T) + 1 < wl ? p.nuttall[2 * (tid + T) + 1] : 0.0; }
   const bool any_second = kNzR == 2 && __builtin_amdgcn_ballot_w64(second) != 0ull;      // wave-uniform
-#endif
   for (int band = 0; band < p.nap; ++band) {
     const int lo_k = p.band_center[band] - hwl;
     D4C_FRESH_TID();
@@ -1129,13 +1004,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       }
       return v;
     };
-#ifdef WORLD_EMU
-    {
-      cplx head[NMAX / 2];
-      for (int n = 0; n < nz; ++n) head[n] = slice(n);
-      block_cfft_dif_head<3>(Z, plan, tw, [&](int n) { return head[n]; }, nz);
-    }
-#else
     {
       constexpr int R = 8;
       const int sh = plan.lg - 3, qq = 1 << sh;         // qq == T: one butterfly per thread (launch_d4c)
@@ -1189,7 +1057,6 @@ __global__ void __launch_bounds__(T, D4C_MIN_WAVES) d4c_frame(D4cParams p) {
       DifStages<lgn - 1, 3, lgn - 1 - 3, T>::run(Z, tw);
       __syncthreads();
     }
-#endif
     if (band == 0) WH_STAMP(32, 16);
     unsigned long long key[kBins];
 #pragma unroll
@@ -1317,13 +1184,9 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
     // band 0.97 -> 0.65
     const dim3 love_grid(max_frames, p.b.n_utt);
     const size_t love_lds = d4c_love_lds_bytes(p.lg_love);
-#ifdef WORLD_EMU
-    devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<0>, love_grid, 256, love_lds, stream, p);
-#else
     if (p.lg_love == 11) devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<11>, love_grid, 128, love_lds, stream, p);
     else if (p.lg_love == 12) devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<12>, love_grid, 256, love_lds, stream, p);
     else devrt::launch_blocks("d4c_lovetrain", d4c_lovetrain<0>, love_grid, p.lg_love <= 11 ? 128 : 256, love_lds, stream, p);
-#endif
   }
   // one radix-8 butterfly per thread: 128 / 256 / 512 threads for the 2048- / 4096- / 8192-point internal FFT
   // (fs <= 24 kHz / <= 48 kHz / <= 96 kHz); the register arrays are sized per shape
@@ -1338,14 +1201,10 @@ void launch_d4c(const D4cParams &p, int max_frames, hipStream_t stream) {
     q.frame_lo = p.frame_lo + lo;
     q.frame_hi = imin(q.frame_lo + per_launch, p.frame_lo + range_frames);
     const dim3 grid(q.frame_hi - q.frame_lo, p.b.n_utt);
-#ifdef WORLD_EMU
-    devrt::launch_blocks("d4c_frame", d4c_frame<16384, 1>, grid, 1, lds, stream, q);
-#else
     if (p.lg_d4c == 11) devrt::launch_blocks("d4c_frame", d4c_frame<2048, 128>, grid, 128, lds, stream, q);
     else if (p.lg_d4c == 12) devrt::launch_blocks("d4c_frame", d4c_frame<4096, 256>, grid, 256, lds, stream, q);
     else if (p.lg_d4c == 13) devrt::launch_blocks("d4c_frame", d4c_frame<8192, 512>, grid, 512, lds, stream, q);
     else devrt::launch_blocks("d4c_frame", d4c_frame<16384, 1024>, grid, 1024, lds, stream, q);
-#endif
   }
   WH_BLOCKS(d4c_finish, dim3(range_frames, p.b.n_utt), 256, 8 * sizeof(double), stream, p);
 }

@@ -105,6 +105,11 @@ void launch_blocks(const char * /*name*/, K kernel, dim3 grid, int /*threads*/, 
   emu_run_end();
 }
 }  // namespace devrt
+#elif defined(WORLD_SIMT)
+// ------------------------------------------------------------------ wave-accurate host emulation of ONE unit's GPU path
+// (TEST INFRASTRUCTURE, tests/emu/simt_host.h: the unit is compiled as the GPU compiles it -- WAVE = 64, real workgroup
+// sizes, every #ifndef WORLD_EMU branch -- with fibres for threads and rendezvous for the cross-lane instructions)
+#include "simt_host.h"
 #else
 // ------------------------------------------------------------------ gfx950
 #include <hip/hip_runtime.h>
@@ -219,7 +224,9 @@ template <int NT> __device__ __forceinline__ int wg_thread() {
 #ifdef WH_FRESH_TID
   // a unit's choice (harvest.hip): an opaque copy per call, so that what a stage derives from the thread index (LDS
   // addresses, butterfly numbers) is recomputed where it is used instead of living in registers across a kernel's outer loop
+#ifndef WORLD_SIMT
   if constexpr (NT > 0) asm volatile("" : "+v"(t));
+#endif
 #endif
   if constexpr (NT > 0) __builtin_assume(t >= 0 && t < NT);
 #endif

@@ -60,6 +60,7 @@ struct Wave {
   unsigned long long seq = 0;                 // rendezvous counter: the operands of operation `seq` live in buf[seq & 1]
   unsigned long long buf[2][64];
   unsigned long long arrived_mask[2] = {0, 0};
+  const void *site[2] = {nullptr, nullptr};    // the instruction (call site) the lanes of this rendezvous came from: all the same, or abort
 };
 // the running block (thread-local: host threads emulate independent launches side by side)
 struct Block {
@@ -85,6 +86,14 @@ static inline void __syncthreads() { simt::barrier(); }
 // ---- host runtime of devrt.h (the classic emulation's: tests/emu/emu_rt.cpp defines it in libworld_emu.so; this unit only
 // launches, so it needs none of it) --------------------------------------------------------------------------------------
 namespace devrt {
+// (device memory is the host's: the few host-side helpers units call between launches)
+static inline void *dmalloc(size_t bytes) { void *p = malloc(bytes ? bytes : 1); memset(p, 0xA5, bytes); return p; }
+static inline void dfree(void *p) { free(p); }
+static inline void h2d(void *dst, const void *src, size_t n, hipStream_t) { memcpy(dst, src, n); }
+static inline void d2h(void *dst, const void *src, size_t n, hipStream_t) { memcpy(dst, src, n); }
+static inline void d2d(void *dst, const void *src, size_t n, hipStream_t) { memcpy(dst, src, n); }
+static inline void dzero(void *dst, size_t n, hipStream_t) { memset(dst, 0, n); }
+static inline void sync(hipStream_t) {}
 template <class K, class... A>
 void launch_blocks(const char *name, K kernel, dim3 grid, int threads, size_t lds, hipStream_t, A... args) {
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;
@@ -94,6 +103,11 @@ void launch_blocks(const char *name, K kernel, dim3 grid, int threads, size_t ld
 
 // ---- scalar intrinsics ---------------------------------------------------------------------------------------------------
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline unsigned __brev(unsigned v) {
   unsigned r = 0;
   for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);

@@ -134,10 +134,20 @@ void run_block(int threads) {
 
 void barrier() { park(1); }
 
-const unsigned long long *exchange(unsigned long long mine, unsigned long long *mask) {
+__attribute__((noinline)) const unsigned long long *exchange(unsigned long long mine, unsigned long long *mask) {
   Fibre *f = g_block.cur;
   Wave &w = R.waves[f->wave];
   const int slot = (int)(w.seq & 1);
+  // Lock-step is only what the GPU does while the wavefront's lanes execute the SAME instruction: lanes that meet in one
+  // rendezvous from different call sites (a cross-lane instruction under divergent control flow) would exchange operands
+  // of unrelated instructions -- refuse instead of computing something (harvest.hip's 32-lane group searches do this)
+  const void *site = __builtin_return_address(0);
+  if (w.arrived_mask[slot] == 0) w.site[slot] = site;
+  else if (w.site[slot] != site) {
+    fprintf(stderr, "simt: lanes of one wavefront met at different cross-lane instructions in %s (divergent control flow is not "
+                    "modelled)\n", R.name);
+    abort();
+  }
   w.buf[slot][f->lane] = mine;
   w.arrived_mask[slot] |= 1ull << f->lane;
   park(2);

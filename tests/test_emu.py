@@ -305,13 +305,13 @@ def test_d4c_runs_its_shipped_code_path_on_the_host(emu):
     src = open(os.path.join(EMU_DIR, "..", "..", "world_amd", "csrc", "d4c.hip")).read()
     assert "WORLD_EMU" not in src                        # not even in a comment: `grep -c WORLD_EMU d4c.hip` is 0
     maps = open("/proc/self/maps").read()
-    assert "libworld_simt_d4c.so" in maps and "libworld_emu.so" in maps
+    assert "libworld_simt.so" in maps and "libworld_emu.so" in maps
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(EMU_DIR, "libworld_emu.so")], capture_output=True, text=True).stdout
     assert "launch_d4c" not in out                       # the classic emulation holds no copy of the unit
-    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(EMU_DIR, "libworld_simt_d4c.so")], capture_output=True, text=True).stdout
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(EMU_DIR, "libworld_simt.so")], capture_output=True, text=True).stdout
     # launchers exported; the fibre runtime and the unit's 64-lane spellings of the shared headers' inline functions local
     assert "launch_d4c" in out and "_ZN4simt" not in out and "wave_sum" not in out and "block_sum" not in out
     # the emulated cross-lane instructions against their definitions (one workgroup of 256 fibres)
     import ctypes as C
-    L = C.CDLL(os.path.join(EMU_DIR, "libworld_simt_d4c.so"))
+    L = C.CDLL(os.path.join(EMU_DIR, "libworld_simt.so"))
     assert hasattr(L, "world_hip_simt_selftest") and L.world_hip_simt_selftest() == 0

@@ -480,9 +480,13 @@ __device__ __forceinline__ double wave_min(double v) {
 __device__ __forceinline__ double wave_min_nonneg(double v) {
 #ifndef WORLD_EMU
   auto vmin = [](double a, double b) {
+#ifdef WORLD_SIMT
+    return a < b ? a : b;                                  // (the instruction's result for the non-negative, NaN-free operands it is given)
+#else
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
   };
   auto bcast = [](double x, auto ctrl_c, auto rows_c) {      // rows named by the mask take the last lane of the row(s) before
     constexpr int CTRL = decltype(ctrl_c)::value, ROWS = decltype(rows_c)::value;

@@ -331,10 +331,13 @@ def spawn_ranks(args):
         world = int(os.environ["WORLD_SIZE"])
         if world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0 or world == 1:
-            have = visible_gpus()
+    if args.gpus == 1 or "WORLD_SIZE" in os.environ:
+        # this process is (or becomes) a rank: it is about to initialise the runtime anyway, count here
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import torch
+            have = torch.cuda.device_count()
     else:
-        have = visible_gpus()
+        have = visible_gpus()                                   # about to exec the launcher: count in a child
     shared_ok = os.environ.get("WORLD_HIP_BENCH_BACKEND") == "gloo"
     if have is not None and have < (1 if shared_ok else args.gpus):
         raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: not running (no CPU path, no fewer-GPU fallback)")

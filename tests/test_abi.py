@@ -183,3 +183,15 @@ def test_shape_limits_are_answered_on_the_host():
     assert lib.world_hip_check_shape(200000, 8192, why, 256) == 1 and b"D4C" in why.value and b"192 kHz" in why.value
     assert lib.world_hip_check_shape(8000, 512, why, 256) == 1 and b"15.8" in why.value
     assert lib.world_hip_check_shape(96000, 4096, why, 256) == 0
+
+
+def test_abi_version_and_hint_are_exported_and_consistent(lib_path):
+    """round 6: the batched ABI carries a version a binding checks before it binds prototypes; the header's macro
+    and the library agree; the launch-geometry hint is part of the ABI and refuses a null context"""
+    lib = ctypes.CDLL(lib_path)
+    text = open(os.path.join(ROOT, "include", "world_hip.h")).read()
+    want = int(re.search(r"#define\s+WORLD_HIP_ABI_VERSION\s+(\d+)", text).group(1))
+    assert lib.world_hip_abi_version() == want == 6
+    assert int(re.search(r"#define\s+WORLD_HIP_HINT_SHARED_DEVICE\s+(\d+)", text).group(1)) == 1
+    lib.world_hip_set_hint.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert lib.world_hip_set_hint(None, 1) == -1

@@ -789,3 +789,22 @@ def test_direct_form_filter_bank_matches_golden_and_reference(tmp_path, ref_orac
         tp, f0 = H.harvest(x, fs, f0_floor=30.0)
         assert np.array_equal(tp, tp_r) and (f0_r > 0).sum() > 20
         assert_f0_close(f0, f0_r, 1e-6, f"f0_floor 30 at {fs} Hz")
+
+
+def test_launch_shape_hint_never_changes_a_bit():
+    """world_hip_set_hint(ctx, WORLD_HIP_HINT_SHARED_DEVICE) only picks launch geometry (Harvest's one-workgroup-per-utterance
+    contour kernels: 1024 threads for a lone job, 256 beside other jobs): a single utterance analysed with and without the
+    hint -- and as row 0 of a batch, which never takes the wide shapes -- gives the same bits"""
+    import torch
+    from world_amd import synth
+    from world_amd.api import WorldHip
+    fs = 48000
+    x = torch.stack([synth.utterance(k, fs, 3.0, device="cuda") for k in (5, 6)])
+    lone, shared = WorldHip(), WorldHip(shared_device=True)
+    a = lone.analyze(x[:1], fs)
+    b = shared.analyze(x[:1], fs)
+    c = lone.analyze(x, fs)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k][0], c[k][0]), k
+    lone.close(); shared.close()

@@ -66,10 +66,6 @@ __global__ void spectral_prepare(CtParams cp, D4cParams dp) {
 // [kmin, kmax]; the walk stops as soon as the bucket holding the threshold contains a
 // single key -- typically after two passes.  Barriers: two for min/max, ONE per pass (the
 // first kSelHists histograms are zeroed up front), two for the final sums.
-// keys one thread of a 256-thread workgroup receives from block_rfft of NMAX points
-template <int NMAX> struct SelKeys {
-  static constexpr int n = 2 * ((NMAX / 4 + 1 + 255) / 256);
-};
 constexpr int kSelHists = 3;
 // key[q], q < mine: bit patterns of this thread's elements (n elements block-wide).
 // hist: kSelHists x 256 ints of LDS.

@@ -380,35 +380,6 @@ __device__ __forceinline__ void dif_first_stage(cplx *z, int lg, const TwLds &tw
     for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = a[k];
   }
 }
-// The same stage for an input whose elements n >= nz are zero (a short window in a long transform): a
-// butterfly with a single non-zero input is the DFT of a delta -- every output equals that input, only the
-// twiddle powers remain -- and the zero elements are never asked for.  src(n) is called for n < nz only.
-template <int LR, class Src>
-__device__ __forceinline__ void dif_first_stage_head(cplx *z, int lg, const TwLds &tw, Src src, int nz) {
-  constexpr int R = 1 << LR;
-  const int sh = lg - LR, q = 1 << sh;
-  int c[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) c[r] = swz(r << sh);
-  for (int j = threadIdx.x; j < q; j += blockDim.x) {
-    cplx a[R];
-    if (j + q >= nz) {                               // only element j itself can be non-zero
-      cplx v; v.re = 0.0; v.im = 0.0;
-      if (j < nz) v = src(j);
-#pragma unroll
-      for (int r = 0; r < R; ++r) a[r] = v;
-    } else {
-#pragma unroll
-      for (int r = 0; r < R; ++r) { cplx v; v.re = 0.0; v.im = 0.0; a[r] = j + r * q < nz ? src(j + r * q) : v; }
-      dft_reg<true, LR>(a);
-    }
-    if (q > 1) mul_powers<LR>(a, twiddle(tw, j, lg, -1));
-    const int s0 = swz(j);
-#pragma unroll
-    for (int k = 0; k < R; ++k) z[s0 ^ c[k]] = a[k];
-  }
-}
-
 // one decimation-in-time stage: R finished sub-transforms of length 2^done are merged
 // epi(n, v): what is stored for output element n (the plain transform stores v); a caller's last stage can fold an
 // element-wise pass over the result into the transform's own stores
@@ -489,30 +460,6 @@ __device__ __forceinline__ void block_cfft_dif_from(cplx *z, const FftPlan &p, c
     case 3: if (MAXLR >= 3) dif_first_stage<3>(z, p.lg, tw, src); break;
     case 2: dif_first_stage<2>(z, p.lg, tw, src); break;
     default: dif_first_stage<1>(z, p.lg, tw, src); break;
-  }
-  int lev = p.lg - p.rl(0);
-  for (int s = 1; s < p.ns; ++s) {
-    __syncthreads();
-    switch (p.rl(s)) {
-      case 4: if (MAXLR >= 4) dif_stage<4>(z, p.lg, lev, tw); break;
-      case 3: if (MAXLR >= 3) dif_stage<3>(z, p.lg, lev, tw); break;
-      case 2: dif_stage<2>(z, p.lg, lev, tw); break;
-      default: dif_stage<1>(z, p.lg, lev, tw); break;
-    }
-    lev -= p.rl(s);
-  }
-  __syncthreads();
-}
-
-// forward transform of a sequence whose elements n >= nz are zero, read from src(n) (dif_first_stage_head)
-template <int MAXLR = 4, class Src>
-__device__ __forceinline__ void block_cfft_dif_head(cplx *z, const FftPlan &p, const TwLds &tw, Src src, int nz) {
-  __syncthreads();                                   // earlier readers of z are done
-  switch (p.rl(0)) {
-    case 4: if (MAXLR >= 4) dif_first_stage_head<4>(z, p.lg, tw, src, nz); break;
-    case 3: if (MAXLR >= 3) dif_first_stage_head<3>(z, p.lg, tw, src, nz); break;
-    case 2: dif_first_stage_head<2>(z, p.lg, tw, src, nz); break;
-    default: dif_first_stage_head<1>(z, p.lg, tw, src, nz); break;
   }
   int lev = p.lg - p.rl(0);
   for (int s = 1; s < p.ns; ++s) {

@@ -302,8 +302,9 @@ def test_d4c_runs_its_shipped_code_path_on_the_host(emu):
     spelling: tests/emu compiles it as the GPU does (WAVE = 64, real workgroup sizes) against tests/emu/simt_host.h, every
     thread a fibre and every cross-lane instruction a lock-step rendezvous, in a shared object of its own.  The golden
     fixtures above therefore ran the shipped d4c_frame / d4c_lovetrain / d4c_finish; this test pins the arrangement."""
-    src = open(os.path.join(EMU_DIR, "..", "..", "world_amd", "csrc", "d4c.hip")).read()
-    assert "WORLD_EMU" not in src                        # not even in a comment: `grep -c WORLD_EMU d4c.hip` is 0
+    for unit in ("d4c.hip", "stonemask.hip", "synthesis.hip", "synthesis.h"):         # the units that run wave-accurately
+        src = open(os.path.join(EMU_DIR, "..", "..", "world_amd", "csrc", unit)).read()
+        assert "WORLD_EMU" not in src, unit              # not even in a comment: `grep -c WORLD_EMU d4c.hip` is 0
     maps = open("/proc/self/maps").read()
     assert "libworld_simt.so" in maps and "libworld_emu.so" in maps
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(EMU_DIR, "libworld_emu.so")], capture_output=True, text=True).stdout

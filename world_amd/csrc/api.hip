@@ -1123,7 +1123,7 @@ static void run_synthesis(WorldHipContext *c, int n_utt, int fs, double frame_pe
   p.frame_period = frame_period / 1000.0;
   p.lowest_f0 = fs / fft_size + 1.0;                                   // integer division (synthesis.cpp:361)
   p.f0 = d_f0; p.sp = d_sp; p.ap = d_ap; p.f_stride = f_stride; p.y = d_y; p.y_stride = y_stride;
-  p.nblk = (max_y + kSyTile - 1) / kSyTile;
+  p.nblk = (max_y + synth_tile_samples() - 1) / synth_tile_samples();
   // Room for a mean pulse rate of 1200 Hz over the longest utterance unless the caller said otherwise (voiced
   // pulses come at f0, unvoiced ones at 500 Hz).  The pulse count is only known on the device; a call that
   // needs more records the count (need), world_hip_sync / world_hip_synthesis_pulses_dropped report it, and the

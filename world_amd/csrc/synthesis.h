@@ -5,11 +5,7 @@
 
 namespace world_hip {
 
-#ifdef WORLD_EMU
-constexpr int kSyThreads = 1;                    // the host emulation runs one thread per workgroup
-#else
-constexpr int kSyThreads = 256;
-#endif
+constexpr int kSyThreads = 256;                  // (round 6: one spelling -- tests/emu runs this unit's real workgroups, simt_host.h)
 constexpr int kSyPer = 8;                       // consecutive samples per thread in the time-base kernels
 constexpr int kSyTile = kSyThreads * kSyPer;    // samples per workgroup
 
@@ -43,5 +39,7 @@ struct SynthParams {
 
 void launch_synthesis(const SynthParams &p, int max_y, hipStream_t stream);
 size_t synth_pulse_lds_bytes(int lg_fft);
+int synth_tile_samples();                        // samples one workgroup of the time-base kernels covers (the unit's own constant:
+                                                 // callers size their per-tile arrays by asking, not by including it)
 
 }  // namespace world_hip

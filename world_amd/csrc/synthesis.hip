@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(kSyThreads) sy_compact(SynthParams p) {
 // One pulse.  LDS: Z (N complex) | C (N/2+1 complex; its head doubles as the log spectrum
 // the first FFT stage reads) | scratch | twiddles.
 // (fft_size 8192 -- the default above 96 kHz: Z alone is 128 KB, and C lives in the pulse's slot of the response buffer)
+int synth_tile_samples() { return kSyTile; }
 size_t synth_pulse_lds_bytes(int lg_fft) {
   const size_t N = (size_t)1 << lg_fft;
   const size_t c_lds = lg_fft > 12 ? 0 : 2 * (N / 2 + 1) + 2;
@@ -239,11 +240,7 @@ __global__ void __launch_bounds__(kSyThreads) sy_pulse(SynthParams p) {
   if (pi >= np) return;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int lgn = p.lg_fft, N = 1 << lgn, H = N / 2, nb = H + 1;
-#ifdef WORLD_EMU
-  const bool c_global = lgn > 12;                       // (one host instantiation serves every size)
-#else
   constexpr bool c_global = NMAX > 4096;
-#endif
   cplx *Z = reinterpret_cast<cplx *>(lds);
   double *const slot = p.resp + ((size_t)u * p.pulse_cap + pi) * p.resp_stride;
   cplx *C = c_global ? reinterpret_cast<cplx *>(slot) : Z + N + 8;
@@ -366,12 +363,8 @@ void launch_synthesis(const SynthParams &p, int max_y, hipStream_t stream) {
   WH_BLOCKS(sy_phase_serial, dim3(p.n_utt), WAVE, 0, stream, p);
   WH_BLOCKS(sy_detect, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
   WH_BLOCKS(sy_compact, dim3(p.nblk, p.n_utt), kSyThreads, small, stream, p);
-#ifdef WORLD_EMU
-  devrt::launch_blocks("sy_pulse", sy_pulse<8192>, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);
-#else
   if (p.lg_fft <= 12) devrt::launch_blocks("sy_pulse", sy_pulse<4096>, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);
   else devrt::launch_blocks("sy_pulse", sy_pulse<8192>, dim3(p.pulse_cap, p.n_utt), kSyThreads, synth_pulse_lds_bytes(p.lg_fft), stream, p);
-#endif
   WH_THREADS(sy_overlap_add, max_y, p.n_utt, 1, stream, p);
 }
 
